@@ -1,0 +1,23 @@
+"""CPU oracle for the LINR-PCGC hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  The product (``linr-pcgc_amd/``) never imports it and has no CPU fallback.
+
+Contents
+  octree.py       numpy restatement of the per-frame multi-scale prep (custom_dataset.py:259-355)
+  network.py      torch-CPU fp32/fp64 restatement of the coding network (model_core.py, upsample.py,
+                  resnet.py) in dense-row form over a neighbour table
+  torchac_port.c  plain-C restatement of torchac 0.9.3's range coder (third-party, un-vendored)
+  ac.py           ctypes loader for torchac_port.c + the float->int16 CDF conversion
+  model_codec.py  weight quantiser + Laplace CDF of model_compression/model_size_est.py
+
+Pinning status (see DESIGN.md "Oracle"):
+  * octree/occupancy/offset prep, bitstream packing: pinned by fixtures generated from the reference's
+    own pure-torch helpers (tests/golden/make_golden.py).
+  * weight quantiser: pinned by loot/gop_32_62/70/side_info.json (mu, b, min, max).
+  * range coder + Laplace-CDF quirk: pinned by the 35,320-byte model stream implied by
+    loot/gop_32_62/70/result.json.
+  * network arithmetic (MinkowskiEngine semantics): PARITY UNPINNED - MinkowskiEngine 0.5.4 is not in
+    /root/reference and not installable here; the restatement follows the reference call sites and
+    MinkowskiEngine's documented semantics.
+"""

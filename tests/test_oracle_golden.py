@@ -1,0 +1,93 @@
+"""CPU: the oracle against the reference-generated golden vectors and the shipped loot/ known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ac, model_codec, octree
+
+
+@pytest.mark.parametrize('name', ['octree_random64.npz', 'octree_shell128.npz'])
+def test_octree_prep_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    frame = octree.prepare_frame(g['points'], None, int(g['min_point_num']))
+    assert frame['scale_num'] == int(g['scale_num'])
+    assert (frame['coord_data_min'] == g['coord_data_min']).all()
+    assert (frame['ori'] == g['ori']).all()
+    for s, sc in enumerate(frame['scales']):
+        assert (sc['coord'] == g['s%d_coord' % s]).all()
+        assert (sc['occ'] == g['s%d_occ' % s]).all()
+        assert (sc['offset_tensor'] == g['s%d_offset' % s]).all()
+        assert (octree.upper_layer(sc['coord'], sc['occ']) == g['s%d_upper' % s]).all()
+        assert (octree.upper_layer(sc['coord'], sc['occ']) == sc['ground_truth']).all()
+
+
+def test_neighbour_table_properties(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    c = g['s0_coord']
+    nbr = octree.neighbour_table(c)
+    assert (nbr[:, 13] == np.arange(len(c))).all()
+    for k in range(27):
+        d = np.array([k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1])
+        hit = nbr[:, k] >= 0
+        assert (c[nbr[hit, k]] == c[hit] + d).all()
+        # mirror identity used by the gather-form backward: nbr[nbr[j,k], 26-k] == j
+        assert (nbr[nbr[hit, k], 26 - k] == np.nonzero(hit)[0]).all()
+    # 7-neighbour occupancy feature == presence of the axis neighbours in the table
+    off = g['s0_offset']
+    for col, k in zip(range(7), [13, 12, 14, 10, 16, 4, 22]):
+        assert ((nbr[:, k] >= 0) == (off[:, col] == 1)).all()
+
+
+def test_quantiser_known_answer(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
+    q, recon, mn, mx = model_codec.quant_uniform2(g['flat'], int(g['bitdepth']))
+    mu, b = model_codec.laplace_params(q)
+    assert float(mu) == float(g['mu']) and float(b) == float(g['b'])
+    assert float(mn) == float(g['min_param']) and float(mx) == float(g['max_param'])
+    assert q.min() == 0 and q.max() == 255
+
+
+def test_model_stream_known_answer(golden_dir):
+    """loot/gop_32_62/70/result.json: model_bpp * P is integral only for P = 24,372,190 (with bpp_t, xyzlow_bpp)
+    => 282,642 model bits = 8*L + header.  The current header formula (model_size_est.py:484, 82 bits) gives
+    L = 35,320; the shipped numbers come from an older revision (keys bpp_t/fake_bpp_all), whose header may have
+    been 90 bits => L = 35,319.  The ideal code length under the quirky Laplace CDF is 35,318.49 B, so a correct
+    range coder must land on 35,319 or 35,320.  The oracle is pinned to that +-1-byte window."""
+    g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
+    P = 24372190
+    for key in ('model_bpp', 'bpp_t', 'xyzlow_bpp'):
+        bits = float(g[key]) * P
+        assert abs(bits - round(bits)) < 1e-6
+    assert round(float(g['model_bpp']) * P) == 35320 * 8 + 82
+    out = model_codec.encode_model(g['flat'], 8)
+    assert len(out['bytes']) in (35319, 35320)
+    rec, sym = model_codec.decode_model(out['bytes'], len(g['flat']), out['mu'], out['b'], out['min_param'],
+                                        out['max_param'])
+    assert (sym.astype(np.uint8) == out['symbols']).all()
+    assert torch.equal(rec, out['recon'])
+
+
+def test_binary_coder_roundtrip_and_rate():
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 17, 50000):
+        p = rng.random(n).astype(np.float32)
+        if n > 4:
+            p[:4] = [0.0, 1.0, 1e-9, 1 - 1e-7]          # saturated probabilities (sigmoid in fp32)
+        s = (rng.random(n) < p).astype(np.int16)
+        if n > 4:
+            s[:4] = [1, 0, 1, 0]                         # worst case: the "impossible" symbol still decodes
+        data = ac.encode_binary(p, s)
+        assert (ac.decode_binary(p, data) == s).all()
+        if n == 50000:
+            c1 = ac.cdf_float_to_int(ac.binary_cdf(p))[:, 1].astype(np.float64)
+            ideal = -np.log2(np.where(s == 1, 65536 - c1, c1) / 65536).sum()
+            assert ideal <= len(data) * 8 <= ideal + 16
+
+
+def test_cdf_conversion_binary_bounds():
+    c = ac.cdf_float_to_int(ac.binary_cdf(np.array([0.0, 1.0, 0.5], dtype=np.float32)))
+    assert c[:, 0].tolist() == [0, 0, 0]
+    assert c[:, 1].tolist() == [65535, 1, 32768]
+    assert c[:, 2].tolist() == [0, 0, 0]               # 65534 + 2 wraps; never read (c_high is hard-wired 2^16)
