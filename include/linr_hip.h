@@ -1,0 +1,163 @@
+/* linr_hip.h - C-ABI of the MI355X (gfx950) coding-network engine for LINR-PCGC.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference (100 % Python) reaches its
+ * native code through MinkowskiEngine 0.5.4 and torchac 0.9.3 wheels; each entry point below names the
+ * reference call site(s) it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _h (host); the caller (PyTorch's caching
+ *     allocator) owns all memory; nothing is allocated, freed or retained across calls.
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no host synchronisation.
+ *   - return value: 0 on success, >0 = hipError_t, <0 = argument error (LINR_E*).  No exceptions cross.
+ *   - feature matrices are row-major float32 [rows, ld] with an explicit leading dimension `*_ld` so that a
+ *     channel slice (ME.cat / merge_two_frames) is a pointer offset, not a copy.
+ *   - the kernel map is int32 nbr[27][ld]: nbr[k*ld + j] = row of coord[j] + delta_k or -1, with
+ *     k = (dx+1) + 3*(dy+1) + 9*(dz+1)  (MinkowskiEngine hypercube region, first axis fastest).
+ */
+#ifndef LINR_HIP_H
+#define LINR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINR_ABI_VERSION 1
+#define LINR_API __attribute__((visibility("default")))
+
+#define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
+#define LINR_ENOSPC   (-2)   /* workspace / arena / output buffer too small */
+#define LINR_EALIGN   (-3)   /* pointer or leading dimension violates the documented alignment */
+
+/* epilogue / mode flags */
+#define LINR_RELU      1u    /* out = max(out, 0)                                   (MinkowskiReLU, nn.ReLU) */
+#define LINR_ACCUM     2u    /* out += result instead of out = result               (gradient fan-in)        */
+#define LINR_RELU_MASK 4u    /* result *= (act > 0): backward of a ReLU whose OUTPUT is `act`                */
+#define LINR_NO_BIAS   8u
+#define LINR_PAD_ROW  16u    /* the gathered operand has a readable all-zero row at index -1 (in - in_ld):
+                                absent neighbours are read from it instead of being branched around      */
+
+LINR_API int linr_abi_version(void);
+/* number of float parameters of LINR_PCGC_Model(scale_num, hidden=8, block_layers=1, outstage=8, instage=1)
+ * in parameters() order (models/model_core.py:31-35, models/upsample.py:43-76).  54,712 for scale_num = 7. */
+LINR_API int64_t linr_param_count(int32_t scale_num);
+
+/* ---- kernel map -------------------------------------------------------------------------------------------
+ * Replaces MinkowskiEngine's CoordinateManager insert + kernel-map generation that every ME.SparseTensor /
+ * MinkowskiConvolution call triggers (models/function_utils.py:13-18,58-69,92-93; models/upsample.py:20-23,
+ * 90-97; models/resnet.py:15-51).  coords: int32 [n,3], unique, sorted by the x-major ravel key (the order
+ * qscTensor guarantees, models/module_utils.py:246-256), each coordinate in [0, 2^20).
+ * Writes nbr[k*ld + row_base + j] = row_base + (index of neighbour) or -1 for j < n.
+ * ws: at least linr_kmap_workspace_bytes(n) bytes, 8-byte aligned. */
+LINR_API size_t linr_kmap_workspace_bytes(int64_t n);
+LINR_API int linr_kmap_build(const int32_t* coords, int64_t n, int32_t* nbr, int64_t ld, int64_t row_base,
+                    void* ws, size_t ws_bytes, void* stream);
+/* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
+LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
+
+/* ---- sparse 3x3x3 convolution on a fixed coordinate set ------------------------------------------------------
+ * Replaces ME.MinkowskiConvolution(kernel_size=3, stride=1, bias=True).forward and its autograd backward
+ * (call sites: models/upsample.py:17-23,90-97,153,171,210; models/resnet.py:15-51,56-57).
+ * W: [27][cin][cout] (the ME `.kernel` tensor), bias: [cout] (`.bias` is [1,cout]).
+ * fwd:        out[j, :cout] = bias + sum_k in[nbr[k][j], :cin] @ W[k]  (+ res[j, :cout]) (ReLU)
+ * bwd_data:   gin[i, :cin] (+)= sum_k gout[nbr[26-k][i], :cout] @ W[k]^T   (* (act[i] > 0))
+ * bwd_weight: gW[k] (+)= sum_j in[nbr[k][j]]^T gout[j] ; gb (+)= sum_j gout[j]   (deterministic two-pass)
+ * cin in 1..8, cout in {4, 8}.  `res`/`act` may be NULL when their flag is absent. */
+LINR_API int linr_spconv_fwd(const float* in, int32_t in_ld, const int32_t* nbr, int64_t nbr_ld, int64_t n,
+                    const float* W, const float* bias, int32_t cin, int32_t cout,
+                    const float* res, int32_t res_ld, float* out, int32_t out_ld, uint32_t flags, void* stream);
+LINR_API int linr_spconv_bwd_data(const float* gout, int32_t gout_ld, const int32_t* nbr, int64_t nbr_ld, int64_t n,
+                         const float* W, int32_t cin, int32_t cout,
+                         const float* act, int32_t act_ld, float* gin, int32_t gin_ld, uint32_t flags,
+                         void* stream);
+LINR_API size_t linr_spconv_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout);
+LINR_API int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld,
+                           const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t cin, int32_t cout,
+                           float* gW, float* gb, uint32_t flags, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pointwise layers ---------------------------------------------------------------------------------------
+ * Replaces ME.MinkowskiConvolution(kernel_size=1) (models/resnet.py:31-37,45-51) and nn.Linear inside
+ * PointwiseMLP (models/module_utils.py:42-81).  Element (ci,co) of the weight is W[ci*ws_ci + co*ws_co]:
+ * ME kernel [cin][cout] -> (cout, 1); nn.Linear weight [cout][cin] -> (1, cin).
+ * fwd: out = in @ W + bias (+res)(ReLU); bwd_data: gin (+)= gout @ W^T (*mask); bwd_weight: gW, gb. */
+LINR_API int linr_linear_fwd(const float* in, int32_t in_ld, int64_t n, const float* W, int32_t ws_ci, int32_t ws_co,
+                    const float* bias, int32_t cin, int32_t cout, const float* res, int32_t res_ld,
+                    float* out, int32_t out_ld, uint32_t flags, void* stream);
+LINR_API int linr_linear_bwd_data(const float* gout, int32_t gout_ld, int64_t n, const float* W, int32_t ws_ci,
+                         int32_t ws_co, int32_t cin, int32_t cout, const float* act, int32_t act_ld,
+                         float* gin, int32_t gin_ld, uint32_t flags, void* stream);
+LINR_API size_t linr_linear_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout);
+LINR_API int linr_linear_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, int64_t n,
+                           int32_t cin, int32_t cout, float* gW, int32_t ws_ci, int32_t ws_co, float* gb,
+                           uint32_t flags, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- occupancy head loss -------------------------------------------------------------------------------------
+ * Replaces sigmoid + nn.BCELoss(reduction='sum') / ln 2 (models/upsample.py:160, models/model_core.py:14,76-81).
+ * fwd: p[j] = sigmoid(z[j]); partial sums of -(t log p + (1-t) log(1-p))/ln2 (logs clamped at -100) are ADDED
+ * into bits_acc (double[1], device) deterministically (fixed-order two-pass); t = target[j*target_ld].
+ * bwd: gz[j] = gscale * d bits / d z[j] following torch's binary_cross_entropy_backward + sigmoid backward. */
+LINR_API size_t linr_bce_workspace_bytes(int64_t n);
+LINR_API int linr_bce_bits_fwd(const float* z, const float* target, int32_t target_ld, int64_t n, float* p,
+                      double* bits_acc, void* ws, size_t ws_bytes, void* stream);
+LINR_API int linr_bce_bits_bwd(const float* p, const float* target, int32_t target_ld, int64_t n, float gscale,
+                      float* gz, void* stream);
+
+/* ---- optimiser -----------------------------------------------------------------------------------------------
+ * Replaces torch.optim.Adam(...).step() over 189 tensors (main.py:231-237,319) with one launch over the flat
+ * parameter buffer.  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) are computed by the host in
+ * double like torch does (hyper-parameters cross the ABI as double and are rounded to float once, like the
+ * Python scalars torch passes to its kernels); L2 weight decay is folded into the gradient. */
+LINR_API int linr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   double step_size, double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,
+                   void* stream);
+
+/* ---- whole-network executor ----------------------------------------------------------------------------------
+ * One frame = all scales of one point cloud concatenated into a single row space (finest first); CNP weights are
+ * shared by all scales, only the scale-context MLP differs (models/model_core.py:31-35).
+ * Replaces LINR_PCGC_Model.logic_core/forward (models/model_core.py:38-81) + CNP.forward
+ * (models/upsample.py:163-217) and the autograd backward that main.py:315-316 runs. */
+typedef struct linr_frame {
+    int64_t rows;                 /* total rows over all scales                                             */
+    int32_t n_scales;             /* scales present in this frame (<= model scale_num)                      */
+    int32_t model_scale_num;      /* LINR_PCGC_Model scale_num (fixes the parameter layout)                 */
+    const int64_t* row_off_h;     /* HOST [n_scales+1] first row of each scale                              */
+    const int32_t* scale_idx_h;   /* HOST [n_scales]  which scale embedding / scale MLP each scale uses     */
+    const int32_t* nbr;           /* [27][rows] kernel map with global row ids                              */
+    const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
+    const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
+} linr_frame;
+
+LINR_API size_t linr_net_arena_bytes(int64_t rows);
+/* stages [stage_begin, stage_end) of the 8-stage head; stage_begin == 0 also runs scale context + block_in.
+ * The encoder calls (0, 8); the decoder calls (k, k+1) after writing decoded occupancy column k-1 into
+ * frame->occ, which executes the identical launches => bitwise identical probabilities (models/upsample.py:249-295).
+ * probs: [8][rows] (stage-major) or NULL.  bits_acc: double[1], accumulated into (caller zeroes). */
+LINR_API int linr_net_forward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes,
+                     int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc, void* stream);
+/* gradient of gscale * bits w.r.t. all parameters, ADDED into grads (flat, linr_param_count floats);
+ * requires a preceding linr_net_forward(…, 0, 8, …) on the same arena. */
+LINR_API int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes,
+                      float gscale, float* grads, void* stream);
+
+/* ---- arithmetic-coder feed (host side) -----------------------------------------------------------------------
+ * Replaces torchac.encode_float_cdf / decode_float_cdf as used by BinaryArithmeticCoding
+ * (models/module_utils.py:8-40; callers models/upsample.py:224-237,275; models/model_core.py:204-208) and by the
+ * model stream (model_compression/model_size_est.py:470-482,545-563).  Bit-compatible with torchac 0.9.3 streams.
+ * All pointers here are HOST pointers.  Return: bytes written (>= 0) or a negative LINR_E* code. */
+LINR_API int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym_h, int64_t n, uint8_t* out_h, int64_t cap);
+LINR_API int     linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h);
+LINR_API int64_t linr_ac_encode_cdf16(const uint16_t* cdf_h, int32_t lp, int32_t cdf_shared, const int16_t* sym_h,
+                             int64_t n, uint8_t* out_h, int64_t cap);
+LINR_API int     linr_ac_decode_cdf16(const uint16_t* cdf_h, int32_t lp, int32_t cdf_shared, int64_t n,
+                             const uint8_t* in_h, int64_t in_len, int16_t* sym_h);
+/* n_streams independent binary streams coded on a thread pool (8 stages x scales are independent streams) */
+LINR_API int linr_ac_encode_binary_batch(const float* const* prob_h, const uint8_t* const* sym_h, const int64_t* n,
+                                int32_t n_streams, uint8_t* const* out_h, const int64_t* cap,
+                                int64_t* out_len, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINR_HIP_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of liblinr_hip.so (include/linr_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblinr_hip.so')
+
+LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
+ABI_VERSION = 1
+
+c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
+c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+
+class LinrFrame(ctypes.Structure):
+    """struct linr_frame (include/linr_hip.h)."""
+    _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('row_off_h', c_ptr),
+                ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('offset_feat', c_ptr), ('occ', c_ptr)]
+
+
+_PROTOS = {
+    'linr_abi_version': (ctypes.c_int, []),
+    'linr_param_count': (c_i64, [c_i32]),
+    'linr_kmap_workspace_bytes': (c_size, [c_i64]),
+    'linr_kmap_build': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
+    'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    'linr_spconv_fwd': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32,
+                                       c_ptr, c_i32, c_u32, c_ptr]),
+    'linr_spconv_bwd_data': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_i32,
+                                            c_ptr, c_i32, c_u32, c_ptr]),
+    'linr_spconv_bwd_weight_workspace_bytes': (c_size, [c_i64, c_i32, c_i32]),
+    'linr_spconv_bwd_weight': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr,
+                                              c_ptr, c_u32, c_ptr, c_size, c_ptr]),
+    'linr_linear_fwd': (ctypes.c_int, [c_ptr, c_i32, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_i32, c_i32, c_ptr, c_i32,
+                                       c_ptr, c_i32, c_u32, c_ptr]),
+    'linr_linear_bwd_data': (ctypes.c_int, [c_ptr, c_i32, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_i32,
+                                            c_ptr, c_i32, c_u32, c_ptr]),
+    'linr_linear_bwd_weight_workspace_bytes': (c_size, [c_i64, c_i32, c_i32]),
+    'linr_linear_bwd_weight': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_i64, c_i32, c_i32, c_ptr, c_i32, c_i32,
+                                              c_ptr, c_u32, c_ptr, c_size, c_ptr]),
+    'linr_bce_workspace_bytes': (c_size, [c_i64]),
+    'linr_bce_bits_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'linr_bce_bits_bwd': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_i64, c_f32, c_ptr, c_ptr]),
+    'linr_adam_step': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_f64,
+                                      c_ptr]),
+    'linr_net_arena_bytes': (c_size, [c_i64]),
+    'linr_net_forward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr,
+                                        c_ptr]),
+    'linr_net_backward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr]),
+    'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
+    'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),
+    'linr_ac_decode_cdf16': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
+    'linr_ac_encode_binary_batch': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32]),
+}
+
+EXPORTS = tuple(_PROTOS)
+_lib = None
+
+
+class LinrError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when liblinr_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LinrError('%s not found: build it with linr-pcgc_amd/csrc/build.sh (or __graft_entry__.build()); '
+                            'there is no CPU / PyTorch fallback for the coding network' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)          # AttributeError if an export is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.linr_abi_version() != ABI_VERSION:
+            raise LinrError('liblinr_hip.so ABI %d != binding ABI %d' % (handle.linr_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+_ERR = {-1: 'LINR_EINVAL (bad argument)', -2: 'LINR_ENOSPC (buffer too small)', -3: 'LINR_EALIGN (misaligned pointer)'}
+
+
+def check(rc, what):
+    """The reference's only error convention is Python assert/ValueError (encoder.py:86-87); we raise RuntimeError."""
+    if rc != 0:
+        raise LinrError('%s failed: %s' % (what, _ERR.get(rc, 'hipError_t %d' % rc)))

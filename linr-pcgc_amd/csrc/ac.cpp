@@ -1,0 +1,198 @@
+// Arithmetic-coder feed (host side).  Produces / consumes streams bit-compatible with torchac 0.9.3 as the reference
+// uses it: BinaryArithmeticCoding (models/module_utils.py:8-40, cdf = [0, 1-p, 1]) and the Laplace model stream
+// (model_compression/model_size_est.py:470-482,545-563).  32-bit range coder with carry-less pending-bit handling
+// over 16-bit cumulative frequencies; bits are packed MSB first, the tail is zero padded.
+//
+// The binary path never materialises a CDF row: the only entry that matters is
+//   c1 = uint16(rint((1 - p) * 65534) + 1)         (torchac: round(cdf * (2^16 - (Lp-1))) + arange(Lp), Lp = 3)
+// symbol 0 owns [0, c1), symbol 1 owns [c1, 2^16).  8 stages x scales are independent streams, coded in parallel.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <atomic>
+#include "../../include/linr_hip.h"
+
+namespace {
+
+struct BitSink {
+    uint8_t* out; int64_t cap; int64_t len = 0; uint32_t acc = 0; int nacc = 0;
+    BitSink(uint8_t* o, int64_t c) : out(o), cap(c) {}
+    inline void put(uint32_t bit) {
+        acc = (acc << 1) | bit;
+        if (++nacc == 8) { if (len < cap) out[len] = (uint8_t)acc; ++len; acc = 0; nacc = 0; }
+    }
+    inline void put_with_pending(uint32_t bit, uint64_t& pending) {
+        put(bit);
+        for (; pending > 0; --pending) put(bit ^ 1u);
+    }
+    inline void finish() { while (nacc != 0) put(0); }
+};
+
+struct RangeEncoder {
+    uint32_t low = 0, high = 0xFFFFFFFFu; uint64_t pending = 0; BitSink sink;
+    RangeEncoder(uint8_t* o, int64_t c) : sink(o, c) {}
+    inline void encode(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        for (;;) {
+            if (high < 0x80000000u) {
+                sink.put_with_pending(0, pending);
+            } else if (low >= 0x80000000u) {
+                sink.put_with_pending(1, pending);
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                ++pending;
+                low = (low << 1) & 0x7FFFFFFFu;
+                high = (high << 1) | 0x80000001u;
+                continue;
+            } else {
+                break;
+            }
+            low <<= 1;
+            high = (high << 1) | 1u;
+        }
+    }
+    inline int64_t finish() {
+        ++pending;
+        sink.put_with_pending(low < 0x40000000u ? 0u : 1u, pending);
+        sink.finish();
+        return sink.len;
+    }
+};
+
+struct BitSource {
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t cache = 0; int ncache = 0;
+    BitSource(const uint8_t* i, int64_t l) : in(i), len(l) {}
+    inline void shift_in(uint32_t& value) {
+        if (ncache == 0) {
+            if (pos == len) { value <<= 1; return; }     // past the end: zeros
+            cache = in[pos++]; ncache = 8;
+        }
+        value = (value << 1) | ((cache >> (ncache - 1)) & 1u);
+        --ncache;
+    }
+};
+
+struct RangeDecoder {
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = 0; BitSource src;
+    RangeDecoder(const uint8_t* i, int64_t l) : src(i, l) { for (int b = 0; b < 32; ++b) src.shift_in(value); }
+    inline uint32_t target() const {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        return (uint32_t)(uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000u - 1) / span);
+    }
+    inline void consume(uint32_t c_low, uint32_t c_high) {
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+        high = (low - 1) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        for (;;) {
+            if (low >= 0x80000000u || high < 0x80000000u) {
+                low <<= 1; high = (high << 1) | 1u;
+            } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                low = (low << 1) & 0x7FFFFFFFu;
+                high = (high << 1) | 0x80000001u;
+                value -= 0x40000000u;
+            } else {
+                break;
+            }
+            src.shift_in(value);
+        }
+    }
+};
+
+inline uint32_t binary_c1(float p) {
+    // float32 arithmetic exactly as torch: (1 - p) * 65534, round half to even, int16 wrap, + 1
+    const float scaled = nearbyintf((1.0f - p) * 65534.0f);
+    return (uint32_t)(((int64_t)scaled + 1) & 0xFFFF);
+}
+
+}  // namespace
+
+extern "C" int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym_h, int64_t n, uint8_t* out_h, int64_t cap) {
+    if (n < 0 || cap < 0 || (n > 0 && (!prob_h || !sym_h)) || (cap > 0 && !out_h)) return LINR_EINVAL;
+    RangeEncoder enc(out_h, cap);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t c1 = binary_c1(prob_h[i]);
+        if (sym_h[i]) enc.encode(c1, 0x10000u); else enc.encode(0u, c1);
+    }
+    const int64_t len = enc.finish();
+    return len <= cap ? len : (int64_t)LINR_ENOSPC;
+}
+
+extern "C" int linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h) {
+    if (n < 0 || in_len < 0 || (n > 0 && (!prob_h || !sym_h)) || (in_len > 0 && !in_h)) return LINR_EINVAL;
+    RangeDecoder dec(in_h, in_len);
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t c1 = binary_c1(prob_h[i]);
+        // torchac's binary search over [0, c1, *] returns symbol 1 iff target >= c1
+        const uint32_t s = dec.target() >= c1 ? 1u : 0u;
+        sym_h[i] = (uint8_t)s;
+        if (i == n - 1) break;
+        if (s) dec.consume(c1, 0x10000u); else dec.consume(0u, c1);
+    }
+    return 0;
+}
+
+extern "C" int64_t linr_ac_encode_cdf16(const uint16_t* cdf_h, int32_t lp, int32_t cdf_shared, const int16_t* sym_h,
+                                        int64_t n, uint8_t* out_h, int64_t cap) {
+    if (n < 0 || cap < 0 || lp < 2 || (n > 0 && (!cdf_h || !sym_h)) || (cap > 0 && !out_h)) return LINR_EINVAL;
+    RangeEncoder enc(out_h, cap);
+    const int max_symbol = lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t* row = cdf_shared ? cdf_h : cdf_h + i * (int64_t)lp;
+        const int s = sym_h[i];
+        if (s < 0 || s > max_symbol) return LINR_EINVAL;
+        enc.encode(row[s], s == max_symbol ? 0x10000u : (uint32_t)row[s + 1]);
+    }
+    const int64_t len = enc.finish();
+    return len <= cap ? len : (int64_t)LINR_ENOSPC;
+}
+
+extern "C" int linr_ac_decode_cdf16(const uint16_t* cdf_h, int32_t lp, int32_t cdf_shared, int64_t n, const uint8_t* in_h,
+                                    int64_t in_len, int16_t* sym_h) {
+    if (n < 0 || in_len < 0 || lp < 2 || (n > 0 && (!cdf_h || !sym_h)) || (in_len > 0 && !in_h)) return LINR_EINVAL;
+    RangeDecoder dec(in_h, in_len);
+    const int max_symbol = lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t* row = cdf_shared ? cdf_h : cdf_h + i * (int64_t)lp;
+        const uint16_t t = (uint16_t)dec.target();
+        int left = 0, right = max_symbol + 1;        // torchac's search (keeps its behaviour on non-monotone rows)
+        while (left + 1 < right) {
+            const int m = (left + right) / 2;
+            const uint16_t v = row[m];
+            if (v < t) left = m; else if (v > t) right = m; else { left = m; break; }
+        }
+        sym_h[i] = (int16_t)left;
+        if (i == n - 1) break;
+        dec.consume(row[left], left == max_symbol ? 0x10000u : (uint32_t)row[left + 1]);
+    }
+    return 0;
+}
+
+extern "C" int linr_ac_encode_binary_batch(const float* const* prob_h, const uint8_t* const* sym_h, const int64_t* n,
+                                           int32_t n_streams, uint8_t* const* out_h, const int64_t* cap, int64_t* out_len,
+                                           int32_t n_threads) {
+    if (n_streams < 0 || (n_streams > 0 && (!prob_h || !sym_h || !n || !out_h || !cap || !out_len))) return LINR_EINVAL;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_streams) n_threads = n_streams;
+    std::atomic<int> next(0);
+    std::atomic<int> err(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_streams) return;
+            const int64_t r = linr_ac_encode_binary(prob_h[i], sym_h[i], n[i], out_h[i], cap[i]);
+            out_len[i] = r;
+            if (r < 0) err.store((int)r);
+        }
+    };
+    if (n_threads <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    return err.load();
+}

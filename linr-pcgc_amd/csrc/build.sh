@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds liblinr_hip.so (gfx950 code objects + C-ABI) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../liblinr_hip.so
+mkdir -p _obj
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall"
+pids=()
+for f in kmap spconv linear loss_optim net; do
+  if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ common.h -nt _obj/$f.o ] || [ ../../include/linr_hip.h -nt _obj/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o _obj/$f.o &
+    pids+=($!)
+  fi
+done
+if [ ! -f _obj/ac.o ] || [ ac.cpp -nt _obj/ac.o ] || [ ../../include/linr_hip.h -nt _obj/ac.o ]; then
+  g++ -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall -c ac.cpp -o _obj/ac.o &
+  pids+=($!)
+fi
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/ac.o -lpthread
+echo "built $(realpath $OUT)"

@@ -1,0 +1,75 @@
+// Kernel-map builder: for every voxel of a sorted coordinate list, the row index of each of its 27 neighbours.
+// Replaces MinkowskiEngine's coordinate hash map + kernel-map generation (see include/linr_hip.h).
+// The list is already sorted by the x-major key, so a neighbour lookup is a binary search, and the three
+// dz = -1,0,+1 neighbours of one (dx,dy) column are adjacent in the list: 9 searches per voxel, not 27.
+#include "common.h"
+
+__device__ __forceinline__ long long linr_key(int x, int y, int z) {
+    return ((long long)(x + 1) << 42) | ((long long)(y + 1) << 21) | (long long)(z + 1);
+}
+
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_keys_k(const int32_t* __restrict__ coords, int64_t n,
+                                                          long long* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i < n) keys[i] = linr_key(coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
+}
+
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_search_k(const long long* __restrict__ keys,
+                                                            const int32_t* __restrict__ coords, int64_t n,
+                                                            int32_t* __restrict__ nbr, int64_t ld, int64_t row_base) {
+    int64_t idx = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (idx >= 9 * n) return;
+    const int q = (int)(idx / n);            // (dx,dy) column: consecutive threads -> consecutive rows
+    const int64_t j = idx - (int64_t)q * n;
+    const int dx = q % 3 - 1, dy = q / 3 - 1;
+    const int x = coords[3 * j] + dx, y = coords[3 * j + 1] + dy, z = coords[3 * j + 2];
+    const long long key0 = linr_key(x, y, z - 1);
+    int64_t lo = 0, hi = n;                  // lower_bound(key0)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key0) lo = mid + 1; else hi = mid;
+    }
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz) {
+        const long long target = key0 + dz;  // z+1 < 2^21: never carries into y
+        if (lo < n && keys[lo] < target) ++lo;   // keys are unique: at most one step per dz
+        const bool hit = lo < n && keys[lo] == target;
+        const int k = q + 9 * dz;
+        nbr[(int64_t)k * ld + row_base + j] = hit ? (int32_t)(row_base + lo) : -1;
+    }
+}
+
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_validate_k(const int32_t* __restrict__ coords, int64_t n,
+                                                              int32_t* __restrict__ bad) {
+    int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    bool ok = x >= 0 && y >= 0 && z >= 0 && x < (1 << 20) && y < (1 << 20) && z < (1 << 20);
+    if (ok && i > 0) ok = linr_key(coords[3 * i - 3], coords[3 * i - 2], coords[3 * i - 1]) < linr_key(x, y, z);
+    if (!ok) atomicOr(bad, 1);
+}
+
+extern "C" size_t linr_kmap_workspace_bytes(int64_t n) { return (size_t)(n < 0 ? 0 : n) * sizeof(long long); }
+
+extern "C" int linr_kmap_build(const int32_t* coords, int64_t n, int32_t* nbr, int64_t ld, int64_t row_base,
+                               void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || ld < n || row_base < 0 || row_base + n > ld) return LINR_EINVAL;
+    if (row_base + n > INT32_MAX) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!coords || !nbr || !ws) return LINR_EINVAL;
+    if (ws_bytes < linr_kmap_workspace_bytes(n)) return LINR_ENOSPC;
+    if (((uintptr_t)ws) & 7u) return LINR_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    long long* keys = (long long*)ws;
+    kmap_keys_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(coords, n, keys);
+    kmap_search_k<<<linr_grid(9 * n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(keys, coords, n, nbr, ld, row_base);
+    return linr_launch_rc();
+}
+
+extern "C" int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream) {
+    if (n < 0 || !bad) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!coords) return LINR_EINVAL;
+    kmap_validate_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(coords, n, bad);
+    return linr_launch_rc();
+}

@@ -1,0 +1,376 @@
+// Whole-network executor: scale-context MLP -> block_in -> 8 x (prune conv + head MLP + sigmoid/BCE, outter block)
+// forward, and the hand-derived backward, as one stream-ordered launch sequence over a flat parameter buffer and a
+// caller-owned activation arena.  Replaces LINR_PCGC_Model.logic_core/forward (models/model_core.py:38-81),
+// CNP.forward (models/upsample.py:163-217), make_block (:88-97), InceptionResNet.forward (models/resnet.py:55-60)
+// and the autograd graph main.py:315-316 differentiates.
+//
+// Arena: every activation / gradient matrix is [1 + rows][ld] with an all-zero row in FRONT (row index -1), so the
+// sparse convolutions read absent neighbours from it (LINR_PAD_ROW) with no branch.
+#include "common.h"
+#include <math.h>
+
+#define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
+#define MAX_SCALES 16
+
+// ---- parameter layout (reference parameters() order) ------------------------------------------------------------
+struct BlockP {
+    int cin;
+    int64_t a_w, a_b;        // .0   conv3 cin->8
+    int64_t c00_w, c00_b;    // .2.layers.0.conv0_0  conv3 8->4
+    int64_t c01_w, c01_b;    // conv0_1  conv3 4->4
+    int64_t c10_w, c10_b;    // conv1_0  1x1 8->4   kernel [8][4]
+    int64_t c11_w, c11_b;    // conv1_1  conv3 4->4
+    int64_t c12_w, c12_b;    // conv1_2  1x1 4->4   kernel [4][4]
+    int64_t b_w, b_b;        // .3   conv3 8->8
+};
+
+struct Layout {
+    int S;
+    int64_t emb;                                   // [S][8]
+    int64_t m0_w[MAX_SCALES], m0_b[MAX_SCALES];    // Linear(15,16): weight [16][15]
+    int64_t m2_w[MAX_SCALES], m2_b[MAX_SCALES];    // Linear(16,8):  weight [8][16]
+    BlockP block_in;
+    int64_t h0_w[8], h0_b[8], h2_w[8], h2_b[8];    // inner_mlps.k.0: Linear(8,24), Linear(24,1)
+    int64_t pr_w[8], pr_b[8];                      // prune_blocks.k.0.conv: conv3 8->8
+    BlockP outter[7];
+    int64_t total;
+};
+
+static int64_t take(int64_t& cur, int64_t n) { int64_t o = cur; cur += n; return o; }
+
+static void layout_block(BlockP& b, int cin, int64_t& cur) {
+    b.cin = cin;
+    b.a_w = take(cur, 27 * cin * 8);  b.a_b = take(cur, 8);
+    b.c00_w = take(cur, 27 * 8 * 4);  b.c00_b = take(cur, 4);
+    b.c01_w = take(cur, 27 * 4 * 4);  b.c01_b = take(cur, 4);
+    b.c10_w = take(cur, 8 * 4);       b.c10_b = take(cur, 4);
+    b.c11_w = take(cur, 27 * 4 * 4);  b.c11_b = take(cur, 4);
+    b.c12_w = take(cur, 4 * 4);       b.c12_b = take(cur, 4);
+    b.b_w = take(cur, 27 * 8 * 8);    b.b_b = take(cur, 8);
+}
+
+static bool make_layout(Layout& L, int S) {
+    if (S < 1 || S > MAX_SCALES) return false;
+    L.S = S;
+    int64_t cur = 0;
+    L.emb = take(cur, (int64_t)S * 8);
+    for (int s = 0; s < S; ++s) {
+        L.m0_w[s] = take(cur, 16 * 15); L.m0_b[s] = take(cur, 16);
+        L.m2_w[s] = take(cur, 8 * 16);  L.m2_b[s] = take(cur, 8);
+    }
+    layout_block(L.block_in, 8, cur);
+    for (int k = 0; k < 8; ++k) {
+        L.h0_w[k] = take(cur, 24 * 8); L.h0_b[k] = take(cur, 24);
+        L.h2_w[k] = take(cur, 24);     L.h2_b[k] = take(cur, 1);
+    }
+    for (int k = 0; k < 8; ++k) { L.pr_w[k] = take(cur, 27 * 8 * 8); L.pr_b[k] = take(cur, 8); }
+    for (int k = 0; k < 7; ++k) layout_block(L.outter[k], k + 1, cur);
+    L.total = cur;
+    return true;
+}
+
+extern "C" int linr_abi_version(void) { return LINR_ABI_VERSION; }
+
+extern "C" int64_t linr_param_count(int32_t scale_num) {
+    Layout L;
+    return make_layout(L, scale_num) ? L.total : (int64_t)LINR_EINVAL;
+}
+
+// ---- arena ------------------------------------------------------------------------------------------------------
+struct Arena {
+    int64_t rows;
+    float* base;
+    int64_t cur;                 // floats
+    int64_t pad_off[160];        // float offset of every pad row
+    int pad_w[160];
+    int npad;
+    // forward (saved for backward)
+    float *MIX, *HID, *X0, *OCC;
+    float *A[8], *H[8], *M[8], *I[8], *O[8];
+    float *C[8], *HH[8], *Z[8], *P[8];
+    // backward scratch
+    float *gZ, *gHH, *gC, *gO, *gXG, *gI, *gA, *gH, *gM, *gX0, *gHID;
+    float* tmp16;                // 16 floats
+    void* slab; size_t slab_bytes;
+};
+
+static float* arena_mat(Arena& a, int ld) {
+    a.cur = (a.cur + 3) & ~(int64_t)3;                       // 16-byte alignment
+    a.pad_off[a.npad] = a.cur; a.pad_w[a.npad] = ld; a.npad++;
+    float* p = a.base ? a.base + a.cur + ld : nullptr;      // row 0 starts after the pad row
+    a.cur += (a.rows + 1) * (int64_t)ld;
+    return p;
+}
+
+static size_t slab_need(int64_t rows) {
+    size_t m = linr_spconv_bwd_weight_workspace_bytes(rows, 8, 8);
+    size_t l = linr_linear_bwd_weight_workspace_bytes(rows, 24, 24);
+    size_t b = linr_bce_workspace_bytes(rows);
+    size_t r = m > l ? m : l;
+    return (r > b ? r : b) + 64;
+}
+
+static void make_arena(Arena& a, int64_t rows, float* base) {
+    a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
+    a.MIX = arena_mat(a, 16); a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
+    for (int b = 0; b < 8; ++b) {
+        a.A[b] = arena_mat(a, 8); a.H[b] = arena_mat(a, 8); a.M[b] = arena_mat(a, 4);
+        a.I[b] = arena_mat(a, 8); a.O[b] = arena_mat(a, 8);
+    }
+    for (int k = 0; k < 8; ++k) {
+        a.C[k] = arena_mat(a, 8); a.HH[k] = arena_mat(a, 24); a.Z[k] = arena_mat(a, 1); a.P[k] = arena_mat(a, 1);
+    }
+    a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gC = arena_mat(a, 8); a.gO = arena_mat(a, 8);
+    a.gXG = arena_mat(a, 8); a.gI = arena_mat(a, 8); a.gA = arena_mat(a, 8); a.gH = arena_mat(a, 8);
+    a.gM = arena_mat(a, 4); a.gX0 = arena_mat(a, 8); a.gHID = arena_mat(a, 16);
+    a.cur = (a.cur + 3) & ~(int64_t)3;
+    a.tmp16 = base ? base + a.cur : nullptr; a.cur += 16;
+    a.cur = (a.cur + 15) & ~(int64_t)15;                     // 64-byte alignment for the slab (doubles inside)
+    a.slab = base ? (void*)(base + a.cur) : nullptr;
+    a.slab_bytes = slab_need(rows);
+    a.cur += (int64_t)((a.slab_bytes + 3) / 4);
+}
+
+extern "C" size_t linr_net_arena_bytes(int64_t rows) {
+    if (rows < 0) return 0;
+    Arena a;
+    make_arena(a, rows, nullptr);
+    return (size_t)a.cur * sizeof(float) + 64;
+}
+
+struct PadList { int64_t off[160]; int w[160]; int n; };
+
+__global__ void zero_pads_k(float* __restrict__ base, PadList pl) {
+    const int b = blockIdx.x;
+    if (b < pl.n && (int)threadIdx.x < pl.w[b]) base[pl.off[b] + threadIdx.x] = 0.0f;
+}
+
+// mix[r] = [emb(8) | offset_feat[r](7) | 0]
+__global__ __launch_bounds__(LINR_BLOCK) void sce_mix_k(const float* __restrict__ emb, const float* __restrict__ off,
+                                                        int64_t n, float* __restrict__ mix) {
+    const int64_t idx = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (idx >= n * 16) return;
+    const int64_t r = idx >> 4;
+    const int c = (int)(idx & 15);
+    float v = 0.0f;
+    if (c < 8) v = emb[c];
+    else if (c < 15) v = off[r * 7 + (c - 8)];
+    mix[idx] = v;
+}
+
+__global__ __launch_bounds__(LINR_BLOCK) void sigmoid_k(const float* __restrict__ z, int64_t n, float* __restrict__ p) {
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i < n) p[i] = 1.0f / (1.0f + expf(-z[i]));
+}
+
+// dst (+)= src over n floats
+__global__ __launch_bounds__(LINR_BLOCK) void axpy_k(const float* __restrict__ src, int64_t n, float* __restrict__ dst,
+                                                     int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
+}
+
+// gb1[m] += cs[m]; gemb[i] += sum_m cs[m] * W1[m][i]   (scale-embedding gradient through Linear(15,16))
+__global__ void sce_emb_grad_k(const float* __restrict__ cs, const float* __restrict__ W1, float* __restrict__ gb1,
+                               float* __restrict__ gemb) {
+    const int t = threadIdx.x;
+    if (t < 16) gb1[t] += cs[t];
+    if (t < 8) {
+        float s = 0.0f;
+        for (int m = 0; m < 16; ++m) s = fmaf(cs[m], W1[m * 15 + t], s);
+        gemb[t] += s;
+    }
+}
+
+struct Ctx {
+    const linr_frame* f;
+    const float* P;
+    float* G;
+    Arena A;
+    Layout L;
+    hipStream_t s;
+    int64_t R;
+};
+
+static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
+                 const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
+    return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.R, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
+                             flags | LINR_PAD_ROW, c.s);
+}
+
+static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
+                       int64_t w_off, int64_t b_off) {
+    return linr_spconv_bwd_weight(in, in_ld, gout, gout_ld, c.f->nbr, c.R, c.R, cin, cout, c.G + w_off, c.G + b_off,
+                                  LINR_ACCUM, c.A.slab, c.A.slab_bytes, c.s);
+}
+
+static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
+                  int cin, int cout, const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld,
+                  unsigned flags) {
+    return linr_linear_launch(in, in_ld, n, W, ws_ci, ws_co, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld, flags,
+                              c.s);
+}
+
+static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
+                        float* gW, int ws_ci, int ws_co, float* gb) {
+    return linr_linear_bwd_weight(in, in_ld, gout, gout_ld, n, cin, cout, gW, ws_ci, ws_co, gb, LINR_ACCUM, c.A.slab,
+                                  c.A.slab_bytes, c.s);
+}
+
+// make_block: conv3(cin->8)+ReLU -> Inception -> conv3(8->8) (+ res)
+static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b, const float* res) {
+    Arena& a = c.A;
+    const float* P = c.P;
+    TRY(conv3(c, false, in, in_ld, P + bp.a_w, P + bp.a_b, bp.cin, 8, nullptr, 0, nullptr, 0, a.A[b], 8, LINR_RELU));
+    // path 0: H[:,0:4] = relu(conv3 8->4 (A));  path 1: H[:,4:8] = relu(A @ conv1_0)
+    TRY(conv3(c, false, a.A[b], 8, P + bp.c00_w, P + bp.c00_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b], 8, LINR_RELU));
+    TRY(linear(c, a.A[b], 8, c.R, P + bp.c10_w, 4, 1, P + bp.c10_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b] + 4, 8, LINR_RELU));
+    // I[:,0:4] = conv3 4->4 (H0) + A[:,0:4]
+    TRY(conv3(c, false, a.H[b], 8, P + bp.c01_w, P + bp.c01_b, 4, 4, a.A[b], 8, nullptr, 0, a.I[b], 8, 0));
+    // M = relu(conv3 4->4 (H1)); I[:,4:8] = M @ conv1_2 + A[:,4:8]
+    TRY(conv3(c, false, a.H[b] + 4, 8, P + bp.c11_w, P + bp.c11_b, 4, 4, nullptr, 0, nullptr, 0, a.M[b], 4, LINR_RELU));
+    TRY(linear(c, a.M[b], 4, c.R, P + bp.c12_w, 4, 1, P + bp.c12_b, 4, 4, a.A[b] + 4, 8, nullptr, 0, a.I[b] + 4, 8, 0));
+    TRY(conv3(c, false, a.I[b], 8, P + bp.b_w, P + bp.b_b, 8, 8, res, 8, nullptr, 0, a.O[b], 8, 0));
+    return 0;
+}
+
+// gO: gradient w.r.t. the block output [R,8].  gin != nullptr: also produce the input gradient (block_in only).
+static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b, const float* gO, float* gin) {
+    Arena& a = c.A;
+    const float* P = c.P;
+    float* G = c.G;
+    // O = conv3(I; b)
+    TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
+    TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI, 8, 0));
+    // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
+    TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, G + bp.c12_w, 4, 1, G + bp.c12_b));
+    TRY(linear(c, a.gI + 4, 8, c.R, P + bp.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, a.M[b], 4, a.gM, 4, LINR_RELU_MASK));
+    // I[:,0:4] = conv3(H0; c01) + A[:,0:4]
+    TRY(conv3_wgrad(c, a.H[b], 8, a.gI, 8, 4, 4, bp.c01_w, bp.c01_b));
+    TRY(conv3(c, true, a.gI, 8, P + bp.c01_w, nullptr, 4, 4, nullptr, 0, a.H[b], 8, a.gH, 8, LINR_RELU_MASK));
+    // M = relu(conv3(H1; c11))
+    TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM, 4, 4, 4, bp.c11_w, bp.c11_b));
+    TRY(conv3(c, true, a.gM, 4, P + bp.c11_w, nullptr, 4, 4, nullptr, 0, a.H[b] + 4, 8, a.gH + 4, 8, LINR_RELU_MASK));
+    // H0 = relu(conv3(A; c00)), H1 = relu(A @ c10); gA = gI (residual) + both paths, masked by A > 0
+    TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
+    TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, G + bp.c10_w, 4, 1, G + bp.c10_b));
+    TRY(conv3(c, true, a.gH, 8, P + bp.c00_w, nullptr, 8, 4, a.gI, 8, nullptr, 0, a.gA, 8, 0));
+    TRY(linear(c, a.gH + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA, 8,
+               LINR_ACCUM | LINR_RELU_MASK));
+    // A = relu(conv3(in; a))
+    TRY(conv3_wgrad(c, in, in_ld, a.gA, 8, bp.cin, 8, bp.a_w, bp.a_b));
+    if (gin) TRY(conv3(c, true, a.gA, 8, P + bp.a_w, nullptr, bp.cin, 8, nullptr, 0, nullptr, 0, gin, 8, 0));
+    return 0;
+}
+
+static int check_frame(const linr_frame* f, const void* params, const void* arena, size_t arena_bytes, Ctx& c) {
+    if (!f || !params || !arena) return LINR_EINVAL;
+    if (f->rows < 0 || f->n_scales < 1 || f->n_scales > MAX_SCALES || !f->row_off_h || !f->scale_idx_h) return LINR_EINVAL;
+    if (f->rows > 0 && (!f->nbr || !f->offset_feat || !f->occ)) return LINR_EINVAL;
+    if (f->rows > INT32_MAX - 1) return LINR_EINVAL;
+    if (!make_layout(c.L, f->model_scale_num)) return LINR_EINVAL;
+    if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
+    for (int s = 0; s < f->n_scales; ++s) {
+        if (f->row_off_h[s + 1] < f->row_off_h[s]) return LINR_EINVAL;
+        if (f->scale_idx_h[s] < 0 || f->scale_idx_h[s] >= f->model_scale_num) return LINR_EINVAL;
+    }
+    if (arena_bytes < linr_net_arena_bytes(f->rows)) return LINR_ENOSPC;
+    if (!linr_aligned16(arena)) return LINR_EALIGN;
+    c.f = f;
+    c.P = (const float*)params;
+    c.R = f->rows;
+    make_arena(c.A, f->rows, (float*)arena);
+    return 0;
+}
+
+extern "C" int linr_net_forward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes,
+                                int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc, void* stream) {
+    Ctx c;
+    TRY(check_frame(f, params, arena, arena_bytes, c));
+    if (stage_begin < 0 || stage_end > 8 || stage_begin >= stage_end) return LINR_EINVAL;
+    c.s = (hipStream_t)stream;
+    c.G = nullptr;
+    if (c.R == 0) return 0;
+    Arena& a = c.A;
+    const float* P = c.P;
+    // ground-truth / decoded occupancy into the padded arena copy (the decoder updates one column per call)
+    TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+    if (stage_begin == 0) {
+        PadList pl;
+        pl.n = a.npad;
+        for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
+        zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
+        // scale context: one small MLP per scale (model_core.py:48-53)
+        for (int s = 0; s < f->n_scales; ++s) {
+            const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
+            if (n == 0) continue;
+            const int si = f->scale_idx_h[s];
+            sce_mix_k<<<linr_grid(n * 16, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P + c.L.emb + si * 8, f->offset_feat + r0 * 7, n,
+                                                                             a.MIX + r0 * 16);
+            TRY(linear(c, a.MIX + r0 * 16, 16, n, P + c.L.m0_w[si], 1, 15, P + c.L.m0_b[si], 15, 16, nullptr, 0, nullptr, 0,
+                       a.HID + r0 * 16, 16, LINR_RELU));
+            TRY(linear(c, a.HID + r0 * 16, 16, n, P + c.L.m2_w[si], 1, 16, P + c.L.m2_b[si], 16, 8, nullptr, 0, nullptr, 0,
+                       a.X0 + r0 * 8, 8, 0));
+        }
+        TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
+    }
+    for (int k = stage_begin; k < stage_end; ++k) {
+        // prior_k = x_glob + outter_blocks[k-1](occ[:, :k])   (upsample.py:206-214; always the original x_glob)
+        if (k > 0) TRY(block_fwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.O[0]));
+        TRY(conv3(c, false, a.O[k], 8, P + c.L.pr_w[k], P + c.L.pr_b[k], 8, 8, nullptr, 0, nullptr, 0, a.C[k], 8, 0));
+        TRY(linear(c, a.C[k], 8, c.R, P + c.L.h0_w[k], 1, 8, P + c.L.h0_b[k], 8, 24, nullptr, 0, nullptr, 0, a.HH[k], 24,
+                   LINR_RELU));
+        TRY(linear(c, a.HH[k], 24, c.R, P + c.L.h2_w[k], 1, 24, P + c.L.h2_b[k], 24, 1, nullptr, 0, nullptr, 0, a.Z[k], 1, 0));
+        if (bits_acc) {
+            TRY(linr_bce_bits_fwd(a.Z[k], a.OCC + k, 8, c.R, a.P[k], bits_acc, a.slab, a.slab_bytes, c.s));
+        } else {
+            sigmoid_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.Z[k], c.R, a.P[k]);
+        }
+        if (probs)
+            TRY(linr_hip_rc(hipMemcpyAsync(probs + (int64_t)k * c.R, a.P[k], (size_t)c.R * sizeof(float),
+                                           hipMemcpyDeviceToDevice, c.s)));
+    }
+    return linr_launch_rc();
+}
+
+extern "C" int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes, float gscale,
+                                 float* grads, void* stream) {
+    Ctx c;
+    TRY(check_frame(f, params, arena, arena_bytes, c));
+    if (!grads) return LINR_EINVAL;
+    c.s = (hipStream_t)stream;
+    c.G = grads;
+    if (c.R == 0) return 0;
+    Arena& a = c.A;
+    const float* P = c.P;
+    float* G = c.G;
+    const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
+    for (int k = 7; k >= 0; --k) {
+        TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
+        // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
+        TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, G + c.L.h2_w[k], 1, 24, G + c.L.h2_b[k]));
+        TRY(linear(c, a.gZ, 1, c.R, P + c.L.h2_w[k], 24, 1, nullptr, 1, 24, nullptr, 0, a.HH[k], 24, a.gHH, 24, LINR_RELU_MASK));
+        TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, G + c.L.h0_w[k], 1, 8, G + c.L.h0_b[k]));
+        TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC, 8, 0));
+        // C = conv3(prior_k; prune_k)
+        TRY(conv3_wgrad(c, a.O[k], 8, a.gC, 8, 8, 8, c.L.pr_w[k], c.L.pr_b[k]));
+        TRY(conv3(c, true, a.gC, 8, P + c.L.pr_w[k], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO, 8, 0));
+        // prior_k = x_glob (+ outter block k-1): both receive gO
+        axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO, c.R * 8, a.gXG, k == 7 ? 0 : 1);
+        if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO, nullptr));
+    }
+    TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
+    for (int s = 0; s < f->n_scales; ++s) {
+        const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
+        if (n == 0) continue;
+        const int si = f->scale_idx_h[s];
+        TRY(linear_wgrad(c, a.HID + r0 * 16, 16, a.gX0 + r0 * 8, 8, n, 16, 8, G + c.L.m2_w[si], 1, 16, G + c.L.m2_b[si]));
+        TRY(linear(c, a.gX0 + r0 * 8, 8, n, P + c.L.m2_w[si], 16, 1, nullptr, 8, 16, nullptr, 0, a.HID + r0 * 16, 16,
+                   a.gHID + r0 * 16, 16, LINR_RELU_MASK));
+        // weight grad of Linear(15,16); the per-scale column sums of gHID feed both its bias and the embedding row
+        TRY(linr_hip_rc(hipMemsetAsync(a.tmp16, 0, 16 * sizeof(float), c.s)));
+        TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, G + c.L.m0_w[si], 1, 15, a.tmp16));
+        sce_emb_grad_k<<<1, LINR_WAVE, 0, c.s>>>(a.tmp16, P + c.L.m0_w[si], G + c.L.m0_b[si], G + c.L.emb + si * 8);
+    }
+    return linr_launch_rc();
+}

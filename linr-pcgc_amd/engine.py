@@ -1,0 +1,83 @@
+"""Frame descriptors and whole-network calls (linr_net_forward / linr_net_backward of include/linr_hip.h).
+
+A ``Frame`` is what the reference passes scale by scale to ``LINR_PCGC_Model.forward`` (main.py:457-475): here all
+scales of one point cloud share one row space (finest first) so the whole multiscale network is one launch sequence.
+Coordinates are static over all epochs, so the kernel map is built once per frame and cached.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+
+class Frame:
+    """All scales of one frame on the GPU: kernel map, 7-neighbour features, child occupancy, activation arena."""
+
+    def __init__(self, scales, model_scale_num, device='cuda', validate=True, with_arena=True):
+        """scales: list of dicts {'coord' int32 [N,3] sorted x-major, 'offset_tensor' [N,7] float,
+        'occ' [N,8] float or 'occ_lst' 8 x [N,1], 'scale_idx'} - the per-scale network inputs of
+        datautils/custom_dataset.py:318-323.  Missing 'occ' (decoder) gives a zero occupancy buffer."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise _lib.LinrError('Frame needs a GPU device: the coding network has no CPU path')
+        self.device = device
+        self.model_scale_num = int(model_scale_num)
+        ns = [int(s['coord'].shape[0]) for s in scales]
+        self.row_off = np.zeros(len(scales) + 1, dtype=np.int64)
+        self.row_off[1:] = np.cumsum(ns)
+        self.rows = int(self.row_off[-1])
+        self.scale_idx = np.asarray([int(s['scale_idx']) for s in scales], dtype=np.int32)
+        self.n_scales = len(scales)
+        R = self.rows
+        self.nbr = torch.empty((27, R), dtype=torch.int32, device=device)
+        self.offset_feat = torch.empty((R, 7), dtype=torch.float32, device=device)
+        self.occ = torch.zeros((R, 8), dtype=torch.float32, device=device)
+        for i, s in enumerate(scales):
+            r0, r1 = int(self.row_off[i]), int(self.row_off[i + 1])
+            coord = torch.as_tensor(s['coord']).to(device=device, dtype=torch.int32).contiguous()
+            ops.kmap_build_into(coord, self.nbr, r0, validate)
+            self.offset_feat[r0:r1] = torch.as_tensor(s['offset_tensor']).to(device=device, dtype=torch.float32)
+            if 'occ' in s and s['occ'] is not None:
+                self.occ[r0:r1] = torch.as_tensor(s['occ']).to(device=device, dtype=torch.float32)
+            elif 'occ_lst' in s and s['occ_lst'] is not None:
+                self.occ[r0:r1] = torch.cat([torch.as_tensor(o).reshape(-1, 1) for o in s['occ_lst']], dim=1).to(
+                    device=device, dtype=torch.float32)
+        self.arena = None
+        if with_arena:
+            self.alloc_arena()
+        self._c = _lib.LinrFrame(rows=R, n_scales=self.n_scales, model_scale_num=self.model_scale_num,
+                                 row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
+                                 nbr=self.nbr.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
+                                 occ=self.occ.data_ptr())
+
+    def alloc_arena(self):
+        nbytes = _lib.lib().linr_net_arena_bytes(self.rows)
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def cref(self):
+        return ctypes.byref(self._c)
+
+    def scale_slice(self, i):
+        return slice(int(self.row_off[i]), int(self.row_off[i + 1]))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def net_forward(frame, flat_params, stage_begin=0, stage_end=8, probs=None, bits=None, arena=None):
+    """Runs stages [stage_begin, stage_end).  probs: float32 [8, rows] or None; bits: float64[1] accumulator or None."""
+    arena = frame.arena if arena is None else arena
+    check(_lib.lib().linr_net_forward(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(), stage_begin,
+                                      stage_end, 0 if probs is None else probs.data_ptr(),
+                                      0 if bits is None else bits.data_ptr(), _stream()), 'linr_net_forward')
+
+
+def net_backward(frame, flat_params, flat_grads, gscale, arena=None):
+    """flat_grads += gscale * d bits / d params (needs a preceding full net_forward on the same arena)."""
+    arena = frame.arena if arena is None else arena
+    check(_lib.lib().linr_net_backward(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(), float(gscale),
+                                       flat_grads.data_ptr(), _stream()), 'linr_net_backward')

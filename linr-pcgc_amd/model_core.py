@@ -1,0 +1,306 @@
+"""LINR_PCGC_Model: drop-in mirror of models/model_core.py on the MI355X engine.
+
+Same constructor dict, same state_dict (189 tensors, reference order), same call surface
+(``forward -> bits``, ``codec``, ``encode``, ``decode``).  All network arithmetic is in HIP kernels
+(csrc/*.hip) behind include/linr_hip.h; this class owns the parameters (as views into ONE flat buffer, the layout
+the kernels index), caches one kernel map + arena per coordinate set, and feeds the C++ range coder.
+
+Two ways in:
+  * reference-style: ``bits = model(putin_args)`` per scale, ``loss.backward()``, any torch optimiser
+    (main.py:457-475,305-321) - autograd is bridged by ``_NetBits``;
+  * fast path used by ``overfit.py`` / ``bench.py``: ``Frame`` with all scales batched + ``train_step`` (forward,
+    backward and the fused Adam update without touching autograd).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, engine, ops
+from .function_utils import pack_bitstream, unpack_bitstream
+from .module_utils import BinaryArithmeticCoding, PointwiseMLP
+from .upsample import CNP
+
+
+class _NetBits(torch.autograd.Function):
+    """bits(frame; params) with the hand-written backward of csrc/net.hip.  Parameter gradients are accumulated straight
+    into the model's flat gradient buffer (the 189 ``.grad`` tensors are views of it)."""
+
+    @staticmethod
+    def forward(ctx, model, frame, *params):
+        bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+        engine.net_forward(frame, model._flat, 0, 8, None, bits)
+        ctx.model, ctx.frame = model, frame
+        return bits[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, frame = ctx.model, ctx.frame
+        tmp = torch.zeros_like(model._flat)
+        engine.net_backward(frame, model._flat, tmp, 1.0)
+        model._ensure_grad_views()
+        model._flat_grad.addcmul_(tmp, gout.to(torch.float32).reshape(1).expand_as(tmp))
+        return (None, None) + (None,) * len(model._plist)
+
+
+class LINR_PCGC_Model(nn.Module):
+    """models/model_core.py:19-37.  inargs: scale_num, in_channel (=7), hidden_channel_conv (=8), block_layers (=1),
+    outstage (=8), instage (=1) - the only configuration main.py:97,218 can build."""
+
+    def __init__(self, inargs):
+        super().__init__()
+        self.scale_num = int(inargs['scale_num'])
+        in_channel = int(inargs['in_channel'])
+        hidden = int(inargs['hidden_channel_conv'])
+        block_layers = int(inargs['block_layers'])
+        if in_channel != 7 or hidden != 8 or block_layers != 1 or inargs['outstage'] != 8 or inargs['instage'] != 1:
+            raise ValueError('the gfx950 engine is specialised for in_channel=7, hidden_channel_conv=8, block_layers=1, '
+                             'outstage=8, instage=1 (the defaults of main.py); got %r' % (inargs,))
+        self.scale_emb = nn.Embedding(self.scale_num, 8)
+        self.scale_mlp = nn.ModuleList([PointwiseMLP([8 + in_channel, 16, 8]) for _ in range(self.scale_num)])
+        self.upsampler = CNP(in_channels=8, channels=hidden, block_layers=block_layers, outstage=8, instage=1)
+        self.sigmoid = nn.Sigmoid()
+        self._flat = None
+        self._flat_grad = None
+        self._plist = []
+        self._frame_cache = {}
+        self._flatten()
+
+    # ---- flat parameter buffer ------------------------------------------------------------------------------------
+    def _flatten(self):
+        """Re-home all parameters as views of one contiguous buffer in parameters() order (the kernels' layout)."""
+        plist = list(self.parameters())
+        total = sum(p.numel() for p in plist)
+        if plist and plist[0].is_cuda and total != _lib.lib().linr_param_count(self.scale_num):
+            raise _lib.LinrError('parameter layout mismatch with liblinr_hip.so')
+        flat = torch.empty(total, dtype=torch.float32, device=plist[0].device)
+        off = 0
+        with torch.no_grad():
+            for p in plist:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                p.grad = None
+                off += n
+        self._flat, self._plist, self._flat_grad = flat, plist, None
+        self._frame_cache = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def _ensure_grad_views(self):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+        off = 0
+        for p in self._plist:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
+                if p.grad is None:
+                    self._flat_grad[off:off + n].zero_()        # zero_grad(set_to_none=True) semantics
+                else:
+                    self._flat_grad[off:off + n].copy_(p.grad.reshape(-1))
+                p.grad = self._flat_grad[off:off + n].view(p.shape)
+            off += n
+
+    def flat_parameters(self):
+        """The contiguous float32 buffer holding every parameter in parameters() order (what the model codec codes)."""
+        return self._flat
+
+    # ---- frames ----------------------------------------------------------------------------------------------------
+    def make_frame(self, scales, validate=True, with_arena=True):
+        """Batched multi-scale frame for the fast path.  scales: list of per-scale input dicts (see engine.Frame)."""
+        return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena)
+
+    def _scale_frame(self, d, need_occ=True):
+        coord = d['coord']
+        occ0 = d['occ_lst'][0] if need_occ else None
+        key = (coord.data_ptr(), int(coord.shape[0]), int(d['scale_idx']), d['offset_tensor'].data_ptr(),
+               None if occ0 is None else occ0.data_ptr())
+        fr = self._frame_cache.get(key)
+        if fr is None:
+            if len(self._frame_cache) >= 1024:
+                self._frame_cache.pop(next(iter(self._frame_cache)))
+            s = {'coord': coord, 'offset_tensor': d['offset_tensor'], 'scale_idx': d['scale_idx']}
+            if need_occ:
+                s['occ_lst'] = d['occ_lst']
+            fr = self.make_frame([s])
+            self._frame_cache[key] = fr
+        return fr
+
+    # ---- reference call surface --------------------------------------------------------------------------------------
+    def forward(self, inargs):
+        """models/model_core.py:72-81: bits of one scale (0-dim float32, differentiable w.r.t. the parameters)."""
+        frame = self._scale_frame(inargs)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
+            return _NetBits.apply(self, frame, *self._plist)
+        bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+        engine.net_forward(frame, self._flat, 0, 8, None, bits)
+        return bits[0].to(torch.float32)
+
+    @torch.no_grad()
+    def frame_probs(self, frame):
+        """One inference forward over a (possibly multi-scale) frame: probs float32 [8, rows], bits float64[1]."""
+        probs = torch.empty((8, frame.rows), dtype=torch.float32, device=frame.device)
+        bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+        engine.net_forward(frame, self._flat, 0, 8, probs, bits)
+        return probs, bits
+
+    @torch.no_grad()
+    def codec(self, inargs):
+        """models/model_core.py:169-227: one forward, the 8 stages as ONE arithmetic-coded stream, timed enc/dec."""
+        st1 = time.time()
+        frame = self._scale_frame(inargs)
+        probs, bits_t = self.frame_probs(frame)
+        p_host = probs.reshape(-1).cpu()
+        sym = frame.occ.t().contiguous().reshape(-1).to(torch.int16).cpu()
+        bac = BinaryArithmeticCoding()
+        st2 = time.time()
+        enc_bytes = bac.encode(p_host, sym)
+        st3 = time.time()
+        recon = bac.decode(p_host, enc_bytes)
+        st4 = time.time()
+        assert bool((recon == sym).all())
+        return {'bits': len(enc_bytes) * 8, 'enc_bytes': enc_bytes, 'enc_time': st3 - st1,
+                'dec_time': (st2 - st1) + (st4 - st3), 'bits_t': bits_t[0].to(torch.float32)}
+
+    @torch.no_grad()
+    def encode(self, in_args, DBG=False):
+        """models/model_core.py:235-266 + CNP.encode (models/upsample.py:219-246): 8 per-stage streams, packed."""
+        frame = self._scale_frame(in_args)
+        probs, _ = self.frame_probs(frame)
+        p_host = probs.cpu().numpy()
+        occ_host = frame.occ.t().contiguous().cpu().numpy().astype(np.uint8)
+        streams = encode_streams([p_host[k] for k in range(8)], [occ_host[k] for k in range(8)])
+        if DBG:
+            bac = BinaryArithmeticCoding()
+            for k in range(8):
+                assert (bac.decode(p_host[k], streams[k]).numpy() == occ_host[k]).all()
+        enc_bytes = pack_bitstream(streams)
+        return {'enc_bytes': enc_bytes, 'bits': len(enc_bytes) * 8, 'x_low': None}
+
+    @torch.no_grad()
+    def decode(self, inagrs):
+        """models/model_core.py:268-286 + CNP.decode (models/upsample.py:249-295): stage-serial, the SAME launches as
+        the encoder's forward, so probabilities are bitwise identical.  Returns 8 x [N,1] float32 occupancy."""
+        streams = unpack_bitstream(inagrs['enc_bytes'])
+        frame = self._scale_frame({'coord': inagrs['coord'], 'offset_tensor': inagrs['offset_tensor'],
+                                   'scale_idx': inagrs['scale_idx']}, need_occ=False)
+        return self.decode_frame(frame, [streams])
+
+    @torch.no_grad()
+    def decode_frame(self, frame, streams_per_scale):
+        """Staged decode of every scale of `frame` at once: stage k of all scales is one launch set."""
+        frame.occ.zero_()
+        probs = torch.empty((8, frame.rows), dtype=torch.float32, device=frame.device)
+        bac = BinaryArithmeticCoding()
+        for k in range(8):
+            engine.net_forward(frame, self._flat, k, k + 1, probs, None)
+            pk = probs[k].cpu()
+            col = torch.empty(frame.rows, dtype=torch.float32)
+            for i in range(frame.n_scales):
+                sl = frame.scale_slice(i)
+                col[sl] = bac.decode(pk[sl], streams_per_scale[i][k]).to(torch.float32)
+            frame.occ[:, k] = col.to(frame.device)
+        return [frame.occ[:, k:k + 1].clone() for k in range(8)]
+
+
+def encode_streams(probs, symbols, n_threads=8):
+    """Codes independent binary streams on a host thread pool (linr_ac_encode_binary_batch)."""
+    import ctypes
+    n = len(probs)
+    probs = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1) for p in probs]
+    symbols = [np.ascontiguousarray(s, dtype=np.uint8).reshape(-1) for s in symbols]
+    outs = [np.empty(2 * p.size + 64, dtype=np.uint8) for p in probs]
+    arr_p = (ctypes.c_void_p * n)(*[p.ctypes.data for p in probs])
+    arr_s = (ctypes.c_void_p * n)(*[s.ctypes.data for s in symbols])
+    arr_o = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    arr_n = (ctypes.c_int64 * n)(*[p.size for p in probs])
+    arr_c = (ctypes.c_int64 * n)(*[o.size for o in outs])
+    arr_l = (ctypes.c_int64 * n)()
+    _lib.check(_lib.lib().linr_ac_encode_binary_batch(arr_p, arr_s, arr_n, n, arr_o, arr_c, arr_l, n_threads),
+               'linr_ac_encode_binary_batch')
+    return [outs[i][:arr_l[i]].tobytes() for i in range(n)]
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas, eps, L2 weight_decay) + StepLR(step_size, gamma) of main.py:231-252,319-321 over the
+    model's flat parameter buffer: one fused launch per step (linr_adam_step).  state_dict()/load_state_dict() use
+    torch.optim.Adam's format so reference checkpoints (``optimizer_state_dict``) round-trip."""
+
+    def __init__(self, model, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, step_size=32, gamma=0.992):
+        self.model = model
+        self.lr, self.initial_lr = float(lr), float(lr)
+        self.betas, self.eps, self.weight_decay = tuple(betas), float(eps), float(weight_decay)
+        self.step_size, self.gamma = int(step_size), float(gamma)
+        flat = model.flat_parameters()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.grad = torch.zeros_like(flat)
+        self.t = 0                      # optimiser steps taken
+        self.sched_steps = 0            # scheduler.step() calls (StepLR epoch counter)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self):
+        self.t += 1
+        ops.adam_step(self.model.flat_parameters(), self.grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.weight_decay)
+
+    def scheduler_step(self):
+        """StepLR.step(): multiply lr by gamma every `step_size` calls (chainable form, so a clamp persists)."""
+        self.sched_steps += 1
+        if self.sched_steps % self.step_size == 0:
+            self.lr *= self.gamma
+
+    def clamp_lr(self, min_lr):
+        """main.py:433-437."""
+        if self.lr < min_lr:
+            self.lr = min_lr
+
+    def state_dict(self):
+        state, off = {}, 0
+        for i, p in enumerate(self.model._plist):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            off += n
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False,
+                 'initial_lr': self.initial_lr, 'params': list(range(len(self.model._plist)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        g = sd['param_groups'][0]
+        self.lr = float(g['lr'])
+        self.initial_lr = float(g.get('initial_lr', self.initial_lr))
+        self.betas, self.eps, self.weight_decay = tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
+        off = 0
+        steps = set()
+        for i, p in enumerate(self.model._plist):
+            n = p.numel()
+            st = sd['state'].get(i)
+            if st is not None:
+                self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps.add(int(float(st['step'])))
+            off += n
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ; the fused Adam keeps one step counter')
+        self.t = steps.pop() if steps else 0
+
+
+def train_step(model, opt, frame, point_num):
+    """One iteration of main.py:305-321 on a batched frame: bits -> loss = bits/point_num -> backward -> Adam ->
+    StepLR.  Returns the device-resident bits accumulator (float64[1]); nothing synchronises with the host."""
+    bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+    engine.net_forward(frame, model.flat_parameters(), 0, 8, None, bits)
+    opt.zero_grad()
+    engine.net_backward(frame, model.flat_parameters(), opt.grad, 1.0 / float(point_num))
+    opt.step()
+    opt.scheduler_step()
+    return bits

@@ -1,0 +1,169 @@
+"""Host-side mirror of models/module_utils.py: PointwiseMLP, BinaryArithmeticCoding, octree helpers.
+
+PointwiseMLP owns parameters only (its arithmetic runs in csrc/linear.hip through the engine).
+BinaryArithmeticCoding feeds the C++ range coder of csrc/ac.cpp (torchac-compatible streams).
+The octree helpers restate octree_level / QuickSearchCoord (models/module_utils.py:86-318) with 64-bit ravel keys and
+torch.searchsorted; they are device-agnostic torch code and run once per frame ("next" row N1 of SURVEY.md §8f).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class PointwiseMLP(nn.Sequential):
+    """models/module_utils.py:42-81: Linear(+ReLU) stack, xavier_uniform(gain=sqrt(2)) weights, zero bias."""
+
+    def __init__(self, dims, doLastRelu=False, init_bias='zeros'):
+        layers = []
+        for i in range(1, len(dims)):
+            fc = nn.Linear(dims[i - 1], dims[i])
+            nn.init.xavier_uniform_(fc.weight, gain=nn.init.calculate_gain('relu'))
+            if init_bias == 'uniform':
+                nn.init.uniform_(fc.bias)
+            elif init_bias == 'zeros':
+                nn.init.zeros_(fc.bias)
+            else:
+                raise ValueError('Unknown init ' + str(init_bias))
+            layers.append(fc)
+            if i < len(dims) - 1 or doLastRelu:
+                layers.append(nn.ReLU())
+        super().__init__(*layers)
+
+
+class BinaryArithmeticCoding:
+    """models/module_utils.py:8-40 on top of linr_ac_encode_binary / linr_ac_decode_binary (cdf = [0, 1-p, 1])."""
+
+    @staticmethod
+    def _host(prob):
+        return np.ascontiguousarray(torch.as_tensor(prob).detach().reshape(-1).to('cpu', torch.float32).numpy())
+
+    def encode(self, prob, occupancy):
+        p = self._host(prob)
+        s = np.ascontiguousarray(torch.as_tensor(occupancy).detach().reshape(-1).to('cpu').numpy().astype(np.uint8))
+        if p.shape != s.shape:
+            raise ValueError('prob and occupancy must have the same number of elements')
+        cap = 2 * p.size + 64                              # worst case is 16 bit per symbol
+        out = np.empty(cap, dtype=np.uint8)
+        n = _lib.lib().linr_ac_encode_binary(p.ctypes.data, s.ctypes.data, p.size, out.ctypes.data, cap)
+        if n < 0:
+            _lib.check(int(n), 'linr_ac_encode_binary')
+        return out[:n].tobytes()
+
+    def decode(self, prob, bitstream):
+        p = self._host(prob)
+        buf = np.frombuffer(bitstream, dtype=np.uint8)
+        out = np.empty(p.size, dtype=np.uint8)
+        _lib.check(_lib.lib().linr_ac_decode_binary(p.ctypes.data, p.size, buf.ctypes.data if buf.size else None,
+                                                    buf.size, out.ctypes.data), 'linr_ac_decode_binary')
+        return torch.from_numpy(out.astype(np.int16))
+
+    def estimate_bitrate(self, prob, occupancy):
+        p = torch.as_tensor(prob).reshape(-1).double()
+        t = torch.as_tensor(occupancy).reshape(-1).double()
+        return float(-(torch.log2(torch.where(t > 0.5, p, 1 - p))).sum())
+
+
+# ---- octree / neighbourhood prep -------------------------------------------------------------------------------------
+OFFSETS_INI = ((0, 0, 0), (-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1))     # glob_params.py:3
+
+
+def ravel_key(coord):
+    """x-major key for coordinates in [-1, 2^20); equal ordering to sort_by_coor_sum_detail (sort_functions.py:46-60)."""
+    c = coord.to(torch.int64) + 1
+    return (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+
+
+def unique_sorted(coord):
+    """torch.unique(dim=0): de-duplicated rows in x-major order, int32."""
+    key = torch.unique(ravel_key(coord))
+    mask = (1 << 21) - 1
+    return torch.stack([(key >> 42) - 1, ((key >> 21) & mask) - 1, (key & mask) - 1], dim=1).to(torch.int32)
+
+
+def contains(sorted_coord, query):
+    """QuickSearchCoord.search with all-ones features (module_utils.py:260-275): float {0,1} column."""
+    keys = ravel_key(sorted_coord)
+    q = ravel_key(query)
+    pos = torch.searchsorted(keys, q)
+    pos_c = pos.clamp(max=keys.numel() - 1)
+    return ((pos < keys.numel()) & (keys[pos_c] == q)).to(torch.float32)
+
+
+class octree_level(nn.Module):
+    """module_utils.py:86-127: parent coordinates + 8-column child occupancy, and its inverse."""
+
+    def __init__(self):
+        super().__init__()
+        self.offsets = torch.tensor([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], dtype=torch.int64)
+
+    def forward(self, leaf, qsc=None):
+        parent = unique_sorted(torch.div(leaf.to(torch.int64), 2, rounding_mode='floor'))
+        off = self.offsets.to(leaf.device)
+        occ = torch.stack([contains(leaf, parent.to(torch.int64) * 2 + off[i]) for i in range(8)], dim=1)
+        return parent, occ
+
+    def upper_layer(self, parent_C, occupancy):
+        off = self.offsets.to(parent_C.device)
+        base = parent_C.to(torch.int64) * 2
+        kids = torch.cat([base[occupancy[:, i] == 1] + off[i] for i in range(8)], dim=0)
+        return unique_sorted(kids)
+
+
+octree_level_obj = octree_level()
+
+
+class qscTensor:
+    """module_utils.py:155-224 (the members the drivers use): sorted unique coords + 7-neighbour occupancy."""
+
+    def __init__(self, coord, feat=None):
+        self.coord = unique_sorted(coord)
+        self.feat = feat
+        self.parent_C = self.occupancy = self.offset_tensor = None
+
+    def get_coord(self):
+        return self.coord
+
+    def search(self, coord_in):
+        return contains(self.coord, coord_in).reshape(-1, 1)
+
+    def set_oct_level(self):
+        self.parent_C, self.occupancy = octree_level_obj(self.coord)
+
+    def get_oct_level(self):
+        return self.parent_C, self.occupancy
+
+    def upper_layer(self, parent, occupancy):
+        return octree_level_obj.upper_layer(parent, occupancy)
+
+    def set_offset_tensor(self, offsets=OFFSETS_INI):
+        offs = torch.as_tensor(offsets, dtype=torch.int64, device=self.coord.device)
+        c = self.coord.to(torch.int64)
+        self.offset_tensor = torch.stack([contains(self.coord, c + o) for o in offs], dim=1)
+
+    def get_offset_tensor(self):
+        return self.offset_tensor
+
+
+def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu'):
+    """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3]."""
+    pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
+    cmin = pts.min(dim=0).values
+    cur = qscTensor(pts - cmin)
+    ori = cur.get_coord()
+    info = []
+    limit = 100000 if scale_num is None else scale_num
+    for s in range(limit):
+        cur.set_oct_level()
+        parent, occ = cur.get_oct_level()
+        low = qscTensor(parent)
+        low.set_offset_tensor()
+        info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),
+                     'ground_truth': cur.get_coord(), 'scale_idx': s, 'occ': occ,
+                     'occ_lst': [occ[:, i:i + 1] for i in range(8)]})
+        if parent.shape[0] < min_point_num or s == limit - 1:
+            break
+        cur = low
+    return {'all_input_info': info, 'point_num': int(ori.shape[0]), 'ori': ori,
+            'coord_data_min': cmin.to('cpu', torch.int32).tolist(), 'scale_num': len(info)}

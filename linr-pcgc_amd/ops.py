@@ -1,0 +1,157 @@
+"""Tensor-level wrappers of the op-level C-ABI entry points (include/linr_hip.h).
+
+These are the MI355X replacements of the MinkowskiEngine operators the reference calls:
+kernel-map build, 3x3x3 sparse convolution fwd / bwd-data / bwd-weight, 1x1 / nn.Linear layers, BCE bits, Adam.
+Every function requires CUDA (ROCm) tensors and launches on the current PyTorch stream; nothing falls back to CPU.
+"""
+import torch
+
+from . import _lib
+from ._lib import LINR_ACCUM, LINR_NO_BIAS, LINR_PAD_ROW, LINR_RELU, LINR_RELU_MASK, check  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.LinrError('%s must be a GPU tensor: the coding network has no CPU path' % name)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError('%s must be contiguous %s' % (name, dtype))
+    return t
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def kmap_build(coords, validate=True):
+    """coords int32 [N,3] sorted by the x-major ravel key (qscTensor order) -> nbr int32 [27,N] (-1 = absent)."""
+    _dev(coords, torch.int32, 'coords')
+    n = coords.shape[0]
+    nbr = torch.empty((27, n), dtype=torch.int32, device=coords.device)
+    kmap_build_into(coords, nbr, 0, validate)
+    return nbr
+
+
+def kmap_build_into(coords, nbr, row_base, validate=True):
+    """Fill columns [row_base, row_base+N) of a shared nbr [27, ld] with global row ids (multi-scale frames)."""
+    L = _lib.lib()
+    n = coords.shape[0]
+    if n == 0:
+        return
+    if validate:
+        bad = torch.zeros(1, dtype=torch.int32, device=coords.device)
+        check(L.linr_kmap_validate(coords.data_ptr(), n, bad.data_ptr(), _stream()), 'linr_kmap_validate')
+        if int(bad.item()) != 0:
+            raise ValueError('coord must be unique, non-negative (< 2^20) and sorted by the x-major ravel key '
+                             '(models/module_utils.py:246-256)')
+    ws = torch.empty(L.linr_kmap_workspace_bytes(n), dtype=torch.uint8, device=coords.device)
+    check(L.linr_kmap_build(coords.data_ptr(), n, nbr.data_ptr(), nbr.shape[1], row_base, ws.data_ptr(), ws.numel(),
+                            _stream()), 'linr_kmap_build')
+
+
+def spconv_fwd(x, nbr, kernel, bias, res=None, relu=False, out=None, pad_row=False):
+    """out = bias + sum_k x[nbr[k]] @ kernel[k] (+res)(ReLU).  x [N,ld>=cin] (a channel slice view is fine)."""
+    n, cin, cout = nbr.shape[1], kernel.shape[1], kernel.shape[2]
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    flags = (LINR_RELU if relu else 0) | (LINR_PAD_ROW if pad_row else 0)
+    check(_lib.lib().linr_spconv_fwd(x.data_ptr(), x.stride(0), nbr.data_ptr(), nbr.stride(0), n, kernel.data_ptr(),
+                                     bias.data_ptr(), cin, cout, _ptr(res), 0 if res is None else res.stride(0),
+                                     out.data_ptr(), out.stride(0), flags, _stream()), 'linr_spconv_fwd')
+    return out
+
+
+def spconv_bwd_data(gout, nbr, kernel, act=None, out=None, accumulate=False, pad_row=False):
+    n, cin = nbr.shape[1], kernel.shape[1]
+    cout = kernel.shape[2]
+    if out is None:
+        out = torch.empty((n, cin), dtype=torch.float32, device=gout.device)
+    flags = (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0) | \
+            (LINR_PAD_ROW if pad_row else 0)
+    check(_lib.lib().linr_spconv_bwd_data(gout.data_ptr(), gout.stride(0), nbr.data_ptr(), nbr.stride(0), n,
+                                          kernel.data_ptr(), cin, cout, _ptr(act),
+                                          0 if act is None else act.stride(0), out.data_ptr(), out.stride(0), flags,
+                                          _stream()), 'linr_spconv_bwd_data')
+    return out
+
+
+def spconv_bwd_weight(x, gout, nbr, cin, cout):
+    n = nbr.shape[1]
+    L = _lib.lib()
+    gw = torch.empty((27, cin, cout), dtype=torch.float32, device=x.device)
+    gb = torch.empty((1, cout), dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(L.linr_spconv_bwd_weight_workspace_bytes(n, cin, cout), 4), dtype=torch.uint8, device=x.device)
+    check(L.linr_spconv_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(),
+                                   nbr.stride(0), n, cin, cout, gw.data_ptr(), gb.data_ptr(), 0, ws.data_ptr(),
+                                   ws.numel(), _stream()), 'linr_spconv_bwd_weight')
+    return gw, gb
+
+
+def linear_fwd(x, weight, bias, cin, cout, layout, res=None, relu=False, out=None):
+    """layout 'me' : weight [cin][cout] (MinkowskiConvolution kernel_size=1); 'torch': weight [cout][cin] (nn.Linear)."""
+    n = x.shape[0]
+    ws_ci, ws_co = (cout, 1) if layout == 'me' else (1, cin)
+    if out is None:
+        out = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    flags = (LINR_RELU if relu else 0) | (LINR_NO_BIAS if bias is None else 0)
+    check(_lib.lib().linr_linear_fwd(x.data_ptr(), x.stride(0), n, weight.data_ptr(), ws_ci, ws_co, _ptr(bias), cin, cout,
+                                     _ptr(res), 0 if res is None else res.stride(0), out.data_ptr(), out.stride(0),
+                                     flags, _stream()), 'linr_linear_fwd')
+    return out
+
+
+def linear_bwd_data(gout, weight, cin, cout, layout, act=None, out=None, accumulate=False):
+    n = gout.shape[0]
+    ws_ci, ws_co = (cout, 1) if layout == 'me' else (1, cin)
+    if out is None:
+        out = torch.empty((n, cin), dtype=torch.float32, device=gout.device)
+    flags = (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0)
+    check(_lib.lib().linr_linear_bwd_data(gout.data_ptr(), gout.stride(0), n, weight.data_ptr(), ws_ci, ws_co, cin, cout,
+                                          _ptr(act), 0 if act is None else act.stride(0), out.data_ptr(),
+                                          out.stride(0), flags, _stream()), 'linr_linear_bwd_data')
+    return out
+
+
+def linear_bwd_weight(x, gout, cin, cout, layout):
+    n = x.shape[0]
+    L = _lib.lib()
+    ws_ci, ws_co = (cout, 1) if layout == 'me' else (1, cin)
+    gw = torch.empty((cin, cout) if layout == 'me' else (cout, cin), dtype=torch.float32, device=x.device)
+    gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(L.linr_linear_bwd_weight_workspace_bytes(n, cin, cout), 4), dtype=torch.uint8, device=x.device)
+    check(L.linr_linear_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), n, cin, cout,
+                                   gw.data_ptr(), ws_ci, ws_co, gb.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                                   _stream()), 'linr_linear_bwd_weight')
+    return gw, gb
+
+
+def bce_bits_fwd(z, target):
+    """z [N] logits, target [N] or a strided column view -> (p [N], bits double[1])."""
+    n = z.shape[0]
+    L = _lib.lib()
+    p = torch.empty((n,), dtype=torch.float32, device=z.device)
+    bits = torch.zeros(1, dtype=torch.float64, device=z.device)
+    ws = torch.empty(max(L.linr_bce_workspace_bytes(n), 8), dtype=torch.uint8, device=z.device)
+    check(L.linr_bce_bits_fwd(z.data_ptr(), target.data_ptr(), target.stride(0), n, p.data_ptr(), bits.data_ptr(),
+                              ws.data_ptr(), ws.numel(), _stream()), 'linr_bce_bits_fwd')
+    return p, bits
+
+
+def bce_bits_bwd(p, target, gscale):
+    n = p.shape[0]
+    gz = torch.empty((n,), dtype=torch.float32, device=p.device)
+    check(_lib.lib().linr_bce_bits_bwd(p.data_ptr(), target.data_ptr(), target.stride(0), n, gscale, gz.data_ptr(),
+                                       _stream()), 'linr_bce_bits_bwd')
+    return gz
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4):
+    """One fused torch.optim.Adam update over flat buffers (main.py:231-237,319); `step` is the 1-based step count."""
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    check(_lib.lib().linr_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                    params.numel(), lr / bc1, bc2_sqrt, beta1, beta2, eps, weight_decay, _stream()),
+          'linr_adam_step')

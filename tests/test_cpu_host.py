@@ -1,0 +1,177 @@
+"""CPU: host logic, the C-ABI library's exports, the C++ range coder against the oracle, golden-vector checks of the
+product's own octree prep and bitstream container.  No GPU compute is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ac as oac
+from oracle import model_codec as omc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from linr_pcgc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from linr_pcgc_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'linr_hip.h')).read()
+    declared = set(re.findall(r'^LINR_API\s+[\w\s\*]+?\b(linr_\w+)\(', header, flags=re.M))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.linr_abi_version() == _lib.ABI_VERSION
+
+
+def test_param_count_matches_reference_checkpoint(lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
+    assert lib.linr_param_count(7) == len(g['flat']) == 54712
+    assert lib.linr_param_count(0) < 0 and lib.linr_param_count(17) < 0
+
+
+def test_state_dict_contract(golden_dir):
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
+    m = LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
+                         'instage': 1})
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g['names'])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g['shapes'])
+    new, off = {}, 0
+    for n, v in sd.items():
+        new[n] = torch.from_numpy(g['flat'][off:off + v.numel()].reshape(v.shape).copy())
+        off += v.numel()
+    m.load_state_dict(new)
+    assert torch.equal(m.flat_parameters(), torch.from_numpy(g['flat']))          # parameters() order == flat order
+    assert torch.equal(torch.cat([p.reshape(-1) for p in m.parameters()]), m.flat_parameters())
+    with pytest.raises(ValueError):
+        LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 16, 'block_layers': 1, 'outstage': 8,
+                         'instage': 1})
+
+
+def test_init_statistics():
+    """ME conv: U(+-1/sqrt(Cin*K)); PointwiseMLP: xavier_uniform(gain sqrt 2), zero bias; Embedding N(0,1)."""
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    torch.manual_seed(0)
+    m = LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
+                         'instage': 1})
+    k = m.upsampler.block_in[0].kernel
+    bound = 1 / np.sqrt(8 * 27)
+    assert float(k.abs().max()) <= bound and float(k.abs().max()) > 0.9 * bound
+    assert float(m.scale_mlp[0][0].bias.abs().max()) == 0.0
+    w = m.upsampler.inner_mlps[0][0][0].weight
+    assert float(w.abs().max()) <= np.sqrt(2) * np.sqrt(6 / (8 + 24)) + 1e-6
+
+
+def test_no_gpu_means_loud_failure():
+    from linr_pcgc_amd import _lib, engine
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.LinrError):
+        engine.Frame([], 7, device='cpu')
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 33, 100003])
+def test_cpp_binary_coder_bit_exact_with_oracle(lib, n):
+    from linr_pcgc_amd.module_utils import BinaryArithmeticCoding
+    rng = np.random.default_rng(n)
+    p = rng.random(n).astype(np.float32)
+    s = (rng.random(n) < p).astype(np.int16)
+    if n > 8:
+        p[:6] = [0.0, 1.0, 1e-9, 1 - 1e-7, 0.5, 0.25]
+        s[:4] = [1, 0, 1, 0]
+    bac = BinaryArithmeticCoding()
+    data = bac.encode(torch.from_numpy(p).reshape(-1, 1), torch.from_numpy(s))
+    assert data == oac.encode_binary(p, s)
+    assert (bac.decode(torch.from_numpy(p), data).numpy() == s).all()
+    assert (oac.decode_binary(p, data) == s).all()
+
+
+def test_cpp_generic_coder_model_stream(lib, golden_dir):
+    from linr_pcgc_amd import model_codec
+    g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
+    out = model_codec.compress_params(torch.from_numpy(g['flat']), 8)
+    ref = omc.encode_model(g['flat'], 8)
+    assert out['final_bytes'] == ref['bytes'] and out['enc_mode'] == 2
+    assert (out['mu'], out['b']) == (float(g['mu']), float(g['b']))
+    assert out['min_param'] == float(g['min_param']) and out['max_param'] == float(g['max_param'])
+    assert len(out['final_bytes']) in (35319, 35320)            # see tests/test_oracle_golden.py for the +-1 byte note
+    rec = model_codec.decompress_params(out, len(g['flat']))
+    assert torch.equal(rec, ref['recon'])
+
+
+def test_batch_encoder_threads(lib):
+    from linr_pcgc_amd.model_core import encode_streams
+    rng = np.random.default_rng(9)
+    ps = [rng.random(n).astype(np.float32) for n in (0, 5, 1000, 40000, 7)]
+    ss = [(rng.random(len(p)) < p).astype(np.uint8) for p in ps]
+    got = encode_streams(ps, ss, n_threads=4)
+    assert got == [oac.encode_binary(p, s.astype(np.int16)) for p, s in zip(ps, ss)]
+
+
+def test_pack_bitstream_golden(golden_dir):
+    from linr_pcgc_amd.function_utils import pack_bitstream, unpack_bitstream
+    g = np.load(os.path.join(golden_dir, 'pack_bitstream.npz'))
+    payload, lens = g['payload'].tobytes(), g['lens']
+    streams, pos = [], 0
+    for n in lens:
+        streams.append(payload[pos:pos + int(n)])
+        pos += int(n)
+    packed = pack_bitstream(streams)
+    assert packed == g['packed'].tobytes()
+    assert [bytes(b) for b in unpack_bitstream(packed)] == streams
+
+
+@pytest.mark.parametrize('name', ['octree_random64.npz', 'octree_shell128.npz'])
+def test_product_octree_prep_golden(golden_dir, name):
+    from linr_pcgc_amd.module_utils import octree_level_obj, prepare_frame
+    g = np.load(os.path.join(golden_dir, name))
+    fr = prepare_frame(g['points'], None, int(g['min_point_num']))
+    assert fr['scale_num'] == int(g['scale_num'])
+    assert fr['coord_data_min'] == g['coord_data_min'].tolist()
+    assert (fr['ori'].numpy() == g['ori']).all()
+    for s, info in enumerate(fr['all_input_info']):
+        assert (info['coord'].numpy() == g['s%d_coord' % s]).all()
+        assert (info['occ'].numpy() == g['s%d_occ' % s]).all()
+        assert (info['offset_tensor'].numpy() == g['s%d_offset' % s]).all()
+        assert (octree_level_obj.upper_layer(info['coord'], info['occ']).numpy() == g['s%d_upper' % s]).all()
+
+
+def test_synthetic_configs():
+    from linr_pcgc_amd import synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    pts = synthetic.sphere_shell(8, 100)
+    assert len(pts) == 125810
+    fr = prepare_frame(pts)
+    assert fr['all_input_info'][0]['coord'].shape[0] == 39305 and fr['scale_num'] == 6
+    key = pts[:, 0].astype(np.int64) << 40 | pts[:, 1].astype(np.int64) << 20 | pts[:, 2]
+    assert (np.diff(key) > 0).all()
+
+
+def test_flat_adam_state_dict_roundtrip():
+    from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model
+    m = LINR_PCGC_Model({'scale_num': 6, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
+                         'instage': 1})
+    opt = FlatAdam(m)
+    opt.exp_avg.normal_()
+    opt.exp_avg_sq.uniform_()
+    opt.t, opt.lr = 17, 0.00731
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4)
+    ref.load_state_dict(sd)                                     # torch accepts our format
+    opt2 = FlatAdam(m)
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.t == 17 and abs(opt2.lr - 0.00731) < 1e-12
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    for i in range(1, 100):
+        opt2.scheduler_step()
+    assert abs(opt2.lr - 0.00731 * 0.992 ** 3) < 1e-12          # StepLR(32, 0.992) stepped per frame

@@ -1,0 +1,391 @@
+"""GPU parity: every HIP kernel and the whole-network executor (through the C-ABI) against the CPU oracle.
+
+Tolerances (the reference states none): fp32 HIP vs fp32 oracle
+  logits  |d| <= 1e-4 + 1e-4 |x|     bits  rel <= 1e-5     gradients  |d| <= 1e-4 * max|g| + 1e-6
+Integer / index / byte work (kernel map, streams, decoded geometry) is bit-exact.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import network as onet          # noqa: E402
+from oracle import octree as ooct           # noqa: E402
+from oracle import ac as oac                # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import linr_pcgc_amd  # noqa: F401
+    from linr_pcgc_amd import _lib
+    _lib.lib()                                  # raises if the HIP library is missing: no fallback
+    return linr_pcgc_amd
+
+
+@pytest.fixture(scope='module')
+def shell(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    scales = []
+    for s in range(int(g['scale_num'])):
+        c = g['s%d_coord' % s]
+        scales.append({'coord': c, 'occ': g['s%d_occ' % s], 'offset_tensor': g['s%d_offset' % s], 'scale_idx': s,
+                       'nbr': ooct.neighbour_table(c)})
+    return {'scales': scales, 'point_num': int(len(g['ori']))}
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), '%s: max err %.3e (tol %.3e at worst)' % (what, float(err.max()), float(tol.min()))
+
+
+# ---- kernel map -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['shell', 'random', 'line', 'single', 'empty'])
+def test_kmap_bit_exact(pkg, shell, case):
+    from linr_pcgc_amd import ops
+    rng = np.random.default_rng(5)
+    if case == 'shell':
+        c = shell['scales'][0]['coord']
+    elif case == 'random':
+        c = ooct.unique_sorted(rng.integers(0, 40, size=(30000, 3)))
+    elif case == 'line':
+        c = ooct.unique_sorted(np.stack([np.arange(5000) % 1000, np.zeros(5000, int), np.arange(5000) // 1000], 1))
+    elif case == 'single':
+        c = np.array([[(1 << 20) - 1, 0, 7]], dtype=np.int32)
+    else:
+        c = np.zeros((0, 3), dtype=np.int32)
+    nbr = ops.kmap_build(torch.from_numpy(c).to(_dev()))
+    ref = ooct.neighbour_table(c) if len(c) else np.zeros((0, 27), np.int32)
+    assert nbr.shape == (27, len(c))
+    assert (nbr.t().cpu().numpy() == ref).all()
+
+
+def test_kmap_rejects_unsorted(pkg):
+    from linr_pcgc_amd import ops
+    c = torch.tensor([[1, 0, 0], [0, 0, 0]], dtype=torch.int32, device=_dev())
+    with pytest.raises(ValueError):
+        ops.kmap_build(c)
+    with pytest.raises(ValueError):
+        ops.kmap_build(torch.tensor([[0, 0, 0], [0, 0, 0]], dtype=torch.int32, device=_dev()))
+
+
+# ---- sparse convolution -------------------------------------------------------------------------------------------------
+CONV_SHAPES = [(8, 8), (8, 4), (4, 4)] + [(k, 8) for k in range(1, 8)]
+
+
+@pytest.mark.parametrize('cin,cout', CONV_SHAPES)
+@pytest.mark.parametrize('pad', [False, True])
+def test_spconv_fwd_bwd(pkg, shell, cin, cout, pad):
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    g = torch.Generator().manual_seed(100 * cin + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) * 0.2
+    b = torch.randn(1, cout, generator=g)
+    res = torch.randn(n, cout, generator=g)
+    go = torch.randn(n, cout, generator=g)
+    nbr_o = torch.from_numpy(sc['nbr']).long()
+    xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = torch.relu(onet.conv3(xo, nbr_o, wo, bo) + res)
+    ref_lin = onet.conv3(xo, nbr_o, wo, bo)
+    ref_lin.backward(go)
+
+    nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
+
+    def padded(t):                       # [1+n, ld] with a zero row in front (LINR_PAD_ROW contract)
+        buf = torch.zeros((n + 1, t.shape[1]), device=dev)
+        buf[1:] = t.to(dev)
+        return buf[1:]
+    xd = padded(x) if pad else x.to(dev)
+    god = padded(go) if pad else go.to(dev)
+    out = ops.spconv_fwd(xd, nbr, w.to(dev), b.to(dev), res=res.to(dev), relu=True, pad_row=pad)
+    _close(out, ref, 1e-4, 1e-4, 'fwd')
+    out2 = ops.spconv_fwd(xd, nbr, w.to(dev), b.to(dev), pad_row=pad)
+    assert torch.equal(out2, ops.spconv_fwd(xd, nbr, w.to(dev), b.to(dev), pad_row=pad)), 'fwd must be bit-reproducible'
+    gin = ops.spconv_bwd_data(god, nbr, w.to(dev), pad_row=pad)
+    _close(gin, xo.grad, 1e-4, 1e-4, 'bwd_data')
+    gw, gb = ops.spconv_bwd_weight(xd, god, nbr, cin, cout)
+    scale = float(wo.grad.abs().max())
+    _close(gw, wo.grad, 0, 1e-4 * scale + 1e-6, 'bwd_weight')
+    _close(gb, bo.grad, 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bwd_bias')
+    gw2, _ = ops.spconv_bwd_weight(xd, god, nbr, cin, cout)
+    assert torch.equal(gw, gw2), 'bwd_weight must be bit-reproducible (two-pass, no atomics)'
+
+
+def test_spconv_pad_equals_branch_bitwise(pkg, shell):
+    """fmaf(0, w, acc) == acc: the zero-row variant and the branch variant must agree bit for bit."""
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    sc = shell['scales'][1]
+    n = len(sc['coord'])
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, 8, generator=g)
+    w, b = torch.randn(27, 8, 8, generator=g).to(dev), torch.randn(1, 8, generator=g).to(dev)
+    nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
+    buf = torch.zeros((n + 1, 8), device=dev)
+    buf[1:] = x.to(dev)
+    assert torch.equal(ops.spconv_fwd(buf[1:], nbr, w, b, pad_row=True), ops.spconv_fwd(x.to(dev), nbr, w, b))
+
+
+def test_spconv_channel_slices(pkg, shell):
+    """ME.cat / merge_two_frames are pointer offsets here: read a 4-channel slice, write into a slice."""
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    g = torch.Generator().manual_seed(3)
+    x8 = torch.randn(n, 8, generator=g)
+    w, b = torch.randn(27, 4, 4, generator=g) * 0.3, torch.randn(1, 4, generator=g)
+    nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
+    ref = onet.conv3(x8[:, 4:8], torch.from_numpy(sc['nbr']).long(), w, b)
+    out8 = torch.full((n, 8), 7.0, device=dev)
+    ops.spconv_fwd(x8.to(dev)[:, 4:8], nbr, w.to(dev), b.to(dev), out=out8[:, 0:4])
+    _close(out8[:, 0:4], ref, 1e-4, 1e-4, 'slice fwd')
+    assert bool((out8[:, 4:8] == 7.0).all())
+
+
+# ---- pointwise ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout,layout', [(15, 16, 'torch'), (16, 8, 'torch'), (8, 24, 'torch'), (24, 1, 'torch'),
+                                             (8, 4, 'me'), (4, 4, 'me')])
+def test_linear_fwd_bwd(pkg, cin, cout, layout):
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    n = 10007
+    g = torch.Generator().manual_seed(cin * 31 + cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn((cin, cout) if layout == 'me' else (cout, cin), generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    go = torch.randn(n, cout, generator=g)
+    xo, wo, bo = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = (xo @ wo if layout == 'me' else xo @ wo.t()) + bo
+    ref.backward(go)
+    out = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), cin, cout, layout)
+    _close(out, ref, 1e-4, 1e-4, 'fwd')
+    gin = ops.linear_bwd_data(go.to(dev), w.to(dev), cin, cout, layout)
+    _close(gin, xo.grad, 1e-4, 1e-4, 'bwd_data')
+    gw, gb = ops.linear_bwd_weight(x.to(dev), go.to(dev), cin, cout, layout)
+    _close(gw, wo.grad, 0, 1e-4 * float(wo.grad.abs().max()) + 1e-6, 'bwd_weight')
+    _close(gb, bo.grad, 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bwd_bias')
+
+
+def test_bce_bits(pkg):
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    n = 50021
+    z = torch.randn(n, generator=g) * 6
+    z[:6] = torch.tensor([120.0, -120.0, 30.0, -30.0, 0.0, 17.5])       # saturating sigmoid, clamped logs
+    t8 = (torch.rand(n, 8, generator=g) < 0.4).float()
+    t8[:6, 3] = torch.tensor([0.0, 1.0, 0.0, 1.0, 1.0, 0.0])
+    zo = z.clone().requires_grad_()
+    ref_bits = torch.nn.functional.binary_cross_entropy(torch.sigmoid(zo), t8[:, 3], reduction='sum') / math.log(2.0)
+    ref_bits.backward()
+    p, bits = ops.bce_bits_fwd(z.to(dev), t8.to(dev)[:, 3])
+    _close(p, torch.sigmoid(z), 1e-6, 1e-7, 'sigmoid')
+    assert abs(float(bits) - float(ref_bits)) <= 1e-5 * float(ref_bits)
+    gz = ops.bce_bits_bwd(p, t8.to(dev)[:, 3], 1.0 / math.log(2.0))
+    _close(gz, zo.grad, 1e-4, 1e-6, 'bce bwd')
+
+
+def test_adam_matches_torch(pkg):
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(54712, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    p, m, v = p0.to(dev), torch.zeros(54712, device=dev), torch.zeros(54712, device=dev)
+    for step in range(1, 6):
+        gr = torch.randn(54712, generator=g) * (0.1 ** step)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(dev), m, v, step, 0.01)
+        _close(p, ref, 2e-6, 2e-7, 'adam step %d' % step)
+
+
+# ---- whole network --------------------------------------------------------------------------------------------------------
+def _model_and_oracle(pkg, scale_num, seed=8807):
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    torch.manual_seed(seed)
+    model = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1,
+                             'outstage': 8, 'instage': 1})
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.cuda(), sd
+
+
+def test_net_forward_matches_oracle(pkg, shell):
+    from linr_pcgc_amd import engine
+    model, sd = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    probs, bits = model.frame_probs(frame)
+    tsc = onet.to_torch_scales(shell['scales'])
+    ref_bits = 0.0
+    for i, s in enumerate(tsc):
+        out = onet.forward_scale(sd, s)
+        sl = frame.scale_slice(i)
+        for k in range(8):
+            ref_p = out['probs'][k].reshape(-1)
+            _close(probs[k, sl], ref_p, 1e-4, 3e-5, 'scale %d stage %d prob' % (i, k))
+            # logits (pre-sigmoid out_F, upsample.py:159) through the inverse sigmoid of well-conditioned probabilities
+            pk = probs[k, sl].double().cpu()
+            mid = (pk > 0.01) & (pk < 0.99)
+            z = torch.log(pk[mid]) - torch.log1p(-pk[mid])
+            _close(z, out['logits'][k].reshape(-1)[mid], 1e-4, 1e-4, 'scale %d stage %d logit' % (i, k))
+        ref_bits += float(out['bits'])
+    assert abs(float(bits) - ref_bits) <= 1e-5 * ref_bits, (float(bits), ref_bits)
+    probs2, bits2 = model.frame_probs(frame)
+    assert torch.equal(probs, probs2) and torch.equal(bits, bits2), 'forward must be bit-reproducible'
+
+
+def test_net_backward_matches_autograd(pkg, shell):
+    from linr_pcgc_amd import engine
+    model, sd = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    flat = model.flat_parameters()
+    bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+    engine.net_forward(frame, flat, 0, 8, None, bits)
+    grads = torch.zeros_like(flat)
+    gscale = 1.0 / shell['point_num']
+    engine.net_backward(frame, flat, grads, gscale)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    loss = onet.frame_bits(sdo, onet.to_torch_scales(shell['scales'])) * gscale
+    loss.backward()
+    off = 0
+    gmax = max(float(v.grad.abs().max()) for v in sdo.values())
+    for name, v in sdo.items():
+        n = v.numel()
+        mine = grads[off:off + n].view(v.shape)
+        _close(mine, v.grad, 1e-3, 1e-4 * gmax, 'grad ' + name)
+        off += n
+    grads2 = torch.zeros_like(flat)
+    engine.net_backward(frame, flat, grads2, gscale)
+    assert torch.equal(grads, grads2), 'backward must be bit-reproducible'
+
+
+def test_multiscale_batch_equals_per_scale(pkg, shell):
+    """Batching all scales into one row space must not change any row's arithmetic (bitwise)."""
+    model, _ = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    probs, _ = model.frame_probs(frame)
+    for i, s in enumerate(shell['scales']):
+        single = model.make_frame([s])
+        p1, _ = model.frame_probs(single)
+        assert torch.equal(p1, probs[:, frame.scale_slice(i)])
+
+
+def test_model_surface_autograd_and_torch_adam(pkg, shell):
+    """Reference-style loop (main.py:305-321, 457-475): per-scale model(d), loss.backward(), torch.optim.Adam."""
+    model, sd = _model_and_oracle(pkg, 5)
+    dev = _dev()
+    inputs = []
+    for s in shell['scales']:
+        occ = torch.from_numpy(s['occ']).to(dev)
+        inputs.append({'coord': torch.from_numpy(s['coord']).to(dev), 'offset_tensor': torch.from_numpy(s['offset_tensor']).to(dev),
+                       'occ_lst': [occ[:, i:i + 1].contiguous() for i in range(8)], 'scale_idx': s['scale_idx'],
+                       'ground_truth': None})
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tsc = onet.to_torch_scales(shell['scales'])
+    losses, losses_o = [], []
+    for it in range(3):
+        bits = 0
+        for d in inputs:
+            bits = bits + model(d)
+        loss = bits / shell['point_num']
+        loss.backward(retain_graph=True)
+        losses.append(loss.item())
+        opt.step()
+        opt.zero_grad()
+        lo = onet.frame_bits(sdo, tsc) / shell['point_num']
+        lo.backward()
+        losses_o.append(lo.item())
+        opt_o.step()
+        opt_o.zero_grad()
+    assert losses[0] > losses[-1]
+    for a, b in zip(losses, losses_o):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses, losses_o)
+
+
+def test_fast_train_step_matches_oracle(pkg, shell):
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, sd = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tsc = onet.to_torch_scales(shell['scales'])
+    for it in range(4):
+        bits = train_step(model, opt, frame, shell['point_num'])
+        lo = onet.frame_bits(sdo, tsc)
+        (lo / shell['point_num']).backward()
+        opt_o.step()
+        opt_o.zero_grad()
+        assert abs(float(bits) - float(lo)) <= 3e-4 * float(lo), (it, float(bits), float(lo))
+    flat_o = torch.cat([v.detach().reshape(-1) for v in sdo.values()])
+    _close(model.flat_parameters(), flat_o, 0, 2e-3, 'parameters after 4 Adam steps')
+
+
+# ---- coding: encoder == decoder, lossless -----------------------------------------------------------------------------------
+def test_encode_decode_lossless(pkg, shell):
+    """decoder.decode_one_frame (decoder.py:153-176): coarse-to-fine, octree rebuilt from decoded occupancy only."""
+    from linr_pcgc_amd.module_utils import octree_level_obj, qscTensor
+    model, _ = _model_and_oracle(pkg, 5)
+    dev = _dev()
+    all_bytes = []
+    for s in shell['scales']:
+        occ = torch.from_numpy(s['occ']).to(dev)
+        d = {'coord': torch.from_numpy(s['coord']).to(dev), 'offset_tensor': torch.from_numpy(s['offset_tensor']).to(dev),
+             'occ_lst': [occ[:, i:i + 1].contiguous() for i in range(8)], 'scale_idx': s['scale_idx']}
+        out = model.encode(d, DBG=True)
+        all_bytes.append(out['enc_bytes'])
+    lowx = torch.from_numpy(shell['scales'][-1]['coord']).to(dev)
+    for s_idx in range(len(all_bytes) - 1, -1, -1):
+        q = qscTensor(lowx)
+        q.set_offset_tensor()
+        assert (q.get_coord().cpu().numpy() == shell['scales'][s_idx]['coord']).all()
+        occ_lst = model.decode({'enc_bytes': all_bytes[s_idx], 'coord': q.get_coord(),
+                                'offset_tensor': q.get_offset_tensor(), 'scale_idx': s_idx})
+        occupancy = torch.cat(occ_lst, dim=-1)
+        assert (occupancy.cpu().numpy() == shell['scales'][s_idx]['occ']).all()
+        lowx = octree_level_obj.upper_layer(q.get_coord(), occupancy)
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'octree_shell128.npz'))
+    assert (lowx.cpu().numpy() == g['ori']).all(), 'decoded geometry must be bit-exact'
+
+
+def test_staged_probs_bitwise_equal_one_shot(pkg, shell):
+    from linr_pcgc_amd import engine
+    model, _ = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    one, _ = model.frame_probs(frame)
+    staged = torch.empty_like(one)
+    for k in range(8):
+        engine.net_forward(frame, model.flat_parameters(), k, k + 1, staged, None)
+    assert torch.equal(one, staged)
+
+
+def test_codec_stream_matches_oracle_coder(pkg, shell):
+    model, _ = _model_and_oracle(pkg, 5)
+    dev = _dev()
+    s = shell['scales'][1]
+    occ = torch.from_numpy(s['occ']).to(dev)
+    d = {'coord': torch.from_numpy(s['coord']).to(dev), 'offset_tensor': torch.from_numpy(s['offset_tensor']).to(dev),
+         'occ_lst': [occ[:, i:i + 1].contiguous() for i in range(8)], 'scale_idx': s['scale_idx']}
+    out = model.codec(d)
+    frame = model._scale_frame(d)
+    probs, bits = model.frame_probs(frame)
+    ref = oac.encode_binary(probs.reshape(-1).cpu().numpy(), s['occ'].T.reshape(-1).astype(np.int16))
+    assert out['enc_bytes'] == ref
+    assert out['bits'] >= float(bits) - 1 and out['bits'] <= float(bits) * 1.01 + 64
