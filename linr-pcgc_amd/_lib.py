@@ -2,6 +2,9 @@
 import ctypes
 import os
 
+import torch  # noqa: F401  - MUST precede loading liblinr_hip.so: both link libamdhip64.so.7 and the process has to
+#                             end up with ONE HIP runtime, the one PyTorch bundles (streams and memory come from it).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblinr_hip.so')
 
