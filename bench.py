@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Bench: BASELINE.json's metric (encode sec/frame + bits/point, lossless) on its config[1] stand-in:
+synthetic "loot10" (10-bit sphere, ~784 k points/frame, 336 k parent rows over 7 scales), 1 GOP of 32 frames,
+first_epoch = 10, one GOP per GPU (no data-path collective).
+
+A step = one frame-epoch of the per-GOP overfit (forward + backward + fused Adam + StepLR on one frame), the unit the
+reference logs as train_time_avg (loot/info.log).  The K timed steps walk the GOP's frames in the reference's order
+(main.py:297-321).  After the timed region the codec leg (model compression, one inference forward + D2H + range coding
+per frame) is timed separately, one frame is decoded and checked bit-exact, and
+    value = epochs * step_time + codec_time_per_frame     [s/frame, whole job: divided by the number of GPUs]
+With the defaults (K = 320 = 10 epochs x 32 frames) the timed region IS config[1]'s overfit.
+
+    python bench.py --gpus 1 --steps 320 --warmup 32
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+EPOCHS = 10          # first_epoch / others_epoch of BASELINE config[1]
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=320)
+    ap.add_argument('--warmup', type=int, default=32)
+    ap.add_argument('--config', default='loot10', help='synthetic sequence (linr_pcgc_amd.synthetic.CONFIGS)')
+    ap.add_argument('--gop', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-rows', type=int, default=0, help='0 = whole frame 0')
+    return ap.parse_args()
+
+
+def kernel_roofline(model, gop, iters=50):
+    """Dominant kernel = the 8->8 sparse-conv gather kernel (forward form; 17 launches per forward, its transposed twin
+    another 17 per backward).  Timed live with events on the launch stream over `iters` launches on frame 0's full row
+    space.  Algorithmic bytes per row: 4*(8+8) feature bytes + 108 neighbour-table bytes."""
+    from linr_pcgc_amd import ops
+    f = gop.frames[0]
+    R = f.rows
+    dev = f.device
+    x = torch.zeros((R + 1, 8), device=dev)
+    x[1:].normal_()
+    out = torch.empty((R, 8), device=dev)
+    w = torch.randn(27, 8, 8, device=dev) * 0.1
+    b = torch.zeros(1, 8, device=dev)
+    for _ in range(5):
+        ops.spconv_fwd(x[1:], f.nbr, w, b, out=out, pad_row=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.spconv_fwd(x[1:], f.nbr, w, b, out=out, pad_row=True)
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / 1e3 / iters
+    alg_bytes = R * (4 * (8 + 8) + 108)
+    achieved = alg_bytes / dur_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')          # PMC-derived HBM bytes per launch (see profiles/README)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('spconv_gather_8x8_fwd_bytes_per_launch')
+        except Exception:
+            traffic = None
+    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'kernel': 'spconv_gather_k<8,8,fwd,LOADW=8,PAD>', 'rows_per_launch': R,
+            'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': round(dur_s * 1e6, 2)}
+
+
+def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
+    """The CPU oracle ("port": ME/torchac are not installable, the reference has no CPU path) on the host cores:
+    one overfit step (forward + autograd backward + Adam) + one inference forward on frame 0."""
+    from oracle import network as onet
+    scales = []
+    for s in gop_info['all_input_info']:
+        n = s['coord'].shape[0]
+        scales.append({'coord': s['coord'].cpu().numpy(), 'occ': s['occ'].cpu().numpy(),
+                       'offset_tensor': s['offset_tensor'].cpu().numpy(), 'scale_idx': s['scale_idx']})
+    rows = sum(len(s['coord']) for s in scales)
+    tsc = onet.to_torch_scales(scales)
+    sd = {k: v.clone().requires_grad_() for k, v in model_sd.items()}
+    flat_p = torch.cat([v.detach().reshape(-1) for v in sd.values()])
+    m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+    t0 = time.time()
+    bits = onet.frame_bits(sd, tsc)
+    (bits / point_num).backward()
+    g = torch.cat([t.grad.reshape(-1) for t in sd.values()])
+    onet.adam_step(flat_p, g, m, v, 1, 0.01)
+    t_step = time.time() - t0
+    with torch.no_grad():
+        t0 = time.time()
+        onet.frame_bits({k: v.detach() for k, v in sd.items()}, tsc)
+        t_fwd = time.time() - t0
+    return {'value': round(EPOCHS * t_step + t_fwd, 3), 'unit': 's/frame', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '1 overfit step (%.2f s) + 1 forward (%.2f s) of frame 0 (%d rows), x%d epochs; AC not included'
+                      % (t_step, t_fwd, rows, EPOCHS), 'bits_frame0_init': float(bits)}
+
+
+def log(msg):
+    if int(os.environ.get('RANK', 0)) == 0:
+        print('[bench %7.1fs] %s' % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
+def host_threads():
+    """CPU threads this process may really use (the GPU box gives one GPU a 16-core share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X: the coding network has no CPU path'
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+
+    # rank r owns GOP r of the sequence: frames [gop*r, gop*(r+1))  (GOPs are independent: no collective)
+    t_setup = time.time()
+    clouds = [synthetic.sequence_frame(args.config, rank * args.gop + t) for t in range(args.gop)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    setup_s = time.time() - t_setup
+    log('setup done: %d frames, frame0 %d points / %d rows, %d scales' % (len(gop), gop.point_nums[0], gop.frames[0].rows, gop.scale_num))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up on a throw-away copy of the optimiser state so the timed steps start from the seeded initialisation
+    from linr_pcgc_amd.model_core import train_step
+    opt = FlatAdam(model)
+    for i in range(args.warmup):
+        train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)])
+    model.load_state_dict(init_sd)
+    opt = FlatAdam(model)
+
+    log('warm-up done')
+    barrier()
+    t0 = time.time()
+    acc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    epoch_loss = []
+    for i in range(args.steps):
+        j = i % len(gop)
+        bits = train_step(model, opt, gop.frames[j], gop.point_nums[j])
+        acc += bits / gop.point_nums[j]
+        if j == len(gop) - 1:
+            opt.clamp_lr(4e-4)
+            epoch_loss.append(acc.clone())
+            acc.zero_()
+    barrier()
+    elapsed = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed * 1e3 / args.steps
+    losses = [float(x) / len(gop) for x in epoch_loss]
+    log('timed %d steps: %.3f ms/step, epoch losses %s' % (args.steps, ms_per_step, ['%.4f' % x for x in losses]))
+
+    # codec leg (outside the K timed steps): model compression + per-frame forward + D2H + AC, then lossless check
+    model_ori = overfit.gen_model(gop.scale_num, 'cuda')
+    barrier()
+    t0 = time.time()
+    enc = codec.encode_gop(model, model_ori, gop, 8)
+    barrier()
+    codec_s = time.time() - t0
+    if dist is not None:
+        t = torch.tensor([codec_s], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        codec_s = float(t)
+    codec_s_per_frame = codec_s / len(gop)
+    log('encode leg: %.3f s/frame, bpp %.4f' % (codec_s_per_frame, enc['bpp']['bpp_all']))
+    t0 = time.time()
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=[0])
+    decode_s = time.time() - t0
+    ref0 = torch.as_tensor(gop.infos[0]['ori']).cuda() + torch.tensor(gop.coord_mins[0], device='cuda', dtype=torch.int32)
+    lossless = bool(torch.equal(dec[0], ref0))
+    log('decode frame 0: %.2f s, lossless=%s' % (decode_s, lossless))
+
+    overfit_s_per_frame = EPOCHS * ms_per_step / 1e3
+    value = (overfit_s_per_frame + codec_s_per_frame) / world
+
+    out = None
+    if rank == 0:
+        out = {'metric': 'encode_sec_per_frame', 'value': round(value, 5), 'unit': 's/frame', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+               'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE config[1] stand-in: synthetic %s (10-bit sphere r~250, %d points and %d '
+                                      'parent rows in frame 0, %d scales), 1 GOP of %d frames per GPU, first_epoch=%d, '
+                                      'lr 0.01 StepLR(32,0.992) Adam wd 1e-4, seed 8807'
+                                      % (args.config, gop.point_nums[0], gop.frames[0].rows, gop.scale_num, len(gop), EPOCHS),
+                          'frames_per_gpu': len(gop), 'epochs': EPOCHS, 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
+               'bits_per_point': round(enc['bpp']['bpp_all'], 5),
+               'bpp_components': {k: round(v, 6) for k, v in enc['bpp'].items()},
+               'lossless_decode_frame0': lossless,
+               'components_s_per_frame': {'overfit': round(overfit_s_per_frame, 5), 'codec_fwd_ac_modelcomp': round(codec_s_per_frame, 5),
+                                          'decode_frame0_s': round(decode_s, 3)},
+               'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
+               'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
+                                    'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
+        out['roofline'] = kernel_roofline(model, gop)
+        log('roofline: %s' % out['roofline'])
+        if world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(host_threads())
+            log('cpu baseline on %d threads ...' % host_threads())
+            out['cpu_baseline'] = cpu_baseline(init_sd, gop.infos[0], gop.point_nums[0], args.cpu_sample_rows)
+        else:
+            out['cpu_baseline'] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        assert lossless, 'decoded geometry differs from the input'
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

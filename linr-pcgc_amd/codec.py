@@ -1,0 +1,132 @@
+"""Per-GOP encode / decode: mirror of encoder.py:57-203, decoder.py:51-176 and test_utils.py:199-232,299-312.
+
+Stream layout is the reference's: per frame and scale ``pack_bitstream`` of the 8 per-stage
+torchac-compatible streams; ``low_enc_bytes`` = pack of per-frame uint8 coarsest coordinates + int32 minima;
+``model.bin`` + side info from model_codec.  An encoded GOP is a dict of byte strings; ``write_gop`` / ``read_gop``
+map it to the reference's directory layout (bins/frameFFFF_scaleS.bin, bins/model.bin, bins/low_enc_bytes.bin,
+side_info.json).
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from .function_utils import pack_bitstream, unpack_bitstream
+from .model_codec import Model_Estimate
+from .model_core import encode_streams
+from .module_utils import octree_level_obj, qscTensor
+
+
+def enc_all_frame_low_xyz(gop):
+    """test_utils.py:199-232: uint8 coarsest-scale coordinates per frame + int32 coordinate minima."""
+    chunks = []
+    for low in gop.low_xyz:
+        mx = int(low.max())
+        if int(np.ceil(np.log2(mx + 1))) > 8:
+            raise AssertionError('downsampled xyzQ should be less than 8 bit')
+        chunks.append(low.cpu().numpy().astype(np.uint8).tobytes())
+    chunks.append(np.asarray(gop.coord_mins, dtype=np.int32).reshape(-1).tobytes())
+    return pack_bitstream(chunks)
+
+
+def dec_all_frame_low_xyz(low_byte):
+    """test_utils.py:299-312."""
+    chunks = unpack_bitstream(low_byte)
+    mins = np.frombuffer(chunks.pop(), dtype=np.int32).reshape(-1, 3)
+    return [np.frombuffer(c, dtype=np.uint8).reshape(-1, 3) for c in chunks], mins
+
+
+def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=8):
+    """encoder.encode_one_gop: quantise the model, then per frame ONE forward over all scales and 8 x scales
+    independent arithmetic-coded streams (thread pool)."""
+    comp = Model_Estimate().compress_model(model, bitdepth, True, model_ori)
+    coded_model = comp['new_model']                      # the de-quantised model is what codes the geometry
+    side_info = {'mu': comp['mu'], 'b': comp['b'], 'min_param': comp['min_param'], 'max_param': comp['max_param'],
+                 'enc_mode': comp['enc_mode'], 'bitdepth': bitdepth}
+    frames_bytes, bits_est = [], 0.0
+    for f in gop.frames:
+        probs, bits = coded_model.frame_probs(f)
+        bits_est += float(bits)
+        p_host = probs.cpu().numpy()
+        occ_host = f.occ.t().contiguous().cpu().numpy().astype(np.uint8)
+        ps, ss = [], []
+        for i in range(f.n_scales):
+            sl = f.scale_slice(i)
+            for k in range(8):
+                ps.append(p_host[k, sl])
+                ss.append(occ_host[k, sl])
+        streams = encode_streams(ps, ss, n_threads)
+        frames_bytes.append([pack_bitstream(streams[8 * i:8 * i + 8]) for i in range(f.n_scales)])
+    low = enc_all_frame_low_xyz(gop)
+    points = sum(gop.point_nums)
+    occ_bits = 8 * sum(len(b) for fb in frames_bytes for b in fb)
+    return {'frames': frames_bytes, 'model_bin': comp['final_bytes'], 'side_info': side_info, 'low_enc_bytes': low,
+            'point_num': points, 'bits_est': bits_est,
+            'bpp': {'point_bpp': occ_bits / points, 'model_bpp': comp['bit_real'] / points,
+                    'xyzlow_bpp': len(low) * 8 / points,
+                    'bpp_all': (occ_bits + comp['bit_real'] + len(low) * 8) / points}}       # test_utils.py:146-157
+
+
+def decode_one_frame(model, frame_enc_bytes, xyz_low):
+    """decoder.decode_one_frame (decoder.py:153-176): coarse to fine, 8 AC-decoded stages per scale."""
+    lowx = xyz_low
+    for s_idx in range(len(frame_enc_bytes) - 1, -1, -1):
+        q = qscTensor(lowx)
+        q.set_offset_tensor()
+        occ_lst = model.decode({'enc_bytes': frame_enc_bytes[s_idx], 'coord': q.get_coord(),
+                                'offset_tensor': q.get_offset_tensor(), 'scale_idx': s_idx})
+        lowx = octree_level_obj.upper_layer(q.get_coord(), torch.cat(occ_lst, dim=-1))
+    return {'dec_coord': lowx}
+
+
+def decode_gop(model_ori, enc, device='cuda', frames=None):
+    """decoder.decode_one_gop: rebuild the model from model.bin, then every frame from its streams alone."""
+    side = dict(enc['side_info'])
+    side['final_bytes'] = enc['model_bin']
+    model, _ = Model_Estimate().decompress_model(model_ori, side)
+    lows, mins = dec_all_frame_low_xyz(enc['low_enc_bytes'])
+    out = []
+    for i in (range(len(enc['frames'])) if frames is None else frames):
+        xyz_low = torch.tensor(lows[i].astype(np.int32), device=device)
+        dec = decode_one_frame(model, list(enc['frames'][i]), xyz_low)['dec_coord']
+        out.append(dec + torch.tensor(mins[i], device=device, dtype=torch.int32))
+    return out
+
+
+def write_gop(enc, result_dir):
+    bins = os.path.join(result_dir, 'bins')
+    os.makedirs(bins, exist_ok=True)
+    for fi, scales in enumerate(enc['frames']):
+        for si, b in enumerate(scales):
+            with open(os.path.join(bins, 'frame%s_scale%d.bin' % (str(fi).zfill(4), si)), 'wb') as f:
+                f.write(b)
+    with open(os.path.join(bins, 'model.bin'), 'wb') as f:
+        f.write(enc['model_bin'])
+    with open(os.path.join(bins, 'low_enc_bytes.bin'), 'wb') as f:
+        f.write(enc['low_enc_bytes'])
+    with open(os.path.join(result_dir, 'side_info.json'), 'w') as f:
+        json.dump(enc['side_info'], f, indent=4)
+
+
+def read_gop(result_dir):
+    bins = os.path.join(result_dir, 'bins')
+    frames, fi = [], 0
+    while True:
+        files = glob.glob(os.path.join(bins, 'frame%s_scale*.bin' % str(fi).zfill(4)))
+        if not files:
+            break
+        scales = []
+        for si in range(len(files)):
+            with open(os.path.join(bins, 'frame%s_scale%d.bin' % (str(fi).zfill(4), si)), 'rb') as f:
+                scales.append(f.read())
+        frames.append(scales)
+        fi += 1
+    with open(os.path.join(bins, 'model.bin'), 'rb') as f:
+        model_bin = f.read()
+    with open(os.path.join(bins, 'low_enc_bytes.bin'), 'rb') as f:
+        low = f.read()
+    with open(os.path.join(result_dir, 'side_info.json')) as f:
+        side = json.load(f)
+    return {'frames': frames, 'model_bin': model_bin, 'low_enc_bytes': low, 'side_info': side}

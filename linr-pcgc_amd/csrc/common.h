@@ -16,7 +16,7 @@ static inline unsigned linr_grid(int64_t n, int per_block) { return (unsigned)((
 // few enough that the partial slabs stay small.
 static inline int linr_reduce_blocks(int64_t n, int rows_per_tile) {
     int64_t tiles = (n + rows_per_tile - 1) / rows_per_tile;
-    int64_t nb = tiles < 1024 ? tiles : 1024;
+    int64_t nb = tiles < 512 ? tiles : 512;
     return (int)(nb < 1 ? 1 : nb);
 }
 

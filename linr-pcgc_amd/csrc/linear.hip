@@ -166,8 +166,16 @@ __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* 
     const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
     const int elems = (cin + 1) * cout;
     if (e >= elems) return;
-    float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * elems + e];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += slab[(int64_t)(b + 0) * elems + e];
+        s1 += slab[(int64_t)(b + 1) * elems + e];
+        s2 += slab[(int64_t)(b + 2) * elems + e];
+        s3 += slab[(int64_t)(b + 3) * elems + e];
+    }
+    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * elems + e];
+    const float s = (s0 + s1) + (s2 + s3);
     const int ci = e / cout, co = e % cout;
     float* d = (ci < cin) ? (gW ? gW + ci * ws_ci + co * ws_co : nullptr) : (gb ? gb + co : nullptr);
     if (d == nullptr) return;

@@ -201,7 +201,7 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     return linr_spconv_bwd_weight(in, in_ld, gout, gout_ld, c.f->nbr, c.R, c.R, cin, cout, c.G + w_off, c.G + b_off,
-                                  LINR_ACCUM, c.A.slab, c.A.slab_bytes, c.s);
+                                  LINR_ACCUM | LINR_PAD_ROW, c.A.slab, c.A.slab_bytes, c.s);
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,

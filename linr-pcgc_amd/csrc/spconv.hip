@@ -239,22 +239,142 @@ __global__ __launch_bounds__(LINR_BLOCK) void spconv_bwd_weight_k(
     }
 }
 
-// second pass: element e of [(P+1)*COUT] summed over blocks in ascending block order
+// second pass: element e of the slab summed over blocks; consecutive lanes own consecutive elements (coalesced),
+// four fixed interleaved partial sums keep loads in flight; the association is fixed => bit-reproducible.
 __global__ __launch_bounds__(LINR_BLOCK) void slab_reduce_k(const float* __restrict__ slab, int nblocks, int elems,
                                                             int split, float* __restrict__ dstA,
                                                             float* __restrict__ dstB, unsigned flags) {
     const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (e >= elems) return;
-    float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(int64_t)b * elems + e];
-    float* d = e < split ? dstA + e : dstB + (e - split);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += slab[(int64_t)(b + 0) * elems + e];
+        s1 += slab[(int64_t)(b + 1) * elems + e];
+        s2 += slab[(int64_t)(b + 2) * elems + e];
+        s3 += slab[(int64_t)(b + 3) * elems + e];
+    }
+    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * elems + e];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* d = e < split ? (dstA ? dstA + e : nullptr) : (dstB ? dstB + (e - split) : nullptr);
     if (d == nullptr) return;
     *d = (flags & LINR_ACCUM) ? *d + s : s;
 }
 
+// ---- v2 backward-weight: no LDS staging --------------------------------------------------------------------------
+// gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  One WAVE owns one row r at a time: lane (k, q) gathers the
+// 4-channel quad q of the k-th neighbour's feature row (16 B), the row's output gradient g[r][0..COUT) is
+// wave-uniform (scalar loads -> SGPR operands), so a lane does 4*COUT FMAs per 2 vector loads and keeps its
+// 4 x COUT accumulators in registers over all rows the wave visits.  Lane 27*XQ is the bias lane (x = (1,0,0,0)).
+// Waves of a block take rows round-robin; the block folds its waves through LDS in wave order and writes one slab.
+#define BW2_WAVES 8
+template <int XQ, int COUT, bool PAD>
+__global__ __launch_bounds__(BW2_WAVES * 64) void spconv_bwd_weight2_k(
+    const float* __restrict__ in, int in_ld, const float* __restrict__ gout, int gout_ld,
+    const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n, int cin_valid, float* __restrict__ slab) {
+    constexpr int CIN = 4 * XQ;
+    constexpr int NI = 27 * XQ;
+    constexpr int NA = 4 * COUT;
+    __shared__ float sacc[64 * (NA + 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = lane / XQ, q = lane % XQ;
+    const bool gather = lane < NI;
+    const bool biasl = lane == NI;
+    float acc[4][COUT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[c][o] = 0.0f;
+    // contiguous row range per block, rows dealt round-robin to its waves
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    const int32_t* nk = nbr + (int64_t)(gather ? k : 0) * nbr_ld;
+#pragma unroll 4
+    for (int64_t r = b0 + wave; r < b1; r += BW2_WAVES) {
+        float g[COUT];
+        const float* gp = gout + r * gout_ld;            // r is wave-uniform: scalar loads
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) g[o] = gp[o];
+        float4 x = make_float4(biasl ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+        if (gather) {
+            const int32_t j = nk[r];
+            if (PAD || j >= 0) x = *reinterpret_cast<const float4*>(in + (int64_t)j * in_ld + 4 * q);
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            acc[0][o] = fmaf(x.x, g[o], acc[0][o]);
+            acc[1][o] = fmaf(x.y, g[o], acc[1][o]);
+            acc[2][o] = fmaf(x.z, g[o], acc[2][o]);
+            acc[3][o] = fmaf(x.w, g[o], acc[3][o]);
+        }
+    }
+    // fold waves in wave order (fixed => reproducible)
+    float* mine = sacc + lane * (NA + 1);
+    for (int w = 0; w < BW2_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const float v = acc[c][o];
+                    mine[c * COUT + o] = (w == 0) ? v : mine[c * COUT + o] + v;
+                }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* dst = slab + (int64_t)blockIdx.x * ((27 * CIN + 1) * COUT);
+        if (gather) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) dst[(k * CIN + 4 * q + c) * COUT + o] = mine[c * COUT + o];
+        } else if (biasl) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) dst[27 * CIN * COUT + o] = mine[o];
+        }
+    }
+    (void)cin_valid;
+}
+
+// slab [nb][27*8+1][8] -> gW[27][cin][8] for cin < 8 (the 8-wide kernel ran on a zero-extended view of the input)
+__global__ __launch_bounds__(LINR_BLOCK) void slab_reduce_narrow_k(const float* __restrict__ slab, int nblocks, int cin,
+                                                                   float* __restrict__ gW, float* __restrict__ gb,
+                                                                   unsigned flags) {
+    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;      // element of the narrow result [(27*cin+1)*8]
+    const int elems = (27 * cin + 1) * 8;
+    if (e >= elems) return;
+    const int o = e % 8, pc = e / 8;
+    const int wide = (pc < 27 * cin) ? ((pc / cin) * 8 + (pc % cin)) * 8 + o : 27 * 64 + o;
+    const int welems = (27 * 8 + 1) * 8;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += slab[(int64_t)(b + 0) * welems + wide];
+        s1 += slab[(int64_t)(b + 1) * welems + wide];
+        s2 += slab[(int64_t)(b + 2) * welems + wide];
+        s3 += slab[(int64_t)(b + 3) * welems + wide];
+    }
+    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * welems + wide];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* d = (pc < 27 * cin) ? (gW ? gW + e : nullptr) : (gb ? gb + o : nullptr);
+    if (d == nullptr) return;
+    *d = (flags & LINR_ACCUM) ? *d + s : s;
+}
+
+static int bw2_blocks(int64_t n) {
+    int64_t nb = (n + 63) / 64;            // at least ~64 rows per block
+    if (nb > 512) nb = 512;               // 2 blocks x 8 waves per CU
+    return (int)(nb < 1 ? 1 : nb);
+}
+
 extern "C" size_t linr_spconv_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout) {
     if (n <= 0) return 0;
-    return (size_t)linr_reduce_blocks(n, BW_TILE) * (27 * cin + 1) * cout * sizeof(float);
+    const size_t v1 = (size_t)linr_reduce_blocks(n, BW_TILE) * (27 * cin + 1) * cout * sizeof(float);
+    const size_t v2 = (size_t)bw2_blocks(n) * (27 * 8 + 1) * 8 * sizeof(float);
+    return v1 > v2 ? v1 : v2;
 }
 
 template <int CIN, int COUT>
@@ -268,6 +388,25 @@ static int launch_bwd_weight(const float* in, int in_ld, const float* gout, int 
     return linr_launch_rc();
 }
 
+template <int XQ, int COUT>
+static int launch_bwd_weight2(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr,
+                              int64_t nbr_ld, int64_t n, int cin, float* gW, float* gb, unsigned flags, float* slab,
+                              hipStream_t s) {
+    const int nb = bw2_blocks(n);
+    if (flags & LINR_PAD_ROW)
+        spconv_bwd_weight2_k<XQ, COUT, true><<<nb, BW2_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, slab);
+    else
+        spconv_bwd_weight2_k<XQ, COUT, false><<<nb, BW2_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, slab);
+    if (cin == 4 * XQ) {
+        const int elems = (27 * cin + 1) * COUT;
+        slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, elems, 27 * cin * COUT, gW, gb, flags);
+    } else {
+        const int elems = (27 * cin + 1) * 8;
+        slab_reduce_narrow_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, cin, gW, gb, flags);
+    }
+    return linr_launch_rc();
+}
+
 extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld,
                                       const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t cin, int32_t cout,
                                       float* gW, float* gb, uint32_t flags, void* ws, size_t ws_bytes, void* stream) {
@@ -277,6 +416,13 @@ extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const floa
     if (ws_bytes < linr_spconv_bwd_weight_workspace_bytes(n, cin, cout)) return LINR_ENOSPC;
     if (((uintptr_t)ws) & 3u) return LINR_EALIGN;
     hipStream_t s = (hipStream_t)stream;
+    // fast path: 16-byte gathers of channel quads (cin < 8 -> the 8-wide kernel on the full 8-float row, extra
+    // channels discarded by the reduction), needs aligned rows of at least 4*XQ floats
+    const bool vec = linr_aligned16(in) && (in_ld % 4 == 0);
+    if (vec && cin == 8 && cout == 8) return launch_bwd_weight2<2, 8>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 8, gW, gb, flags, (float*)ws, s);
+    if (vec && cin == 8 && cout == 4) return launch_bwd_weight2<2, 4>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 8, gW, gb, flags, (float*)ws, s);
+    if (vec && cin == 4 && cout == 4) return launch_bwd_weight2<1, 4>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 4, gW, gb, flags, (float*)ws, s);
+    if (vec && cin < 8 && cout == 8 && in_ld >= 8) return launch_bwd_weight2<2, 8>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, gW, gb, flags, (float*)ws, s);
 #define LINR_BW_CASE(CI, CO) \
     if (cin == CI && cout == CO) return launch_bwd_weight<CI, CO>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, gW, gb, flags, (float*)ws, s);
     LINR_BW_CASE(8, 8) LINR_BW_CASE(8, 4) LINR_BW_CASE(4, 4)

@@ -116,20 +116,23 @@ class LINR_PCGC_Model(nn.Module):
         return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena)
 
     def _scale_frame(self, d, need_occ=True):
+        """Kernel map + arena for one scale's inputs.  Encoder-side inputs are cached by tensor identity; the cache
+        entry pins the tensors so a recycled allocation can never alias a stale kernel map.  Decoder-side frames
+        (fresh coordinates every call) are not cached."""
         coord = d['coord']
-        occ0 = d['occ_lst'][0] if need_occ else None
-        key = (coord.data_ptr(), int(coord.shape[0]), int(d['scale_idx']), d['offset_tensor'].data_ptr(),
-               None if occ0 is None else occ0.data_ptr())
-        fr = self._frame_cache.get(key)
-        if fr is None:
+        s = {'coord': coord, 'offset_tensor': d['offset_tensor'], 'scale_idx': d['scale_idx']}
+        if not need_occ:
+            return self.make_frame([s])
+        occ0 = d['occ_lst'][0]
+        key = (coord.data_ptr(), int(coord.shape[0]), int(d['scale_idx']), d['offset_tensor'].data_ptr(), occ0.data_ptr())
+        hit = self._frame_cache.get(key)
+        if hit is None:
             if len(self._frame_cache) >= 1024:
                 self._frame_cache.pop(next(iter(self._frame_cache)))
-            s = {'coord': coord, 'offset_tensor': d['offset_tensor'], 'scale_idx': d['scale_idx']}
-            if need_occ:
-                s['occ_lst'] = d['occ_lst']
-            fr = self.make_frame([s])
-            self._frame_cache[key] = fr
-        return fr
+            s['occ_lst'] = d['occ_lst']
+            hit = (self.make_frame([s]), coord, d['offset_tensor'], list(d['occ_lst']))
+            self._frame_cache[key] = hit
+        return hit[0]
 
     # ---- reference call surface --------------------------------------------------------------------------------------
     def forward(self, inargs):

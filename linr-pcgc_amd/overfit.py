@@ -1,0 +1,80 @@
+"""Per-GOP overfitting on the fast path: mirror of main.overfit_one_gop's hot loop (main.py:297-437).
+
+The reference re-reads a pickle from disk, rebuilds ~60 coordinate maps per scale and synchronises with the host
+~20 times per scale-step.  Here every frame of the GOP is resident in HBM (kernel map, features,
+occupancy), a step is one stream-ordered launch sequence (forward, backward, fused Adam) and the host reads the loss
+once per epoch.
+"""
+import torch
+
+from .model_core import FlatAdam, LINR_PCGC_Model, train_step
+from .module_utils import prepare_frame
+
+
+def gen_model(scale_num, device='cuda', seed=None):
+    """Gen_Model of main.py:97,218."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    m = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1,
+                         'outstage': 8, 'instage': 1})
+    return m.to(device)
+
+
+class Gop:
+    """A group of pictures resident on one GPU: per frame the batched multi-scale Frame + side data."""
+
+    def __init__(self, model, clouds, scale_num=None, min_point_num=64, device='cuda'):
+        self.frames, self.point_nums, self.coord_mins, self.low_xyz, self.infos = [], [], [], [], []
+        self.scale_num = scale_num
+        for pts in clouds:
+            fr = prepare_frame(pts, self.scale_num, min_point_num, device=device)
+            if self.scale_num is None:
+                self.scale_num = fr['scale_num']             # frozen from frame 0 (main.py:77-78)
+            self.infos.append(fr)
+        self.model_scale_num = model.scale_num if model is not None else self.scale_num
+        max_rows = 0
+        from . import engine
+        for fr in self.infos:
+            f = engine.Frame(fr['all_input_info'], self.model_scale_num, device, validate=True, with_arena=False)
+            self.frames.append(f)
+            self.point_nums.append(fr['point_num'])
+            self.coord_mins.append(fr['coord_data_min'])
+            self.low_xyz.append(fr['all_input_info'][-1]['coord'])
+            max_rows = max(max_rows, f.rows)
+        # one activation arena shared by all frames of the GOP (a step finishes before the next begins)
+        from . import _lib
+        arena = torch.empty(_lib.lib().linr_net_arena_bytes(max_rows), dtype=torch.uint8, device=device)
+        for f in self.frames:
+            f.arena = arena
+
+    def __len__(self):
+        return len(self.frames)
+
+
+def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None):
+    """main.py:297-437: frames in fixed order, one optimiser + StepLR step per frame, lr clamp after each epoch.
+    Returns the per-epoch mean loss (bits per point), like the reference logs."""
+    losses = []
+    for epoch in range(epochs):
+        acc = torch.zeros(1, dtype=torch.float64, device=gop.frames[0].device)
+        for f, pn in zip(gop.frames, gop.point_nums):
+            bits = train_step(model, opt, f, pn)
+            acc += bits / pn
+        opt.clamp_lr(min_lr)
+        loss_mean = float(acc) / len(gop)                    # the only host sync of the epoch
+        losses.append(loss_mean)
+        if on_epoch is not None:
+            on_epoch(epoch, loss_mean)
+    return losses
+
+
+def checkpoint(model, opt, epoch, loss, bitdepth=8):
+    """main.py:365-374 checkpoint dict (same keys, torch.optim.Adam state format)."""
+    return {'model': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, 'epoch': epoch,
+            'optimizer_state_dict': opt.state_dict(), 'loss': loss, 'bitdepth': bitdepth}
+
+
+def warm_start(model, opt, ckpt):
+    """main.py:241-248: GOPs >= 1 start from GOP 0's model AND optimiser state."""
+    model.load_state_dict(ckpt['model'])
+    opt.load_state_dict(ckpt['optimizer_state_dict'])
