@@ -124,7 +124,8 @@ typedef struct linr_frame {
     int32_t model_scale_num;      /* LINR_PCGC_Model scale_num (fixes the parameter layout)                 */
     const int64_t* row_off_h;     /* HOST [n_scales+1] first row of each scale                              */
     const int32_t* scale_idx_h;   /* HOST [n_scales]  which scale embedding / scale MLP each scale uses     */
-    const int32_t* nbr;           /* [27][rows] kernel map with global row ids                              */
+    const int32_t* nbr;           /* [27][nbr_ld] kernel map with global row ids                            */
+    int64_t nbr_ld;               /* leading dimension of nbr (>= rows; a multiple of 4 enables 16-byte index loads) */
     const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
 } linr_frame;
@@ -140,6 +141,13 @@ LINR_API int linr_net_forward(const linr_frame* f, const float* params, float* a
  * requires a preceding linr_net_forward(…, 0, 8, …) on the same arena. */
 LINR_API int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes,
                       float gscale, float* grads, void* stream);
+
+/* One iteration of main.py:305-321 in a single call: forward (bits added into bits_acc), backward of
+ * gscale * bits (gscale = 1/point_num), deterministic gradient reduction and the fused Adam update of `params`
+ * (hyper-parameters as in linr_adam_step).  Nothing synchronises with the host. */
+LINR_API int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
+                        float* exp_avg, float* exp_avg_sq, double step_size, double bc2_sqrt, double beta1,
+                        double beta2, double eps, double weight_decay, double* bits_acc, void* stream);
 
 /* ---- arithmetic-coder feed (host side) -----------------------------------------------------------------------
  * Replaces torchac.encode_float_cdf / decode_float_cdf as used by BinaryArithmeticCoding

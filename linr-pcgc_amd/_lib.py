@@ -18,7 +18,7 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 class LinrFrame(ctypes.Structure):
     """struct linr_frame (include/linr_hip.h)."""
     _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('row_off_h', c_ptr),
-                ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('offset_feat', c_ptr), ('occ', c_ptr)]
+                ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('offset_feat', c_ptr), ('occ', c_ptr)]
 
 
 _PROTOS = {
@@ -50,6 +50,8 @@ _PROTOS = {
     'linr_net_forward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr,
                                         c_ptr]),
     'linr_net_backward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr]),
+    'linr_net_train_step': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr, c_f64,
+                                           c_f64, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
     'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),

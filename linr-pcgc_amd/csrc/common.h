@@ -20,6 +20,25 @@ static inline int linr_reduce_blocks(int64_t n, int rows_per_tile) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
+// Destination of per-block partial weight gradients: element e of block b lands at base[b*block_stride + off + e].
+// The network executor points this at one big [LINR_WG_BLOCKS][n_params] slab indexed by flat parameter offset, so
+// ONE final pass sums every parameter's partials in fixed order (deterministic) - fused with Adam in the train step.
+struct LinrWgradDst {
+    float* base;
+    int64_t block_stride;
+    int64_t w_off;       // weight tensor offset
+    int64_t b_off;       // bias offset
+    int cin_valid;       // conv3 only: input channels actually present (<= kernel width)
+};
+struct LinrLinDst {      // pointwise layers: element (ci,co) at w_off + ci*ws_ci + co*ws_co, bias co at b_off + co
+    float* base;
+    int64_t block_stride;
+    int64_t w_off;
+    int ws_ci, ws_co;
+    int64_t b_off;
+};
+#define LINR_WG_BLOCKS 512   // persistent blocks of every weight-gradient kernel (2 per CU x 8 waves)
+
 // ---- internal launchers shared with the network executor (C++ linkage, not exported) ---------------------------
 // epilogue order of both: acc (+ bias) -> + res -> + old (LINR_ACCUM) -> * (act > 0) (LINR_RELU_MASK) -> ReLU
 __attribute__((visibility("hidden")))
@@ -30,3 +49,10 @@ __attribute__((visibility("hidden")))
 int linr_linear_launch(const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
                        int cin, int cout, const float* res, int res_ld, const float* act, int act_ld, float* out,
                        int out_ld, unsigned flags, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_conv3_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr,
+                             int64_t nbr_ld, int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, unsigned flags,
+                             hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
+                              LinrLinDst d, int nblocks, hipStream_t s);

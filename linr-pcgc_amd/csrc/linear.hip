@@ -99,65 +99,104 @@ extern "C" int linr_linear_bwd_data(const float* gout, int32_t gout_ld, int64_t 
                          flags, (hipStream_t)stream);
 }
 
-// ---- backward-weight: same two-pass slab scheme as the sparse convolution -------------------------------------
-#define LBW_TILE 64
+// ---- backward-weight on the matrix cores -------------------------------------------------------------------------------
+// gW[ci][co] = sum_r x[r][ci] * g[r][co] is X^T G with the reduction over rows: exactly the K dimension of
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, k-ordered => bit-reproducible).  A wave walks 16-row chunks of its
+// block's contiguous row range; lane l feeds A[m = l&15][k = l>>4] = x[row0 + (l>>4)][m] and
+// B[k = l>>4][n = l&15] = g[row0 + (l>>4)][n] straight from global memory (64-byte coalesced runs), no LDS.
+// The bias gradient rides along as the pseudo input channel m == cin with x == 1.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define XTG_WAVES 4
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(LINR_BLOCK) void linear_bwd_weight_k(const float* __restrict__ in, int in_ld,
-                                                                  const float* __restrict__ gout, int gout_ld,
-                                                                  int64_t n, float* __restrict__ slab) {
-    constexpr int PP = CIN + 1;                       // + bias pseudo-input (x == 1)
-    constexpr int G = LINR_BLOCK / PP;
-    constexpr int XS = PP | 1;
-    __shared__ float sx[LBW_TILE * XS];
-    __shared__ float sg[LBW_TILE * COUT];
-    __shared__ float sred[(G > 1) ? (G - 1) * PP * COUT : 1];
-    const int tid = threadIdx.x;
-    const int pair = tid % PP, grp = tid / PP;
-    const bool active = grp < G;
-    float acc[COUT];
+template <int MT, int NT>
+__global__ __launch_bounds__(XTG_WAVES * 64) void xtg_wgrad_k(const float* __restrict__ X, int x_ld, int M,
+                                                             const float* __restrict__ G, int g_ld, int N, int64_t n,
+                                                             LinrLinDst d) {
+    __shared__ float sacc[64 * (MT * NT * 4 + 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mm = lane & 15, rr = lane >> 4;
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
-    const int64_t tiles = (n + LBW_TILE - 1) / LBW_TILE;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t row0 = t * LBW_TILE;
-        __syncthreads();
-        for (int it = tid; it < LBW_TILE * PP; it += LINR_BLOCK) {
-            const int r = it / PP, c = it % PP;
-            const int64_t row = row0 + r;
-            float v = 0.0f;
-            if (row < n) v = (c < CIN) ? in[row * in_ld + c] : 1.0f;
-            sx[r * XS + c] = v;
-        }
-        for (int it = tid; it < LBW_TILE * COUT; it += LINR_BLOCK) {
-            const int r = it / COUT, c = it % COUT;
-            const int64_t row = row0 + r;
-            sg[it] = row < n ? gout[row * gout_ld + c] : 0.0f;
-        }
-        __syncthreads();
-        if (active) {
-            for (int r = grp; r < LBW_TILE; r += G) {
-                const float x = sx[r * XS + pair];
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int o = 0; o < COUT; ++o) acc[o] = fmaf(x, sg[r * COUT + o], acc[o]);
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    for (int64_t c0 = b0 + 16 * wave; c0 < b1; c0 += 16 * XTG_WAVES) {
+        float av[4][MT], bv[4][NT];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int64_t row = c0 + 4 * s4 + rr;
+            const bool ok = row < b1;
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int m = 16 * a + mm;
+                float v = 0.0f;
+                if (ok && m < M) v = X[row * x_ld + m];
+                if (ok && m == M) v = 1.0f;
+                av[s4][a] = v;
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int nn = 16 * b + mm;
+                bv[s4][b] = (ok && nn < N) ? G[row * g_ld + nn] : 0.0f;
             }
         }
-    }
-    __syncthreads();
-    if (active && grp > 0) {
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) sred[((grp - 1) * PP + pair) * COUT + o] = acc[o];
-    }
-    __syncthreads();
-    if (grp == 0) {
-        for (int g = 1; g < G; ++g) {
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) acc[o] += sred[((g - 1) * PP + pair) * COUT + o];
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][a], bv[s4][b], acc[a][b], 0, 0, 0);
+    }
+    float* mine = sacc + lane * (MT * NT * 4 + 1);
+    for (int w = 0; w < XTG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (a * NT + b) * 4 + j;
+                        mine[e] = (w == 0) ? acc[a][b][j] : mine[e] + acc[a][b][j];
+                    }
         }
-        float* dst = slab + ((int64_t)blockIdx.x * PP + pair) * COUT;
-#pragma unroll
-        for (int o = 0; o < COUT; ++o) dst[o] = acc[o];
+        __syncthreads();
     }
+    if (wave == 0) {
+        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 16 * a + rr * 4 + j;          // C/D map: row = (lane>>4)*4 + reg, col = lane&15
+                    const int nn = 16 * b + mm;
+                    if (nn < N) {
+                        const float v = mine[(a * NT + b) * 4 + j];
+                        if (m < M) dst[d.w_off + m * d.ws_ci + nn * d.ws_co] = v;
+                        else if (m == M) dst[d.b_off + nn] = v;
+                    }
+                }
+    }
+}
+
+int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
+                              LinrLinDst d, int nblocks, hipStream_t s) {
+    const int mt = (cin + 1 + 15) / 16, nt = (cout + 15) / 16;
+#define LINR_GO(A, B) do { xtg_wgrad_k<A, B><<<nblocks, XTG_WAVES * 64, 0, s>>>(in, in_ld, cin, gout, gout_ld, cout, n, d); return linr_launch_rc(); } while (0)
+    if (mt == 1 && nt == 1) LINR_GO(1, 1);
+    if (mt == 2 && nt == 1) LINR_GO(2, 1);
+    if (mt == 1 && nt == 2) LINR_GO(1, 2);
+    if (mt == 2 && nt == 2) LINR_GO(2, 2);
+#undef LINR_GO
+    return LINR_EINVAL;
 }
 
 __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* __restrict__ slab, int nblocks, int cin,
@@ -182,29 +221,31 @@ __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* 
     *d = (flags & LINR_ACCUM) ? *d + s : s;
 }
 
+static int lin_blocks(int64_t n) {
+    int64_t nb = (n + 255) / 256;
+    if (nb > LINR_WG_BLOCKS) nb = LINR_WG_BLOCKS;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
 extern "C" size_t linr_linear_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout) {
     if (n <= 0) return 0;
-    return (size_t)linr_reduce_blocks(n, LBW_TILE) * (cin + 1) * cout * sizeof(float);
+    return (size_t)lin_blocks(n) * (cin + 1) * cout * sizeof(float);
 }
 
 extern "C" int linr_linear_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, int64_t n,
                                       int32_t cin, int32_t cout, float* gW, int32_t ws_ci, int32_t ws_co, float* gb,
                                       uint32_t flags, void* ws, size_t ws_bytes, void* stream) {
-    if (n < 0 || in_ld < cin || gout_ld < cout) return LINR_EINVAL;
+    if (n < 0 || in_ld < cin || gout_ld < cout || cin < 1 || cout < 1 || cin > 31 || cout > 32) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!in || !gout || !ws) return LINR_EINVAL;
     if (ws_bytes < linr_linear_bwd_weight_workspace_bytes(n, cin, cout)) return LINR_ENOSPC;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = linr_reduce_blocks(n, LBW_TILE);
-    float* slab = (float*)ws;
-#define LINR_CASE(CI, CO)                                                                                   \
-    if (cin == CI && cout == CO) {                                                                          \
-        linear_bwd_weight_k<CI, CO><<<nb, LINR_BLOCK, 0, s>>>(in, in_ld, gout, gout_ld, n, slab);            \
-    } else
-    LINR_CASE(15, 16) LINR_CASE(16, 8) LINR_CASE(8, 24) LINR_CASE(24, 1) LINR_CASE(8, 4) LINR_CASE(4, 4)
-    return LINR_EINVAL;
-#undef LINR_CASE
-    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, cin, cout, gW, ws_ci,
-                                                                                       ws_co, gb, flags);
+    const int nb = lin_blocks(n);
+    // dense [cin+1][cout] partial per block (bias = row cin); the reduce pass scatters to the caller's strides
+    LinrLinDst d = {(float*)ws, (int64_t)(cin + 1) * cout, 0, cout, 1, (int64_t)cin * cout};
+    int rc = linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, nb, s);
+    if (rc) return rc;
+    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, cin, cout, gW,
+                                                                                       ws_ci, ws_co, gb, flags);
     return linr_launch_rc();
 }

@@ -90,7 +90,9 @@ struct Arena {
     float *C[8], *HH[8], *Z[8], *P[8];
     // backward scratch
     float *gZ, *gHH, *gC, *gO, *gXG, *gI, *gA, *gH, *gM, *gX0, *gHID;
-    float* tmp16;                // 16 floats
+    float* BIG;                  // [LINR_WG_BLOCKS][n_params] per-block partial weight gradients
+    float* GSUM;                 // [n_params] their fixed-order sum (the gradient of this backward call)
+    int64_t n_params;
     void* slab; size_t slab_bytes;
 };
 
@@ -102,15 +104,9 @@ static float* arena_mat(Arena& a, int ld) {
     return p;
 }
 
-static size_t slab_need(int64_t rows) {
-    size_t m = linr_spconv_bwd_weight_workspace_bytes(rows, 8, 8);
-    size_t l = linr_linear_bwd_weight_workspace_bytes(rows, 24, 24);
-    size_t b = linr_bce_workspace_bytes(rows);
-    size_t r = m > l ? m : l;
-    return (r > b ? r : b) + 64;
-}
+static size_t slab_need(int64_t rows) { return linr_bce_workspace_bytes(rows) + 64; }
 
-static void make_arena(Arena& a, int64_t rows, float* base) {
+static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
     a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
     a.MIX = arena_mat(a, 16); a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
     for (int b = 0; b < 8; ++b) {
@@ -123,8 +119,10 @@ static void make_arena(Arena& a, int64_t rows, float* base) {
     a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gC = arena_mat(a, 8); a.gO = arena_mat(a, 8);
     a.gXG = arena_mat(a, 8); a.gI = arena_mat(a, 8); a.gA = arena_mat(a, 8); a.gH = arena_mat(a, 8);
     a.gM = arena_mat(a, 4); a.gX0 = arena_mat(a, 8); a.gHID = arena_mat(a, 16);
-    a.cur = (a.cur + 3) & ~(int64_t)3;
-    a.tmp16 = base ? base + a.cur : nullptr; a.cur += 16;
+    a.n_params = n_params;
+    a.cur = (a.cur + 15) & ~(int64_t)15;
+    a.GSUM = base ? base + a.cur : nullptr; a.cur += (n_params + 15) & ~(int64_t)15;
+    a.BIG = base ? base + a.cur : nullptr; a.cur += (int64_t)LINR_WG_BLOCKS * n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;                     // 64-byte alignment for the slab (doubles inside)
     a.slab = base ? (void*)(base + a.cur) : nullptr;
     a.slab_bytes = slab_need(rows);
@@ -134,7 +132,9 @@ static void make_arena(Arena& a, int64_t rows, float* base) {
 extern "C" size_t linr_net_arena_bytes(int64_t rows) {
     if (rows < 0) return 0;
     Arena a;
-    make_arena(a, rows, nullptr);
+    Layout L;
+    make_layout(L, MAX_SCALES);                               // sized for the largest model: the arena is model-agnostic
+    make_arena(a, rows, nullptr, L.total);
     return (size_t)a.cur * sizeof(float) + 64;
 }
 
@@ -170,38 +170,53 @@ __global__ __launch_bounds__(LINR_BLOCK) void axpy_k(const float* __restrict__ s
     if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 
-// gb1[m] += cs[m]; gemb[i] += sum_m cs[m] * W1[m][i]   (scale-embedding gradient through Linear(15,16))
-__global__ void sce_emb_grad_k(const float* __restrict__ cs, const float* __restrict__ W1, float* __restrict__ gb1,
-                               float* __restrict__ gemb) {
+// gemb[i] = sum_m gb1[m] * W1[m][i]   (scale-embedding gradient through Linear(15,16); the embedding row is a
+// constant input of every row of its scale, so its gradient is W1[:, :8]^T applied to the bias gradient)
+__global__ void sce_emb_grad_k(const float* __restrict__ gb1, const float* __restrict__ W1, float* __restrict__ gemb) {
     const int t = threadIdx.x;
-    if (t < 16) gb1[t] += cs[t];
     if (t < 8) {
         float s = 0.0f;
-        for (int m = 0; m < 16; ++m) s = fmaf(cs[m], W1[m * 15 + t], s);
-        gemb[t] += s;
+        for (int m = 0; m < 16; ++m) s = fmaf(gb1[m], W1[m * 15 + t], s);
+        gemb[t] = s;
     }
+}
+
+// gsum[p] = sum_b big[b][p] in a fixed association (8 interleaved partial sums, ascending b) => bit-reproducible
+__global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
+                                                             float* __restrict__ gsum) {
+    const int64_t p = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.0f;
+    for (int b = 0; b < nblocks; b += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += big[(int64_t)(b + i) * total + p];
+    }
+    gsum[p] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 struct Ctx {
     const linr_frame* f;
     const float* P;
-    float* G;
     Arena A;
     Layout L;
     hipStream_t s;
     int64_t R;
+    int64_t nbr_ld;
 };
 
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
-    return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.R, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
+    return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
                              flags | LINR_PAD_ROW, c.s);
 }
 
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
-    return linr_spconv_bwd_weight(in, in_ld, gout, gout_ld, c.f->nbr, c.R, c.R, cin, cout, c.G + w_off, c.G + b_off,
-                                  LINR_ACCUM | LINR_PAD_ROW, c.A.slab, c.A.slab_bytes, c.s);
+    LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
+    return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
+                                    LINR_PAD_ROW, c.s);
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
@@ -212,9 +227,9 @@ static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W,
 }
 
 static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
-                        float* gW, int ws_ci, int ws_co, float* gb) {
-    return linr_linear_bwd_weight(in, in_ld, gout, gout_ld, n, cin, cout, gW, ws_ci, ws_co, gb, LINR_ACCUM, c.A.slab,
-                                  c.A.slab_bytes, c.s);
+                        int64_t w_off, int ws_ci, int ws_co, int64_t b_off) {
+    LinrLinDst d = {c.A.BIG, c.L.total, w_off, ws_ci, ws_co, b_off};
+    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, LINR_WG_BLOCKS, c.s);
 }
 
 // make_block: conv3(cin->8)+ReLU -> Inception -> conv3(8->8) (+ res)
@@ -238,12 +253,11 @@ static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
 static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b, const float* gO, float* gin) {
     Arena& a = c.A;
     const float* P = c.P;
-    float* G = c.G;
     // O = conv3(I; b)
     TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
     TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI, 8, 0));
     // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
-    TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, G + bp.c12_w, 4, 1, G + bp.c12_b));
+    TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
     TRY(linear(c, a.gI + 4, 8, c.R, P + bp.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, a.M[b], 4, a.gM, 4, LINR_RELU_MASK));
     // I[:,0:4] = conv3(H0; c01) + A[:,0:4]
     TRY(conv3_wgrad(c, a.H[b], 8, a.gI, 8, 4, 4, bp.c01_w, bp.c01_b));
@@ -253,7 +267,7 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     TRY(conv3(c, true, a.gM, 4, P + bp.c11_w, nullptr, 4, 4, nullptr, 0, a.H[b] + 4, 8, a.gH + 4, 8, LINR_RELU_MASK));
     // H0 = relu(conv3(A; c00)), H1 = relu(A @ c10); gA = gI (residual) + both paths, masked by A > 0
     TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
-    TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, G + bp.c10_w, 4, 1, G + bp.c10_b));
+    TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
     TRY(conv3(c, true, a.gH, 8, P + bp.c00_w, nullptr, 8, 4, a.gI, 8, nullptr, 0, a.gA, 8, 0));
     TRY(linear(c, a.gH + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA, 8,
                LINR_ACCUM | LINR_RELU_MASK));
@@ -267,7 +281,7 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     if (!f || !params || !arena) return LINR_EINVAL;
     if (f->rows < 0 || f->n_scales < 1 || f->n_scales > MAX_SCALES || !f->row_off_h || !f->scale_idx_h) return LINR_EINVAL;
     if (f->rows > 0 && (!f->nbr || !f->offset_feat || !f->occ)) return LINR_EINVAL;
-    if (f->rows > INT32_MAX - 1) return LINR_EINVAL;
+    if (f->rows > INT32_MAX - 1 || f->nbr_ld < f->rows) return LINR_EINVAL;
     if (!make_layout(c.L, f->model_scale_num)) return LINR_EINVAL;
     if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
     for (int s = 0; s < f->n_scales; ++s) {
@@ -279,7 +293,8 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     c.f = f;
     c.P = (const float*)params;
     c.R = f->rows;
-    make_arena(c.A, f->rows, (float*)arena);
+    c.nbr_ld = f->nbr_ld;
+    make_arena(c.A, f->rows, (float*)arena, c.L.total);
     return 0;
 }
 
@@ -289,7 +304,6 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     TRY(check_frame(f, params, arena, arena_bytes, c));
     if (stage_begin < 0 || stage_end > 8 || stage_begin >= stage_end) return LINR_EINVAL;
     c.s = (hipStream_t)stream;
-    c.G = nullptr;
     if (c.R == 0) return 0;
     Arena& a = c.A;
     const float* P = c.P;
@@ -333,24 +347,21 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     return linr_launch_rc();
 }
 
-extern "C" int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes, float gscale,
-                                 float* grads, void* stream) {
-    Ctx c;
-    TRY(check_frame(f, params, arena, arena_bytes, c));
-    if (!grads) return LINR_EINVAL;
-    c.s = (hipStream_t)stream;
-    c.G = grads;
-    if (c.R == 0) return 0;
+// backward of gscale * bits: leaves the parameter gradient of THIS call in arena GSUM (flat, parameters() order)
+static int backward_core(Ctx& c, float gscale) {
+    const linr_frame* f = c.f;
     Arena& a = c.A;
     const float* P = c.P;
-    float* G = c.G;
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
+    // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
+    TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
+                                     LINR_WG_BLOCKS, c.s)));
     for (int k = 7; k >= 0; --k) {
         TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
         // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
-        TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, G + c.L.h2_w[k], 1, 24, G + c.L.h2_b[k]));
+        TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, c.L.h2_w[k], 1, 24, c.L.h2_b[k]));
         TRY(linear(c, a.gZ, 1, c.R, P + c.L.h2_w[k], 24, 1, nullptr, 1, 24, nullptr, 0, a.HH[k], 24, a.gHH, 24, LINR_RELU_MASK));
-        TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, G + c.L.h0_w[k], 1, 8, G + c.L.h0_b[k]));
+        TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, c.L.h0_w[k], 1, 8, c.L.h0_b[k]));
         TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC, 8, 0));
         // C = conv3(prior_k; prune_k)
         TRY(conv3_wgrad(c, a.O[k], 8, a.gC, 8, 8, 8, c.L.pr_w[k], c.L.pr_b[k]));
@@ -364,13 +375,43 @@ extern "C" int linr_net_backward(const linr_frame* f, const float* params, float
         const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
         if (n == 0) continue;
         const int si = f->scale_idx_h[s];
-        TRY(linear_wgrad(c, a.HID + r0 * 16, 16, a.gX0 + r0 * 8, 8, n, 16, 8, G + c.L.m2_w[si], 1, 16, G + c.L.m2_b[si]));
+        TRY(linear_wgrad(c, a.HID + r0 * 16, 16, a.gX0 + r0 * 8, 8, n, 16, 8, c.L.m2_w[si], 1, 16, c.L.m2_b[si]));
         TRY(linear(c, a.gX0 + r0 * 8, 8, n, P + c.L.m2_w[si], 16, 1, nullptr, 8, 16, nullptr, 0, a.HID + r0 * 16, 16,
                    a.gHID + r0 * 16, 16, LINR_RELU_MASK));
-        // weight grad of Linear(15,16); the per-scale column sums of gHID feed both its bias and the embedding row
-        TRY(linr_hip_rc(hipMemsetAsync(a.tmp16, 0, 16 * sizeof(float), c.s)));
-        TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, G + c.L.m0_w[si], 1, 15, a.tmp16));
-        sce_emb_grad_k<<<1, LINR_WAVE, 0, c.s>>>(a.tmp16, P + c.L.m0_w[si], G + c.L.m0_b[si], G + c.L.emb + si * 8);
+        TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, c.L.m0_w[si], 1, 15, c.L.m0_b[si]));
+    }
+    // one pass sums every parameter's per-block partials in fixed order
+    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
+    for (int s = 0; s < f->n_scales; ++s) {
+        if (f->row_off_h[s + 1] == f->row_off_h[s]) continue;
+        const int si = f->scale_idx_h[s];
+        sce_emb_grad_k<<<1, LINR_WAVE, 0, c.s>>>(a.GSUM + c.L.m0_b[si], P + c.L.m0_w[si], a.GSUM + c.L.emb + si * 8);
     }
     return linr_launch_rc();
+}
+
+extern "C" int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes, float gscale,
+                                 float* grads, void* stream) {
+    Ctx c;
+    TRY(check_frame(f, params, arena, arena_bytes, c));
+    if (!grads) return LINR_EINVAL;
+    c.s = (hipStream_t)stream;
+    if (c.R == 0) return 0;
+    TRY(backward_core(c, gscale));
+    axpy_k<<<linr_grid(c.L.total, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(c.A.GSUM, c.L.total, grads, 1);
+    return linr_launch_rc();
+}
+
+extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
+                                   float* exp_avg, float* exp_avg_sq, double step_size, double bc2_sqrt, double beta1,
+                                   double beta2, double eps, double weight_decay, double* bits_acc, void* stream) {
+    if (!exp_avg || !exp_avg_sq || !bits_acc) return LINR_EINVAL;
+    TRY(linr_net_forward(f, params, arena, arena_bytes, 0, 8, nullptr, bits_acc, stream));
+    Ctx c;
+    TRY(check_frame(f, params, arena, arena_bytes, c));
+    c.s = (hipStream_t)stream;
+    if (c.R == 0) return 0;
+    TRY(backward_core(c, gscale));
+    return linr_adam_step(params, c.A.GSUM, exp_avg, exp_avg_sq, c.L.total, step_size, bc2_sqrt, beta1, beta2, eps,
+                          weight_decay, stream);
 }

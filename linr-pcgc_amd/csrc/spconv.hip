@@ -261,58 +261,81 @@ __global__ __launch_bounds__(LINR_BLOCK) void slab_reduce_k(const float* __restr
     *d = (flags & LINR_ACCUM) ? *d + s : s;
 }
 
-// ---- v2 backward-weight: no LDS staging --------------------------------------------------------------------------
-// gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  One WAVE owns one row r at a time: lane (k, q) gathers the
-// 4-channel quad q of the k-th neighbour's feature row (16 B), the row's output gradient g[r][0..COUT) is
-// wave-uniform (scalar loads -> SGPR operands), so a lane does 4*COUT FMAs per 2 vector loads and keeps its
-// 4 x COUT accumulators in registers over all rows the wave visits.  Lane 27*XQ is the bias lane (x = (1,0,0,0)).
-// Waves of a block take rows round-robin; the block folds its waves through LDS in wave order and writes one slab.
-#define BW2_WAVES 8
-template <int XQ, int COUT, bool PAD>
-__global__ __launch_bounds__(BW2_WAVES * 64) void spconv_bwd_weight2_k(
+// ---- backward-weight v3: no LDS staging, wave-per-row-group ---------------------------------------------------------
+// gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  One WAVE owns a group of 8 consecutive rows at a time: lane
+// (k, q) gathers the 4-channel quad q of the k-th neighbour's feature row (16 B) for all 8 rows up front (8 gathers in
+// flight), the rows' output gradients g[r][0..COUT) are wave-uniform (scalar loads -> SGPR operands), so a lane does
+// 4*COUT FMAs per vector load and keeps its 4 x COUT accumulators in registers over all rows the wave visits.
+// Lane 27*XQ is the bias lane (x = (1,0,0,0)).  A block owns a contiguous row range, folds its waves through LDS in
+// wave order and writes ONE partial per destination element; partials of all blocks are summed later in fixed order
+// (deterministic; no float atomics).
+#define WG_WAVES 8
+template <int XQ, int COUT, bool PAD, bool VIDX>
+__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_k(
     const float* __restrict__ in, int in_ld, const float* __restrict__ gout, int gout_ld,
-    const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n, int cin_valid, float* __restrict__ slab) {
+    const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n, LinrWgradDst d) {
     constexpr int CIN = 4 * XQ;
     constexpr int NI = 27 * XQ;
     constexpr int NA = 4 * COUT;
     __shared__ float sacc[64 * (NA + 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = lane / XQ, q = lane % XQ;
-    const bool gather = lane < NI;
+    const int kk = lane / XQ, q = lane % XQ;
+    const int k = kk < 27 ? kk : 26;
+    const bool live = lane < NI;
     const bool biasl = lane == NI;
     float acc[4][COUT];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[c][o] = 0.0f;
-    // contiguous row range per block, rows dealt round-robin to its waves
-    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 7) & ~(int64_t)7;                       // 8-row groups never straddle blocks
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const int32_t* nk = nbr + (int64_t)(gather ? k : 0) * nbr_ld;
-#pragma unroll 4
-    for (int64_t r = b0 + wave; r < b1; r += BW2_WAVES) {
-        float g[COUT];
-        const float* gp = gout + r * gout_ld;            // r is wave-uniform: scalar loads
+    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
+    for (int64_t g0 = b0 + 8 * wave; g0 < b1; g0 += 8 * WG_WAVES) {
+        int32_t idx[8];
+        if (VIDX && g0 + 8 <= n) {
+            const int4 a = *reinterpret_cast<const int4*>(nk + g0);
+            const int4 b = *reinterpret_cast<const int4*>(nk + g0 + 4);
+            idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
+            idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+        } else {
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) g[o] = gp[o];
-        float4 x = make_float4(biasl ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
-        if (gather) {
-            const int32_t j = nk[r];
-            if (PAD || j >= 0) x = *reinterpret_cast<const float4*>(in + (int64_t)j * in_ld + 4 * q);
+            for (int u = 0; u < 8; ++u) idx[u] = (g0 + u < n) ? nk[g0 + u] : -1;
+        }
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (PAD) {
+                x[u] = *reinterpret_cast<const float4*>(in + (int64_t)idx[u] * in_ld + 4 * q);
+            } else {
+                x[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx[u] >= 0) x[u] = *reinterpret_cast<const float4*>(in + (int64_t)idx[u] * in_ld + 4 * q);
+            }
+            if (biasl) x[u] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) {
-            acc[0][o] = fmaf(x.x, g[o], acc[0][o]);
-            acc[1][o] = fmaf(x.y, g[o], acc[1][o]);
-            acc[2][o] = fmaf(x.z, g[o], acc[2][o]);
-            acc[3][o] = fmaf(x.w, g[o], acc[3][o]);
+        for (int u = 0; u < 8; ++u) {
+            if (g0 + u < n) {                             // wave-uniform
+                const float* gp = gout + (g0 + u) * gout_ld;
+                float g[COUT];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) g[o] = gp[o];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    acc[0][o] = fmaf(x[u].x, g[o], acc[0][o]);
+                    acc[1][o] = fmaf(x[u].y, g[o], acc[1][o]);
+                    acc[2][o] = fmaf(x[u].z, g[o], acc[2][o]);
+                    acc[3][o] = fmaf(x[u].w, g[o], acc[3][o]);
+                }
+            }
         }
     }
     // fold waves in wave order (fixed => reproducible)
     float* mine = sacc + lane * (NA + 1);
-    for (int w = 0; w < BW2_WAVES; ++w) {
+    for (int w = 0; w < WG_WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -325,56 +348,58 @@ __global__ __launch_bounds__(BW2_WAVES * 64) void spconv_bwd_weight2_k(
         __syncthreads();
     }
     if (wave == 0) {
-        float* dst = slab + (int64_t)blockIdx.x * ((27 * CIN + 1) * COUT);
-        if (gather) {
+        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+        if (live) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c) {
+                const int ci = 4 * q + c;
+                if (ci < d.cin_valid) {
 #pragma unroll
-                for (int o = 0; o < COUT; ++o) dst[(k * CIN + 4 * q + c) * COUT + o] = mine[c * COUT + o];
+                    for (int o = 0; o < COUT; ++o) dst[d.w_off + (kk * d.cin_valid + ci) * COUT + o] = mine[c * COUT + o];
+                }
+            }
         } else if (biasl) {
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) dst[27 * CIN * COUT + o] = mine[o];
+            for (int o = 0; o < COUT; ++o) dst[d.b_off + o] = mine[o];
         }
     }
-    (void)cin_valid;
 }
 
-// slab [nb][27*8+1][8] -> gW[27][cin][8] for cin < 8 (the 8-wide kernel ran on a zero-extended view of the input)
-__global__ __launch_bounds__(LINR_BLOCK) void slab_reduce_narrow_k(const float* __restrict__ slab, int nblocks, int cin,
-                                                                   float* __restrict__ gW, float* __restrict__ gb,
-                                                                   unsigned flags) {
-    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;      // element of the narrow result [(27*cin+1)*8]
-    const int elems = (27 * cin + 1) * 8;
-    if (e >= elems) return;
-    const int o = e % 8, pc = e / 8;
-    const int wide = (pc < 27 * cin) ? ((pc / cin) * 8 + (pc % cin)) * 8 + o : 27 * 64 + o;
-    const int welems = (27 * 8 + 1) * 8;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += slab[(int64_t)(b + 0) * welems + wide];
-        s1 += slab[(int64_t)(b + 1) * welems + wide];
-        s2 += slab[(int64_t)(b + 2) * welems + wide];
-        s3 += slab[(int64_t)(b + 3) * welems + wide];
-    }
-    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * welems + wide];
-    const float s = (s0 + s1) + (s2 + s3);
-    float* d = (pc < 27 * cin) ? (gW ? gW + e : nullptr) : (gb ? gb + o : nullptr);
-    if (d == nullptr) return;
-    *d = (flags & LINR_ACCUM) ? *d + s : s;
+// internal: partial weight gradients of one conv3 into `d` (every one of `nblocks` blocks writes its partial).
+// cin < 8 with cout == 8 runs the 8-wide kernel on the zero-extended 8-float row and drops channels >= cin.
+int linr_conv3_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr,
+                             int64_t nbr_ld, int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, unsigned flags,
+                             hipStream_t s) {
+    const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+    const bool pad = (flags & LINR_PAD_ROW) != 0;
+    d.cin_valid = cin;
+#define LINR_GO(XQ, CO)                                                                                                  \
+    do {                                                                                                                 \
+        if (pad && vidx) spconv_wgrad_k<XQ, CO, true, true><<<nblocks, WG_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, d);        \
+        else if (pad) spconv_wgrad_k<XQ, CO, true, false><<<nblocks, WG_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, d);          \
+        else if (vidx) spconv_wgrad_k<XQ, CO, false, true><<<nblocks, WG_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, d);         \
+        else spconv_wgrad_k<XQ, CO, false, false><<<nblocks, WG_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, d);                  \
+        return linr_launch_rc();                                                                                         \
+    } while (0)
+    if (cin == 8 && cout == 8) LINR_GO(2, 8);
+    if (cin == 8 && cout == 4) LINR_GO(2, 4);
+    if (cin == 4 && cout == 4) LINR_GO(1, 4);
+    if (cin < 8 && cout == 8 && in_ld >= 8) LINR_GO(2, 8);
+#undef LINR_GO
+    return LINR_EINVAL;
 }
 
-static int bw2_blocks(int64_t n) {
+static int wg_blocks(int64_t n) {
     int64_t nb = (n + 63) / 64;            // at least ~64 rows per block
-    if (nb > 512) nb = 512;               // 2 blocks x 8 waves per CU
+    if (nb > LINR_WG_BLOCKS) nb = LINR_WG_BLOCKS;
     return (int)(nb < 1 ? 1 : nb);
 }
 
 extern "C" size_t linr_spconv_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout) {
     if (n <= 0) return 0;
     const size_t v1 = (size_t)linr_reduce_blocks(n, BW_TILE) * (27 * cin + 1) * cout * sizeof(float);
-    const size_t v2 = (size_t)bw2_blocks(n) * (27 * 8 + 1) * 8 * sizeof(float);
-    return v1 > v2 ? v1 : v2;
+    const size_t v3 = (size_t)wg_blocks(n) * (27 * cin + 1) * cout * sizeof(float);
+    return v1 > v3 ? v1 : v3;
 }
 
 template <int CIN, int COUT>
@@ -388,25 +413,6 @@ static int launch_bwd_weight(const float* in, int in_ld, const float* gout, int 
     return linr_launch_rc();
 }
 
-template <int XQ, int COUT>
-static int launch_bwd_weight2(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr,
-                              int64_t nbr_ld, int64_t n, int cin, float* gW, float* gb, unsigned flags, float* slab,
-                              hipStream_t s) {
-    const int nb = bw2_blocks(n);
-    if (flags & LINR_PAD_ROW)
-        spconv_bwd_weight2_k<XQ, COUT, true><<<nb, BW2_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, slab);
-    else
-        spconv_bwd_weight2_k<XQ, COUT, false><<<nb, BW2_WAVES * 64, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, slab);
-    if (cin == 4 * XQ) {
-        const int elems = (27 * cin + 1) * COUT;
-        slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, elems, 27 * cin * COUT, gW, gb, flags);
-    } else {
-        const int elems = (27 * cin + 1) * 8;
-        slab_reduce_narrow_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, cin, gW, gb, flags);
-    }
-    return linr_launch_rc();
-}
-
 extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld,
                                       const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t cin, int32_t cout,
                                       float* gW, float* gb, uint32_t flags, void* ws, size_t ws_bytes, void* stream) {
@@ -416,13 +422,17 @@ extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const floa
     if (ws_bytes < linr_spconv_bwd_weight_workspace_bytes(n, cin, cout)) return LINR_ENOSPC;
     if (((uintptr_t)ws) & 3u) return LINR_EALIGN;
     hipStream_t s = (hipStream_t)stream;
-    // fast path: 16-byte gathers of channel quads (cin < 8 -> the 8-wide kernel on the full 8-float row, extra
-    // channels discarded by the reduction), needs aligned rows of at least 4*XQ floats
+    // fast path (v3): 16-byte gathers of channel quads; needs 16-byte aligned rows (cin < 8: full 8-float rows)
     const bool vec = linr_aligned16(in) && (in_ld % 4 == 0);
-    if (vec && cin == 8 && cout == 8) return launch_bwd_weight2<2, 8>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 8, gW, gb, flags, (float*)ws, s);
-    if (vec && cin == 8 && cout == 4) return launch_bwd_weight2<2, 4>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 8, gW, gb, flags, (float*)ws, s);
-    if (vec && cin == 4 && cout == 4) return launch_bwd_weight2<1, 4>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, 4, gW, gb, flags, (float*)ws, s);
-    if (vec && cin < 8 && cout == 8 && in_ld >= 8) return launch_bwd_weight2<2, 8>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, gW, gb, flags, (float*)ws, s);
+    if (vec && ((cin == 8 && (cout == 8 || cout == 4)) || (cin == 4 && cout == 4) || (cin < 8 && cout == 8 && in_ld >= 8))) {
+        const int nb = wg_blocks(n);
+        const int elems = (27 * cin + 1) * cout;
+        LinrWgradDst d = {(float*)ws, elems, 0, 27 * cin * cout, cin};
+        int rc = linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, flags, s);
+        if (rc) return rc;
+        slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, elems, 27 * cin * cout, gW, gb, flags);
+        return linr_launch_rc();
+    }
 #define LINR_BW_CASE(CI, CO) \
     if (cin == CI && cout == CO) return launch_bwd_weight<CI, CO>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, gW, gb, flags, (float*)ws, s);
     LINR_BW_CASE(8, 8) LINR_BW_CASE(8, 4) LINR_BW_CASE(4, 4)

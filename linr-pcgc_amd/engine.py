@@ -32,7 +32,8 @@ class Frame:
         self.scale_idx = np.asarray([int(s['scale_idx']) for s in scales], dtype=np.int32)
         self.n_scales = len(scales)
         R = self.rows
-        self.nbr = torch.empty((27, R), dtype=torch.int32, device=device)
+        self.nbr_ld = (R + 63) // 64 * 64          # padded leading dimension: 16-byte aligned index rows
+        self.nbr = torch.empty((27, self.nbr_ld), dtype=torch.int32, device=device)
         self.offset_feat = torch.empty((R, 7), dtype=torch.float32, device=device)
         self.occ = torch.zeros((R, 8), dtype=torch.float32, device=device)
         for i, s in enumerate(scales):
@@ -50,7 +51,7 @@ class Frame:
             self.alloc_arena()
         self._c = _lib.LinrFrame(rows=R, n_scales=self.n_scales, model_scale_num=self.model_scale_num,
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
-                                 nbr=self.nbr.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
+                                 nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, offset_feat=self.offset_feat.data_ptr(),
                                  occ=self.occ.data_ptr())
 
     def alloc_arena(self):
@@ -81,3 +82,15 @@ def net_backward(frame, flat_params, flat_grads, gscale, arena=None):
     arena = frame.arena if arena is None else arena
     check(_lib.lib().linr_net_backward(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(), float(gscale),
                                        flat_grads.data_ptr(), _stream()), 'linr_net_backward')
+
+
+def net_train_step(frame, flat_params, exp_avg, exp_avg_sq, gscale, step, lr, beta1, beta2, eps, weight_decay, bits,
+                   arena=None):
+    """linr_net_train_step: forward + backward + deterministic gradient reduction + fused Adam in one call."""
+    arena = frame.arena if arena is None else arena
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    check(_lib.lib().linr_net_train_step(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(),
+                                         float(gscale), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), lr / bc1, bc2_sqrt,
+                                         beta1, beta2, eps, weight_decay, bits.data_ptr(), _stream()),
+          'linr_net_train_step')

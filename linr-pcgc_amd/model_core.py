@@ -299,11 +299,11 @@ class FlatAdam:
 
 def train_step(model, opt, frame, point_num):
     """One iteration of main.py:305-321 on a batched frame: bits -> loss = bits/point_num -> backward -> Adam ->
-    StepLR.  Returns the device-resident bits accumulator (float64[1]); nothing synchronises with the host."""
+    StepLR, as ONE C-ABI call (linr_net_train_step).  Returns the device-resident bits accumulator (float64[1]);
+    nothing synchronises with the host."""
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
-    engine.net_forward(frame, model.flat_parameters(), 0, 8, None, bits)
-    opt.zero_grad()
-    engine.net_backward(frame, model.flat_parameters(), opt.grad, 1.0 / float(point_num))
-    opt.step()
+    opt.t += 1
+    engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), opt.t,
+                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits)
     opt.scheduler_step()
     return bits
