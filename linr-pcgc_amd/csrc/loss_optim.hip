@@ -35,11 +35,19 @@ __global__ __launch_bounds__(LINR_BLOCK) void bce_bits_fwd_k(const float* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = sred[0];
 }
 
-__global__ void bce_bits_finish_k(const double* __restrict__ partial, int nblocks, double* __restrict__ bits_acc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one block; thread t sums partials t, t+256, ... then a fixed LDS tree: the association is fixed => bit-reproducible
+__global__ __launch_bounds__(LINR_BLOCK) void bce_bits_finish_k(const double* __restrict__ partial, int nblocks,
+                                                                double* __restrict__ bits_acc) {
+    __shared__ double sred[LINR_BLOCK];
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b];
-    *bits_acc += s * 1.4426950408889634;   // 1 / ln 2
+    for (int b = threadIdx.x; b < nblocks; b += LINR_BLOCK) s += partial[b];
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = LINR_BLOCK / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sred[threadIdx.x] += sred[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *bits_acc += sred[0] * 1.4426950408889634;   // 1 / ln 2
 }
 
 // torch: binary_cross_entropy_backward  g_p = g * (p - t) / max((1-p)*p, 1e-12), then sigmoid backward * p*(1-p)
@@ -68,7 +76,7 @@ extern "C" int linr_bce_bits_fwd(const float* z, const float* target, int32_t ta
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)linr_grid(n, BCE_ROWS_PER_BLOCK);
     bce_bits_fwd_k<<<nb, LINR_BLOCK, 0, s>>>(z, target, target_ld, n, p, (double*)ws);
-    bce_bits_finish_k<<<1, LINR_WAVE, 0, s>>>((const double*)ws, nb, bits_acc);
+    bce_bits_finish_k<<<1, LINR_BLOCK, 0, s>>>((const double*)ws, nb, bits_acc);
     return linr_launch_rc();
 }
 
