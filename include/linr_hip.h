@@ -54,6 +54,11 @@ LINR_API int64_t linr_param_count(int32_t scale_num);
 LINR_API size_t linr_kmap_workspace_bytes(int64_t n);
 LINR_API int linr_kmap_build(const int32_t* coords, int64_t n, int32_t* nbr, int64_t ld, int64_t row_base,
                     void* ws, size_t ws_bytes, void* stream);
+/* Compressed form of the same map for x-major sorted coordinates: the dz = -1,0,+1 neighbours of a (dx,dy) column are
+ * consecutive rows, so lo[q*ld + j] = row of the first present neighbour of column q = (dx+1)+3(dy+1) and bit
+ * q*3 + (dz+1) of mask[j] says which are present: 40 B/row instead of 108.  Rows of nbr must hold global row ids. */
+LINR_API int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t* lo, uint32_t* mask, int64_t ld,
+                       void* stream);
 /* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
 LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
 
@@ -126,6 +131,8 @@ typedef struct linr_frame {
     const int32_t* scale_idx_h;   /* HOST [n_scales]  which scale embedding / scale MLP each scale uses     */
     const int32_t* nbr;           /* [27][nbr_ld] kernel map with global row ids                            */
     int64_t nbr_ld;               /* leading dimension of nbr (>= rows; a multiple of 4 enables 16-byte index loads) */
+    const int32_t* nbr_lo;        /* [9][nbr_ld]  compressed kernel map (linr_kmap_compress), or NULL            */
+    const uint32_t* nbr_mask;     /* [nbr_ld]     27-bit presence masks of the compressed map, or NULL           */
     const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
 } linr_frame;

@@ -18,7 +18,8 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 class LinrFrame(ctypes.Structure):
     """struct linr_frame (include/linr_hip.h)."""
     _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('row_off_h', c_ptr),
-                ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('offset_feat', c_ptr), ('occ', c_ptr)]
+                ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('nbr_lo', c_ptr), ('nbr_mask', c_ptr),
+                ('offset_feat', c_ptr), ('occ', c_ptr)]
 
 
 _PROTOS = {
@@ -27,6 +28,7 @@ _PROTOS = {
     'linr_kmap_workspace_bytes': (c_size, [c_i64]),
     'linr_kmap_build': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    'linr_kmap_compress': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'linr_spconv_fwd': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32,
                                        c_ptr, c_i32, c_u32, c_ptr]),
     'linr_spconv_bwd_data': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_i32,

@@ -56,3 +56,7 @@ int linr_conv3_wgrad_partial(const float* in, int in_ld, const float* gout, int 
 __attribute__((visibility("hidden")))
 int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
                               LinrLinDst d, int nblocks, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                      int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
+                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s);

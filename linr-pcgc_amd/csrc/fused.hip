@@ -1,0 +1,244 @@
+// Executor-only kernels on the COMPRESSED kernel map (csrc/net.hip is their only caller).
+//
+// Compressed kernel map: the coordinate list is sorted x-major, so the up-to-three dz = -1,0,+1 neighbours of one
+// (dx,dy) column are consecutive rows.  Per row: lo[q] = row of the first present neighbour of column q = (dx+1)+3(dy+1)
+// (9 x int32) + a 27-bit presence mask = 40 B instead of 27 x int32 = 108 B.  The 36 MB table of a loot-like frame
+// becomes 13.5 MB, i.e. one XCD's share (1.7 MB) stays L2-resident across the ~140 conv passes of a training step.
+#include "common.h"
+#include <stdlib.h>
+
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_compress_k(const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n,
+                                                              int32_t* __restrict__ lo, uint32_t* __restrict__ mask,
+                                                              int64_t ld) {
+    const int64_t row = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (row >= n) return;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int32_t a = nbr[(int64_t)q * nbr_ld + row];
+        const int32_t b = nbr[(int64_t)(q + 9) * nbr_ld + row];
+        const int32_t c = nbr[(int64_t)(q + 18) * nbr_ld + row];
+        const uint32_t m3 = (a >= 0 ? 1u : 0u) | (b >= 0 ? 2u : 0u) | (c >= 0 ? 4u : 0u);
+        lo[(int64_t)q * ld + row] = a >= 0 ? a : (b >= 0 ? b : (c >= 0 ? c : 0));
+        m |= m3 << (3 * q);
+    }
+    mask[row] = m;
+}
+
+extern "C" int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t* lo, uint32_t* mask, int64_t ld,
+                                  void* stream) {
+    if (n < 0 || nbr_ld < n || ld < n) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!nbr || !lo || !mask) return LINR_EINVAL;
+    kmap_compress_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, nbr_ld, n, lo, mask, ld);
+    return linr_launch_rc();
+}
+
+// byte offsets (from the pad row) of the 27 neighbours of `row`; absent -> 0 (the pad row itself)
+template <bool BWD>
+__device__ __forceinline__ void decode_offsets(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
+                                               int64_t ld, int64_t row, uint32_t rowbytes, uint32_t (&off)[27]) {
+    const uint32_t m = mask[row];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const uint32_t base = (uint32_t)lo[(int64_t)q * ld + row] + 1u;     // +1: row index -> offset from the pad row
+        const uint32_t b0 = (m >> (3 * q)) & 1u, b1 = (m >> (3 * q + 1)) & 1u, b2 = (m >> (3 * q + 2)) & 1u;
+        const uint32_t o0 = b0 ? base * rowbytes : 0u;
+        const uint32_t o1 = b1 ? (base + b0) * rowbytes : 0u;
+        const uint32_t o2 = b2 ? (base + b0 + b1) * rowbytes : 0u;
+        // forward uses offset k, backward-data the mirrored offset 26-k  (k = q + 9*dz)
+        if (!BWD) { off[q] = o0; off[q + 9] = o1; off[q + 18] = o2; }
+        else      { off[26 - q] = o0; off[26 - (q + 9)] = o1; off[26 - (q + 18)] = o2; }
+    }
+}
+
+template <int W> struct RowLoadF {
+    static __device__ __forceinline__ void run(const char* __restrict__ p, float* x) {
+#pragma unroll
+        for (int v = 0; v < W / 4; ++v) {
+            const float4 t = *reinterpret_cast<const float4*>(p + 16 * v);
+            x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+        }
+    }
+};
+
+// Plain conv3 forward / backward-data on the compressed map.  Same arithmetic order as spconv_gather_k (k ascending,
+// gathered channel ascending) => bit-identical results.  `in` must have the zero pad row at index -1.
+//   BWD == false: acc[o] += x[i] * W[(k*GIN + i)*GOUT + o]
+//   BWD == true : acc[o] += x[i] * W[(k*GOUT + o)*GIN + i]   (gathered rows come from the mirrored offset)
+template <int GIN, int GOUT, bool BWD, int LOADW>
+__global__ __launch_bounds__(LINR_BLOCK) void cconv_k(const float* __restrict__ in, int in_ld,
+                                                      const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
+                                                      int64_t ld, int64_t n, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      int res_ld, const float* __restrict__ act, int act_ld,
+                                                      float* __restrict__ out, int out_ld, unsigned flags) {
+    const int64_t row = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (row >= n) return;
+    const char* pad = reinterpret_cast<const char*>(in - in_ld);
+    uint32_t off[27];
+    decode_offsets<BWD>(lo, mask, ld, row, (uint32_t)in_ld * 4u, off);
+    float acc[GOUT];
+#pragma unroll
+    for (int o = 0; o < GOUT; ++o) acc[o] = (bias != nullptr) ? bias[o] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        float x[LOADW];
+        RowLoadF<LOADW>::run(pad + off[k], x);
+        const float* __restrict__ wk = W + k * GIN * GOUT;
+#pragma unroll
+        for (int i = 0; i < GIN; ++i) {
+#pragma unroll
+            for (int o = 0; o < GOUT; ++o) {
+                const float w = BWD ? wk[o * GIN + i] : wk[i * GOUT + o];
+                acc[o] = fmaf(x[i], w, acc[o]);
+            }
+        }
+    }
+    // epilogue order: + res, + old (ACCUM), * mask, ReLU
+    if (res != nullptr) {
+        const float* r = res + row * res_ld;
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) acc[o] += r[o];
+    }
+    float* op = out + row * out_ld;
+    if (flags & LINR_ACCUM) {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) acc[o] += op[o];
+    }
+    if (flags & LINR_RELU_MASK) {
+        const float* a = act + row * act_ld;
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) acc[o] = a[o] > 0.0f ? acc[o] : 0.0f;
+    }
+    if (flags & LINR_RELU) {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) acc[o] = fmaxf(acc[o], 0.0f);
+    }
+    if ((GOUT % 4 == 0) && (out_ld % 4 == 0)) {
+#pragma unroll
+        for (int v = 0; v < GOUT / 4; ++v)
+            *reinterpret_cast<float4*>(op + 4 * v) = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+    } else {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) op[o] = acc[o];
+    }
+}
+
+// ---- the same convolution on the matrix cores ----------------------------------------------------------------------------
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4 outer products (K = 1); with CBSZ = 4 the A operand of block ABID is
+// broadcast to all 16 blocks, so ONE instruction computes, for all 64 lanes at once,
+//        acc[row(lane)][4*ABID + i] += W[ci][4*ABID + i] * x[row(lane)][ci]        i = 0..3
+// i.e. 64 rows x 4 output channels x 1 input channel = 256 FMAs with NO padding (the 16-wide MFMA shapes waste half
+// of their N dimension at Cout = 8).  The lane keeps the thread-per-row layout of the VALU kernel: B = the lane's
+// gathered feature x[ci], D = the lane's 4 accumulators, A = the weight row held by lanes 0..GOUT-1 (read from an LDS
+// copy of the whole [27][Cin][Cout] kernel).  K = 1 makes every instruction a single-rounding fmaf(x, w, acc), issued
+// in the same order as the VALU kernel (k ascending, ci ascending) => bit-identical results, at the MFMA rate
+// (measured 91-119 TFLOP/s for this stream vs 52-71 TFLOP/s for v_pk_fma_f32; tools/mfma_probe.hip, valu_probe.hip).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Measured dead ends for this kernel (kept out of the tree): hand-pinned software pipelines
+// (2-3 offsets ahead, or a whole dz-plane of gathers in flight) and wave-cooperative staging of each (dx,dy) column's
+// contiguous neighbour range through LDS were all slower than the compiler's own interleaving below.
+template <int GIN, int GOUT, bool BWD, int LOADW>
+__global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
+                                                           const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
+                                                           int64_t ld, int64_t n, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ res,
+                                                           int res_ld, const float* __restrict__ act, int act_ld,
+                                                           float* __restrict__ out, int out_ld, unsigned flags) {
+    static_assert(GOUT == 4 || GOUT == 8, "output channels must fill 1 or 2 MFMA blocks");
+    __shared__ float sW[27 * GIN * GOUT];
+    for (int t = threadIdx.x; t < 27 * GIN * GOUT; t += LINR_BLOCK) sW[t] = W[t];
+    const int lane = threadIdx.x & 63;
+    const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    const bool live = row_raw < n;
+    const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
+    const char* pad = reinterpret_cast<const char*>(in - in_ld);
+    uint32_t off[27];
+    decode_offsets<BWD>(lo, mask, ld, row, (uint32_t)in_ld * 4u, off);
+    f32x4 acc[GOUT / 4];
+#pragma unroll
+    for (int h = 0; h < GOUT / 4; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = (bias != nullptr) ? bias[4 * h + j] : 0.0f;
+    // lane c < GOUT supplies weight(input i, output c); other lanes' A values are never read
+    const int c = lane < GOUT ? lane : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        float x[LOADW];
+        RowLoadF<LOADW>::run(pad + off[k], x);
+        float w[GIN];
+#pragma unroll
+        for (int i = 0; i < GIN; ++i) w[i] = BWD ? sW[(k * GOUT + c) * GIN + i] : sW[(k * GIN + i) * GOUT + c];
+#pragma unroll
+        for (int i = 0; i < GIN; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc[0], 4, 0, 0);
+            if (GOUT == 8) acc[GOUT / 4 - 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc[GOUT / 4 - 1], 4, 1, 0);
+        }
+    }
+    if (!live) return;
+    float a[GOUT];
+#pragma unroll
+    for (int h = 0; h < GOUT / 4; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[4 * h + j] = acc[h][j];
+    // epilogue order: + res, + old (ACCUM), * mask, ReLU
+    if (res != nullptr) {
+        const float* r = res + row * res_ld;
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) a[o] += r[o];
+    }
+    float* op = out + row * out_ld;
+    if (flags & LINR_ACCUM) {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) a[o] += op[o];
+    }
+    if (flags & LINR_RELU_MASK) {
+        const float* m = act + row * act_ld;
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) a[o] = m[o] > 0.0f ? a[o] : 0.0f;
+    }
+    if (flags & LINR_RELU) {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) a[o] = fmaxf(a[o], 0.0f);
+    }
+    if (out_ld % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < GOUT / 4; ++v)
+            *reinterpret_cast<float4*>(op + 4 * v) = make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
+    } else {
+#pragma unroll
+        for (int o = 0; o < GOUT; ++o) op[o] = a[o];
+    }
+}
+
+// executor entry: all matrices are arena matrices (16-byte aligned rows, ld in {4, 8}, pad row present)
+int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                      int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
+                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s) {
+    if (n == 0) return 0;
+    const unsigned grid = linr_grid(n, LINR_BLOCK);
+    static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;
+#define GO(GI, GO_, B, LW)                                                                                              \
+    do {                                                                                                                \
+        if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                         \
+            cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_BLOCK, 0, s>>>(                       \
+                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags);                     \
+        else                                                                                                            \
+            cconv_k<GI, GO_, B, LW><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act,   \
+                                                                act_ld, out, out_ld, flags);                            \
+        return linr_launch_rc();                                                                                        \
+    } while (0)
+#define CASE(CI, CO)                                                      \
+    if (cin == CI && cout == CO) {                                        \
+        if (!bwd) GO(CI, CO, false, ((CI + 3) / 4 * 4));                  \
+        else GO(CO, CI, true, ((CO + 3) / 4 * 4));                        \
+    }
+    CASE(8, 8) CASE(8, 4) CASE(4, 4)
+    CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(5, 8) CASE(6, 8) CASE(7, 8)
+#undef CASE
+#undef GO
+    return LINR_EINVAL;
+}

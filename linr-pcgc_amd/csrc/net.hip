@@ -208,6 +208,9 @@ struct Ctx {
 
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
+    if (c.f->nbr_lo && c.f->nbr_mask)
+        return linr_cconv_launch(bwd, in, in_ld, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld,
+                                 act, act_ld, out, out_ld, flags, c.s);
     return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
                              flags | LINR_PAD_ROW, c.s);
 }

@@ -11,6 +11,7 @@
 //                    keeps its COUT accumulators in registers across all of its tiles, block partials go to a
 //                    slab and a second kernel sums the slabs in fixed order (deterministic, no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 template <int W> struct RowLoad {
     static __device__ __forceinline__ void run(const float* __restrict__ p, float* x) {
@@ -30,7 +31,7 @@ template <int W> struct RowLoad {
 //      needs neither a branch nor a select: the 27 index loads and 27 row gathers are straight-line code the
 //      scheduler can keep in flight together.  Adding fmaf(0, w, acc) leaves acc bit-identical, so PAD and
 //      non-PAD builds give the same bits (w is finite).
-template <int GIN, int GOUT, bool BWD, int LOADW, bool PAD>
+template <int GIN, int GOUT, bool BWD, int LOADW, bool PAD, bool WFIXED = false>
 __global__ __launch_bounds__(LINR_BLOCK) void spconv_gather_k(
     const float* __restrict__ in, int in_ld, const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ res, int res_ld,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void spconv_gather_k(
 #pragma unroll
                 for (int i = 0; i < GIN; ++i) x[i] = p[i];
             }
-            const float* __restrict__ wk = W + k * GIN * GOUT;
+            const float* __restrict__ wk = W + (WFIXED ? 0 : k * GIN * GOUT);   // WFIXED: timing experiment only
 #pragma unroll
             for (int i = 0; i < GIN; ++i) {
 #pragma unroll
@@ -109,7 +110,11 @@ static int launch_gather(const float* in, int in_ld, const int32_t* nbr, int64_t
 #define LINR_GO(LWV, PADV)                                                                                          \
     spconv_gather_k<GIN, GOUT, BWD, LWV, PADV><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, nbr, nbr_ld, n, W, bias, res,  \
                                                                            res_ld, act, act_ld, out, out_ld, flags)
-    if (vec && pad) LINR_GO(LW, true);
+    static const int wfixed = getenv("LINR_DEBUG_WFIXED") ? atoi(getenv("LINR_DEBUG_WFIXED")) : 0;
+    if (vec && pad && wfixed && GIN == 8 && GOUT == 8)
+        spconv_gather_k<GIN, GOUT, BWD, LW, true, true><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, nbr, nbr_ld, n, W, bias, res,
+                                                                                   res_ld, act, act_ld, out, out_ld, flags);
+    else if (vec && pad) LINR_GO(LW, true);
     else if (vec) LINR_GO(LW, false);
     else if (pad) LINR_GO(0, true);
     else LINR_GO(0, false);

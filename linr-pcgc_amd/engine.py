@@ -46,12 +46,18 @@ class Frame:
             elif 'occ_lst' in s and s['occ_lst'] is not None:
                 self.occ[r0:r1] = torch.cat([torch.as_tensor(o).reshape(-1, 1) for o in s['occ_lst']], dim=1).to(
                     device=device, dtype=torch.float32)
+        # compressed kernel map (9 column bases + 27-bit mask per row) used by the network executor
+        self.nbr_lo = torch.empty((9, self.nbr_ld), dtype=torch.int32, device=device)
+        self.nbr_mask = torch.empty((self.nbr_ld,), dtype=torch.int32, device=device)
+        check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
+                                            self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
         self.arena = None
         if with_arena:
             self.alloc_arena()
         self._c = _lib.LinrFrame(rows=R, n_scales=self.n_scales, model_scale_num=self.model_scale_num,
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
-                                 nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, offset_feat=self.offset_feat.data_ptr(),
+                                 nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
+                                 nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
                                  occ=self.occ.data_ptr())
 
     def alloc_arena(self):
