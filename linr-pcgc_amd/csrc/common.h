@@ -60,3 +60,15 @@ __attribute__((visibility("hidden")))
 int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
                       const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                           const float* W, const float* bias, float* c_out, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* target, int target_ld, float* p_out,
+                           double* partial, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
+                         const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
+                         int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
+                         hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s);

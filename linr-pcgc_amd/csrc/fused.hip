@@ -140,13 +140,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Measured dead ends for this kernel (kept out of the tree): hand-pinned software pipelines
 // (2-3 offsets ahead, or a whole dz-plane of gathers in flight) and wave-cooperative staging of each (dx,dy) column's
 // contiguous neighbour range through LDS were all slower than the compiler's own interleaving below.
-template <int GIN, int GOUT, bool BWD, int LOADW>
+// occupancy head fused behind the prune convolution (models/upsample.py:153-160 + models/model_core.py:76-81):
+// z = w2 . relu(W1 c + b1) + b2, p = sigmoid(z), bits partial of the block.  EPI == 1 selects it.
+struct HeadArgs {
+    const float* w1;      // [24][8]  inner_mlps.k.0.0.weight
+    const float* b1;      // [24]
+    const float* w2;      // [24]     inner_mlps.k.0.2.weight
+    const float* b2;      // [1]
+    const float* target;  // occupancy column (stride target_ld) or nullptr (decoder: probabilities only)
+    int target_ld;
+    float* p_out;         // [n]
+    double* partial;      // [gridDim.x] block partial sums of nats, or nullptr
+};
+
+template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0>
 __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
                                                            const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                            int64_t ld, int64_t n, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            int res_ld, const float* __restrict__ act, int act_ld,
-                                                           float* __restrict__ out, int out_ld, unsigned flags) {
+                                                           float* __restrict__ out, int out_ld, unsigned flags,
+                                                           HeadArgs hd = HeadArgs()) {
     static_assert(GOUT == 4 || GOUT == 8, "output channels must fill 1 or 2 MFMA blocks");
     __shared__ float sW[27 * GIN * GOUT];
     for (int t = threadIdx.x; t < 27 * GIN * GOUT; t += LINR_BLOCK) sW[t] = W[t];
@@ -178,12 +192,46 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
             if (GOUT == 8) acc[GOUT / 4 - 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc[GOUT / 4 - 1], 4, 1, 0);
         }
     }
-    if (!live) return;
     float a[GOUT];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[4 * h + j] = acc[h][j];
+    if constexpr (EPI == 1) {
+        // ---- fused occupancy head: the conv output row a[0..8) is C_k --------------------------------------------
+        float* op = out + row * out_ld;
+        if (live) {
+            *reinterpret_cast<float4*>(op) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(a[4], a[5], a[6], a[7]);
+        }
+        float z = hd.b2[0];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            float hj = hd.b1[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hj = fmaf(a[i], hd.w1[j * 8 + i], hj);
+            z = fmaf(fmaxf(hj, 0.0f), hd.w2[j], z);
+        }
+        const float p = 1.0f / (1.0f + expf(-z));
+        if (live) hd.p_out[row] = p;
+        if (hd.partial != nullptr) {          // wave-uniform (kernel argument)
+            __shared__ double sred[LINR_BLOCK];
+            double nats = 0.0;
+            if (live) {
+                const float t = hd.target[row * hd.target_ld];
+                nats = (double)((t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f));
+            }
+            sred[threadIdx.x] = nats;
+            __syncthreads();
+            for (int s2 = LINR_BLOCK / 2; s2 > 0; s2 >>= 1) {
+                if ((int)threadIdx.x < s2) sred[threadIdx.x] += sred[threadIdx.x + s2];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) hd.partial[blockIdx.x] = sred[0];
+        }
+        return;
+    } else {
+    if (!live) return;
     // epilogue order: + res, + old (ACCUM), * mask, ReLU
     if (res != nullptr) {
         const float* r = res + row * res_ld;
@@ -212,6 +260,137 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
 #pragma unroll
         for (int o = 0; o < GOUT; ++o) op[o] = a[o];
     }
+    }
+}
+
+// prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
+int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                           const float* W, const float* bias, float* c_out, const float* w1, const float* b1,
+                           const float* w2, const float* b2, const float* target, int target_ld, float* p_out,
+                           double* partial, hipStream_t s) {
+    if (n == 0) return 0;
+    HeadArgs hd = {w1, b1, w2, b2, target, target_ld, p_out, partial};
+    cconv_mfma_k<8, 8, false, 8, 1><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(in, 8, lo, mask, ld, n, W, bias, nullptr, 0,
+                                                                                   nullptr, 0, c_out, 8, 0, hd);
+    return linr_launch_rc();
+}
+
+// ---- fused backward of the occupancy head ------------------------------------------------------------------------------
+// Per row: recompute the hidden layer from C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]).  The weight gradients
+//   gW1[24][8] = sum_r gh[r] (x) c[r],  gb1 = sum_r gh[r],  gw2[24] = sum_r gz[r] h[r],  gb2 = sum_r gz[r]
+// are X^T G products with the row reduction as the K dimension of v_mfma_f32_16x16x4_f32: each wave transposes its
+// 64 rows of X = [gh | h] (48 cols) and G = [c | 1 | gz] (10 cols) through a wave-private LDS tile into fragment layout.
+// Persistent blocks (LINR_WG_BLOCKS) keep the 3 accumulator tiles in registers and emit one partial per parameter.
+#define HB_LDW 59          // 48 + 10 columns, odd stride
+struct HeadBwdArgs {
+    const float* c;  const float* p;  const float* target; int target_ld;
+    const float* w1; const float* b1; const float* w2;
+    float gscale;                     // d loss / d nats
+    float* gc;                        // [n][8]
+    float* big; int64_t block_stride; int64_t off_w1, off_b1, off_w2, off_b2;
+};
+
+__global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64_t n) {
+    __shared__ float sT[(LINR_BLOCK / 64) * 64 * HB_LDW];
+    __shared__ float sfold[64 * 13];
+    __shared__ float sgz[LINR_BLOCK / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mm = lane & 15, rr = lane >> 4;
+    float* T = sT + wave * 64 * HB_LDW;
+    f32x4 acc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) acc[a] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float gz_sum = 0.0f;
+    const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t row = t * LINR_BLOCK + threadIdx.x;
+        const bool live = row < n;
+        float c[8], gc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c[i] = 0.0f; gc[i] = 0.0f; }
+        float gz = 0.0f;
+        if (live) {
+            const float4 c0 = *reinterpret_cast<const float4*>(A.c + row * 8);
+            const float4 c1 = *reinterpret_cast<const float4*>(A.c + row * 8 + 4);
+            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+            const float pp = A.p[row], tt = A.target[row * A.target_ld];
+            const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
+            gz = gp * ((1.0f - pp) * pp);
+        }
+        float* Tr = T + lane * HB_LDW;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            float hj = A.b1[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hj = fmaf(c[i], A.w1[j * 8 + i], hj);
+            const float gh = (live && hj > 0.0f) ? gz * A.w2[j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gc[i] = fmaf(gh, A.w1[j * 8 + i], gc[i]);
+            Tr[j] = gh;
+            Tr[24 + j] = live ? fmaxf(hj, 0.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Tr[48 + i] = c[i];
+        Tr[56] = live ? 1.0f : 0.0f;
+        Tr[57] = gz;
+        gz_sum += gz;
+        if (live) {
+            *reinterpret_cast<float4*>(A.gc + row * 8) = make_float4(gc[0], gc[1], gc[2], gc[3]);
+            *reinterpret_cast<float4*>(A.gc + row * 8 + 4) = make_float4(gc[4], gc[5], gc[6], gc[7]);
+        }
+        // X^T G over this wave's 64 rows (wave-private tile: in-order LDS, no block barrier needed)
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float* Tq = T + (4 * s4 + rr) * HB_LDW;
+            const float b = (mm < 10) ? Tq[48 + mm] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tq[16 * a + mm], b, acc[a], 0, 0, 0);
+        }
+    }
+    // fold the 4 waves in wave order, then one partial per destination element
+    float* mine = sfold + lane * 13;
+    for (int w = 0; w < LINR_BLOCK / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[a * 4 + j] = (w == 0) ? acc[a][j] : mine[a * 4 + j] + acc[a][j];
+        }
+        __syncthreads();
+    }
+    // gb2: fixed-order wave reduction, then waves in order
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
+    if (lane == 0) sgz[wave] = gz_sum;
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = A.big + (int64_t)blockIdx.x * A.block_stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = 16 * a + rr * 4 + j;      // C/D map: row = (lane>>4)*4 + reg, col = lane&15
+                const float v = mine[a * 4 + j];
+                if (m < 24) {
+                    if (mm < 8) dst[A.off_w1 + m * 8 + mm] = v;
+                    else if (mm == 8) dst[A.off_b1 + m] = v;
+                } else if (mm == 9) {
+                    dst[A.off_w2 + (m - 24)] = v;
+                }
+            }
+        if (lane == 0) dst[A.off_b2] = ((sgz[0] + sgz[1]) + sgz[2]) + sgz[3];
+    }
+}
+
+int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
+                         const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
+                         int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
+                         hipStream_t s) {
+    if (n == 0) return 0;
+    HeadBwdArgs A = {c, p, target, target_ld, w1, b1, w2, gscale, gc, big, block_stride, off_w1, off_b1, off_w2, off_b2};
+    head_bwd_k<<<LINR_WG_BLOCKS, LINR_BLOCK, 0, s>>>(A, n);
+    return linr_launch_rc();
 }
 
 // executor entry: all matrices are arena matrices (16-byte aligned rows, ld in {4, 8}, pad row present)

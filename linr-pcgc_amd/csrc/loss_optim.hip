@@ -61,6 +61,11 @@ __global__ __launch_bounds__(LINR_BLOCK) void bce_bits_bwd_k(const float* __rest
     gz[row] = gp * ((1.0f - pp) * pp);
 }
 
+int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s) {
+    bce_bits_finish_k<<<1, LINR_BLOCK, 0, s>>>(partial, count, bits_acc);
+    return linr_launch_rc();
+}
+
 extern "C" size_t linr_bce_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
     return (size_t)linr_grid(n, BCE_ROWS_PER_BLOCK) * sizeof(double);

@@ -104,7 +104,10 @@ static float* arena_mat(Arena& a, int ld) {
     return p;
 }
 
-static size_t slab_need(int64_t rows) { return linr_bce_workspace_bytes(rows) + 64; }
+static size_t slab_need(int64_t rows) {
+    const size_t a = linr_bce_workspace_bytes(rows), b = (size_t)8 * linr_grid(rows, LINR_BLOCK) * sizeof(double);
+    return (a > b ? a : b) + 64;
+}
 
 static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
     a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
@@ -331,22 +334,36 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         }
         TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
     }
+    const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
+    bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
         // prior_k = x_glob + outter_blocks[k-1](occ[:, :k])   (upsample.py:206-214; always the original x_glob)
         if (k > 0) TRY(block_fwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.O[0]));
-        TRY(conv3(c, false, a.O[k], 8, P + c.L.pr_w[k], P + c.L.pr_b[k], 8, 8, nullptr, 0, nullptr, 0, a.C[k], 8, 0));
-        TRY(linear(c, a.C[k], 8, c.R, P + c.L.h0_w[k], 1, 8, P + c.L.h0_b[k], 8, 24, nullptr, 0, nullptr, 0, a.HH[k], 24,
-                   LINR_RELU));
-        TRY(linear(c, a.HH[k], 24, c.R, P + c.L.h2_w[k], 1, 24, P + c.L.h2_b[k], 24, 1, nullptr, 0, nullptr, 0, a.Z[k], 1, 0));
-        if (bits_acc) {
-            TRY(linr_bce_bits_fwd(a.Z[k], a.OCC + k, 8, c.R, a.P[k], bits_acc, a.slab, a.slab_bytes, c.s));
+        if (c.f->nbr_lo && c.f->nbr_mask) {
+            // prune conv + MLP + sigmoid + BCE partials in one launch (csrc/fused.hip)
+            double* part = bits_acc ? (double*)a.slab + (int64_t)k * nblk : nullptr;
+            TRY(linr_cconv_head_launch(a.O[k], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + c.L.pr_w[k], P + c.L.pr_b[k],
+                                       a.C[k], P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], P + c.L.h2_b[k],
+                                       a.OCC + k, 8, a.P[k], part, c.s));
+            if (bits_acc) fused_bits = true;
         } else {
-            sigmoid_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.Z[k], c.R, a.P[k]);
+            TRY(conv3(c, false, a.O[k], 8, P + c.L.pr_w[k], P + c.L.pr_b[k], 8, 8, nullptr, 0, nullptr, 0, a.C[k], 8, 0));
+            TRY(linear(c, a.C[k], 8, c.R, P + c.L.h0_w[k], 1, 8, P + c.L.h0_b[k], 8, 24, nullptr, 0, nullptr, 0, a.HH[k], 24,
+                       LINR_RELU));
+            TRY(linear(c, a.HH[k], 24, c.R, P + c.L.h2_w[k], 1, 24, P + c.L.h2_b[k], 24, 1, nullptr, 0, nullptr, 0, a.Z[k], 1, 0));
+            if (bits_acc) {
+                TRY(linr_bce_bits_fwd(a.Z[k], a.OCC + k, 8, c.R, a.P[k], bits_acc, a.slab, a.slab_bytes, c.s));
+            } else {
+                sigmoid_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.Z[k], c.R, a.P[k]);
+            }
         }
         if (probs)
             TRY(linr_hip_rc(hipMemcpyAsync(probs + (int64_t)k * c.R, a.P[k], (size_t)c.R * sizeof(float),
                                            hipMemcpyDeviceToDevice, c.s)));
     }
+    if (fused_bits)   // all stages' block partials in one fixed-order pass
+        TRY(linr_bits_finish_launch((const double*)a.slab + (int64_t)stage_begin * nblk, (int)((stage_end - stage_begin) * nblk),
+                                    bits_acc, c.s));
     return linr_launch_rc();
 }
 
@@ -360,12 +377,18 @@ static int backward_core(Ctx& c, float gscale) {
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));
     for (int k = 7; k >= 0; --k) {
-        TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
-        // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
-        TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, c.L.h2_w[k], 1, 24, c.L.h2_b[k]));
-        TRY(linear(c, a.gZ, 1, c.R, P + c.L.h2_w[k], 24, 1, nullptr, 1, 24, nullptr, 0, a.HH[k], 24, a.gHH, 24, LINR_RELU_MASK));
-        TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, c.L.h0_w[k], 1, 8, c.L.h0_b[k]));
-        TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC, 8, 0));
+        if (c.f->nbr_lo && c.f->nbr_mask) {
+            // recompute the hidden layer, gC and the four head-parameter gradients in one launch (csrc/fused.hip)
+            TRY(linr_head_bwd_launch(a.C[k], a.P[k], a.OCC + k, 8, P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], gz_scale,
+                                     a.gC, c.R, a.BIG, c.L.total, c.L.h0_w[k], c.L.h0_b[k], c.L.h2_w[k], c.L.h2_b[k], c.s));
+        } else {
+            TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
+            // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
+            TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, c.L.h2_w[k], 1, 24, c.L.h2_b[k]));
+            TRY(linear(c, a.gZ, 1, c.R, P + c.L.h2_w[k], 24, 1, nullptr, 1, 24, nullptr, 0, a.HH[k], 24, a.gHH, 24, LINR_RELU_MASK));
+            TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, c.L.h0_w[k], 1, 8, c.L.h0_b[k]));
+            TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC, 8, 0));
+        }
         // C = conv3(prior_k; prune_k)
         TRY(conv3_wgrad(c, a.O[k], 8, a.gC, 8, 8, 8, c.L.pr_w[k], c.L.pr_b[k]));
         TRY(conv3(c, true, a.gC, 8, P + c.L.pr_w[k], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO, 8, 0));
