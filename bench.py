@@ -43,9 +43,11 @@ def parse():
 
 
 def kernel_roofline(model, gop, iters=50):
-    """Dominant kernel = the 8->8 sparse-conv gather kernel (forward form; 17 launches per forward, its transposed twin
-    another 17 per backward).  Timed live with events on the launch stream over `iters` launches on frame 0's full row
-    space.  Algorithmic bytes per row: 4*(8+8) feature bytes + 108 neighbour-table bytes."""
+    """Dominant kernel = the 8->8 sparse-conv kernel the executor launches (cconv_mfma_k<8,8,fwd>: compressed kernel
+    map + v_mfma_f32_4x4x1; 17 launches per forward, its transposed twin another 17 per backward).  Timed live with
+    events on the launch stream over `iters` launches on frame 0's full row space, through the C-ABI entry
+    linr_spconv_cmap.  Algorithmic bytes per row: 4*(8+8) feature bytes + 108 neighbour-table bytes
+    (the kernel actually streams the 40 B/row compressed table, so it may exceed 1.0 against this figure one day)."""
     from linr_pcgc_amd import ops
     f = gop.frames[0]
     R = f.rows
@@ -54,14 +56,17 @@ def kernel_roofline(model, gop, iters=50):
     x[1:].normal_()
     out = torch.empty((R, 8), device=dev)
     w = torch.randn(27, 8, 8, device=dev) * 0.1
-    b = torch.zeros(1, 8, device=dev)
+    b = torch.zeros(8, device=dev)
+
+    def go():
+        ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out)
     for _ in range(5):
-        ops.spconv_fwd(x[1:], f.nbr, w, b, out=out, pad_row=True)
+        go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        ops.spconv_fwd(x[1:], f.nbr, w, b, out=out, pad_row=True)
+        go()
     e1.record()
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / iters
@@ -71,12 +76,12 @@ def kernel_roofline(model, gop, iters=50):
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')          # PMC-derived HBM bytes per launch (see profiles/README)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('spconv_gather_8x8_fwd_bytes_per_launch')
+            traffic = json.load(open(tpath)).get('cconv_mfma_8x8_fwd_bytes_per_launch')
         except Exception:
             traffic = None
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'kernel': 'spconv_gather_k<8,8,fwd,LOADW=8,PAD>', 'rows_per_launch': R,
+            'kernel': 'cconv_mfma_k<8,8,fwd,LOADW=8>', 'rows_per_launch': R,
             'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': round(dur_s * 1e6, 2)}
 
 

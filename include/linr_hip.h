@@ -82,6 +82,17 @@ LINR_API int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const float*
                            const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t cin, int32_t cout,
                            float* gW, float* gb, uint32_t flags, void* ws, size_t ws_bytes, void* stream);
 
+/* The same convolution on the COMPRESSED kernel map (linr_kmap_compress) and the matrix cores
+ * (v_mfma_f32_4x4x1_16b_f32 with broadcast weights: 64 rows x 4 output channels x 1 input channel per instruction, no
+ * padding; K = 1 keeps every product a single-rounding fmaf in the order k ascending, channel ascending, so results are
+ * bit-identical to linr_spconv_fwd / _bwd_data).  This is what the network executor launches.  Requirements: `in`
+ * 16-byte aligned with in_ld in {4, 8} and a zero row at index -1 (LINR_PAD_ROW contract), cout (fwd) / cin (bwd) in {4, 8}.
+ * bwd != 0 selects backward-data with `in` = output gradient, `out` = input gradient. */
+LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const int32_t* lo, const uint32_t* mask,
+                     int64_t ld, int64_t n, const float* W, const float* bias, int32_t cin, int32_t cout,
+                     const float* res, int32_t res_ld, const float* act, int32_t act_ld, float* out, int32_t out_ld,
+                     uint32_t flags, void* stream);
+
 /* ---- pointwise layers ---------------------------------------------------------------------------------------
  * Replaces ME.MinkowskiConvolution(kernel_size=1) (models/resnet.py:31-37,45-51) and nn.Linear inside
  * PointwiseMLP (models/module_utils.py:42-81).  Element (ci,co) of the weight is W[ci*ws_ci + co*ws_co]:

@@ -263,6 +263,23 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
     }
 }
 
+extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                                int64_t n, const float* W, const float* bias, int32_t cin, int32_t cout, const float* res,
+                                int32_t res_ld, const float* act, int32_t act_ld, float* out, int32_t out_ld, uint32_t flags,
+                                void* stream) {
+    if (n < 0 || ld < n || (in_ld != 4 && in_ld != 8)) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !lo || !mask || !W || !out) return LINR_EINVAL;
+    if (!linr_aligned16(in) || !linr_aligned16(out)) return LINR_EALIGN;
+    const int gin = bwd ? cout : cin, gout = bwd ? cin : cout;
+    if (in_ld < gin || out_ld < gout || (gout != 4 && gout != 8)) return LINR_EINVAL;
+    if ((flags & LINR_RELU_MASK) && (!act || act_ld < gout)) return LINR_EINVAL;
+    if (res && res_ld < gout) return LINR_EINVAL;
+    if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;     // 32-bit byte offsets
+    return linr_cconv_launch(bwd != 0, in, in_ld, lo, mask, ld, n, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
+                             flags, (hipStream_t)stream);
+}
+
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
 int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                            const float* W, const float* bias, float* c_out, const float* w1, const float* b1,

@@ -155,3 +155,29 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.9
     check(_lib.lib().linr_adam_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                     params.numel(), lr / bc1, bc2_sqrt, beta1, beta2, eps, weight_decay, _stream()),
           'linr_adam_step')
+
+
+def kmap_compress(nbr, n=None):
+    """nbr int32 [27, ld] (global row ids, x-major sorted rows) -> (lo int32 [9, ld], mask int32 [ld])."""
+    ld = nbr.shape[1]
+    n = ld if n is None else n
+    lo = torch.zeros((9, ld), dtype=torch.int32, device=nbr.device)
+    mask = torch.zeros((ld,), dtype=torch.int32, device=nbr.device)
+    check(_lib.lib().linr_kmap_compress(nbr.data_ptr(), nbr.stride(0), n, lo.data_ptr(), mask.data_ptr(), ld, _stream()),
+          'linr_kmap_compress')
+    return lo, mask
+
+
+def spconv_cmap(x, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None, relu=False, out=None, accumulate=False):
+    """The executor's conv kernel (compressed map + MFMA).  x must be a view buf[1:] of a buffer whose row 0 is zero."""
+    cin, cout = kernel.shape[1], kernel.shape[2]
+    width = cin if bwd else cout
+    if out is None:
+        out = torch.empty((n, width), dtype=torch.float32, device=x.device)
+    flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0) | \
+        LINR_PAD_ROW
+    check(_lib.lib().linr_spconv_cmap(1 if bwd else 0, x.data_ptr(), x.stride(0), lo.data_ptr(), mask.data_ptr(),
+                                      lo.stride(0), n, kernel.data_ptr(), _ptr(bias), cin, cout, _ptr(res),
+                                      0 if res is None else res.stride(0), _ptr(act), 0 if act is None else act.stride(0),
+                                      out.data_ptr(), out.stride(0), flags, _stream()), 'linr_spconv_cmap')
+    return out

@@ -389,3 +389,95 @@ def test_codec_stream_matches_oracle_coder(pkg, shell):
     ref = oac.encode_binary(probs.reshape(-1).cpu().numpy(), s['occ'].T.reshape(-1).astype(np.int16))
     assert out['enc_bytes'] == ref
     assert out['bits'] >= float(bits) - 1 and out['bits'] <= float(bits) * 1.01 + 64
+
+
+# ---- executor kernels through their own C-ABI entry ------------------------------------------------------------------------
+@pytest.mark.parametrize('cin,cout', [(8, 8), (8, 4), (4, 4), (3, 8), (7, 8)])
+def test_cmap_mfma_conv_bit_identical_to_gather_kernel(pkg, shell, cin, cout):
+    """Compressed kernel map + v_mfma_f32_4x4x1 must reproduce the plain gather kernel bit for bit (K = 1 MFMA = fmaf)."""
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    g = torch.Generator().manual_seed(cin * 17 + cout)
+    nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
+    lo, mask = ops.kmap_compress(nbr)
+    # the compressed map must decode to the same table
+    dec = torch.full_like(nbr, -1)
+    for q in range(9):
+        b0, b1, b2 = (mask >> (3 * q)) & 1, (mask >> (3 * q + 1)) & 1, (mask >> (3 * q + 2)) & 1
+        dec[q] = torch.where(b0 == 1, lo[q], dec[q])
+        dec[q + 9] = torch.where(b1 == 1, lo[q] + b0, dec[q + 9])
+        dec[q + 18] = torch.where(b2 == 1, lo[q] + b0 + b1, dec[q + 18])
+    assert torch.equal(dec, nbr)
+    ld_in = 8
+    xb = torch.zeros((n + 1, ld_in), device=dev)
+    xb[1:, :cin] = torch.randn(n, cin, generator=g).to(dev)
+    w = (torch.randn(27, cin, cout, generator=g) * 0.2).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    ref = ops.spconv_fwd(xb[1:], nbr, w, b.view(1, -1), relu=True, pad_row=True)
+    got = ops.spconv_cmap(xb[1:], lo, mask, n, w, b, relu=True)
+    assert torch.equal(ref, got)
+    if cin in (4, 8):                       # backward-data: gathered width cout, produced width cin
+        gb = torch.zeros((n + 1, 8), device=dev)
+        gb[1:, :cout] = torch.randn(n, cout, generator=g).to(dev)
+        ref_b = ops.spconv_bwd_data(gb[1:], nbr, w, pad_row=True)
+        got_b = ops.spconv_cmap(gb[1:], lo, mask, n, w, None, bwd=True)
+        assert torch.equal(ref_b, got_b)
+
+
+def test_full_size_frame_properties(pkg):
+    """BASELINE config[1] size (784,314 points, 7 scales): size-independent properties instead of the slow oracle:
+    determinism, staged == one-shot probabilities, train step lowers the bits, encode -> decode is lossless."""
+    from linr_pcgc_amd import codec, engine, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    pts = synthetic.sequence_frame('loot10', 3)
+    gop = overfit.Gop(None, [pts], None, 64, 'cuda')
+    assert gop.point_nums[0] > 700000 and gop.scale_num == 7
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    f = gop.frames[0]
+    p1, b1 = model.frame_probs(f)
+    p2, b2 = model.frame_probs(f)
+    assert torch.equal(p1, p2) and torch.equal(b1, b2)
+    staged = torch.empty_like(p1)
+    for k in range(8):
+        engine.net_forward(f, model.flat_parameters(), k, k + 1, staged, None)
+    assert torch.equal(p1, staged)
+    assert bool(((p1 >= 0) & (p1 <= 1)).all())
+    # closed-form check of the bits accumulator against the probabilities it was computed from
+    t = f.occ.t().double()
+    pd = p1.double()
+    nats = -(t * torch.log(pd).clamp(min=-100) + (1 - t) * torch.log1p(-pd).clamp(min=-100)).sum()
+    assert abs(float(nats) / math.log(2) - float(b1)) <= 2e-5 * float(b1)
+    opt = FlatAdam(model)
+    for _ in range(5):
+        train_step(model, opt, f, gop.point_nums[0])
+    _, b3 = model.frame_probs(f)
+    assert float(b3) < float(b1)
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda')
+    ref = torch.as_tensor(gop.infos[0]['ori']).cuda() + torch.tensor(gop.coord_mins[0], device='cuda', dtype=torch.int32)
+    assert torch.equal(dec[0], ref), 'decoded geometry must be bit-exact at full size'
+    assert abs(enc['bpp']['point_bpp'] * gop.point_nums[0] - enc['bits_est']) <= 0.01 * enc['bits_est'] + 8 * 64
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 65])
+def test_tiny_and_ragged_frames(pkg, n):
+    """Edge cases: a scale with a single voxel, row counts around the wave size, and a zero-row scale."""
+    from linr_pcgc_amd import engine
+    rng = np.random.default_rng(n)
+    model, sd = _model_and_oracle(pkg, 3)
+    c = ooct.unique_sorted(rng.integers(0, 6, size=(4 * n, 3)))[:n]
+    n = len(c)
+    scales = [{'coord': c, 'occ': (rng.random((n, 8)) < 0.5).astype(np.float32), 'offset_tensor': ooct.offset_tensor(c),
+               'scale_idx': 1},
+              {'coord': np.zeros((0, 3), np.int32), 'occ': np.zeros((0, 8), np.float32),
+               'offset_tensor': np.zeros((0, 7), np.float32), 'scale_idx': 0}]
+    frame = model.make_frame(scales)
+    probs, bits = model.frame_probs(frame)
+    sc = dict(scales[0]); sc['nbr'] = ooct.neighbour_table(c)
+    out = onet.forward_scale(sd, onet.to_torch_scales([sc])[0])
+    assert abs(float(bits) - float(out['bits'])) <= 1e-5 * float(out['bits']) + 1e-6
+    grads = torch.zeros_like(model.flat_parameters())
+    engine.net_backward(frame, model.flat_parameters(), grads, 1.0)
+    assert bool(torch.isfinite(grads).all())
