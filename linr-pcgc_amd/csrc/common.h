@@ -72,3 +72,19 @@ int linr_head_bwd_launch(const float* c, const float* p, const float* target, in
                          hipStream_t s);
 __attribute__((visibility("hidden")))
 int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_dual44_fwd_launch(const float* H, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w01,
+                           const float* b01, const float* w11, const float* b11, const float* A, const float* w12,
+                           const float* b12, float* M, float* I, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_dual44_bwd_launch(const float* gI, const float* gM, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_conv_pw_fwd_launch(const float* A, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
+                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* wb,
+                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s);
+__attribute__((visibility("hidden")))
+int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
+                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s);

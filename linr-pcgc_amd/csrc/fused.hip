@@ -153,6 +153,17 @@ struct HeadArgs {
     double* partial;      // [gridDim.x] block partial sums of nats, or nullptr
 };
 
+// pointwise side paths of the Inception block fused into conv epilogues (models/resnet.py:55-60):
+//   EPI == 2 (fwd 8->4, conv0_0): also out[4:8] = relu(in[row] @ W10 + b10)                    (conv1_0 is a centre tap)
+//   EPI == 3 (bwd 8->8, block tail conv): also gM = (gI[4:8] @ W12^T) * (M > 0)                 (backward of conv1_2 + ReLU)
+//   EPI == 4 (bwd of conv0_0, gathered 4 -> produced 8): a += res; a += gH[row][4:8] @ W10^T; a *= (A > 0)
+struct PwArgs {
+    const float* w;       // the 1x1 kernel [cin][cout] (ME layout)
+    const float* b;       // its bias (EPI 2) or nullptr
+    const float* aux;     // EPI 3: M [n][4];  EPI 4: gH [n][8] (own-row gradient of H)
+    float* aux_out;       // EPI 3: gM [n][4]
+};
+
 template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0>
 __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
                                                            const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            int res_ld, const float* __restrict__ act, int act_ld,
                                                            float* __restrict__ out, int out_ld, unsigned flags,
-                                                           HeadArgs hd = HeadArgs()) {
+                                                           HeadArgs hd = HeadArgs(), PwArgs pw = PwArgs()) {
     static_assert(GOUT == 4 || GOUT == 8, "output channels must fill 1 or 2 MFMA blocks");
     __shared__ float sW[27 * GIN * GOUT];
     for (int t = threadIdx.x; t < 27 * GIN * GOUT; t += LINR_BLOCK) sW[t] = W[t];
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
         return;
     } else {
     if (!live) return;
-    // epilogue order: + res, + old (ACCUM), * mask, ReLU
+    // epilogue order: + res, + old (ACCUM), [+ own-row pointwise term], * mask, ReLU
     if (res != nullptr) {
         const float* r = res + row * res_ld;
 #pragma unroll
@@ -242,6 +253,45 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
     if (flags & LINR_ACCUM) {
 #pragma unroll
         for (int o = 0; o < GOUT; ++o) a[o] += op[o];
+    }
+    if constexpr (EPI == 4) {          // gA += gH[row][4:8] @ W10^T     (W10 [8][4]: gin[i] = sum_o g[o] * W10[i][o])
+        const float4 g4 = *reinterpret_cast<const float4*>(pw.aux + row * 8 + 4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) t = fmaf(g[o], pw.w[i * 4 + o], t);
+            a[i] += t;
+        }
+    }
+    if constexpr (EPI == 3) {          // store gI, then gM = (gI[4:8] @ W12^T) * (M > 0)   (W12 [4][4])
+        const float4 m4 = *reinterpret_cast<const float4*>(pw.aux + row * 4);
+        const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+        float gm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) t = fmaf(a[4 + o], pw.w[i * 4 + o], t);
+            gm[i] = mv[i] > 0.0f ? t : 0.0f;
+        }
+        *reinterpret_cast<float4*>(pw.aux_out + row * 4) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+    }
+    if constexpr (EPI == 2) {          // conv0_0 half: ReLU, store; conv1_0 half: relu(in[row] @ W10 + b10)
+        const char* self = reinterpret_cast<const char*>(in) + (uint32_t)row * ((uint32_t)in_ld * 4u);
+        float xc[8];
+        RowLoadF<8>::run(self, xc);
+        float h1[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) h1[o] = pw.b[o];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) h1[o] = fmaf(xc[i], pw.w[i * 4 + o], h1[o]);
+        *reinterpret_cast<float4*>(op) = make_float4(fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(a[2], 0.0f), fmaxf(a[3], 0.0f));
+        *reinterpret_cast<float4*>(op + 4) = make_float4(fmaxf(h1[0], 0.0f), fmaxf(h1[1], 0.0f), fmaxf(h1[2], 0.0f), fmaxf(h1[3], 0.0f));
+        return;
     }
     if (flags & LINR_RELU_MASK) {
         const float* m = act + row * act_ld;
@@ -289,6 +339,131 @@ int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* m
     HeadArgs hd = {w1, b1, w2, b2, target, target_ld, p_out, partial};
     cconv_mfma_k<8, 8, false, 8, 1><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(in, 8, lo, mask, ld, n, W, bias, nullptr, 0,
                                                                                    nullptr, 0, c_out, 8, 0, hd);
+    return linr_launch_rc();
+}
+
+// ---- the two 4->4 convolutions of the Inception block as ONE pass --------------------------------------------------------
+// forward (models/resnet.py:56-57): in = H [n][8];  I[:,0:4] = conv(H[:,0:4]; W01) + b01 + A[:,0:4]
+//                                   M = relu(conv(H[:,4:8]; W11) + b11);  I[:,4:8] = M @ W12 + b12 + A[:,4:8]
+// backward: gH = [bwd(gI[:,0:4]; W01) | bwd(gM; W11)] * (H > 0), gathered at the mirrored offsets from two matrices.
+// One 32-byte (or 2 x 16-byte) gather per neighbour serves both convolutions; lanes 0-3 hold W01's tap, lanes 4-7 W11's.
+struct DualArgs {
+    const float* in2; int in2_ld;      // bwd: second gathered matrix (gM, ld 4); fwd: unused
+    const float* w01; const float* w11;
+    const float* b01; const float* b11;
+    const float* a_res;                // fwd: A [n][8] (residual)
+    const float* w12; const float* b12;
+    float* m_out;                      // fwd: M [n][4]
+    const float* act;                  // bwd: H [n][8] for the ReLU mask
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __restrict__ in, int in_ld,
+                                                             const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
+                                                             int64_t ld, int64_t n, DualArgs d, float* __restrict__ out) {
+    __shared__ float sW[2 * 27 * 16];
+    for (int t = threadIdx.x; t < 27 * 16; t += LINR_BLOCK) { sW[t] = d.w01[t]; sW[27 * 16 + t] = d.w11[t]; }
+    const int lane = threadIdx.x & 63;
+    const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    const bool live = row_raw < n;
+    const int64_t row = live ? row_raw : n - 1;
+    uint32_t off[27];
+    decode_offsets<BWD>(lo, mask, ld, row, 1u, off);                  // row index + 1 (0 = pad row); scaled per matrix below
+    const char* pad0 = reinterpret_cast<const char*>(in - in_ld);
+    const uint32_t rb0 = (uint32_t)in_ld * 4u;
+    const char* pad1 = BWD ? reinterpret_cast<const char*>(d.in2 - d.in2_ld) : pad0 + 16;     // fwd: second half of the same row
+    const uint32_t rb1 = BWD ? (uint32_t)d.in2_ld * 4u : rb0;
+    f32x4 acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc0[j] = BWD ? 0.0f : d.b01[j]; acc1[j] = BWD ? 0.0f : d.b11[j]; }
+    const int c = lane < 8 ? lane : 0;
+    const float* sWc = sW + (c >= 4 ? 27 * 16 : 0);
+    const int cc = c & 3;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        float x0[4], x1[4];
+        RowLoadF<4>::run(pad0 + off[k] * rb0, x0);
+        RowLoadF<4>::run(pad1 + off[k] * rb1, x1);
+        float w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = BWD ? sWc[(k * 4 + cc) * 4 + i] : sWc[(k * 4 + i) * 4 + cc];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x0[i], acc0, 4, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x1[i], acc1, 4, 1, 0);
+        }
+    }
+    if (!live) return;
+    float* op = out + row * 8;
+    if (BWD) {
+        const float4 h0 = *reinterpret_cast<const float4*>(d.act + row * 8);
+        const float4 h1 = *reinterpret_cast<const float4*>(d.act + row * 8 + 4);
+        *reinterpret_cast<float4*>(op) = make_float4(h0.x > 0.0f ? acc0[0] : 0.0f, h0.y > 0.0f ? acc0[1] : 0.0f,
+                                                     h0.z > 0.0f ? acc0[2] : 0.0f, h0.w > 0.0f ? acc0[3] : 0.0f);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(h1.x > 0.0f ? acc1[0] : 0.0f, h1.y > 0.0f ? acc1[1] : 0.0f,
+                                                         h1.z > 0.0f ? acc1[2] : 0.0f, h1.w > 0.0f ? acc1[3] : 0.0f);
+    } else {
+        const float4 a0 = *reinterpret_cast<const float4*>(d.a_res + row * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(d.a_res + row * 8 + 4);
+        const float m[4] = {fmaxf(acc1[0], 0.0f), fmaxf(acc1[1], 0.0f), fmaxf(acc1[2], 0.0f), fmaxf(acc1[3], 0.0f)};
+        *reinterpret_cast<float4*>(d.m_out + row * 4) = make_float4(m[0], m[1], m[2], m[3]);
+        float i1[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) i1[o] = d.b12[o];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) i1[o] = fmaf(m[i], d.w12[i * 4 + o], i1[o]);
+        *reinterpret_cast<float4*>(op) = make_float4(acc0[0] + a0.x, acc0[1] + a0.y, acc0[2] + a0.z, acc0[3] + a0.w);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(i1[0] + a1.x, i1[1] + a1.y, i1[2] + a1.z, i1[3] + a1.w);
+    }
+}
+
+int linr_dual44_fwd_launch(const float* H, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w01,
+                           const float* b01, const float* w11, const float* b11, const float* A, const float* w12,
+                           const float* b12, float* M, float* I, hipStream_t s) {
+    if (n == 0) return 0;
+    DualArgs d = {nullptr, 0, w01, w11, b01, b11, A, w12, b12, M, nullptr};
+    cconv_dual44_k<false><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(H, 8, lo, mask, ld, n, d, I);
+    return linr_launch_rc();
+}
+
+int linr_dual44_bwd_launch(const float* gI, const float* gM, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s) {
+    if (n == 0) return 0;
+    DualArgs d = {gM, 4, w01, w11, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
+    cconv_dual44_k<true><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gI, 8, lo, mask, ld, n, d, gH);
+    return linr_launch_rc();
+}
+
+// conv0_0 (8->4) + conv1_0 (1x1 8->4) forward with both ReLUs: H = [relu(conv3(A)) | relu(A @ W10 + b10)]
+int linr_conv_pw_fwd_launch(const float* A, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
+                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s) {
+    if (n == 0) return 0;
+    PwArgs pw = {w10, b10, nullptr, nullptr};
+    cconv_mfma_k<8, 4, false, 8, 2><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(A, 8, lo, mask, ld, n, w00, b00, nullptr, 0,
+                                                                                   nullptr, 0, H, 8, 0, HeadArgs(), pw);
+    return linr_launch_rc();
+}
+
+// backward of the block's tail conv: gI = bwd(gO; Wb) and gM = (gI[:,4:8] @ W12^T) * (M > 0)
+int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* wb,
+                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s) {
+    if (n == 0) return 0;
+    PwArgs pw = {w12, nullptr, M, gM};
+    cconv_mfma_k<8, 8, true, 8, 3><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gO, 8, lo, mask, ld, n, wb, nullptr, nullptr, 0,
+                                                                                  nullptr, 0, gI, 8, 0, HeadArgs(), pw);
+    return linr_launch_rc();
+}
+
+// gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
+int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
+                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s) {
+    if (n == 0) return 0;
+    PwArgs pw = {w10, nullptr, gH, nullptr};
+    cconv_mfma_k<4, 8, true, 4, 4><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8,
+                                                                                  gA, 8, LINR_RELU_MASK, HeadArgs(), pw);
     return linr_launch_rc();
 }
 

@@ -243,6 +243,14 @@ static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     Arena& a = c.A;
     const float* P = c.P;
     TRY(conv3(c, false, in, in_ld, P + bp.a_w, P + bp.a_b, bp.cin, 8, nullptr, 0, nullptr, 0, a.A[b], 8, LINR_RELU));
+    if (c.f->nbr_lo && c.f->nbr_mask) {
+        // Inception block in two launches (csrc/fused.hip): [conv0_0 | conv1_0 centre tap] -> H, then the two 4->4 convs
+        // as one pass with conv1_2 and the residual in the epilogue -> M, I
+        TRY(linr_conv_pw_fwd_launch(a.A[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c00_b, P + bp.c10_w,
+                                    P + bp.c10_b, a.H[b], c.s));
+        TRY(linr_dual44_fwd_launch(a.H[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c01_b, P + bp.c11_w,
+                                   P + bp.c11_b, a.A[b], P + bp.c12_w, P + bp.c12_b, a.M[b], a.I[b], c.s));
+    } else {
     // path 0: H[:,0:4] = relu(conv3 8->4 (A));  path 1: H[:,4:8] = relu(A @ conv1_0)
     TRY(conv3(c, false, a.A[b], 8, P + bp.c00_w, P + bp.c00_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b], 8, LINR_RELU));
     TRY(linear(c, a.A[b], 8, c.R, P + bp.c10_w, 4, 1, P + bp.c10_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b] + 4, 8, LINR_RELU));
@@ -251,6 +259,7 @@ static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     // M = relu(conv3 4->4 (H1)); I[:,4:8] = M @ conv1_2 + A[:,4:8]
     TRY(conv3(c, false, a.H[b] + 4, 8, P + bp.c11_w, P + bp.c11_b, 4, 4, nullptr, 0, nullptr, 0, a.M[b], 4, LINR_RELU));
     TRY(linear(c, a.M[b], 4, c.R, P + bp.c12_w, 4, 1, P + bp.c12_b, 4, 4, a.A[b] + 4, 8, nullptr, 0, a.I[b] + 4, 8, 0));
+    }
     TRY(conv3(c, false, a.I[b], 8, P + bp.b_w, P + bp.b_b, 8, 8, res, 8, nullptr, 0, a.O[b], 8, 0));
     return 0;
 }
@@ -261,6 +270,17 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     const float* P = c.P;
     // O = conv3(I; b)
     TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
+    if (c.f->nbr_lo && c.f->nbr_mask) {
+        // fused backward (csrc/fused.hip): gI (+ gM in the epilogue) -> dual 4->4 backward -> gA with both side paths
+        TRY(linr_conv_bwd_gm_launch(gO, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI, a.gM, c.s));
+        TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
+        TRY(conv3_wgrad(c, a.H[b], 8, a.gI, 8, 4, 4, bp.c01_w, bp.c01_b));
+        TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM, 4, 4, 4, bp.c11_w, bp.c11_b));
+        TRY(linr_dual44_bwd_launch(a.gI, a.gM, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH, c.s));
+        TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
+        TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
+        TRY(linr_conv_bwd_ga_launch(a.gH, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI, a.A[b], a.gA, c.s));
+    } else {
     TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI, 8, 0));
     // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
     TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
@@ -277,6 +297,7 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     TRY(conv3(c, true, a.gH, 8, P + bp.c00_w, nullptr, 8, 4, a.gI, 8, nullptr, 0, a.gA, 8, 0));
     TRY(linear(c, a.gH + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA, 8,
                LINR_ACCUM | LINR_RELU_MASK));
+    }
     // A = relu(conv3(in; a))
     TRY(conv3_wgrad(c, in, in_ld, a.gA, 8, bp.cin, 8, bp.a_w, bp.a_b));
     if (gin) TRY(conv3(c, true, a.gA, 8, P + bp.a_w, nullptr, bp.cin, 8, nullptr, 0, nullptr, 0, gin, 8, 0));
