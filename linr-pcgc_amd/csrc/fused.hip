@@ -137,6 +137,14 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_k(const float* __restrict__ 
 // (measured 91-119 TFLOP/s for this stream vs 52-71 TFLOP/s for v_pk_fma_f32; tools/mfma_probe.hip, valu_probe.hip).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#include <utility>
+template <class F, int... Ks>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Ks...>) {
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // Measured dead ends for this kernel (kept out of the tree): hand-pinned software pipelines
 // (2-3 offsets ahead, or a whole dz-plane of gathers in flight) and wave-cooperative staging of each (dx,dy) column's
 // contiguous neighbour range through LDS were all slower than the compiler's own interleaving below.
@@ -173,9 +181,26 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
                                                            float* __restrict__ out, int out_ld, unsigned flags,
                                                            HeadArgs hd = HeadArgs(), PwArgs pw = PwArgs()) {
     static_assert(GOUT == 4 || GOUT == 8, "output channels must fill 1 or 2 MFMA blocks");
-    __shared__ float sW[27 * GIN * GOUT];
-    for (int t = threadIdx.x; t < 27 * GIN * GOUT; t += LINR_BLOCK) sW[t] = W[t];
+    // All weights of the convolution live in registers for the whole kernel: the A operand of the 16-block MFMA is taken
+    // from block ABID (an immediate), so ONE VGPR carries 16 different weight 4-vectors - block b of register wv[g][i]
+    // holds W(k = g*KPV + b/HB, input i, outputs 4*(b%HB) .. +3).  27 x Cin x Cout floats = at most 32 VGPRs, loaded once;
+    // the loop below has no weight traffic at all (an LDS copy + 4 ds_reads and waits per offset cost ~8 us per launch).
+    constexpr int HB = GOUT / 4;                 // output halves (MFMA blocks) per offset
+    constexpr int KPV = 16 / HB;                 // offsets packed per register
+    constexpr int NG = (27 + KPV - 1) / KPV;
     const int lane = threadIdx.x & 63;
+    float wv[NG][GIN];
+    {
+        const int blk = lane >> 2, j = lane & 3;
+        const int kl = blk / HB, co = 4 * (blk % HB) + j;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int k = g * KPV + kl;
+#pragma unroll
+            for (int i = 0; i < GIN; ++i)
+                wv[g][i] = (k < 27) ? (BWD ? W[(k * GOUT + co) * GIN + i] : W[(k * GIN + i) * GOUT + co]) : 0.0f;
+        }
+    }
     const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     const bool live = row_raw < n;
     const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
@@ -187,22 +212,27 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
     for (int h = 0; h < GOUT / 4; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[h][j] = (bias != nullptr) ? bias[4 * h + j] : 0.0f;
-    // lane c < GOUT supplies weight(input i, output c); other lanes' A values are never read
-    const int c = lane < GOUT ? lane : 0;
-    __syncthreads();
+    // Left to itself hipcc waits (vmcnt(0)) right after every 16-byte gather - 54 serial round trips per wave.  The loop
+    // is therefore pipelined by hand: the gather of offset k+PF is issued before the MFMAs of offset k and
+    // sched_barrier keeps it there, so the compiler's own counted vmcnt leaves PF rows in flight.
+    constexpr int PF = 3;
+    float x[PF + 1][LOADW];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        float x[LOADW];
-        RowLoadF<LOADW>::run(pad + off[k], x);
-        float w[GIN];
-#pragma unroll
-        for (int i = 0; i < GIN; ++i) w[i] = BWD ? sW[(k * GOUT + c) * GIN + i] : sW[(k * GIN + i) * GOUT + c];
+    for (int u = 0; u < PF; ++u) RowLoadF<LOADW>::run(pad + off[u], x[u]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<27>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int g = k / KPV, ab = (k % KPV) * HB;
+        if constexpr (k + PF < 27) RowLoadF<LOADW>::run(pad + off[k + PF], x[(k + PF) % (PF + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < GIN; ++i) {
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc[0], 4, 0, 0);
-            if (GOUT == 8) acc[GOUT / 4 - 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x[i], acc[GOUT / 4 - 1], 4, 1, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[0], 4, ab, 0);
+            if constexpr (GOUT == 8)
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[1], 4, ab + 1, 0);
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    });
     float a[GOUT];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
@@ -361,9 +391,21 @@ template <bool BWD>
 __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __restrict__ in, int in_ld,
                                                              const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                              int64_t ld, int64_t n, DualArgs d, float* __restrict__ out) {
-    __shared__ float sW[2 * 27 * 16];
-    for (int t = threadIdx.x; t < 27 * 16; t += LINR_BLOCK) { sW[t] = d.w01[t]; sW[27 * 16 + t] = d.w11[t]; }
+    // register-resident weights (see cconv_mfma_k): block b of wv[g][i] holds, for offset k = g*8 + b/2, the tap of
+    // W01 (b even) or W11 (b odd) for input i and outputs 0..3
     const int lane = threadIdx.x & 63;
+    float wv[4][4];
+    {
+        const int blk = lane >> 2, j = lane & 3;
+        const int kl = blk >> 1;
+        const float* Wsel = (blk & 1) ? d.w11 : d.w01;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = g * 8 + kl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[g][i] = (k < 27) ? (BWD ? Wsel[(k * 4 + j) * 4 + i] : Wsel[(k * 4 + i) * 4 + j]) : 0.0f;
+        }
+    }
     const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     const bool live = row_raw < n;
     const int64_t row = live ? row_raw : n - 1;
@@ -376,24 +418,29 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __rest
     f32x4 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc0[j] = BWD ? 0.0f : d.b01[j]; acc1[j] = BWD ? 0.0f : d.b11[j]; }
-    const int c = lane < 8 ? lane : 0;
-    const float* sWc = sW + (c >= 4 ? 27 * 16 : 0);
-    const int cc = c & 3;
-    __syncthreads();
+    constexpr int PF = 3;                             // gathers run PF offsets ahead of the MFMAs (see cconv_mfma_k)
+    float x0[PF + 1][4], x1[PF + 1][4];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        float x0[4], x1[4];
-        RowLoadF<4>::run(pad0 + off[k] * rb0, x0);
-        RowLoadF<4>::run(pad1 + off[k] * rb1, x1);
-        float w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = BWD ? sWc[(k * 4 + cc) * 4 + i] : sWc[(k * 4 + i) * 4 + cc];
+    for (int u = 0; u < PF; ++u) {
+        RowLoadF<4>::run(pad0 + off[u] * rb0, x0[u]);
+        RowLoadF<4>::run(pad1 + off[u] * rb1, x1[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<27>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;            // weight tap (decode_offsets already mirrored `off` for BWD)
+        constexpr int g = k / 8, ab = (k % 8) * 2;
+        if constexpr (k + PF < 27) {
+            RowLoadF<4>::run(pad0 + off[k + PF] * rb0, x0[(k + PF) % (PF + 1)]);
+            RowLoadF<4>::run(pad1 + off[k + PF] * rb1, x1[(k + PF) % (PF + 1)]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x0[i], acc0, 4, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[i], x1[i], acc1, 4, 1, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x0[k % (PF + 1)][i], acc0, 4, ab, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x1[k % (PF + 1)][i], acc1, 4, ab + 1, 0);
         }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    });
     if (!live) return;
     float* op = out + row * 8;
     if (BWD) {
