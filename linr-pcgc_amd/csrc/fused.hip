@@ -6,6 +6,7 @@
 // becomes 13.5 MB, i.e. one XCD's share (1.7 MB) stays L2-resident across the ~140 conv passes of a training step.
 #include "common.h"
 #include <stdlib.h>
+#define WG_WAVES 8
 
 __global__ __launch_bounds__(LINR_BLOCK) void kmap_compress_k(const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n,
                                                               int32_t* __restrict__ lo, uint32_t* __restrict__ mask,
@@ -511,6 +512,159 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
     PwArgs pw = {w10, nullptr, gH, nullptr};
     cconv_mfma_k<4, 8, true, 4, 4><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8,
                                                                                   gA, 8, LINR_RELU_MASK, HeadArgs(), pw);
+    return linr_launch_rc();
+}
+
+// ---- backward-weight on the matrix cores -------------------------------------------------------------------------------------
+// gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  Same wave-per-row-group organisation as spconv_wgrad_k (lane = one
+// (offset k, channel quad q) pair, 16-byte gather of that quad for 8 rows at a time, persistent accumulators), but the
+// 4 x COUT outer product per lane and row runs as v_mfma_f32_4x4x1_16b_f32:   D_b[i][j] += A_{4b+i} * B_{4b+j}
+// with A = component c of the lane's gathered quad and B = g[r][4h + j]: lane 4b+j, register i of accumulator (c, h)
+// sums x_{pair 4b+i}[c] * g[4h+j].  Lanes are laid out so that the 4 pairs of a block share q:
+//     lane = 4b + i   ->   q = b & 1 (XQ == 2) ,  k = 4*(b >> 1) + i   (XQ == 1: k = lane, 27 pairs)
+// which lets the DUAL variant (the two 4->4 convs of an Inception block, q selects the conv) feed each block its own
+// gradient matrix.  Pair k == 27 is the bias pseudo-pair (x = (1,0,0,0)).  K = 1 keeps exact fp32 FMAs.
+struct WgradSrc {
+    const float* in; int in_ld;           // gathered matrix (quad q at column 4q)
+    const float* g0; int g0_ld;           // output gradient (DUAL: of conv 0)
+    const float* g1; int g1_ld;           // DUAL: output gradient of conv 1
+};
+struct WgradDual { int64_t w_off1, b_off1; };
+
+template <int XQ, int COUT, bool DUAL, bool VIDX>
+__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S, const int32_t* __restrict__ nbr,
+                                                                    int64_t nbr_ld, int64_t n, LinrWgradDst d, WgradDual dd) {
+    static_assert(!DUAL || (XQ == 2 && COUT == 4), "dual mode = two 4->4 convolutions");
+    constexpr int HB = COUT / 4;
+    constexpr int NA = 4 * HB * 4;
+    __shared__ float sacc[64 * (NA + 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = lane >> 2, li = lane & 3;
+    const int q = (XQ == 2) ? (blk & 1) : 0;
+    const int kk = (XQ == 2) ? 4 * (blk >> 1) + li : lane;          // 27 == bias pseudo-pair, > 27 idle
+    const bool live = kk < 27;
+    const bool biasl = kk == 27;
+    const int k = live ? kk : 26;
+    f32x4 acc[4][HB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < HB; ++h) acc[c][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
+    const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
+    const uint32_t rowbytes = (uint32_t)S.in_ld * 4u;
+    const float* gsel = (DUAL && q) ? S.g1 : S.g0;
+    const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
+    for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
+        int32_t idx[8];
+        if (VIDX && g0r + 8 <= n) {
+            const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
+            const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
+            idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
+            idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) idx[u] = (g0r + u < n) ? nk[g0r + u] : -1;
+        }
+        float4 x[8];
+        float bg[8][HB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[u] + 1) * rowbytes);
+            if (!live) x[u] = make_float4(biasl ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
+            const int64_t r = (g0r + u < n) ? g0r + u : n - 1;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) bg[u][h] = (g0r + u < n) ? gsel[r * gld + 4 * h + li] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].x, bg[u][h], acc[0][h], 0, 0, 0);
+                acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].y, bg[u][h], acc[1][h], 0, 0, 0);
+                acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].z, bg[u][h], acc[2][h], 0, 0, 0);
+                acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].w, bg[u][h], acc[3][h], 0, 0, 0);
+            }
+        }
+    }
+    // fold waves in wave order (fixed => reproducible)
+    float* mine = sacc + lane * (NA + 1);
+    for (int w = 0; w < WG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = (c * HB + h) * 4 + i;
+                        mine[e] = (w == 0) ? acc[c][h][i] : mine[e] + acc[c][h][i];
+                    }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // lane 4b + j, register i of accumulator (c, h)  <->  pair (k_i, q), input channel 4q + c, output channel 4h + j
+        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+        const int64_t w_off = (DUAL && q) ? dd.w_off1 : d.w_off;
+        const int64_t b_off = (DUAL && q) ? dd.b_off1 : d.b_off;
+        const int cinv = DUAL ? 4 : d.cin_valid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ki = (XQ == 2) ? 4 * (blk >> 1) + i : 4 * blk + i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ci = DUAL ? c : 4 * q + c;
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float v = mine[(c * HB + h) * 4 + i];
+                    const int co = 4 * h + li;
+                    if (ki < 27) {
+                        if (ci < cinv) dst[w_off + (ki * cinv + ci) * COUT + co] = v;
+                    } else if (ki == 27 && c == 0 && (XQ == 1 || DUAL || q == 0)) {
+                        dst[b_off + co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
+                          int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s) {
+    const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+    WgradSrc S = {in, in_ld, gout, gout_ld, nullptr, 0};
+    WgradDual dd = {0, 0};
+    d.cin_valid = cin;
+#define GO(XQ, CO)                                                                                                           \
+    do {                                                                                                                     \
+        if (vidx) spconv_wgrad_mfma_k<XQ, CO, false, true><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);      \
+        else spconv_wgrad_mfma_k<XQ, CO, false, false><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);          \
+        return linr_launch_rc();                                                                                             \
+    } while (0)
+    if (cin == 8 && cout == 8) GO(2, 8);
+    if (cin == 8 && cout == 4) GO(2, 4);
+    if (cin == 4 && cout == 4) GO(1, 4);
+    if (cin < 8 && cout == 8 && in_ld >= 8) GO(2, 8);
+#undef GO
+    return LINR_EINVAL;
+}
+
+// both 4->4 convolutions of an Inception block: in = H [n][8]; conv 0 reads H[:,0:4] with gradient g0, conv 1 H[:,4:8] with g1
+int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
+                            int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
+                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s) {
+    const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+    WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
+    LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
+    WgradDual dd = {w_off1, b_off1};
+    if (vidx) spconv_wgrad_mfma_k<2, 4, true, true><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);
+    else spconv_wgrad_mfma_k<2, 4, true, false><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);
     return linr_launch_rc();
 }
 

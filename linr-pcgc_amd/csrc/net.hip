@@ -8,6 +8,7 @@
 // sparse convolutions read absent neighbours from it (LINR_PAD_ROW) with no branch.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
 #define MAX_SCALES 16
@@ -221,6 +222,9 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
+    static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
+    if (use_mfma)
+        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.s);
     return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
                                     LINR_PAD_ROW, c.s);
 }
@@ -274,8 +278,8 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
         // fused backward (csrc/fused.hip): gI (+ gM in the epilogue) -> dual 4->4 backward -> gA with both side paths
         TRY(linr_conv_bwd_gm_launch(gO, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI, a.gM, c.s));
         TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
-        TRY(conv3_wgrad(c, a.H[b], 8, a.gI, 8, 4, 4, bp.c01_w, bp.c01_b));
-        TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM, 4, 4, 4, bp.c11_w, bp.c11_b));
+        TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI, 8, a.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
+                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.s));
         TRY(linr_dual44_bwd_launch(a.gI, a.gM, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH, c.s));
         TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
         TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
