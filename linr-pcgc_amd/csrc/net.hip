@@ -82,15 +82,17 @@ struct Arena {
     int64_t rows;
     float* base;
     int64_t cur;                 // floats
-    int64_t pad_off[160];        // float offset of every pad row
-    int pad_w[160];
+    int64_t pad_off[200];        // float offset of every pad row
+    int pad_w[200];
     int npad;
     // forward (saved for backward)
     float *MIX, *HID, *X0, *OCC;
     float *A[8], *H[8], *M[8], *I[8], *O[8];
     float *C[8], *HH[8], *Z[8], *P[8];
     // backward scratch
-    float *gZ, *gHH, *gC, *gO, *gXG, *gI, *gA, *gH, *gM, *gX0, *gHID;
+    float *gZ, *gHH, *gXG, *gX0, *gHID;
+    float *gC[8], *gO[8], *gI[8], *gA[8], *gH[8], *gM[8];   // one set per stage / block: weight-gradient kernels run on a
+                                                           // second stream and may still read them when the chain moves on
     float* BIG;                  // [LINR_WG_BLOCKS][n_params] per-block partial weight gradients
     float* GSUM;                 // [n_params] their fixed-order sum (the gradient of this backward call)
     int64_t n_params;
@@ -120,9 +122,11 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
     for (int k = 0; k < 8; ++k) {
         a.C[k] = arena_mat(a, 8); a.HH[k] = arena_mat(a, 24); a.Z[k] = arena_mat(a, 1); a.P[k] = arena_mat(a, 1);
     }
-    a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gC = arena_mat(a, 8); a.gO = arena_mat(a, 8);
-    a.gXG = arena_mat(a, 8); a.gI = arena_mat(a, 8); a.gA = arena_mat(a, 8); a.gH = arena_mat(a, 8);
-    a.gM = arena_mat(a, 4); a.gX0 = arena_mat(a, 8); a.gHID = arena_mat(a, 16);
+    a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gXG = arena_mat(a, 8); a.gX0 = arena_mat(a, 8); a.gHID = arena_mat(a, 16);
+    for (int i = 0; i < 8; ++i) {
+        a.gC[i] = arena_mat(a, 8); a.gO[i] = arena_mat(a, 8); a.gI[i] = arena_mat(a, 8); a.gA[i] = arena_mat(a, 8);
+        a.gH[i] = arena_mat(a, 8); a.gM[i] = arena_mat(a, 4);
+    }
     a.n_params = n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;
     a.GSUM = base ? base + a.cur : nullptr; a.cur += (n_params + 15) & ~(int64_t)15;
@@ -142,7 +146,7 @@ extern "C" size_t linr_net_arena_bytes(int64_t rows) {
     return (size_t)a.cur * sizeof(float) + 64;
 }
 
-struct PadList { int64_t off[160]; int w[160]; int n; };
+struct PadList { int64_t off[200]; int w[200]; int n; };
 
 __global__ void zero_pads_k(float* __restrict__ base, PadList pl) {
     const int b = blockIdx.x;
@@ -205,10 +209,38 @@ struct Ctx {
     const float* P;
     Arena A;
     Layout L;
-    hipStream_t s;
+    hipStream_t s;           // the caller's stream: forward and the backward data chain
+    hipStream_t ws;          // weight-gradient kernels (== s, or the auxiliary stream when overlapping)
     int64_t R;
     int64_t nbr_ld;
 };
+
+// Weight-gradient kernels only feed the final reduction, so they run on a second stream next to the backward data
+// chain (both are latency-bound on their own).  The stream and a small event pool are created once per process.
+static hipStream_t g_aux = nullptr;
+static hipEvent_t g_ev[64];
+static int g_ev_next = 0;
+static bool g_aux_ok = false;
+
+static bool aux_init() {
+    if (g_aux_ok) return true;
+    const char* e = getenv("LINR_WGRAD_STREAM");
+    if (e && atoi(e) == 0) return false;
+    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 64; ++i)
+        if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    g_aux_ok = true;
+    return true;
+}
+
+// everything issued on `from` so far happens-before whatever is issued on `to` next
+static int stream_order(hipStream_t from, hipStream_t to) {
+    if (from == to) return 0;
+    hipEvent_t ev = g_ev[g_ev_next];
+    g_ev_next = (g_ev_next + 1) & 63;
+    TRY(linr_hip_rc(hipEventRecord(ev, from)));
+    return linr_hip_rc(hipStreamWaitEvent(to, ev, 0));
+}
 
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
@@ -223,10 +255,11 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
     static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
+    TRY(stream_order(c.s, c.ws));
     if (use_mfma)
-        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.s);
+        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws);
     return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
-                                    LINR_PAD_ROW, c.s);
+                                    LINR_PAD_ROW, c.ws);
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
@@ -239,7 +272,8 @@ static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W,
 static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
                         int64_t w_off, int ws_ci, int ws_co, int64_t b_off) {
     LinrLinDst d = {c.A.BIG, c.L.total, w_off, ws_ci, ws_co, b_off};
-    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, LINR_WG_BLOCKS, c.s);
+    TRY(stream_order(c.s, c.ws));
+    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, LINR_WG_BLOCKS, c.ws);
 }
 
 // make_block: conv3(cin->8)+ReLU -> Inception -> conv3(8->8) (+ res)
@@ -276,35 +310,36 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
     if (c.f->nbr_lo && c.f->nbr_mask) {
         // fused backward (csrc/fused.hip): gI (+ gM in the epilogue) -> dual 4->4 backward -> gA with both side paths
-        TRY(linr_conv_bwd_gm_launch(gO, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI, a.gM, c.s));
-        TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
-        TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI, 8, a.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
-                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.s));
-        TRY(linr_dual44_bwd_launch(a.gI, a.gM, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH, c.s));
-        TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
-        TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
-        TRY(linr_conv_bwd_ga_launch(a.gH, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI, a.A[b], a.gA, c.s));
+        TRY(linr_conv_bwd_gm_launch(gO, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI[b], a.gM[b], c.s));
+        TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI[b], 8, a.gM[b], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
+                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws));
+        TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
+        TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
+        TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
+        TRY(linr_conv_bwd_ga_launch(a.gH[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI[b], a.A[b], a.gA[b], c.s));
     } else {
-    TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI, 8, 0));
+    TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI[b], 8, 0));
     // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
-    TRY(linear_wgrad(c, a.M[b], 4, a.gI + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
-    TRY(linear(c, a.gI + 4, 8, c.R, P + bp.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, a.M[b], 4, a.gM, 4, LINR_RELU_MASK));
+    TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
+    TRY(linear(c, a.gI[b] + 4, 8, c.R, P + bp.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, a.M[b], 4, a.gM[b], 4, LINR_RELU_MASK));
     // I[:,0:4] = conv3(H0; c01) + A[:,0:4]
-    TRY(conv3_wgrad(c, a.H[b], 8, a.gI, 8, 4, 4, bp.c01_w, bp.c01_b));
-    TRY(conv3(c, true, a.gI, 8, P + bp.c01_w, nullptr, 4, 4, nullptr, 0, a.H[b], 8, a.gH, 8, LINR_RELU_MASK));
+    TRY(conv3_wgrad(c, a.H[b], 8, a.gI[b], 8, 4, 4, bp.c01_w, bp.c01_b));
+    TRY(conv3(c, true, a.gI[b], 8, P + bp.c01_w, nullptr, 4, 4, nullptr, 0, a.H[b], 8, a.gH[b], 8, LINR_RELU_MASK));
     // M = relu(conv3(H1; c11))
-    TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM, 4, 4, 4, bp.c11_w, bp.c11_b));
-    TRY(conv3(c, true, a.gM, 4, P + bp.c11_w, nullptr, 4, 4, nullptr, 0, a.H[b] + 4, 8, a.gH + 4, 8, LINR_RELU_MASK));
+    TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM[b], 4, 4, 4, bp.c11_w, bp.c11_b));
+    TRY(conv3(c, true, a.gM[b], 4, P + bp.c11_w, nullptr, 4, 4, nullptr, 0, a.H[b] + 4, 8, a.gH[b] + 4, 8, LINR_RELU_MASK));
     // H0 = relu(conv3(A; c00)), H1 = relu(A @ c10); gA = gI (residual) + both paths, masked by A > 0
-    TRY(conv3_wgrad(c, a.A[b], 8, a.gH, 8, 8, 4, bp.c00_w, bp.c00_b));
-    TRY(linear_wgrad(c, a.A[b], 8, a.gH + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
-    TRY(conv3(c, true, a.gH, 8, P + bp.c00_w, nullptr, 8, 4, a.gI, 8, nullptr, 0, a.gA, 8, 0));
-    TRY(linear(c, a.gH + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA, 8,
+    TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
+    TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
+    TRY(conv3(c, true, a.gH[b], 8, P + bp.c00_w, nullptr, 8, 4, a.gI[b], 8, nullptr, 0, a.gA[b], 8, 0));
+    TRY(linear(c, a.gH[b] + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA[b], 8,
                LINR_ACCUM | LINR_RELU_MASK));
     }
     // A = relu(conv3(in; a))
-    TRY(conv3_wgrad(c, in, in_ld, a.gA, 8, bp.cin, 8, bp.a_w, bp.a_b));
-    if (gin) TRY(conv3(c, true, a.gA, 8, P + bp.a_w, nullptr, bp.cin, 8, nullptr, 0, nullptr, 0, gin, 8, 0));
+    TRY(conv3_wgrad(c, in, in_ld, a.gA[b], 8, bp.cin, 8, bp.a_w, bp.a_b));
+    if (gin) TRY(conv3(c, true, a.gA[b], 8, P + bp.a_w, nullptr, bp.cin, 8, nullptr, 0, nullptr, 0, gin, 8, 0));
     return 0;
 }
 
@@ -398,6 +433,7 @@ static int backward_core(Ctx& c, float gscale) {
     Arena& a = c.A;
     const float* P = c.P;
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
+    c.ws = (c.f->nbr_lo && c.f->nbr_mask && aux_init()) ? g_aux : c.s;
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));
@@ -405,21 +441,21 @@ static int backward_core(Ctx& c, float gscale) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
             // recompute the hidden layer, gC and the four head-parameter gradients in one launch (csrc/fused.hip)
             TRY(linr_head_bwd_launch(a.C[k], a.P[k], a.OCC + k, 8, P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], gz_scale,
-                                     a.gC, c.R, a.BIG, c.L.total, c.L.h0_w[k], c.L.h0_b[k], c.L.h2_w[k], c.L.h2_b[k], c.s));
+                                     a.gC[k], c.R, a.BIG, c.L.total, c.L.h0_w[k], c.L.h0_b[k], c.L.h2_w[k], c.L.h2_b[k], c.s));
         } else {
             TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
             // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
             TRY(linear_wgrad(c, a.HH[k], 24, a.gZ, 1, c.R, 24, 1, c.L.h2_w[k], 1, 24, c.L.h2_b[k]));
             TRY(linear(c, a.gZ, 1, c.R, P + c.L.h2_w[k], 24, 1, nullptr, 1, 24, nullptr, 0, a.HH[k], 24, a.gHH, 24, LINR_RELU_MASK));
             TRY(linear_wgrad(c, a.C[k], 8, a.gHH, 24, c.R, 8, 24, c.L.h0_w[k], 1, 8, c.L.h0_b[k]));
-            TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC, 8, 0));
+            TRY(linear(c, a.gHH, 24, c.R, P + c.L.h0_w[k], 8, 1, nullptr, 24, 8, nullptr, 0, nullptr, 0, a.gC[k], 8, 0));
         }
         // C = conv3(prior_k; prune_k)
-        TRY(conv3_wgrad(c, a.O[k], 8, a.gC, 8, 8, 8, c.L.pr_w[k], c.L.pr_b[k]));
-        TRY(conv3(c, true, a.gC, 8, P + c.L.pr_w[k], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO, 8, 0));
+        TRY(conv3_wgrad(c, a.O[k], 8, a.gC[k], 8, 8, 8, c.L.pr_w[k], c.L.pr_b[k]));
+        TRY(conv3(c, true, a.gC[k], 8, P + c.L.pr_w[k], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO[k], 8, 0));
         // prior_k = x_glob (+ outter block k-1): both receive gO
-        axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO, c.R * 8, a.gXG, k == 7 ? 0 : 1);
-        if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO, nullptr));
+        axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO[k], c.R * 8, a.gXG, k == 7 ? 0 : 1);
+        if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
     TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
     for (int s = 0; s < f->n_scales; ++s) {
@@ -431,7 +467,8 @@ static int backward_core(Ctx& c, float gscale) {
                    a.gHID + r0 * 16, 16, LINR_RELU_MASK));
         TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, c.L.m0_w[si], 1, 15, c.L.m0_b[si]));
     }
-    // one pass sums every parameter's per-block partials in fixed order
+    // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
+    TRY(stream_order(c.ws, c.s));
     wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
     for (int s = 0; s < f->n_scales; ++s) {
         if (f->row_off_h[s + 1] == f->row_off_h[s]) continue;
