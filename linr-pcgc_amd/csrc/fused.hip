@@ -173,8 +173,30 @@ struct PwArgs {
     float* aux_out;       // EPI 3: gM [n][4]
 };
 
-template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0>
-__global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
+// STAGE: neighbour rows come from an LDS copy instead of per-lane global gathers.  In the x-major row order the
+// neighbours a block's 256 consecutive rows need lie in THREE nearly contiguous row ranges, one per x-slab (dx = -1, 0, +1;
+// each covers the dy, dz = -1..1 columns of that slab).  The block finds the three [min, max] ranges (LDS atomics), copies
+// them with fully coalesced 16-byte loads (~26 wave-loads instead of 216 divergent ones - the texture addresser's
+// lane-request rate is what bounds the direct-gather kernel), and the 27 taps read rows from LDS.  A block whose ranges do
+// not fit (scale boundaries, sphere poles) falls back to direct gathers.  Arithmetic order is unchanged => identical bits.
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+#define STAGE_SLOTS 384                  // rows per slab window incl. the zero slot
+#define STAGE_SLAB_BYTES (STAGE_SLOTS * 32)
+
+#ifndef LINR_CONV_BLOCK
+#define LINR_CONV_BLOCK 256
+#endif
+template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0, bool STAGE = false>
+__global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
                                                            const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                            int64_t ld, int64_t n, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
@@ -202,38 +224,119 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
                 wv[g][i] = (k < 27) ? (BWD ? W[(k * GOUT + co) * GIN + i] : W[(k * GIN + i) * GOUT + co]) : 0.0f;
         }
     }
-    const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    const int64_t row_raw = (int64_t)blockIdx.x * LINR_CONV_BLOCK + threadIdx.x;
     const bool live = row_raw < n;
     const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
     const char* pad = reinterpret_cast<const char*>(in - in_ld);
+    const uint32_t rowbytes = (uint32_t)in_ld * 4u;
     uint32_t off[27];
-    decode_offsets<BWD>(lo, mask, ld, row, (uint32_t)in_ld * 4u, off);
+    decode_offsets<BWD>(lo, mask, ld, row, STAGE ? 1u : rowbytes, off);       // STAGE: row index + 1 (0 = absent)
     f32x4 acc[GOUT / 4];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[h][j] = (bias != nullptr) ? bias[4 * h + j] : 0.0f;
-    // Left to itself hipcc waits (vmcnt(0)) right after every 16-byte gather - 54 serial round trips per wave.  The loop
-    // is therefore pipelined by hand: the gather of offset k+PF is issued before the MFMAs of offset k and
-    // sched_barrier keeps it there, so the compiler's own counted vmcnt leaves PF rows in flight.
     constexpr int PF = 3;
     float x[PF + 1][LOADW];
+    // the offset loop; SRC = 0: rows from global memory (per-lane gathers), SRC = 1: rows from the LDS windows.
+    // Left to itself hipcc waits (vmcnt(0)) right after every 16-byte gather - 54 serial round trips per wave.  The loop
+    // is therefore pipelined by hand: the load of offset k+PF is issued before the MFMAs of offset k and sched_barrier
+    // keeps it there, so the compiler's own counted waits leave PF rows in flight.
+    // `ld(off, x)` fetches one row: the LDS variant indexes the __shared__ array itself so that the compiler emits
+    // ds_read (a generic pointer would become flat loads, which force vmcnt(0)/lgkmcnt(0) waits and kill the pipeline)
+    auto taps = [&](auto ld) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) RowLoadF<LOADW>::run(pad + off[u], x[u]);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<27>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int g = k / KPV, ab = (k % KPV) * HB;
-        if constexpr (k + PF < 27) RowLoadF<LOADW>::run(pad + off[k + PF], x[(k + PF) % (PF + 1)]);
+        for (int u = 0; u < PF; ++u) ld(off[u], x[u]);
         __builtin_amdgcn_sched_barrier(0);
+        static_for<27>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int g = k / KPV, ab = (k % KPV) * HB;
+            if constexpr (k + PF < 27) ld(off[k + PF], x[(k + PF) % (PF + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < GIN; ++i) {
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[0], 4, ab, 0);
-            if constexpr (GOUT == 8)
-                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[1], 4, ab + 1, 0);
+            for (int i = 0; i < GIN; ++i) {
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[0], 4, ab, 0);
+                if constexpr (GOUT == 8)
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[1], 4, ab + 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto ld_global = [&](uint32_t o, float (&xr)[LOADW]) { RowLoadF<LOADW>::run(pad + o, xr); };
+    if constexpr (!STAGE) {
+        taps(ld_global);
+    } else {
+        __shared__ float4 sX[3 * STAGE_SLOTS * 2];
+        auto ld_lds = [&](uint32_t o, float (&xr)[LOADW]) {
+#pragma unroll
+            for (int v = 0; v < LOADW / 4; ++v) {
+                const float4 t = sX[(o >> 4) + v];
+                xr[4 * v] = t.x; xr[4 * v + 1] = t.y; xr[4 * v + 2] = t.z; xr[4 * v + 3] = t.w;
+            }
+        };
+        __shared__ int smm[6];
+        char* xs = reinterpret_cast<char*>(sX);
+        if (threadIdx.x < 3) { smm[threadIdx.x] = 0x7fffffff; smm[3 + threadIdx.x] = -1; }
+        if (threadIdx.x < 6) sX[(threadIdx.x >> 1) * STAGE_SLOTS * 2 + (threadIdx.x & 1)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+        static_for<27>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int sl = (BWD ? 26 - k : k) % 3;        // x-slab of the table offset this tap reads
+            if (off[k] != 0u) { const int j = (int)off[k] - 1; mn[sl] = min(mn[sl], j); mx[sl] = max(mx[sl], j); }
+        });
+        // wave-level reduction first: 256 same-address LDS atomics per slab serialise (measured: ~10 us per launch and slab)
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int wmn = wave_min_i32(mn[sl]), wmx = wave_max_i32(mx[sl]);
+            if ((threadIdx.x & 63) == 0 && wmx >= 0) { atomicMin(&smm[sl], wmn); atomicMax(&smm[3 + sl], wmx); }
         }
-        __builtin_amdgcn_sched_barrier(0);
-    });
+        __syncthreads();
+        int lo_s[3], span[3];
+        bool fits = true;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            lo_s[sl] = smm[sl];
+            span[sl] = smm[3 + sl] < 0 ? 0 : smm[3 + sl] - smm[sl] + 1;
+            fits = fits && span[sl] <= STAGE_SLOTS - 1;
+        }
+        if (fits) {                                            // block-uniform
+            // all (<= 9) 16-byte pieces of this thread are requested before the first one is written to LDS
+            constexpr int PPT = (STAGE_SLOTS * 2 + LINR_CONV_BLOCK - 1) / LINR_CONV_BLOCK;     // pieces per thread and slab
+            float4 v[3][PPT];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                const int pieces = (int)(((uint32_t)span[sl] * rowbytes) >> 4);
+                const char* srcg = reinterpret_cast<const char*>(in) + (int64_t)lo_s[sl] * rowbytes;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const int pidx = (int)threadIdx.x + j * LINR_CONV_BLOCK;
+                    v[sl][j] = (pidx < pieces) ? *reinterpret_cast<const float4*>(srcg + 16 * pidx) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+                const int pieces = (int)(((uint32_t)span[sl] * rowbytes) >> 4);
+                char* dst = xs + sl * STAGE_SLAB_BYTES + rowbytes;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const int pidx = (int)threadIdx.x + j * LINR_CONV_BLOCK;
+                    if (pidx < pieces) *reinterpret_cast<float4*>(dst + 16 * pidx) = v[sl][j];
+                }
+            }
+            static_for<27>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int sl = (BWD ? 26 - k : k) % 3;
+                off[k] = (uint32_t)(sl * STAGE_SLAB_BYTES) + (off[k] ? ((off[k] - 1u) - (uint32_t)lo_s[sl] + 1u) * rowbytes : 0u);
+            });
+            __syncthreads();
+            taps(ld_lds);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) off[k] *= rowbytes;
+            taps(ld_global);
+        }
+    }
     float a[GOUT];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
@@ -257,7 +360,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
         const float p = 1.0f / (1.0f + expf(-z));
         if (live) hd.p_out[row] = p;
         if (hd.partial != nullptr) {          // wave-uniform (kernel argument)
-            __shared__ double sred[LINR_BLOCK];
+            __shared__ double sred[LINR_CONV_BLOCK];
             double nats = 0.0;
             if (live) {
                 const float t = hd.target[row * hd.target_ld];
@@ -265,7 +368,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_mfma_k(const float* __restri
             }
             sred[threadIdx.x] = nats;
             __syncthreads();
-            for (int s2 = LINR_BLOCK / 2; s2 > 0; s2 >>= 1) {
+            for (int s2 = LINR_CONV_BLOCK / 2; s2 > 0; s2 >>= 1) {
                 if ((int)threadIdx.x < s2) sred[threadIdx.x] += sred[threadIdx.x + s2];
                 __syncthreads();
             }
@@ -368,7 +471,7 @@ int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* m
                            double* partial, hipStream_t s) {
     if (n == 0) return 0;
     HeadArgs hd = {w1, b1, w2, b2, target, target_ld, p_out, partial};
-    cconv_mfma_k<8, 8, false, 8, 1><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(in, 8, lo, mask, ld, n, W, bias, nullptr, 0,
+    cconv_mfma_k<8, 8, false, 8, 1><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(in, 8, lo, mask, ld, n, W, bias, nullptr, 0,
                                                                                    nullptr, 0, c_out, 8, 0, hd);
     return linr_launch_rc();
 }
@@ -490,7 +593,7 @@ int linr_conv_pw_fwd_launch(const float* A, const int32_t* lo, const uint32_t* m
                             const float* b00, const float* w10, const float* b10, float* H, hipStream_t s) {
     if (n == 0) return 0;
     PwArgs pw = {w10, b10, nullptr, nullptr};
-    cconv_mfma_k<8, 4, false, 8, 2><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(A, 8, lo, mask, ld, n, w00, b00, nullptr, 0,
+    cconv_mfma_k<8, 4, false, 8, 2><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(A, 8, lo, mask, ld, n, w00, b00, nullptr, 0,
                                                                                    nullptr, 0, H, 8, 0, HeadArgs(), pw);
     return linr_launch_rc();
 }
@@ -500,7 +603,7 @@ int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* 
                             const float* w12, const float* M, float* gI, float* gM, hipStream_t s) {
     if (n == 0) return 0;
     PwArgs pw = {w12, nullptr, M, gM};
-    cconv_mfma_k<8, 8, true, 8, 3><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gO, 8, lo, mask, ld, n, wb, nullptr, nullptr, 0,
+    cconv_mfma_k<8, 8, true, 8, 3><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(gO, 8, lo, mask, ld, n, wb, nullptr, nullptr, 0,
                                                                                   nullptr, 0, gI, 8, 0, HeadArgs(), pw);
     return linr_launch_rc();
 }
@@ -510,7 +613,7 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
                             const float* w10, const float* gI, const float* A, float* gA, hipStream_t s) {
     if (n == 0) return 0;
     PwArgs pw = {w10, nullptr, gH, nullptr};
-    cconv_mfma_k<4, 8, true, 4, 4><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8,
+    cconv_mfma_k<4, 8, true, 4, 4><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8,
                                                                                   gA, 8, LINR_RELU_MASK, HeadArgs(), pw);
     return linr_launch_rc();
 }
@@ -791,15 +894,18 @@ int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, c
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
                       const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s) {
     if (n == 0) return 0;
-    const unsigned grid = linr_grid(n, LINR_BLOCK);
-    static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;
+    const unsigned grid = linr_grid(n, LINR_CONV_BLOCK);
+    static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;   // 2 = MFMA + LDS staging (measured equal)
 #define GO(GI, GO_, B, LW)                                                                                              \
     do {                                                                                                                \
-        if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                         \
-            cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_BLOCK, 0, s>>>(                       \
+        if (use_mfma == 2 && (GO_ == 4 || GO_ == 8))                                                                    \
+            cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW, 0, true><<<grid, LINR_CONV_BLOCK, 0, s>>>(              \
+                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags);                     \
+        else if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                    \
+            cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_CONV_BLOCK, 0, s>>>(                       \
                 in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags);                     \
         else                                                                                                            \
-            cconv_k<GI, GO_, B, LW><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act,   \
+            cconv_k<GI, GO_, B, LW><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act,   \
                                                                 act_ld, out, out_ld, flags);                            \
         return linr_launch_rc();                                                                                        \
     } while (0)
