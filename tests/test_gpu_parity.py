@@ -481,3 +481,44 @@ def test_tiny_and_ragged_frames(pkg, n):
     grads = torch.zeros_like(model.flat_parameters())
     engine.net_backward(frame, model.flat_parameters(), grads, 1.0)
     assert bool(torch.isfinite(grads).all())
+
+
+def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
+    """main.overfit_enc_dec in miniature: GOP 0 from scratch -> checkpoint -> GOP 1 warm start (model + Adam state) ->
+    encode -> reference directory layout on disk -> decode from the files alone -> lossless; model codec round trip."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sphere_shell(6, 20 + t) for t in range(4)]
+    gop0 = overfit.Gop(None, clouds[:2], None, 64, 'cuda')
+    model = overfit.gen_model(gop0.scale_num, 'cuda', seed=8807)
+    opt = FlatAdam(model)
+    l0 = overfit.overfit_gop(model, opt, gop0, 3)
+    assert l0[-1] < l0[0]
+    ck = overfit.checkpoint(model, opt, 2, l0[-1])
+    assert set(ck) == {'model', 'epoch', 'optimizer_state_dict', 'loss', 'bitdepth'}
+    assert len(ck['model']) == 1 + 4 * gop0.scale_num + 160           # 189 tensors at scale_num 7
+    torch.save(ck, tmp_path / 'model.pth')
+    ck2 = torch.load(tmp_path / 'model.pth', weights_only=False)
+    gop1 = overfit.Gop(None, clouds[2:], gop0.scale_num, 64, 'cuda')
+    m1 = overfit.gen_model(gop0.scale_num, 'cuda', seed=1)
+    o1 = FlatAdam(m1)
+    overfit.warm_start(m1, o1, ck2)
+    assert torch.equal(m1.flat_parameters(), model.flat_parameters()) and o1.t == opt.t and abs(o1.lr - opt.lr) < 1e-15
+    assert torch.equal(o1.exp_avg, opt.exp_avg)
+    l1 = overfit.overfit_gop(m1, o1, gop1, 2)
+    assert l1[0] < l0[0]                                         # warm start begins far below the cold-start loss
+    est = Model_Estimate()
+    test = est.compress_test(m1, overfit.gen_model(gop0.scale_num, 'cuda'), 8)
+    assert test['enc_mode'] in (0, 1, 2) and test['bit_real'] > 0
+    enc = codec.encode_gop(m1, overfit.gen_model(gop0.scale_num, 'cuda'), gop1, 8)
+    codec.write_gop(enc, str(tmp_path / 'gop_2_3'))
+    names = sorted(os.listdir(tmp_path / 'gop_2_3' / 'bins'))
+    assert 'model.bin' in names and 'low_enc_bytes.bin' in names and 'frame0000_scale0.bin' in names
+    back = codec.read_gop(str(tmp_path / 'gop_2_3'))
+    assert back['frames'] == enc['frames'] and back['model_bin'] == enc['model_bin']
+    dec = codec.decode_gop(overfit.gen_model(gop0.scale_num, 'cuda'), back, 'cuda')
+    for d, info, mn in zip(dec, gop1.infos, gop1.coord_mins):
+        ref = torch.as_tensor(info['ori']).cuda() + torch.tensor(mn, device='cuda', dtype=torch.int32)
+        assert torch.equal(d, ref)
+    assert 0 < enc['bpp']['point_bpp'] < 8 and enc['bpp']['model_bpp'] > 0      # tiny clouds: the 35 KB model dominates bpp_all
