@@ -39,6 +39,17 @@ struct LinrLinDst {      // pointwise layers: element (ci,co) at w_off + ci*ws_c
 };
 #define LINR_WG_BLOCKS 512   // persistent blocks of every weight-gradient kernel (2 per CU x 8 waves)
 
+// Grouped launches: independent layers of equal shape (the 7 outter blocks, the 8 occupancy heads, whose inputs are the
+// ground-truth occupancy and x_glob during overfitting / encoding) run as ONE launch with gridDim.y = groups.  Group g adds
+// these ELEMENT offsets to the kernel's base pointers; a plain launch passes all zeros.  Per-row arithmetic is identical
+// in grouped and plain launches, so the staged decoder (plain) reproduces the encoder (grouped) bit for bit.
+#define LINR_MAXG 8
+struct Grp {
+    int64_t in[LINR_MAXG], w[LINR_MAXG], b[LINR_MAXG], res[LINR_MAXG], act[LINR_MAXG], out[LINR_MAXG];
+    int64_t e0[LINR_MAXG], e1[LINR_MAXG], e2[LINR_MAXG], e3[LINR_MAXG], e4[LINR_MAXG], e5[LINR_MAXG], e6[LINR_MAXG];
+};
+
+
 // ---- internal launchers shared with the network executor (C++ linkage, not exported) ---------------------------
 // epilogue order of both: acc (+ bias) -> + res -> + old (LINR_ACCUM) -> * (act > 0) (LINR_RELU_MASK) -> ReLU
 __attribute__((visibility("hidden")))
@@ -59,12 +70,13 @@ int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int
 __attribute__((visibility("hidden")))
 int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
-                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s);
+                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s,
+                      const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                            const float* W, const float* bias, float* c_out, const float* w1, const float* b1,
                            const float* w2, const float* b2, const float* target, int target_ld, float* p_out,
-                           double* partial, hipStream_t s);
+                           double* partial, hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
@@ -75,19 +87,23 @@ int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, 
 __attribute__((visibility("hidden")))
 int linr_dual44_fwd_launch(const float* H, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w01,
                            const float* b01, const float* w11, const float* b11, const float* A, const float* w12,
-                           const float* b12, float* M, float* I, hipStream_t s);
+                           const float* b12, float* M, float* I, hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_dual44_bwd_launch(const float* gI, const float* gM, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
-                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s);
+                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s,
+                           const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv_pw_fwd_launch(const float* A, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s);
+                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s,
+                            const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* wb,
-                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s);
+                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s,
+                            const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s);
+                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s,
+                            const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s);

@@ -202,8 +202,24 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
                                                            const float* __restrict__ bias, const float* __restrict__ res,
                                                            int res_ld, const float* __restrict__ act, int act_ld,
                                                            float* __restrict__ out, int out_ld, unsigned flags,
-                                                           HeadArgs hd = HeadArgs(), PwArgs pw = PwArgs()) {
+                                                           HeadArgs hd = HeadArgs(), PwArgs pw = PwArgs(), Grp gp = Grp()) {
     static_assert(GOUT == 4 || GOUT == 8, "output channels must fill 1 or 2 MFMA blocks");
+    {   // group offsets (all zero for a plain launch)
+        const int gi = blockIdx.y;
+        in += gp.in[gi]; W += gp.w[gi]; out += gp.out[gi];
+        if (bias) bias += gp.b[gi];
+        if (res) res += gp.res[gi];
+        if (act) act += gp.act[gi];
+        if constexpr (EPI == 1) {
+            hd.w1 += gp.e0[gi]; hd.b1 += gp.e1[gi]; hd.w2 += gp.e2[gi]; hd.b2 += gp.e3[gi];
+            if (hd.target) hd.target += gp.e4[gi];
+            hd.p_out += gp.e5[gi];
+            if (hd.partial) hd.partial += gp.e6[gi];
+        }
+        if constexpr (EPI == 2) { pw.w += gp.e0[gi]; pw.b += gp.e1[gi]; }
+        if constexpr (EPI == 3) { pw.w += gp.e0[gi]; pw.aux += gp.e1[gi]; pw.aux_out += gp.e2[gi]; }
+        if constexpr (EPI == 4) { pw.w += gp.e0[gi]; pw.aux += gp.e1[gi]; }
+    }
     // All weights of the convolution live in registers for the whole kernel: the A operand of the 16-block MFMA is taken
     // from block ABID (an immediate), so ONE VGPR carries 16 different weight 4-vectors - block b of register wv[g][i]
     // holds W(k = g*KPV + b/HB, input i, outputs 4*(b%HB) .. +3).  27 x Cin x Cout floats = at most 32 VGPRs, loaded once;
@@ -461,18 +477,19 @@ extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, con
     if (res && res_ld < gout) return LINR_EINVAL;
     if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;     // 32-bit byte offsets
     return linr_cconv_launch(bwd != 0, in, in_ld, lo, mask, ld, n, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
-                             flags, (hipStream_t)stream);
+                             flags, (hipStream_t)stream, nullptr, 1);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
 int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                            const float* W, const float* bias, float* c_out, const float* w1, const float* b1,
                            const float* w2, const float* b2, const float* target, int target_ld, float* p_out,
-                           double* partial, hipStream_t s) {
+                           double* partial, hipStream_t s, const Grp* gp, int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     HeadArgs hd = {w1, b1, w2, b2, target, target_ld, p_out, partial};
-    cconv_mfma_k<8, 8, false, 8, 1><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(in, 8, lo, mask, ld, n, W, bias, nullptr, 0,
-                                                                                   nullptr, 0, c_out, 8, 0, hd);
+    cconv_mfma_k<8, 8, false, 8, 1><<<dim3(linr_grid(n, LINR_CONV_BLOCK), ngroups), LINR_CONV_BLOCK, 0, s>>>(
+        in, 8, lo, mask, ld, n, W, bias, nullptr, 0, nullptr, 0, c_out, 8, 0, hd, PwArgs(), g0);
     return linr_launch_rc();
 }
 
@@ -494,7 +511,21 @@ struct DualArgs {
 template <bool BWD>
 __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __restrict__ in, int in_ld,
                                                              const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
-                                                             int64_t ld, int64_t n, DualArgs d, float* __restrict__ out) {
+                                                             int64_t ld, int64_t n, DualArgs d, float* __restrict__ out,
+                                                             Grp gp = Grp()) {
+    {   // group offsets: in, e0 = in2, w = w01, e1 = w11, b = b01, e2 = b11, res = a_res, e3 = w12, e4 = b12, e5 = m_out, act, out
+        const int gi = blockIdx.y;
+        in += gp.in[gi]; out += gp.out[gi];
+        if (d.in2) d.in2 += gp.e0[gi];
+        d.w01 += gp.w[gi]; d.w11 += gp.e1[gi];
+        if (d.b01) d.b01 += gp.b[gi];
+        if (d.b11) d.b11 += gp.e2[gi];
+        if (d.a_res) d.a_res += gp.res[gi];
+        if (d.w12) d.w12 += gp.e3[gi];
+        if (d.b12) d.b12 += gp.e4[gi];
+        if (d.m_out) d.m_out += gp.e5[gi];
+        if (d.act) d.act += gp.act[gi];
+    }
     // register-resident weights (see cconv_mfma_k): block b of wv[g][i] holds, for offset k = g*8 + b/2, the tap of
     // W01 (b even) or W11 (b odd) for input i and outputs 0..3
     const int lane = threadIdx.x & 63;
@@ -573,48 +604,57 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __rest
 
 int linr_dual44_fwd_launch(const float* H, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w01,
                            const float* b01, const float* w11, const float* b11, const float* A, const float* w12,
-                           const float* b12, float* M, float* I, hipStream_t s) {
+                           const float* b12, float* M, float* I, hipStream_t s, const Grp* gp, int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     DualArgs d = {nullptr, 0, w01, w11, b01, b11, A, w12, b12, M, nullptr};
-    cconv_dual44_k<false><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(H, 8, lo, mask, ld, n, d, I);
+    cconv_dual44_k<false><<<dim3(linr_grid(n, LINR_BLOCK), ngroups), LINR_BLOCK, 0, s>>>(H, 8, lo, mask, ld, n, d, I, g0);
     return linr_launch_rc();
 }
 
 int linr_dual44_bwd_launch(const float* gI, const float* gM, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
-                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s) {
+                           const float* w01, const float* w11, const float* H, float* gH, hipStream_t s, const Grp* gp,
+                           int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     DualArgs d = {gM, 4, w01, w11, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, H};
-    cconv_dual44_k<true><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(gI, 8, lo, mask, ld, n, d, gH);
+    cconv_dual44_k<true><<<dim3(linr_grid(n, LINR_BLOCK), ngroups), LINR_BLOCK, 0, s>>>(gI, 8, lo, mask, ld, n, d, gH, g0);
     return linr_launch_rc();
 }
 
 // conv0_0 (8->4) + conv1_0 (1x1 8->4) forward with both ReLUs: H = [relu(conv3(A)) | relu(A @ W10 + b10)]
 int linr_conv_pw_fwd_launch(const float* A, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s) {
+                            const float* b00, const float* w10, const float* b10, float* H, hipStream_t s, const Grp* gp,
+                            int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     PwArgs pw = {w10, b10, nullptr, nullptr};
-    cconv_mfma_k<8, 4, false, 8, 2><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(A, 8, lo, mask, ld, n, w00, b00, nullptr, 0,
-                                                                                   nullptr, 0, H, 8, 0, HeadArgs(), pw);
+    cconv_mfma_k<8, 4, false, 8, 2><<<dim3(linr_grid(n, LINR_CONV_BLOCK), ngroups), LINR_CONV_BLOCK, 0, s>>>(
+        A, 8, lo, mask, ld, n, w00, b00, nullptr, 0, nullptr, 0, H, 8, 0, HeadArgs(), pw, g0);
     return linr_launch_rc();
 }
 
 // backward of the block's tail conv: gI = bwd(gO; Wb) and gM = (gI[:,4:8] @ W12^T) * (M > 0)
 int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* wb,
-                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s) {
+                            const float* w12, const float* M, float* gI, float* gM, hipStream_t s, const Grp* gp,
+                            int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     PwArgs pw = {w12, nullptr, M, gM};
-    cconv_mfma_k<8, 8, true, 8, 3><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(gO, 8, lo, mask, ld, n, wb, nullptr, nullptr, 0,
-                                                                                  nullptr, 0, gI, 8, 0, HeadArgs(), pw);
+    cconv_mfma_k<8, 8, true, 8, 3><<<dim3(linr_grid(n, LINR_CONV_BLOCK), ngroups), LINR_CONV_BLOCK, 0, s>>>(
+        gO, 8, lo, mask, ld, n, wb, nullptr, nullptr, 0, nullptr, 0, gI, 8, 0, HeadArgs(), pw, g0);
     return linr_launch_rc();
 }
 
 // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
 int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s) {
+                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s, const Grp* gp,
+                            int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     PwArgs pw = {w10, nullptr, gH, nullptr};
-    cconv_mfma_k<4, 8, true, 4, 4><<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8,
-                                                                                  gA, 8, LINR_RELU_MASK, HeadArgs(), pw);
+    cconv_mfma_k<4, 8, true, 4, 4><<<dim3(linr_grid(n, LINR_CONV_BLOCK), ngroups), LINR_CONV_BLOCK, 0, s>>>(
+        gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8, gA, 8, LINR_RELU_MASK, HeadArgs(), pw, g0);
     return linr_launch_rc();
 }
 
@@ -892,18 +932,20 @@ int linr_head_bwd_launch(const float* c, const float* p, const float* target, in
 // executor entry: all matrices are arena matrices (16-byte aligned rows, ld in {4, 8}, pad row present)
 int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
-                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s) {
+                      const float* act, int act_ld, float* out, int out_ld, unsigned flags, hipStream_t s, const Grp* gp,
+                      int ngroups) {
     if (n == 0) return 0;
-    const unsigned grid = linr_grid(n, LINR_CONV_BLOCK);
+    const Grp g0 = gp ? *gp : Grp();
+    const dim3 grid(linr_grid(n, LINR_CONV_BLOCK), ngroups);
     static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;   // 2 = MFMA + LDS staging (measured equal)
 #define GO(GI, GO_, B, LW)                                                                                              \
     do {                                                                                                                \
         if (use_mfma == 2 && (GO_ == 4 || GO_ == 8))                                                                    \
             cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW, 0, true><<<grid, LINR_CONV_BLOCK, 0, s>>>(              \
-                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags);                     \
+                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
         else if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                    \
             cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_CONV_BLOCK, 0, s>>>(                       \
-                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags);                     \
+                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
         else                                                                                                            \
             cconv_k<GI, GO_, B, LW><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act,   \
                                                                 act_ld, out, out_ld, flags);                            \

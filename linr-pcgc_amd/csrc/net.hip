@@ -93,6 +93,7 @@ struct Arena {
     float *gZ, *gHH, *gXG, *gX0, *gHID;
     float *gC[8], *gO[8], *gI[8], *gA[8], *gH[8], *gM[8];   // one set per stage / block: weight-gradient kernels run on a
                                                            // second stream and may still read them when the chain moves on
+    float* WPAD;                 // [7][27][8][8] first-conv kernels of the outter blocks zero-extended to 8 input channels
     float* BIG;                  // [LINR_WG_BLOCKS][n_params] per-block partial weight gradients
     float* GSUM;                 // [n_params] their fixed-order sum (the gradient of this backward call)
     int64_t n_params;
@@ -130,6 +131,7 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
     a.n_params = n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;
     a.GSUM = base ? base + a.cur : nullptr; a.cur += (n_params + 15) & ~(int64_t)15;
+    a.WPAD = base ? base + a.cur : nullptr; a.cur += 7 * 27 * 64;
     a.BIG = base ? base + a.cur : nullptr; a.cur += (int64_t)LINR_WG_BLOCKS * n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;                     // 64-byte alignment for the slab (doubles inside)
     a.slab = base ? (void*)(base + a.cur) : nullptr;
@@ -364,6 +366,88 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     return 0;
 }
 
+// WPAD[g][k][ci][co] = ci <= g ? W_a(outter block g)[k][ci][co] : 0     (block g has cin = g + 1)
+struct PadSrc { int64_t off[7]; };
+__global__ __launch_bounds__(LINR_BLOCK) void pad_weights_k(const float* __restrict__ P, PadSrc src, float* __restrict__ wpad) {
+    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (e >= 7 * 1728) return;
+    const int g = e / 1728, r = e % 1728;
+    const int k = r / 64, ci = (r / 8) % 8, co = r % 8, cin = g + 1;
+    wpad[e] = ci < cin ? P[src.off[g] + (k * cin + ci) * 8 + co] : 0.0f;
+}
+
+static void goffs(int64_t* dst, const float* const* ptrs, int n) {
+    for (int i = 0; i < n; ++i) dst[i] = ptrs[i] - ptrs[0];
+}
+
+// Teacher-forced forward of all 8 stages with the 7 outter blocks and the 8 heads as grouped launches (their inputs -
+// the ground-truth occupancy and x_glob - are all known up front).  Same kernels and per-row arithmetic as the staged
+// path below, so the decoder reproduces these probabilities bit for bit.
+static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
+    Arena& a = c.A;
+    const float* P = c.P;
+    const Layout& L = c.L;
+    const int32_t* lo = c.f->nbr_lo;
+    const uint32_t* mk = c.f->nbr_mask;
+    const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
+    PadSrc ps;
+    for (int g = 0; g < 7; ++g) ps.off[g] = L.outter[g].a_w;
+    pad_weights_k<<<linr_grid(7 * 1728, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, ps, a.WPAD);
+    const float *pA[7], *pH[7], *pM[7], *pI[7], *pO[7], *p_ab[7], *p_c00w[7], *p_c00b[7], *p_c10w[7], *p_c10b[7], *p_c01w[7],
+        *p_c01b[7], *p_c11w[7], *p_c11b[7], *p_c12w[7], *p_c12b[7], *p_bw[7], *p_bb[7];
+    for (int g = 0; g < 7; ++g) {
+        const BlockP& bp = L.outter[g];
+        pA[g] = a.A[g + 1]; pH[g] = a.H[g + 1]; pM[g] = a.M[g + 1]; pI[g] = a.I[g + 1]; pO[g] = a.O[g + 1];
+        p_ab[g] = P + bp.a_b; p_c00w[g] = P + bp.c00_w; p_c00b[g] = P + bp.c00_b; p_c10w[g] = P + bp.c10_w; p_c10b[g] = P + bp.c10_b;
+        p_c01w[g] = P + bp.c01_w; p_c01b[g] = P + bp.c01_b; p_c11w[g] = P + bp.c11_w; p_c11b[g] = P + bp.c11_b;
+        p_c12w[g] = P + bp.c12_w; p_c12b[g] = P + bp.c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
+    }
+    {   // first conv of every outter block on the zero-extended kernels: A[b] = relu(conv3(occ; WPAD[b-1]) + a_b)
+        Grp gp = Grp();
+        for (int g = 0; g < 7; ++g) gp.w[g] = (int64_t)g * 1728;
+        goffs(gp.b, p_ab, 7); goffs(gp.out, pA, 7);
+        TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[0], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
+                              LINR_RELU, c.s, &gp, 7));
+    }
+    {   // H = [relu(conv0_0(A)) | relu(conv1_0(A))]
+        Grp gp = Grp();
+        goffs(gp.in, pA, 7); goffs(gp.w, p_c00w, 7); goffs(gp.b, p_c00b, 7); goffs(gp.out, pH, 7);
+        goffs(gp.e0, p_c10w, 7); goffs(gp.e1, p_c10b, 7);
+        TRY(linr_conv_pw_fwd_launch(pA[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c00b[0], p_c10w[0], p_c10b[0], a.H[1], c.s, &gp, 7));
+    }
+    {   // both 4->4 convs + conv1_2 + residual -> M, I
+        Grp gp = Grp();
+        goffs(gp.in, pH, 7); goffs(gp.w, p_c01w, 7); goffs(gp.b, p_c01b, 7); goffs(gp.e1, p_c11w, 7); goffs(gp.e2, p_c11b, 7);
+        goffs(gp.res, pA, 7); goffs(gp.e3, p_c12w, 7); goffs(gp.e4, p_c12b, 7); goffs(gp.e5, pM, 7); goffs(gp.out, pI, 7);
+        TRY(linr_dual44_fwd_launch(pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c01b[0], p_c11w[0], p_c11b[0], pA[0], p_c12w[0],
+                                   p_c12b[0], a.M[1], a.I[1], c.s, &gp, 7));
+    }
+    {   // O[b] = conv3(I; b) + x_glob
+        Grp gp = Grp();
+        goffs(gp.in, pI, 7); goffs(gp.w, p_bw, 7); goffs(gp.b, p_bb, 7); goffs(gp.out, pO, 7);
+        TRY(linr_cconv_launch(false, pI[0], 8, lo, mk, c.nbr_ld, c.R, p_bw[0], p_bb[0], 8, 8, a.O[0], 8, nullptr, 0, a.O[1], 8, 0,
+                              c.s, &gp, 7));
+    }
+    {   // the 8 occupancy heads
+        const float *hO[8], *hC[8], *hP[8], *h_prw[8], *h_prb[8], *h_w1[8], *h_b1[8], *h_w2[8], *h_b2[8];
+        for (int k = 0; k < 8; ++k) {
+            hO[k] = a.O[k]; hC[k] = a.C[k]; hP[k] = a.P[k]; h_prw[k] = P + L.pr_w[k]; h_prb[k] = P + L.pr_b[k];
+            h_w1[k] = P + L.h0_w[k]; h_b1[k] = P + L.h0_b[k]; h_w2[k] = P + L.h2_w[k]; h_b2[k] = P + L.h2_b[k];
+        }
+        Grp gp = Grp();
+        goffs(gp.in, hO, 8); goffs(gp.w, h_prw, 8); goffs(gp.b, h_prb, 8); goffs(gp.out, hC, 8);
+        goffs(gp.e0, h_w1, 8); goffs(gp.e1, h_b1, 8); goffs(gp.e2, h_w2, 8); goffs(gp.e3, h_b2, 8); goffs(gp.e5, hP, 8);
+        for (int k = 0; k < 8; ++k) { gp.e4[k] = k; gp.e6[k] = (int64_t)k * nblk; }
+        TRY(linr_cconv_head_launch(a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], h_prb[0], a.C[0], h_w1[0], h_b1[0], h_w2[0], h_b2[0],
+                                   a.OCC, 8, a.P[0], bits_acc ? (double*)a.slab : nullptr, c.s, &gp, 8));
+    }
+    if (bits_acc) TRY(linr_bits_finish_launch((const double*)a.slab, (int)(8 * nblk), bits_acc, c.s));
+    if (probs)
+        for (int k = 0; k < 8; ++k)
+            TRY(linr_hip_rc(hipMemcpyAsync(probs + (int64_t)k * c.R, a.P[k], (size_t)c.R * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+    return linr_launch_rc();
+}
+
 extern "C" int linr_net_forward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes,
                                 int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc, void* stream) {
     Ctx c;
@@ -394,6 +478,8 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         }
         TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
     }
+    static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
+    if (batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask) return forward_batched(c, probs, bits_acc);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
