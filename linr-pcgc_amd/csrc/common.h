@@ -66,7 +66,7 @@ int linr_conv3_wgrad_partial(const float* in, int in_ld, const float* gout, int 
                              hipStream_t s);
 __attribute__((visibility("hidden")))
 int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
-                              LinrLinDst d, int nblocks, hipStream_t s);
+                              LinrLinDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,
@@ -81,7 +81,7 @@ __attribute__((visibility("hidden")))
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
-                         hipStream_t s);
+                         hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s);
 __attribute__((visibility("hidden")))
@@ -106,8 +106,10 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
                             const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
-                          int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s);
+                          int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr,
+                          int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
-                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s);
+                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp = nullptr,
+                            int ngroups = 1);

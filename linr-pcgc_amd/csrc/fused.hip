@@ -676,8 +676,17 @@ struct WgradDual { int64_t w_off1, b_off1; };
 
 template <int XQ, int COUT, bool DUAL, bool VIDX>
 __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S, const int32_t* __restrict__ nbr,
-                                                                    int64_t nbr_ld, int64_t n, LinrWgradDst d, WgradDual dd) {
+                                                                    int64_t nbr_ld, int64_t n, LinrWgradDst d, WgradDual dd,
+                                                                    Grp gp = Grp()) {
     static_assert(!DUAL || (XQ == 2 && COUT == 4), "dual mode = two 4->4 convolutions");
+    {   // group offsets: in, res = g0, act = g1, w/b = slab offsets of conv 0, e0/e1 = of conv 1, e2 = cin_valid override
+        const int gi = blockIdx.y;
+        S.in += gp.in[gi]; S.g0 += gp.res[gi];
+        if (S.g1) S.g1 += gp.act[gi];
+        d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
+        dd.w_off1 += gp.e0[gi]; dd.b_off1 += gp.e1[gi];
+        if (gp.e2[gi] > 0) d.cin_valid = (int)gp.e2[gi];
+    }
     constexpr int HB = COUT / 4;
     constexpr int NA = 4 * HB * 4;
     __shared__ float sacc[64 * (NA + 1)];
@@ -779,15 +788,18 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
 }
 
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
-                          int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s) {
+                          int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
+                          int ngroups) {
     const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+    const Grp g0 = gp ? *gp : Grp();
+    const dim3 grid(nblocks, ngroups);
     WgradSrc S = {in, in_ld, gout, gout_ld, nullptr, 0};
     WgradDual dd = {0, 0};
     d.cin_valid = cin;
 #define GO(XQ, CO)                                                                                                           \
     do {                                                                                                                     \
-        if (vidx) spconv_wgrad_mfma_k<XQ, CO, false, true><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);      \
-        else spconv_wgrad_mfma_k<XQ, CO, false, false><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);          \
+        if (vidx) spconv_wgrad_mfma_k<XQ, CO, false, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);     \
+        else spconv_wgrad_mfma_k<XQ, CO, false, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);         \
         return linr_launch_rc();                                                                                             \
     } while (0)
     if (cin == 8 && cout == 8) GO(2, 8);
@@ -801,13 +813,15 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 // both 4->4 convolutions of an Inception block: in = H [n][8]; conv 0 reads H[:,0:4] with gradient g0, conv 1 H[:,4:8] with g1
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
-                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s) {
+                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups) {
     const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+    const Grp grp = gp ? *gp : Grp();
+    const dim3 grid(nblocks, ngroups);
     WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     WgradDual dd = {w_off1, b_off1};
-    if (vidx) spconv_wgrad_mfma_k<2, 4, true, true><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);
-    else spconv_wgrad_mfma_k<2, 4, true, false><<<nblocks, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd);
+    if (vidx) spconv_wgrad_mfma_k<2, 4, true, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
+    else spconv_wgrad_mfma_k<2, 4, true, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
     return linr_launch_rc();
 }
 
@@ -826,7 +840,13 @@ struct HeadBwdArgs {
     float* big; int64_t block_stride; int64_t off_w1, off_b1, off_w2, off_b2;
 };
 
-__global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64_t n) {
+__global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64_t n, Grp gp = Grp()) {
+    {   // group offsets: in = c, e0 = p, e1 = target, w = w1, b = b1, e2 = w2, out = gc, e3..e6 = slab offsets of w1, b1, w2, b2
+        const int gi = blockIdx.y;
+        A.c += gp.in[gi]; A.p += gp.e0[gi]; A.target += gp.e1[gi]; A.w1 += gp.w[gi]; A.b1 += gp.b[gi]; A.w2 += gp.e2[gi];
+        A.gc += gp.out[gi];
+        A.off_w1 += gp.e3[gi]; A.off_b1 += gp.e4[gi]; A.off_w2 += gp.e5[gi]; A.off_b2 += gp.e6[gi];
+    }
     __shared__ float sT[(LINR_BLOCK / 64) * 64 * HB_LDW];
     __shared__ float sfold[64 * 13];
     __shared__ float sgz[LINR_BLOCK / 64];
@@ -922,10 +942,11 @@ __global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
-                         hipStream_t s) {
+                         hipStream_t s, const Grp* gp, int ngroups) {
     if (n == 0) return 0;
+    const Grp g0 = gp ? *gp : Grp();
     HeadBwdArgs A = {c, p, target, target_ld, w1, b1, w2, gscale, gc, big, block_stride, off_w1, off_b1, off_w2, off_b2};
-    head_bwd_k<<<LINR_WG_BLOCKS, LINR_BLOCK, 0, s>>>(A, n);
+    head_bwd_k<<<dim3(LINR_WG_BLOCKS, ngroups), LINR_BLOCK, 0, s>>>(A, n, g0);
     return linr_launch_rc();
 }
 

@@ -111,7 +111,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MT, int NT>
 __global__ __launch_bounds__(XTG_WAVES * 64) void xtg_wgrad_k(const float* __restrict__ X, int x_ld, int M,
                                                              const float* __restrict__ G, int g_ld, int N, int64_t n,
-                                                             LinrLinDst d) {
+                                                             LinrLinDst d, Grp gp = Grp()) {
+    {   // group offsets: in = X, res = G, w/b = slab offsets
+        const int gi = blockIdx.y;
+        X += gp.in[gi]; G += gp.res[gi]; d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
+    }
     __shared__ float sacc[64 * (MT * NT * 4 + 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -188,9 +192,11 @@ __global__ __launch_bounds__(XTG_WAVES * 64) void xtg_wgrad_k(const float* __res
 }
 
 int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
-                              LinrLinDst d, int nblocks, hipStream_t s) {
+                              LinrLinDst d, int nblocks, hipStream_t s, const Grp* gp, int ngroups) {
     const int mt = (cin + 1 + 15) / 16, nt = (cout + 15) / 16;
-#define LINR_GO(A, B) do { xtg_wgrad_k<A, B><<<nblocks, XTG_WAVES * 64, 0, s>>>(in, in_ld, cin, gout, gout_ld, cout, n, d); return linr_launch_rc(); } while (0)
+    const Grp g0 = gp ? *gp : Grp();
+    const dim3 grid(nblocks, ngroups);
+#define LINR_GO(A, B) do { xtg_wgrad_k<A, B><<<grid, XTG_WAVES * 64, 0, s>>>(in, in_ld, cin, gout, gout_ld, cout, n, d, g0); return linr_launch_rc(); } while (0)
     if (mt == 1 && nt == 1) LINR_GO(1, 1);
     if (mt == 2 && nt == 1) LINR_GO(2, 1);
     if (mt == 1 && nt == 2) LINR_GO(1, 2);

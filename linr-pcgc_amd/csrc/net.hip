@@ -513,6 +513,141 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     return linr_launch_rc();
 }
 
+struct Ptr8 { const float* p[8]; };
+// dst = ((((((s7 + s6) + s5) + s4) + s3) + s2) + s1) + s0: the accumulation order of the stage-by-stage backward
+__global__ __launch_bounds__(LINR_BLOCK) void sum8_k(Ptr8 src, int64_t n, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float t = src.p[7][i];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) t = t + src.p[k][i];
+    dst[i] = t;
+}
+
+static void goffs_i(int64_t* dst, const int64_t* v, int n) {
+    for (int i = 0; i < n; ++i) dst[i] = v[i] - v[0];
+}
+
+// Backward of the 8 heads and the 7 outter blocks as grouped launches (one launch per layer, gridDim.y = group); every
+// kernel, its per-row arithmetic and the slab rows it writes are those of the stage-by-stage path, so gradients are
+// bitwise the same.
+static int backward_batched(Ctx& c, float gz_scale) {
+    Arena& a = c.A;
+    const float* P = c.P;
+    const Layout& L = c.L;
+    const int32_t* lo = c.f->nbr_lo;
+    const uint32_t* mk = c.f->nbr_mask;
+    {
+        const float *hC[8], *hP[8], *hO[8], *h_gC[8], *h_gO[8], *h_prw[8], *h_w1[8], *h_b1[8], *h_w2[8];
+        int64_t o_w1[8], o_b1[8], o_w2[8], o_b2[8], o_prw[8], o_prb[8];
+        for (int k = 0; k < 8; ++k) {
+            hC[k] = a.C[k]; hP[k] = a.P[k]; hO[k] = a.O[k]; h_gC[k] = a.gC[k]; h_gO[k] = a.gO[k]; h_prw[k] = P + L.pr_w[k];
+            h_w1[k] = P + L.h0_w[k]; h_b1[k] = P + L.h0_b[k]; h_w2[k] = P + L.h2_w[k];
+            o_w1[k] = L.h0_w[k]; o_b1[k] = L.h0_b[k]; o_w2[k] = L.h2_w[k]; o_b2[k] = L.h2_b[k];
+            o_prw[k] = L.pr_w[k]; o_prb[k] = L.pr_b[k];
+        }
+        {   // heads: gC and the four head-parameter gradients
+            Grp gp = Grp();
+            goffs(gp.in, hC, 8); goffs(gp.e0, hP, 8); goffs(gp.w, h_w1, 8); goffs(gp.b, h_b1, 8); goffs(gp.e2, h_w2, 8);
+            goffs(gp.out, h_gC, 8);
+            for (int k = 0; k < 8; ++k) gp.e1[k] = k;
+            goffs_i(gp.e3, o_w1, 8); goffs_i(gp.e4, o_b1, 8); goffs_i(gp.e5, o_w2, 8); goffs_i(gp.e6, o_b2, 8);
+            TRY(linr_head_bwd_launch(a.C[0], a.P[0], a.OCC, 8, h_w1[0], h_b1[0], h_w2[0], gz_scale, a.gC[0], c.R, a.BIG, L.total,
+                                     o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8));
+        }
+        {   // C = conv3(prior_k; prune_k): weight gradients ...
+            Grp gp = Grp();
+            goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
+            LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
+            TRY(stream_order(c.s, c.ws));
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8));
+        }
+        {   // ... and gO[k] = bwd(gC[k])
+            Grp gp = Grp();
+            goffs(gp.in, h_gC, 8); goffs(gp.w, h_prw, 8); goffs(gp.out, h_gO, 8);
+            TRY(linr_cconv_launch(true, a.gC[0], 8, lo, mk, c.nbr_ld, c.R, h_prw[0], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO[0],
+                                  8, 0, c.s, &gp, 8));
+        }
+        Ptr8 src;
+        for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
+        sum8_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(src, c.R * 8, a.gXG);
+    }
+    // outter blocks 1..7 (group g = block g + 1); gO[b] is the gradient of the block output
+    const float *pA[7], *pH[7], *pM[7], *pI[7], *p_gO[7], *p_gI[7], *p_gM[7], *p_gH[7], *p_gA[7], *p_bw[7], *p_c12w[7], *p_c01w[7],
+        *p_c11w[7], *p_c00w[7], *p_c10w[7];
+    int64_t o_bw[7], o_bb[7], o_c12w[7], o_c12b[7], o_c01w[7], o_c01b[7], o_c11w[7], o_c11b[7], o_c00w[7], o_c00b[7], o_c10w[7],
+        o_c10b[7], o_aw[7], o_ab[7];
+    for (int g = 0; g < 7; ++g) {
+        const BlockP& bp = L.outter[g];
+        const int b = g + 1;
+        pA[g] = a.A[b]; pH[g] = a.H[b]; pM[g] = a.M[b]; pI[g] = a.I[b]; p_gO[g] = a.gO[b]; p_gI[g] = a.gI[b]; p_gM[g] = a.gM[b];
+        p_gH[g] = a.gH[b]; p_gA[g] = a.gA[b];
+        p_bw[g] = P + bp.b_w; p_c12w[g] = P + bp.c12_w; p_c01w[g] = P + bp.c01_w; p_c11w[g] = P + bp.c11_w;
+        p_c00w[g] = P + bp.c00_w; p_c10w[g] = P + bp.c10_w;
+        o_bw[g] = bp.b_w; o_bb[g] = bp.b_b; o_c12w[g] = bp.c12_w; o_c12b[g] = bp.c12_b; o_c01w[g] = bp.c01_w; o_c01b[g] = bp.c01_b;
+        o_c11w[g] = bp.c11_w; o_c11b[g] = bp.c11_b; o_c00w[g] = bp.c00_w; o_c00b[g] = bp.c00_b; o_c10w[g] = bp.c10_w;
+        o_c10b[g] = bp.c10_b; o_aw[g] = bp.a_w; o_ab[g] = bp.a_b;
+    }
+    {   // O = conv3(I; b): weight gradient
+        Grp gp = Grp();
+        goffs(gp.in, pI, 7); goffs(gp.res, p_gO, 7); goffs_i(gp.w, o_bw, 7); goffs_i(gp.b, o_bb, 7);
+        LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+    }
+    {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
+        Grp gp = Grp();
+        goffs(gp.in, p_gO, 7); goffs(gp.w, p_bw, 7); goffs(gp.out, p_gI, 7); goffs(gp.e0, p_c12w, 7); goffs(gp.e1, pM, 7);
+        goffs(gp.e2, p_gM, 7);
+        TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[1], a.gM[1], c.s, &gp, 7));
+    }
+    {   // conv1_2 weight gradient: M^T gI[:,4:8]
+        Grp gp = Grp();
+        goffs(gp.in, pM, 7); goffs(gp.res, p_gI, 7); goffs_i(gp.w, o_c12w, 7); goffs_i(gp.b, o_c12b, 7);
+        LinrLinDst d = {a.BIG, L.total, o_c12w[0], 4, 1, o_c12b[0]};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+    }
+    {   // both 4->4 convs: weight gradients, then gH
+        Grp gp = Grp();
+        goffs(gp.in, pH, 7); goffs(gp.res, p_gI, 7); goffs(gp.act, p_gM, 7); goffs_i(gp.w, o_c01w, 7); goffs_i(gp.b, o_c01b, 7);
+        goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
+                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7));
+        Grp gq = Grp();
+        goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
+        goffs(gq.act, pH, 7);
+        TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[1], c.s, &gq, 7));
+    }
+    {   // conv0_0 (8->4) and conv1_0 (1x1 8->4) weight gradients
+        Grp gp = Grp();
+        goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
+        LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+        Grp gq = Grp();
+        goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
+        LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
+        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, LINR_WG_BLOCKS, c.ws, &gq, 7));
+    }
+    {   // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
+        Grp gp = Grp();
+        goffs(gp.in, p_gH, 7); goffs(gp.w, p_c00w, 7); goffs(gp.res, p_gI, 7); goffs(gp.act, pA, 7); goffs(gp.out, p_gA, 7);
+        goffs(gp.e0, p_c10w, 7); goffs(gp.e1, p_gH, 7);
+        TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[1], c.s, &gp, 7));
+    }
+    {   // A = relu(conv3(occ[:, :b]; a)): weight gradient on the first b channels of the occupancy rows
+        Grp gp = Grp();
+        goffs(gp.res, p_gA, 7); goffs_i(gp.w, o_aw, 7); goffs_i(gp.b, o_ab, 7);
+        for (int g = 0; g < 7; ++g) gp.e2[g] = g + 1;
+        LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+    }
+    return 0;
+}
+
 // backward of gscale * bits: leaves the parameter gradient of THIS call in arena GSUM (flat, parameters() order)
 static int backward_core(Ctx& c, float gscale) {
     const linr_frame* f = c.f;
@@ -523,7 +658,10 @@ static int backward_core(Ctx& c, float gscale) {
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));
-    for (int k = 7; k >= 0; --k) {
+    static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
+    const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
+    if (grouped) TRY(backward_batched(c, gz_scale));
+    for (int k = grouped ? -1 : 7; k >= 0; --k) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
             // recompute the hidden layer, gC and the four head-parameter gradients in one launch (csrc/fused.hip)
             TRY(linr_head_bwd_launch(a.C[k], a.P[k], a.OCC + k, 8, P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], gz_scale,

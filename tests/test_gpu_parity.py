@@ -376,6 +376,24 @@ def test_staged_probs_bitwise_equal_one_shot(pkg, shell):
     assert torch.equal(one, staged)
 
 
+def test_grouped_launches_bitwise_equal_stage_by_stage(pkg, golden_dir, tmp_path):
+    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads, weight gradients on a second stream)
+    against the stage-by-stage single-stream one: probabilities, bits and every gradient must be the same bits."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(__file__), '_dump_net.py')
+    golden = os.path.join(golden_dir, 'octree_shell128.npz')
+    res = {}
+    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1'}),
+                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0'})):
+        out = str(tmp_path / (tag + '.npz'))
+        subprocess.run([sys.executable, script, golden, out], check=True, env=dict(os.environ, **env), timeout=600)
+        res[tag] = np.load(out)
+    for key in ('probs', 'bits', 'grads'):
+        assert np.array_equal(res['grouped'][key], res['staged'][key]), key
+    assert float(np.abs(res['grouped']['grads']).max()) > 0
+
+
 def test_codec_stream_matches_oracle_coder(pkg, shell):
     model, _ = _model_and_oracle(pkg, 5)
     dev = _dev()
