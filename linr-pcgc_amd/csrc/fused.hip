@@ -661,12 +661,14 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
 // ---- backward-weight on the matrix cores -------------------------------------------------------------------------------------
 // gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  Same wave-per-row-group organisation as spconv_wgrad_k (lane = one
 // (offset k, channel quad q) pair, 16-byte gather of that quad for 8 rows at a time, persistent accumulators), but the
-// 4 x COUT outer product per lane and row runs as v_mfma_f32_4x4x1_16b_f32:   D_b[i][j] += A_{4b+i} * B_{4b+j}
-// with A = component c of the lane's gathered quad and B = g[r][4h + j]: lane 4b+j, register i of accumulator (c, h)
-// sums x_{pair 4b+i}[c] * g[4h+j].  Lanes are laid out so that the 4 pairs of a block share q:
-//     lane = 4b + i   ->   q = b & 1 (XQ == 2) ,  k = 4*(b >> 1) + i   (XQ == 1: k = lane, 27 pairs)
-// which lets the DUAL variant (the two 4->4 convs of an Inception block, q selects the conv) feed each block its own
-// gradient matrix.  Pair k == 27 is the bias pseudo-pair (x = (1,0,0,0)).  K = 1 keeps exact fp32 FMAs.
+// 4 x COUT outer product per lane and row runs as v_mfma_f32_4x4x1_16b_f32 with the A operand broadcast from one block:
+//     D[i] on lane l += A(lane 4*abid + i) * B(lane l)          (CBSZ = 4: one block feeds all 16; CBSZ = 3: one per half)
+// B = component c of the lane's own gathered quad, A = the output gradient: a wave loads the g rows of its 8-row group
+// with ONE coalesced dword load (lane l holds g[row l / COUT][l % COUT]), so block 2u + h (COUT 8) or u (COUT 4) already
+// holds g[row u][4h .. 4h+3] and ABID selects it - no per-row gradient loads, no shuffles.  Register i of accumulator
+// (c, h) on a lane is gW[k][4q + c][4h + i] of the lane's own pair.  DUAL (the two 4->4 convs of an Inception block):
+// lanes 0..31 are conv 0, lanes 32..63 conv 1, each half loads its own gradient matrix and CBSZ = 3 keeps them apart.
+// Pair k == 27 is the bias pseudo-pair (x = (1,0,0,0)).  K = 1 keeps exact fp32 FMAs in row order.
 struct WgradSrc {
     const float* in; int in_ld;           // gathered matrix (quad q at column 4q)
     const float* g0; int g0_ld;           // output gradient (DUAL: of conv 0)
@@ -689,12 +691,12 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     }
     constexpr int HB = COUT / 4;
     constexpr int NA = 4 * HB * 4;
+    constexpr int CBSZ = DUAL ? 3 : 4;
     __shared__ float sacc[64 * (NA + 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = lane >> 2, li = lane & 3;
-    const int q = (XQ == 2) ? (blk & 1) : 0;
-    const int kk = (XQ == 2) ? 4 * (blk >> 1) + li : lane;          // 27 == bias pseudo-pair, > 27 idle
+    const int q = DUAL ? (lane >> 5) : (XQ == 2 ? (lane & 1) : 0);
+    const int kk = DUAL ? (lane & 31) : (XQ == 2 ? (lane >> 1) : lane);          // 27 == bias pseudo-pair, > 27 idle
     const bool live = kk < 27;
     const bool biasl = kk == 27;
     const int k = live ? kk : 26;
@@ -710,8 +712,11 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int32_t* nk = nbr + (int64_t)k * nbr_ld;
     const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
     const uint32_t rowbytes = (uint32_t)S.in_ld * 4u;
+    // this lane's element of the 8-row gradient tile: row gu, channel gc of matrix gsel
     const float* gsel = (DUAL && q) ? S.g1 : S.g0;
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
+    const int gl = DUAL ? (lane & 31) : lane;
+    const int gu = (gl / COUT) & 7, gc = gl % COUT;
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
         if (VIDX && g0r + 8 <= n) {
@@ -723,26 +728,24 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
 #pragma unroll
             for (int u = 0; u < 8; ++u) idx[u] = (g0r + u < n) ? nk[g0r + u] : -1;
         }
+        const float gv = (g0r + gu < n) ? gsel[(g0r + gu) * gld + gc] : 0.0f;
         float4 x[8];
-        float bg[8][HB];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[u] + 1) * rowbytes);
             if (!live) x[u] = make_float4(biasl ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
-            const int64_t r = (g0r + u < n) ? g0r + u : n - 1;
-#pragma unroll
-            for (int h = 0; h < HB; ++h) bg[u][h] = (g0r + u < n) ? gsel[r * gld + 4 * h + li] : 0.0f;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-#pragma unroll
-            for (int h = 0; h < HB; ++h) {
-                acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].x, bg[u][h], acc[0][h], 0, 0, 0);
-                acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].y, bg[u][h], acc[1][h], 0, 0, 0);
-                acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].z, bg[u][h], acc[2][h], 0, 0, 0);
-                acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[u].w, bg[u][h], acc[3][h], 0, 0, 0);
-            }
-        }
+        static_for<8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            static_for<HB>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                constexpr int ab = u * HB + h;           // the block holding g[row u][4h .. 4h+3]
+                acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
+                acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
+                acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
+                acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
+            });
+        });
     }
     // fold waves in wave order (fixed => reproducible)
     float* mine = sacc + lane * (NA + 1);
@@ -761,28 +764,26 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         __syncthreads();
     }
     if (wave == 0) {
-        // lane 4b + j, register i of accumulator (c, h)  <->  pair (k_i, q), input channel 4q + c, output channel 4h + j
+        // register i of accumulator (c, h)  <->  pair (kk, q), input channel 4q + c, output channel 4h + i
         float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
         const int64_t w_off = (DUAL && q) ? dd.w_off1 : d.w_off;
         const int64_t b_off = (DUAL && q) ? dd.b_off1 : d.b_off;
         const int cinv = DUAL ? 4 : d.cin_valid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ki = (XQ == 2) ? 4 * (blk >> 1) + i : 4 * blk + i;
+        for (int c = 0; c < 4; ++c) {
+            const int ci = DUAL ? c : 4 * q + c;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ci = DUAL ? c : 4 * q + c;
+            for (int h = 0; h < HB; ++h)
 #pragma unroll
-                for (int h = 0; h < HB; ++h) {
+                for (int i = 0; i < 4; ++i) {
                     const float v = mine[(c * HB + h) * 4 + i];
-                    const int co = 4 * h + li;
-                    if (ki < 27) {
-                        if (ci < cinv) dst[w_off + (ki * cinv + ci) * COUT + co] = v;
-                    } else if (ki == 27 && c == 0 && (XQ == 1 || DUAL || q == 0)) {
+                    const int co = 4 * h + i;
+                    if (live) {
+                        if (ci < cinv) dst[w_off + (kk * cinv + ci) * COUT + co] = v;
+                    } else if (biasl && c == 0 && (XQ == 1 || DUAL || q == 0)) {
                         dst[b_off + co] = v;
                     }
                 }
-            }
         }
     }
 }
