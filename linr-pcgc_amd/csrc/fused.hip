@@ -676,10 +676,13 @@ struct WgradSrc {
 };
 struct WgradDual { int64_t w_off1, b_off1; };
 
-template <int XQ, int COUT, bool DUAL, bool VIDX>
+// IDX: where a lane's neighbour indices come from - 0: nbr[27][ld], scalar loads; 1: nbr, 16-byte loads;
+// 2: the compressed map (nbr = its 9 column bases lo[9][ld], plus the 27-bit masks): 40 instead of 108 index bytes per row
+// and 9 + 1 instead of 27 distinct cache lines per load instruction.
+template <int XQ, int COUT, bool DUAL, int IDX>
 __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S, const int32_t* __restrict__ nbr,
-                                                                    int64_t nbr_ld, int64_t n, LinrWgradDst d, WgradDual dd,
-                                                                    Grp gp = Grp()) {
+                                                                    const uint32_t* __restrict__ cmask, int64_t nbr_ld,
+                                                                    int64_t n, LinrWgradDst d, WgradDual dd, Grp gp = Grp()) {
     static_assert(!DUAL || (XQ == 2 && COUT == 4), "dual mode = two 4->4 convolutions");
     {   // group offsets: in, res = g0, act = g1, w/b = slab offsets of conv 0, e0/e1 = of conv 1, e2 = cin_valid override
         const int gi = blockIdx.y;
@@ -709,7 +712,11 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     per = (per + 7) & ~(int64_t)7;
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
+    const int32_t* nk = nbr + (int64_t)(IDX == 2 ? k % 9 : k) * nbr_ld;
+    // compressed map: tap k = q9 + 9 j is present iff bit (3 q9 + j) of the row's mask is set and then sits at
+    // lo[q9][r] + (number of present taps below it in the same column)
+    const int cshift = 3 * (k % 9), cj = k / 9;
+    const uint32_t cpm = 1u << cj, cam = cpm - 1u;
     const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
     const uint32_t rowbytes = (uint32_t)S.in_ld * 4u;
     // this lane's element of the 8-row gradient tile: row gu, channel gc of matrix gsel
@@ -719,11 +726,30 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
-        if (VIDX && g0r + 8 <= n) {
+        if (IDX >= 1 && g0r + 8 <= n) {
             const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
             const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
             idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
             idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+            if constexpr (IDX == 2) {
+                const uint4 ma = *reinterpret_cast<const uint4*>(cmask + g0r);
+                const uint4 mb = *reinterpret_cast<const uint4*>(cmask + g0r + 4);
+                const uint32_t m[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t bits = m[u] >> cshift;
+                    idx[u] = (bits & cpm) ? idx[u] + __popc(bits & cam) : -1;
+                }
+            }
+        } else if constexpr (IDX == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                idx[u] = -1;
+                if (g0r + u < n) {
+                    const uint32_t bits = cmask[g0r + u] >> cshift;
+                    if (bits & cpm) idx[u] = nk[g0r + u] + __popc(bits & cam);
+                }
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) idx[u] = (g0r + u < n) ? nk[g0r + u] : -1;
@@ -790,8 +816,10 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
 
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
-                          int ngroups) {
-    const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+                          int ngroups, const int32_t* lo, const uint32_t* mask) {
+    const bool al = (nbr_ld % 4 == 0);
+    const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
+    const int32_t* tab = idx == 2 ? lo : nbr;
     const Grp g0 = gp ? *gp : Grp();
     const dim3 grid(nblocks, ngroups);
     WgradSrc S = {in, in_ld, gout, gout_ld, nullptr, 0};
@@ -799,8 +827,9 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
     d.cin_valid = cin;
 #define GO(XQ, CO)                                                                                                           \
     do {                                                                                                                     \
-        if (vidx) spconv_wgrad_mfma_k<XQ, CO, false, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);     \
-        else spconv_wgrad_mfma_k<XQ, CO, false, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);         \
+        if (idx == 2) spconv_wgrad_mfma_k<XQ, CO, false, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
+        else if (idx == 1) spconv_wgrad_mfma_k<XQ, CO, false, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
+        else spconv_wgrad_mfma_k<XQ, CO, false, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0);         \
         return linr_launch_rc();                                                                                             \
     } while (0)
     if (cin == 8 && cout == 8) GO(2, 8);
@@ -814,15 +843,19 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 // both 4->4 convolutions of an Inception block: in = H [n][8]; conv 0 reads H[:,0:4] with gradient g0, conv 1 H[:,4:8] with g1
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
-                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups) {
-    const bool vidx = (nbr_ld % 4 == 0) && linr_aligned16(nbr);
+                            int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups,
+                            const int32_t* lo, const uint32_t* mask) {
+    const bool al = (nbr_ld % 4 == 0);
+    const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
+    const int32_t* tab = idx == 2 ? lo : nbr;
     const Grp grp = gp ? *gp : Grp();
     const dim3 grid(nblocks, ngroups);
     WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     WgradDual dd = {w_off1, b_off1};
-    if (vidx) spconv_wgrad_mfma_k<2, 4, true, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
-    else spconv_wgrad_mfma_k<2, 4, true, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
+    if (idx == 2) spconv_wgrad_mfma_k<2, 4, true, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
+    else if (idx == 1) spconv_wgrad_mfma_k<2, 4, true, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
+    else spconv_wgrad_mfma_k<2, 4, true, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     return linr_launch_rc();
 }
 

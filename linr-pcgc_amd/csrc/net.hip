@@ -253,13 +253,20 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
                              flags | LINR_PAD_ROW, c.s);
 }
 
+// LINR_WGRAD_CMAP=0: weight-gradient kernels read the full nbr[27][ld] table instead of the compressed map
+static bool wg_cmap() {
+    static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 1;
+    return v != 0;
+}
+
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
     static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
     TRY(stream_order(c.s, c.ws));
     if (use_mfma)
-        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws);
+        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
+                                     wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
     return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
                                     LINR_PAD_ROW, c.ws);
 }
@@ -316,7 +323,8 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
         TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI[b], 8, a.gM[b], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
-                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws));
+                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap() ? c.f->nbr_lo : nullptr,
+                                    c.f->nbr_mask));
         TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
         TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
         TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
@@ -560,7 +568,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
-            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8));
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? lo : nullptr, mk));
         }
         {   // ... and gO[k] = bwd(gC[k])
             Grp gp = Grp();
@@ -593,7 +601,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pI, 7); goffs(gp.res, p_gO, 7); goffs_i(gp.w, o_bw, 7); goffs_i(gp.b, o_bb, 7);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
@@ -614,7 +622,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7));
+                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
         Grp gq = Grp();
         goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
         goffs(gq.act, pH, 7);
@@ -625,7 +633,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
         Grp gq = Grp();
         goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
@@ -643,7 +651,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         for (int g = 0; g < 7; ++g) gp.e2[g] = g + 1;
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     return 0;
 }

@@ -433,7 +433,9 @@ extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const floa
         const int nb = wg_blocks(n);
         const int elems = (27 * cin + 1) * cout;
         LinrWgradDst d = {(float*)ws, elems, 0, 27 * cin * cout, cin};
-        int rc = linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, flags, s);
+        // rows with a zero pad row in front (LINR_PAD_ROW) take the executor's matrix-core kernel (csrc/fused.hip)
+        int rc = (flags & LINR_PAD_ROW) ? linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, s)
+                                        : linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, flags, s);
         if (rc) return rc;
         slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, elems, 27 * cin * cout, gW, gb, flags);
         return linr_launch_rc();

@@ -78,14 +78,16 @@ def spconv_bwd_data(gout, nbr, kernel, act=None, out=None, accumulate=False, pad
     return out
 
 
-def spconv_bwd_weight(x, gout, nbr, cin, cout):
+def spconv_bwd_weight(x, gout, nbr, cin, cout, pad_row=False):
+    """gW [27,cin,cout], gb [1,cout].  pad_row: x is a view buf[1:] of a buffer whose row 0 is zero (matrix-core kernel)."""
     n = nbr.shape[1]
     L = _lib.lib()
     gw = torch.empty((27, cin, cout), dtype=torch.float32, device=x.device)
     gb = torch.empty((1, cout), dtype=torch.float32, device=x.device)
     ws = torch.empty(max(L.linr_spconv_bwd_weight_workspace_bytes(n, cin, cout), 4), dtype=torch.uint8, device=x.device)
     check(L.linr_spconv_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(),
-                                   nbr.stride(0), n, cin, cout, gw.data_ptr(), gb.data_ptr(), 0, ws.data_ptr(),
+                                   nbr.stride(0), n, cin, cout, gw.data_ptr(), gb.data_ptr(), LINR_PAD_ROW if pad_row else 0,
+                                   ws.data_ptr(),
                                    ws.numel(), _stream()), 'linr_spconv_bwd_weight')
     return gw, gb
 

@@ -116,11 +116,11 @@ def test_spconv_fwd_bwd(pkg, shell, cin, cout, pad):
     assert torch.equal(out2, ops.spconv_fwd(xd, nbr, w.to(dev), b.to(dev), pad_row=pad)), 'fwd must be bit-reproducible'
     gin = ops.spconv_bwd_data(god, nbr, w.to(dev), pad_row=pad)
     _close(gin, xo.grad, 1e-4, 1e-4, 'bwd_data')
-    gw, gb = ops.spconv_bwd_weight(xd, god, nbr, cin, cout)
+    gw, gb = ops.spconv_bwd_weight(xd, god, nbr, cin, cout, pad_row=pad)
     scale = float(wo.grad.abs().max())
     _close(gw, wo.grad, 0, 1e-4 * scale + 1e-6, 'bwd_weight')
     _close(gb, bo.grad, 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bwd_bias')
-    gw2, _ = ops.spconv_bwd_weight(xd, god, nbr, cin, cout)
+    gw2, _ = ops.spconv_bwd_weight(xd, god, nbr, cin, cout, pad_row=pad)
     assert torch.equal(gw, gw2), 'bwd_weight must be bit-reproducible (two-pass, no atomics)'
 
 
