@@ -47,6 +47,7 @@ struct LinrLinDst {      // pointwise layers: element (ci,co) at w_off + ci*ws_c
 struct Grp {
     int64_t in[LINR_MAXG], w[LINR_MAXG], b[LINR_MAXG], res[LINR_MAXG], act[LINR_MAXG], out[LINR_MAXG];
     int64_t e0[LINR_MAXG], e1[LINR_MAXG], e2[LINR_MAXG], e3[LINR_MAXG], e4[LINR_MAXG], e5[LINR_MAXG], e6[LINR_MAXG];
+    int64_t n[LINR_MAXG];      // > 0: the group's own row count (groups of unequal size: the scales of a frame)
 };
 
 

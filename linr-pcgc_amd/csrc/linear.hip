@@ -115,6 +115,7 @@ __global__ __launch_bounds__(XTG_WAVES * 64) void xtg_wgrad_k(const float* __res
     {   // group offsets: in = X, res = G, w/b = slab offsets
         const int gi = blockIdx.y;
         X += gp.in[gi]; G += gp.res[gi]; d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
+        if (gp.n[gi] > 0) n = gp.n[gi];
     }
     __shared__ float sacc[64 * (MT * NT * 4 + 1)];
     const int lane = threadIdx.x & 63;

@@ -168,6 +168,92 @@ __global__ __launch_bounds__(LINR_BLOCK) void sce_mix_k(const float* __restrict_
     mix[idx] = v;
 }
 
+// Scale context of all scales in one launch (model_core.py:48-53): x0[r] = W2 relu(W1 [emb | offset_feat[r]] + b1) + b2 with
+// the weights of r's scale.  Same fmaf chains as sce_mix_k + linear_k<15,16> + linear_k<16,8> (bias first, inputs
+// ascending), so both routes give the same bits.  MIX and HID are kept for the backward pass.
+struct SceArgs {
+    int64_t row_off[MAX_SCALES + 1];
+    int64_t emb[MAX_SCALES], w1[MAX_SCALES], b1[MAX_SCALES], w2[MAX_SCALES], b2[MAX_SCALES];   // parameter offsets per scale
+    int n_scales;
+};
+
+__device__ __forceinline__ int sce_scale_of(const SceArgs& a, int64_t r) {
+    int s = 0;
+    for (int i = 1; i < a.n_scales; ++i) s += (r >= a.row_off[i]) ? 1 : 0;
+    return s;
+}
+
+__global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
+                                                        int64_t n, float* __restrict__ mix, float* __restrict__ hid,
+                                                        float* __restrict__ x0) {
+    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int s = sce_scale_of(a, r);
+    const float* emb = P + a.emb[s];
+    const float* W1 = P + a.w1[s];
+    const float* b1 = P + a.b1[s];
+    const float* W2 = P + a.w2[s];
+    const float* b2 = P + a.b2[s];
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = emb[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[8 + i] = off[r * 7 + i];
+    x[15] = 0.0f;
+    float4* mp = reinterpret_cast<float4*>(mix + r * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mp[v] = make_float4(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]);
+    float h[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) h[o] = b1[o];
+#pragma unroll
+    for (int i = 0; i < 15; ++i)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) h[o] = fmaf(x[i], W1[o * 15 + i], h[o]);
+#pragma unroll
+    for (int o = 0; o < 16; ++o) h[o] = fmaxf(h[o], 0.0f);
+    float4* hp = reinterpret_cast<float4*>(hid + r * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) hp[v] = make_float4(h[4 * v], h[4 * v + 1], h[4 * v + 2], h[4 * v + 3]);
+    float y[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) y[o] = b2[o];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) y[o] = fmaf(h[i], W2[o * 16 + i], y[o]);
+    float4* yp = reinterpret_cast<float4*>(x0 + r * 8);
+    yp[0] = make_float4(y[0], y[1], y[2], y[3]);
+    yp[1] = make_float4(y[4], y[5], y[6], y[7]);
+}
+
+// ghid[r] = (W2^T gx0[r]) * (hid[r] > 0)     (linear_k<8,16> with the ReLU mask, weights of r's scale)
+__global__ __launch_bounds__(LINR_BLOCK) void sce_bwd_k(const float* __restrict__ P, SceArgs a, int64_t n,
+                                                        const float* __restrict__ gx0, const float* __restrict__ hid,
+                                                        float* __restrict__ ghid) {
+    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const float* W2 = P + a.w2[sce_scale_of(a, r)];
+    const float4 g0 = *reinterpret_cast<const float4*>(gx0 + r * 8);
+    const float4 g1 = *reinterpret_cast<const float4*>(gx0 + r * 8 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = fmaf(g[i], W2[i * 16 + o], acc[o]);
+    const float4* hp = reinterpret_cast<const float4*>(hid + r * 16);
+    float4* op = reinterpret_cast<float4*>(ghid + r * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float4 h = hp[v];
+        op[v] = make_float4(h.x > 0.0f ? acc[4 * v] : 0.0f, h.y > 0.0f ? acc[4 * v + 1] : 0.0f,
+                            h.z > 0.0f ? acc[4 * v + 2] : 0.0f, h.w > 0.0f ? acc[4 * v + 3] : 0.0f);
+    }
+}
+
 __global__ __launch_bounds__(LINR_BLOCK) void sigmoid_k(const float* __restrict__ z, int64_t n, float* __restrict__ p) {
     const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (i < n) p[i] = 1.0f / (1.0f + expf(-z[i]));
@@ -182,6 +268,18 @@ __global__ __launch_bounds__(LINR_BLOCK) void axpy_k(const float* __restrict__ s
 
 // gemb[i] = sum_m gb1[m] * W1[m][i]   (scale-embedding gradient through Linear(15,16); the embedding row is a
 // constant input of every row of its scale, so its gradient is W1[:, :8]^T applied to the bias gradient)
+struct EmbArgs { int64_t gb1[MAX_SCALES], w1[MAX_SCALES], gemb[MAX_SCALES]; };
+__global__ void sce_emb_grad_all_k(const float* __restrict__ P, float* __restrict__ gsum, EmbArgs a) {
+    const int t = threadIdx.x, g = blockIdx.x;
+    if (t < 8) {
+        const float* gb1 = gsum + a.gb1[g];
+        const float* W1 = P + a.w1[g];
+        float s = 0.0f;
+        for (int m = 0; m < 16; ++m) s = fmaf(gb1[m], W1[m * 15 + t], s);
+        gsum[a.gemb[g] + t] = s;
+    }
+}
+
 __global__ void sce_emb_grad_k(const float* __restrict__ gb1, const float* __restrict__ W1, float* __restrict__ gemb) {
     const int t = threadIdx.x;
     if (t < 8) {
@@ -374,6 +472,18 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     return 0;
 }
 
+static SceArgs sce_args(const Ctx& c) {
+    SceArgs a;
+    a.n_scales = c.f->n_scales;
+    for (int s = 0; s < c.f->n_scales; ++s) {
+        const int si = c.f->scale_idx_h[s];
+        a.row_off[s] = c.f->row_off_h[s];
+        a.emb[s] = c.L.emb + si * 8; a.w1[s] = c.L.m0_w[si]; a.b1[s] = c.L.m0_b[si]; a.w2[s] = c.L.m2_w[si]; a.b2[s] = c.L.m2_b[si];
+    }
+    a.row_off[c.f->n_scales] = c.f->rows;
+    return a;
+}
+
 // WPAD[g][k][ci][co] = ci <= g ? W_a(outter block g)[k][ci][co] : 0     (block g has cin = g + 1)
 struct PadSrc { int64_t off[7]; };
 __global__ __launch_bounds__(LINR_BLOCK) void pad_weights_k(const float* __restrict__ P, PadSrc src, float* __restrict__ wpad) {
@@ -473,6 +583,10 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
         zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
         // scale context: one small MLP per scale (model_core.py:48-53)
+        static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
+        if (sce_fused) {
+            sce_fwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, f->offset_feat, sce_args(c), c.R, a.MIX, a.HID, a.X0);
+        } else
         for (int s = 0; s < f->n_scales; ++s) {
             const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
             if (n == 0) continue;
@@ -690,6 +804,32 @@ static int backward_core(Ctx& c, float gscale) {
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
     TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
+    // scale context: all non-empty scales as one launch per layer when they fit one grouped launch
+    int ns = 0, sl[MAX_SCALES];
+    for (int s = 0; s < f->n_scales; ++s)
+        if (f->row_off_h[s + 1] > f->row_off_h[s]) sl[ns++] = s;
+    static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
+    const bool sce_grouped = sce_fused && ns >= 1 && ns <= LINR_MAXG;
+    if (sce_grouped) {
+        sce_bwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, sce_args(c), c.R, a.gX0, a.HID, a.gHID);
+        Grp g2 = Grp(), g0 = Grp();
+        const int64_t r00 = f->row_off_h[sl[0]];
+        const int si0 = f->scale_idx_h[sl[0]];
+        for (int j = 0; j < ns; ++j) {
+            const int64_t r0 = f->row_off_h[sl[j]], n = f->row_off_h[sl[j] + 1] - r0;
+            const int si = f->scale_idx_h[sl[j]];
+            g2.in[j] = (r0 - r00) * 16; g2.res[j] = (r0 - r00) * 8; g2.w[j] = c.L.m2_w[si] - c.L.m2_w[si0];
+            g2.b[j] = c.L.m2_b[si] - c.L.m2_b[si0]; g2.n[j] = n;
+            g0.in[j] = (r0 - r00) * 16; g0.res[j] = (r0 - r00) * 16; g0.w[j] = c.L.m0_w[si] - c.L.m0_w[si0];
+            g0.b[j] = c.L.m0_b[si] - c.L.m0_b[si0]; g0.n[j] = n;
+        }
+        const int64_t nmax = f->rows;          // every group carries its own row count
+        LinrLinDst d2 = {a.BIG, c.L.total, c.L.m2_w[si0], 1, 16, c.L.m2_b[si0]};
+        LinrLinDst d0 = {a.BIG, c.L.total, c.L.m0_w[si0], 1, 15, c.L.m0_b[si0]};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, LINR_WG_BLOCKS, c.ws, &g2, ns));
+        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, LINR_WG_BLOCKS, c.ws, &g0, ns));
+    } else
     for (int s = 0; s < f->n_scales; ++s) {
         const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
         if (n == 0) continue;
@@ -702,10 +842,13 @@ static int backward_core(Ctx& c, float gscale) {
     // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
     TRY(stream_order(c.ws, c.s));
     wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
-    for (int s = 0; s < f->n_scales; ++s) {
-        if (f->row_off_h[s + 1] == f->row_off_h[s]) continue;
-        const int si = f->scale_idx_h[s];
-        sce_emb_grad_k<<<1, LINR_WAVE, 0, c.s>>>(a.GSUM + c.L.m0_b[si], P + c.L.m0_w[si], a.GSUM + c.L.emb + si * 8);
+    if (ns > 0) {
+        EmbArgs ea;
+        for (int j = 0; j < ns; ++j) {
+            const int si = f->scale_idx_h[sl[j]];
+            ea.gb1[j] = c.L.m0_b[si]; ea.w1[j] = c.L.m0_w[si]; ea.gemb[j] = c.L.emb + si * 8;
+        }
+        sce_emb_grad_all_k<<<ns, LINR_WAVE, 0, c.s>>>(P, a.GSUM, ea);
     }
     return linr_launch_rc();
 }

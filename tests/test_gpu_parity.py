@@ -377,15 +377,16 @@ def test_staged_probs_bitwise_equal_one_shot(pkg, shell):
 
 
 def test_grouped_launches_bitwise_equal_stage_by_stage(pkg, golden_dir, tmp_path):
-    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads, weight gradients on a second stream)
-    against the stage-by-stage single-stream one: probabilities, bits and every gradient must be the same bits."""
+    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads / all scales of the scale context,
+    compressed-map weight gradients on a second stream) against the stage-by-stage, scale-by-scale single-stream one:
+    probabilities, bits and every gradient must be the same bits."""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(__file__), '_dump_net.py')
     golden = os.path.join(golden_dir, 'octree_shell128.npz')
     res = {}
-    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1'}),
-                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0'})):
+    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_SCE_FUSED': '1', 'LINR_WGRAD_CMAP': '1'}),
+                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '0'})):
         out = str(tmp_path / (tag + '.npz'))
         subprocess.run([sys.executable, script, golden, out], check=True, env=dict(os.environ, **env), timeout=600)
         res[tag] = np.load(out)
