@@ -106,6 +106,9 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
                             const float* w10, const float* gI, const float* A, float* gA, hipStream_t s,
                             const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
+int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* P,
+                          const int64_t* w_off, const int64_t* b_off, float* out, const int64_t* out_off, hipStream_t s);
+__attribute__((visibility("hidden")))
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr,
                           int ngroups = 1, const int32_t* lo = nullptr, const uint32_t* mask = nullptr);

@@ -658,6 +658,100 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
     return linr_launch_rc();
 }
 
+// ---- first convolutions of the 7 outter blocks: one gather, 56 outputs -----------------------------------------------------
+// Block b (1..7) starts with conv3(occ[:, :b] -> 8) + ReLU on the SAME occupancy rows (models/upsample.py:206-214), so the
+// grouped forward gathers each neighbour's 8 occupancy floats once and feeds all 7 kernels: per offset 28 (block, input
+// channel) pairs x 2 output quads = 56 MFMA blocks instead of 7 x 16 with zero-extended kernels, and 1/7 of the gathers.
+// The weights sit in LDS as the A-operand image wl[k][v][lane]: block (lane >> 2) of register v is combo 16 v + block,
+// combo c <-> pair p = c / 2 (block g = tri^-1(p), channel ci = p - g (g + 1) / 2), quad h = c % 2.  Per output the chain is
+// bias, then k ascending, ci ascending fmaf - the chain of cconv_mfma_k on that block alone, so the decoder's
+// block-by-block forward gives the same bits.
+struct Occ7Args { int64_t w[7], b[7], out[7]; };       // parameter offsets (kernel, bias) and output element offsets per block
+
+__host__ __device__ constexpr int occ7_g(int p) { return p < 1 ? 0 : p < 3 ? 1 : p < 6 ? 2 : p < 10 ? 3 : p < 15 ? 4 : p < 21 ? 5 : 6; }
+
+__global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __restrict__ occ, const int32_t* __restrict__ lo,
+                                                               const uint32_t* __restrict__ mask, int64_t ld, int64_t n,
+                                                               const float* __restrict__ P, Occ7Args a,
+                                                               float* __restrict__ out) {
+    __shared__ float wl[27 * 4 * 64];
+    for (int e = threadIdx.x; e < 27 * 256; e += LINR_CONV_BLOCK) {
+        const int k = e >> 8, c = (e & 255) >> 2, j = e & 3;
+        float w = 0.0f;
+        if (c < 56) {
+            const int pr = c >> 1, h = c & 1, g = occ7_g(pr), ci = pr - g * (g + 1) / 2;
+            w = P[a.w[g] + (k * (g + 1) + ci) * 8 + 4 * h + j];
+        }
+        wl[e] = w;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t row_raw = (int64_t)blockIdx.x * LINR_CONV_BLOCK + threadIdx.x;
+    const bool live = row_raw < n;
+    const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
+    const char* pad = reinterpret_cast<const char*>(occ - 8);
+    uint32_t off[27];
+    decode_offsets<false>(lo, mask, ld, row, 32u, off);
+    f32x4 acc[7][2];
+#pragma unroll
+    for (int g = 0; g < 7; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][h][j] = P[a.b[g] + 4 * h + j];
+    constexpr int PF = 3;
+    float x[PF + 1][8];
+    float wr[2][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) RowLoadF<8>::run(pad + off[u], x[u]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wr[0][v] = wl[v * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<27>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k + PF < 27) RowLoadF<8>::run(pad + off[k + PF], x[(k + PF) % (PF + 1)]);
+        if constexpr (k + 1 < 27) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wr[(k + 1) & 1][v] = wl[((k + 1) * 4 + v) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // input channel outermost: consecutive MFMAs write different accumulators (no back-to-back dependent issue), and
+        // every output still sees its channels in ascending order
+        static_for<7>([&](auto cic) {
+            constexpr int ci = decltype(cic)::value;
+            static_for<7 - ci>([&](auto gc) {
+                constexpr int g = ci + decltype(gc)::value;
+                static_for<2>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    constexpr int c = 2 * (g * (g + 1) / 2 + ci) + h;
+                    acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[k & 1][c / 16], x[k % (PF + 1)][ci], acc[g][h], 4, c % 16, 0);
+                });
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        float* op = out + a.out[g] + row * 8;
+        *reinterpret_cast<float4*>(op) = make_float4(fmaxf(acc[g][0][0], 0.0f), fmaxf(acc[g][0][1], 0.0f),
+                                                     fmaxf(acc[g][0][2], 0.0f), fmaxf(acc[g][0][3], 0.0f));
+        *reinterpret_cast<float4*>(op + 4) = make_float4(fmaxf(acc[g][1][0], 0.0f), fmaxf(acc[g][1][1], 0.0f),
+                                                         fmaxf(acc[g][1][2], 0.0f), fmaxf(acc[g][1][3], 0.0f));
+    }
+}
+
+// occ: arena copy of the occupancy [n][8] with the zero pad row in front; w_off / b_off: parameter offsets of the 7 first
+// convolutions (kernel [27][b][8] of block b) ; out + out_off[g]: A matrix of block g + 1
+int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* P,
+                          const int64_t* w_off, const int64_t* b_off, float* out, const int64_t* out_off, hipStream_t s) {
+    if (n == 0) return 0;
+    Occ7Args a;
+    for (int g = 0; g < 7; ++g) { a.w[g] = w_off[g]; a.b[g] = b_off[g]; a.out[g] = out_off[g]; }
+    occ_conv7_k<<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(occ, lo, mask, ld, n, P, a, out);
+    return linr_launch_rc();
+}
+
 // ---- backward-weight on the matrix cores -------------------------------------------------------------------------------------
 // gW[k][ci][co] = sum_r x[nbr[k][r]][ci] * g[r][co].  Same wave-per-row-group organisation as spconv_wgrad_k (lane = one
 // (offset k, channel quad q) pair, 16-byte gather of that quad for 8 rows at a time, persistent accumulators), but the

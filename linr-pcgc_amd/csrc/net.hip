@@ -508,9 +508,6 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
     const int32_t* lo = c.f->nbr_lo;
     const uint32_t* mk = c.f->nbr_mask;
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
-    PadSrc ps;
-    for (int g = 0; g < 7; ++g) ps.off[g] = L.outter[g].a_w;
-    pad_weights_k<<<linr_grid(7 * 1728, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, ps, a.WPAD);
     const float *pA[7], *pH[7], *pM[7], *pI[7], *pO[7], *p_ab[7], *p_c00w[7], *p_c00b[7], *p_c10w[7], *p_c10b[7], *p_c01w[7],
         *p_c01b[7], *p_c11w[7], *p_c11b[7], *p_c12w[7], *p_c12b[7], *p_bw[7], *p_bb[7];
     for (int g = 0; g < 7; ++g) {
@@ -520,12 +517,22 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
         p_c01w[g] = P + bp.c01_w; p_c01b[g] = P + bp.c01_b; p_c11w[g] = P + bp.c11_w; p_c11b[g] = P + bp.c11_b;
         p_c12w[g] = P + bp.c12_w; p_c12b[g] = P + bp.c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
     }
-    {   // first conv of every outter block on the zero-extended kernels: A[b] = relu(conv3(occ; WPAD[b-1]) + a_b)
-        Grp gp = Grp();
-        for (int g = 0; g < 7; ++g) gp.w[g] = (int64_t)g * 1728;
-        goffs(gp.b, p_ab, 7); goffs(gp.out, pA, 7);
-        TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[0], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
-                              LINR_RELU, c.s, &gp, 7));
+    {   // first conv of every outter block: A[b] = relu(conv3(occ[:, :b]; a) + a_b), one shared gather (csrc/fused.hip)
+        static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
+        if (shared) {
+            int64_t w_off[7], b_off[7], o_off[7];
+            for (int g = 0; g < 7; ++g) { w_off[g] = L.outter[g].a_w; b_off[g] = L.outter[g].a_b; o_off[g] = pA[g] - pA[0]; }
+            TRY(linr_occ_conv7_launch(a.OCC, lo, mk, c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, c.s));
+        } else {
+            PadSrc ps;
+            for (int g = 0; g < 7; ++g) ps.off[g] = L.outter[g].a_w;
+            pad_weights_k<<<linr_grid(7 * 1728, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, ps, a.WPAD);
+            Grp gp = Grp();
+            for (int g = 0; g < 7; ++g) gp.w[g] = (int64_t)g * 1728;
+            goffs(gp.b, p_ab, 7); goffs(gp.out, pA, 7);
+            TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[0], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
+                                  LINR_RELU, c.s, &gp, 7));
+        }
     }
     {   // H = [relu(conv0_0(A)) | relu(conv1_0(A))]
         Grp gp = Grp();
