@@ -480,6 +480,80 @@ def test_full_size_frame_properties(pkg):
     assert abs(enc['bpp']['point_bpp'] * gop.point_nums[0] - enc['bits_est']) <= 0.01 * enc['bits_est'] + 8 * 64
 
 
+def _frame_properties(gop, model, steps=3):
+    """size-independent checks shared by the full-size configs"""
+    from linr_pcgc_amd import codec, engine, overfit
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    f = gop.frames[0]
+    p1, b1 = model.frame_probs(f)
+    p2, b2 = model.frame_probs(f)
+    assert torch.equal(p1, p2) and torch.equal(b1, b2)
+    staged = torch.empty_like(p1)
+    for k in range(8):
+        engine.net_forward(f, model.flat_parameters(), k, k + 1, staged, None)
+    assert torch.equal(p1, staged)
+    t = f.occ.t().double()
+    pd = p1.double()
+    nats = -(t * torch.log(pd).clamp(min=-100) + (1 - t) * torch.log1p(-pd).clamp(min=-100)).sum()
+    assert abs(float(nats) / math.log(2) - float(b1)) <= 2e-5 * float(b1)
+    opt = FlatAdam(model, lr=1e-3)          # small steps: the gradient must be a descent direction (no Adam overshoot)
+    for _ in range(steps):
+        train_step(model, opt, f, gop.point_nums[0])
+    _, b3 = model.frame_probs(f)
+    assert steps == 0 or float(b3) < float(b1)
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda')
+    ref = torch.as_tensor(gop.infos[0]['ori']).cuda() + torch.tensor(gop.coord_mins[0], device='cuda', dtype=torch.int32)
+    assert torch.equal(dec[0], ref), 'decoded geometry must be bit-exact'
+    return float(b1), float(b3), enc
+
+
+def test_config0_sphere8_against_oracle(pkg):
+    """BASELINE config[0]: the 8-bit sphere (125,810 points, 6 scales), gop_size=1, frame_num=1, first_epoch=2 - the one
+    full-size case the CPU oracle finishes in seconds: bits of the seeded initialisation against the oracle, then the
+    2-epoch overfit + encode + decode flow."""
+    from linr_pcgc_amd import overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    pts = synthetic.sequence_frame('sphere8', 0)
+    gop = overfit.Gop(None, [pts], None, 64, 'cuda')
+    assert gop.point_nums[0] == 125810 and gop.scale_num == 6 and 53000 < gop.frames[0].rows < 55000
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    _, bits = model.frame_probs(gop.frames[0])
+    scales = []
+    for info in gop.infos[0]['all_input_info']:
+        c = info['coord'].cpu().numpy().astype(np.int32)
+        scales.append({'coord': c, 'occ': info['occ'].cpu().numpy().astype(np.float32),
+                       'offset_tensor': info['offset_tensor'].cpu().numpy().astype(np.float32),
+                       'scale_idx': info['scale_idx'], 'nbr': ooct.neighbour_table(c)})
+    ref_bits = float(onet.frame_bits(sd, onet.to_torch_scales(scales)))
+    assert abs(float(bits) - ref_bits) <= 1e-5 * ref_bits, (float(bits), ref_bits)
+    opt = FlatAdam(model)
+    losses = overfit.overfit_gop(model, opt, gop, 2)
+    assert losses[1] < losses[0]
+    _frame_properties(gop, model, steps=0)
+
+
+def test_config3_andrew10_dense_shell_properties(pkg):
+    """BASELINE config[3] stand-in: 2-voxel-thick 10-bit shell (1,306,322 points, K_eff ~ 17): stresses the kernel-map
+    build and the gathers; size-independent properties."""
+    from linr_pcgc_amd import overfit, synthetic
+    pts = synthetic.sequence_frame('andrew10', 0)
+    gop = overfit.Gop(None, [pts], None, 64, 'cuda')
+    assert gop.point_nums[0] == 1306322 and gop.scale_num == 7
+    _frame_properties(gop, overfit.gen_model(gop.scale_num, 'cuda', seed=8807))
+
+
+def test_config4_owlii11_size_properties(pkg):
+    """BASELINE config[4] stand-in geometry: 11-bit sphere (~2.9 M points, 8 scales, ~1.24 M rows) through the fp32 path
+    (the bf16 / int8-weight variant of that config is not built yet)."""
+    from linr_pcgc_amd import overfit, synthetic
+    pts = synthetic.sequence_frame('owlii11', 0)
+    gop = overfit.Gop(None, [pts], None, 64, 'cuda')
+    assert gop.point_nums[0] > 2800000 and gop.scale_num == 8 and gop.frames[0].rows > 1200000
+    _frame_properties(gop, overfit.gen_model(gop.scale_num, 'cuda', seed=8807), steps=2)
+
+
 @pytest.mark.parametrize('n', [1, 2, 63, 65])
 def test_tiny_and_ragged_frames(pkg, n):
     """Edge cases: a scale with a single voxel, row counts around the wave size, and a zero-row scale."""
