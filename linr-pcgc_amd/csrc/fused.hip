@@ -960,12 +960,16 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
 }
 
 // ---- fused backward of the occupancy head ------------------------------------------------------------------------------
-// Per row: recompute the hidden layer from C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]).  The weight gradients
-//   gW1[24][8] = sum_r gh[r] (x) c[r],  gb1 = sum_r gh[r],  gw2[24] = sum_r gz[r] h[r],  gb2 = sum_r gz[r]
+// Per row: recompute the hidden layer from C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]).  The per-row MLP runs on
+// the matrix cores like the convolutions (v_mfma_f32_4x4x1, weights as broadcast A blocks held in 8 VGPRs; K = 1 keeps
+// the forward head's fmaf chains: bias first, inputs ascending).  The weight gradients
+//   gW1[24][8] = sum_r gh[r] (x) c[r],  gb1 = sum_r gh[r]
 // are X^T G products with the row reduction as the K dimension of v_mfma_f32_16x16x4_f32: each wave transposes its
-// 64 rows of X = [gh | h] (48 cols) and G = [c | 1 | gz] (10 cols) through a wave-private LDS tile into fragment layout.
-// Persistent blocks (LINR_WG_BLOCKS) keep the 3 accumulator tiles in registers and emit one partial per parameter.
-#define HB_LDW 59          // 48 + 10 columns, odd stride
+// 64 rows of X = gh (24 cols) and G = [c | 1] (9 cols) through a wave-private LDS tile into fragment layout;
+//   gw2[24] = sum_r gz[r] h[r],  gb2 = sum_r gz[r]
+// accumulate per lane and are reduced once per block (fixed shuffle tree, waves in order).
+// Persistent blocks (LINR_WG_BLOCKS) keep all accumulators in registers and emit one partial per parameter.
+#define HB_LDW 33          // 24 + 9 columns, odd stride
 struct HeadBwdArgs {
     const float* c;  const float* p;  const float* target; int target_ld;
     const float* w1; const float* b1; const float* w2;
@@ -974,7 +978,7 @@ struct HeadBwdArgs {
     float* big; int64_t block_stride; int64_t off_w1, off_b1, off_w2, off_b2;
 };
 
-__global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64_t n, Grp gp = Grp()) {
+__global__ __launch_bounds__(LINR_BLOCK, 4) void head_bwd_k(HeadBwdArgs A, int64_t n, Grp gp = Grp()) {
     {   // group offsets: in = c, e0 = p, e1 = target, w = w1, b = b1, e2 = w2, out = gc, e3..e6 = slab offsets of w1, b1, w2, b2
         const int gi = blockIdx.y;
         A.c += gp.in[gi]; A.p += gp.e0[gi]; A.target += gp.e1[gi]; A.w1 += gp.w[gi]; A.b1 += gp.b[gi]; A.w2 += gp.e2[gi];
@@ -982,23 +986,45 @@ __global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64
         A.off_w1 += gp.e3[gi]; A.off_b1 += gp.e4[gi]; A.off_w2 += gp.e5[gi]; A.off_b2 += gp.e6[gi];
     }
     __shared__ float sT[(LINR_BLOCK / 64) * 64 * HB_LDW];
-    __shared__ float sfold[64 * 13];
-    __shared__ float sgz[LINR_BLOCK / 64];
+    __shared__ float sfold[64 * 9];
+    __shared__ float sw2[(LINR_BLOCK / 64) * 25];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mm = lane & 15, rr = lane >> 4;
-    float* T = sT + wave * 64 * HB_LDW;
-    f32x4 acc[3];
+    // A-operand images of the weights: block (lane >> 2) of register v is "combo" 16 v + block
+    //   wA: combo = 6 i + hq -> W1[4 hq + j][i] (i < 8), combos 48..53 -> b1[4 (combo - 48) + j]
+    //   wB: combo = 2 jj + q -> W1[jj][4 q + j]  (jj < 24)
+    //   wC: block hq < 6     -> w2[4 hq + j]
+    float wA[4], wB[3], wC;
+    {
+        const int blk = lane >> 2, j = lane & 3;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) acc[a] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int v = 0; v < 4; ++v) {
+            const int cb = 16 * v + blk;
+            wA[v] = cb < 48 ? A.w1[(4 * (cb % 6) + j) * 8 + cb / 6] : (cb < 54 ? A.b1[4 * (cb - 48) + j] : 0.0f);
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int cb = 16 * v + blk;
+            wB[v] = A.w1[(cb / 2) * 8 + 4 * (cb % 2) + j];
+        }
+        wC = blk < 6 ? A.w2[4 * blk + j] : 0.0f;
+    }
+    float* T = sT + wave * 64 * HB_LDW;
+    f32x4 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) acc[a] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float gw2[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) gw2[j] = 0.0f;
     float gz_sum = 0.0f;
     const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t row = t * LINR_BLOCK + threadIdx.x;
         const bool live = row < n;
-        float c[8], gc[8];
+        float c[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { c[i] = 0.0f; gc[i] = 0.0f; }
+        for (int i = 0; i < 8; ++i) c[i] = 0.0f;
         float gz = 0.0f;
         if (live) {
             const float4 c0 = *reinterpret_cast<const float4*>(A.c + row * 8);
@@ -1008,56 +1034,93 @@ __global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64
             const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
             gz = gp * ((1.0f - pp) * pp);
         }
+        // hpre = b1 + W1 c  (6 output quads; bias through x = 1, then inputs ascending)
+        f32x4 hp[6];
+        static_for<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);   // combo 48 + hq
+        });
+        static_for<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<6>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                constexpr int cb = 6 * i + hq;
+                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
+            });
+        });
+        // gh = [hpre > 0] gz w2 ;  gw2 += gz relu(hpre)
+        float gh[24];
+        static_for<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            const f32x4 g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wC, gz, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hv = hp[hq][j];
+                gh[4 * hq + j] = (live && hv > 0.0f) ? g4[j] : 0.0f;
+                gw2[4 * hq + j] = fmaf(gz, fmaxf(hv, 0.0f), gw2[4 * hq + j]);
+            }
+        });
+        // gC = W1^T gh  (2 output quads, hidden units ascending)
+        f32x4 gcq[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+        static_for<24>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<2>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int cb = 2 * jj + q;
+                gcq[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wB[cb / 16], gh[jj], gcq[q], 4, cb % 16, 0);
+            });
+        });
+        if (live) {
+            *reinterpret_cast<float4*>(A.gc + row * 8) = make_float4(gcq[0][0], gcq[0][1], gcq[0][2], gcq[0][3]);
+            *reinterpret_cast<float4*>(A.gc + row * 8 + 4) = make_float4(gcq[1][0], gcq[1][1], gcq[1][2], gcq[1][3]);
+        }
+        gz_sum += gz;
         float* Tr = T + lane * HB_LDW;
 #pragma unroll
-        for (int j = 0; j < 24; ++j) {
-            float hj = A.b1[j];
+        for (int j = 0; j < 24; ++j) Tr[j] = gh[j];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) hj = fmaf(c[i], A.w1[j * 8 + i], hj);
-            const float gh = (live && hj > 0.0f) ? gz * A.w2[j] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gc[i] = fmaf(gh, A.w1[j * 8 + i], gc[i]);
-            Tr[j] = gh;
-            Tr[24 + j] = live ? fmaxf(hj, 0.0f) : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Tr[48 + i] = c[i];
-        Tr[56] = live ? 1.0f : 0.0f;
-        Tr[57] = gz;
-        gz_sum += gz;
-        if (live) {
-            *reinterpret_cast<float4*>(A.gc + row * 8) = make_float4(gc[0], gc[1], gc[2], gc[3]);
-            *reinterpret_cast<float4*>(A.gc + row * 8 + 4) = make_float4(gc[4], gc[5], gc[6], gc[7]);
-        }
+        for (int i = 0; i < 8; ++i) Tr[24 + i] = c[i];
+        Tr[32] = live ? 1.0f : 0.0f;
         // X^T G over this wave's 64 rows (wave-private tile: in-order LDS, no block barrier needed)
 #pragma unroll 4
         for (int s4 = 0; s4 < 16; ++s4) {
             const float* Tq = T + (4 * s4 + rr) * HB_LDW;
-            const float b = (mm < 10) ? Tq[48 + mm] : 0.0f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tq[16 * a + mm], b, acc[a], 0, 0, 0);
+            const float b = (mm < 9) ? Tq[24 + mm] : 0.0f;
+            const float a0 = Tq[mm];
+            const float a1 = (mm < 8) ? Tq[16 + mm] : 0.0f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
         }
     }
     // fold the 4 waves in wave order, then one partial per destination element
-    float* mine = sfold + lane * 13;
+    float* mine = sfold + lane * 9;
     for (int w = 0; w < LINR_BLOCK / 64; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mine[a * 4 + j] = (w == 0) ? acc[a][j] : mine[a * 4 + j] + acc[a][j];
         }
         __syncthreads();
     }
-    // gb2: fixed-order wave reduction, then waves in order
+    // gw2, gb2: fixed-order wave reduction, then waves in order
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
-    if (lane == 0) sgz[wave] = gz_sum;
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) gw2[j] += __shfl_xor(gw2[j], d, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) sw2[wave * 25 + j] = gw2[j];
+        sw2[wave * 25 + 24] = gz_sum;
+    }
     __syncthreads();
     if (wave == 0) {
         float* dst = A.big + (int64_t)blockIdx.x * A.block_stride;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = 16 * a + rr * 4 + j;      // C/D map: row = (lane>>4)*4 + reg, col = lane&15
@@ -1065,11 +1128,13 @@ __global__ __launch_bounds__(LINR_BLOCK, 2) void head_bwd_k(HeadBwdArgs A, int64
                 if (m < 24) {
                     if (mm < 8) dst[A.off_w1 + m * 8 + mm] = v;
                     else if (mm == 8) dst[A.off_b1 + m] = v;
-                } else if (mm == 9) {
-                    dst[A.off_w2 + (m - 24)] = v;
                 }
             }
-        if (lane == 0) dst[A.off_b2] = ((sgz[0] + sgz[1]) + sgz[2]) + sgz[3];
+        if (lane < 25) {
+            const float v = ((sw2[lane] + sw2[25 + lane]) + sw2[50 + lane]) + sw2[75 + lane];
+            if (lane < 24) dst[A.off_w2 + lane] = v;
+            else dst[A.off_b2] = v;
+        }
     }
 }
 
