@@ -195,7 +195,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 #ifndef LINR_CONV_BLOCK
 #define LINR_CONV_BLOCK 256
 #endif
-template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0, bool STAGE = false, int DIAG = 0>
+template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0, bool STAGE = false>
 __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
                                                            const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                            int64_t ld, int64_t n, const float* __restrict__ W,
@@ -261,22 +261,16 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
     // `ld(off, x)` fetches one row: the LDS variant indexes the __shared__ array itself so that the compiler emits
     // ds_read (a generic pointer would become flat loads, which force vmcnt(0)/lgkmcnt(0) waits and kill the pipeline)
     auto taps = [&](auto ld) {
-        if constexpr (DIAG == 1) {
 #pragma unroll
-            for (int u = 0; u <= PF; ++u)
-#pragma unroll
-                for (int i = 0; i < LOADW; ++i) x[u][i] = __int_as_float(off[u] + i);
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) if constexpr (DIAG != 1) ld(off[u], x[u]);
+        for (int u = 0; u < PF; ++u) ld(off[u], x[u]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<27>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int g = k / KPV, ab = (k % KPV) * HB;
-            if constexpr (k + PF < 27 && DIAG != 1) ld(off[k + PF], x[(k + PF) % (PF + 1)]);
+            if constexpr (k + PF < 27) ld(off[k + PF], x[(k + PF) % (PF + 1)]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < (DIAG == 2 ? 1 : GIN); ++i) {
+            for (int i = 0; i < GIN; ++i) {
                 acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[0], 4, ab, 0);
                 if constexpr (GOUT == 8)
                     acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[1], 4, ab + 1, 0);
@@ -1157,18 +1151,11 @@ int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, c
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
     const dim3 grid(linr_grid(n, LINR_CONV_BLOCK), ngroups);
-    static const int diag = getenv("LINR_CONV_DIAG") ? atoi(getenv("LINR_CONV_DIAG")) : 0;
     static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;   // 2 = MFMA + LDS staging (measured equal)
 #define GO(GI, GO_, B, LW)                                                                                              \
     do {                                                                                                                \
         if (use_mfma == 2 && (GO_ == 4 || GO_ == 8))                                                                    \
             cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW, 0, true><<<grid, LINR_CONV_BLOCK, 0, s>>>(              \
-                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
-        else if (diag == 1 && GI == 8 && GO_ == 8 && !B)                                                                \
-            cconv_mfma_k<8, 8, false, 8, 0, false, 1><<<grid, LINR_CONV_BLOCK, 0, s>>>(                                       \
-                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
-        else if (diag == 2 && GI == 8 && GO_ == 8 && !B)                                                                \
-            cconv_mfma_k<8, 8, false, 8, 0, false, 2><<<grid, LINR_CONV_BLOCK, 0, s>>>(                                       \
                 in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
         else if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                    \
             cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_CONV_BLOCK, 0, s>>>(                       \
