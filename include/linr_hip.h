@@ -59,6 +59,10 @@ LINR_API int linr_kmap_build(const int32_t* coords, int64_t n, int32_t* nbr, int
  * q*3 + (dz+1) of mask[j] says which are present: 40 B/row instead of 108.  Rows of nbr must hold global row ids. */
 LINR_API int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n, int32_t* lo, uint32_t* mask, int64_t ld,
                        void* stream);
+/* The 7-neighbour occupancy features of the scale context (qscTensor.set_offset_tensor, models/module_utils.py:201-224,
+ * offsets of glob_params.py:3) read off the kernel map: out[j*7 + i] = 1.0f if neighbour i of voxel row_base + j exists.
+ * Replaces 7 QuickSearchCoord.search calls per scale in decoder.decode_one_frame (decoder.py:160-166). */
+LINR_API int linr_kmap_offset_feat(const int32_t* nbr, int64_t ld, int64_t row_base, int64_t n, float* out, void* stream);
 /* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
 LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
 

@@ -16,7 +16,7 @@ import torch
 from .function_utils import pack_bitstream, unpack_bitstream
 from .model_codec import Model_Estimate
 from .model_core import encode_streams
-from .module_utils import octree_level_obj, qscTensor
+from .module_utils import octree_level_obj, qscTensor, unique_sorted  # noqa: F401
 
 
 def enc_all_frame_low_xyz(gop):
@@ -70,14 +70,14 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=8):
 
 
 def decode_one_frame(model, frame_enc_bytes, xyz_low):
-    """decoder.decode_one_frame (decoder.py:153-176): coarse to fine, 8 AC-decoded stages per scale."""
-    lowx = xyz_low
+    """decoder.decode_one_frame (decoder.py:153-176): coarse to fine, 8 AC-decoded stages per scale.  The 7-neighbour
+    occupancy the reference rebuilds with qscTensor.set_offset_tensor comes out of the scale's kernel map instead
+    (linr_kmap_offset_feat), so a scale costs one kernel-map build, 8 stage forwards and 8 host round trips."""
+    lowx = unique_sorted(xyz_low)
     for s_idx in range(len(frame_enc_bytes) - 1, -1, -1):
-        q = qscTensor(lowx)
-        q.set_offset_tensor()
-        occ_lst = model.decode({'enc_bytes': frame_enc_bytes[s_idx], 'coord': q.get_coord(),
-                                'offset_tensor': q.get_offset_tensor(), 'scale_idx': s_idx})
-        lowx = octree_level_obj.upper_layer(q.get_coord(), torch.cat(occ_lst, dim=-1))
+        occ_lst = model.decode({'enc_bytes': frame_enc_bytes[s_idx], 'coord': lowx, 'offset_tensor': None,
+                                'scale_idx': s_idx})
+        lowx = octree_level_obj.upper_layer(lowx, torch.cat(occ_lst, dim=-1))
     return {'dec_coord': lowx}
 
 

@@ -73,3 +73,23 @@ extern "C" int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad
     kmap_validate_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(coords, n, bad);
     return linr_launch_rc();
 }
+
+// 7-neighbour occupancy of every voxel (qscTensor.set_offset_tensor, models/module_utils.py:201-224; offsets in the order of
+// glob_params.py:3: self, -x, +x, -y, +y, -z, +z) read off the kernel map it is a subset of: tap k = (dx+1)+3(dy+1)+9(dz+1).
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_offset_feat_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t row_base,
+                                                                 int64_t n, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (e >= n * 7) return;
+    const int64_t r = e / 7;
+    const int j = (int)(e % 7);
+    const int taps[7] = {13, 12, 14, 10, 16, 4, 22};
+    out[e] = nbr[(int64_t)taps[j] * ld + row_base + r] >= 0 ? 1.0f : 0.0f;
+}
+
+extern "C" int linr_kmap_offset_feat(const int32_t* nbr, int64_t ld, int64_t row_base, int64_t n, float* out, void* stream) {
+    if (n < 0 || row_base < 0 || ld < row_base + n) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!nbr || !out) return LINR_EINVAL;
+    kmap_offset_feat_k<<<linr_grid(n * 7, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, ld, row_base, n, out);
+    return linr_launch_rc();
+}

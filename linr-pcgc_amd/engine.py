@@ -17,7 +17,8 @@ class Frame:
     """All scales of one frame on the GPU: kernel map, 7-neighbour features, child occupancy, activation arena."""
 
     def __init__(self, scales, model_scale_num, device='cuda', validate=True, with_arena=True):
-        """scales: list of dicts {'coord' int32 [N,3] sorted x-major, 'offset_tensor' [N,7] float,
+        """scales: list of dicts {'coord' int32 [N,3] sorted x-major, 'offset_tensor' [N,7] float (None: derived from the
+        kernel map),
         'occ' [N,8] float or 'occ_lst' 8 x [N,1], 'scale_idx'} - the per-scale network inputs of
         datautils/custom_dataset.py:318-323.  Missing 'occ' (decoder) gives a zero occupancy buffer."""
         device = torch.device(device)
@@ -40,7 +41,11 @@ class Frame:
             r0, r1 = int(self.row_off[i]), int(self.row_off[i + 1])
             coord = torch.as_tensor(s['coord']).to(device=device, dtype=torch.int32).contiguous()
             ops.kmap_build_into(coord, self.nbr, r0, validate)
-            self.offset_feat[r0:r1] = torch.as_tensor(s['offset_tensor']).to(device=device, dtype=torch.float32)
+            if s.get('offset_tensor') is None:       # decoder fast path: the 7-neighbour occupancy is part of the kernel map
+                check(_lib.lib().linr_kmap_offset_feat(self.nbr.data_ptr(), self.nbr_ld, r0, r1 - r0,
+                                                       self.offset_feat[r0:r1].data_ptr(), _stream()), 'linr_kmap_offset_feat')
+            else:
+                self.offset_feat[r0:r1] = torch.as_tensor(s['offset_tensor']).to(device=device, dtype=torch.float32)
             if 'occ' in s and s['occ'] is not None:
                 self.occ[r0:r1] = torch.as_tensor(s['occ']).to(device=device, dtype=torch.float32)
             elif 'occ_lst' in s and s['occ_lst'] is not None:

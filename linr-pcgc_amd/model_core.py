@@ -120,7 +120,7 @@ class LINR_PCGC_Model(nn.Module):
         entry pins the tensors so a recycled allocation can never alias a stale kernel map.  Decoder-side frames
         (fresh coordinates every call) are not cached."""
         coord = d['coord']
-        s = {'coord': coord, 'offset_tensor': d['offset_tensor'], 'scale_idx': d['scale_idx']}
+        s = {'coord': coord, 'offset_tensor': d.get('offset_tensor'), 'scale_idx': d['scale_idx']}
         if not need_occ:
             return self.make_frame([s])
         occ0 = d['occ_lst'][0]
@@ -190,24 +190,42 @@ class LINR_PCGC_Model(nn.Module):
         """models/model_core.py:268-286 + CNP.decode (models/upsample.py:249-295): stage-serial, the SAME launches as
         the encoder's forward, so probabilities are bitwise identical.  Returns 8 x [N,1] float32 occupancy."""
         streams = unpack_bitstream(inagrs['enc_bytes'])
-        frame = self._scale_frame({'coord': inagrs['coord'], 'offset_tensor': inagrs['offset_tensor'],
+        frame = self._scale_frame({'coord': inagrs['coord'], 'offset_tensor': inagrs.get('offset_tensor'),
                                    'scale_idx': inagrs['scale_idx']}, need_occ=False)
         return self.decode_frame(frame, [streams])
 
+    def _host_buffers(self, rows):
+        """Pinned staging buffers of the staged decoder (probabilities down, decoded symbols up), grown on demand."""
+        buf = getattr(self, '_dec_host', None)
+        if buf is None or buf[0].numel() < rows:
+            cap = max(rows, 1 << 16)
+            buf = (torch.empty(cap, dtype=torch.float32, pin_memory=True), torch.empty(cap, dtype=torch.uint8, pin_memory=True))
+            self._dec_host = buf
+        return buf
+
     @torch.no_grad()
     def decode_frame(self, frame, streams_per_scale):
-        """Staged decode of every scale of `frame` at once: stage k of all scales is one launch set."""
+        """Staged decode of every scale of `frame` at once: stage k of all scales is one launch set.  Host side per
+        stage: one D2H of the probabilities into pinned memory, linr_ac_decode_binary per scale straight on those
+        buffers, one H2D of the decoded byte column (no torch CPU ops: they fan out over every host core)."""
         frame.occ.zero_()
-        probs = torch.empty((8, frame.rows), dtype=torch.float32, device=frame.device)
-        bac = BinaryArithmeticCoding()
+        rows = frame.rows
+        probs = torch.empty((8, rows), dtype=torch.float32, device=frame.device)
+        p_host, s_host = self._host_buffers(rows)
+        p_np, s_np = p_host.numpy(), s_host.numpy()
+        L = _lib.lib()
         for k in range(8):
             engine.net_forward(frame, self._flat, k, k + 1, probs, None)
-            pk = probs[k].cpu()
-            col = torch.empty(frame.rows, dtype=torch.float32)
+            p_host[:rows].copy_(probs[k])                       # synchronous D2H
             for i in range(frame.n_scales):
                 sl = frame.scale_slice(i)
-                col[sl] = bac.decode(pk[sl], streams_per_scale[i][k]).to(torch.float32)
-            frame.occ[:, k] = col.to(frame.device)
+                n = sl.stop - sl.start
+                if n == 0:
+                    continue
+                buf = np.frombuffer(streams_per_scale[i][k], dtype=np.uint8)
+                _lib.check(L.linr_ac_decode_binary(p_np[sl.start:].ctypes.data, n, buf.ctypes.data if buf.size else None,
+                                                   buf.size, s_np[sl.start:].ctypes.data), 'linr_ac_decode_binary')
+            frame.occ[:, k] = s_host[:rows].to(frame.device, non_blocking=False).to(torch.float32)
         return [frame.occ[:, k:k + 1].clone() for k in range(8)]
 
 

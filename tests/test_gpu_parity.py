@@ -70,6 +70,16 @@ def test_kmap_bit_exact(pkg, shell, case):
     assert (nbr.t().cpu().numpy() == ref).all()
 
 
+def test_offset_features_from_kernel_map(pkg, shell):
+    """linr_kmap_offset_feat == qscTensor.set_offset_tensor (the reference's 7 coordinate searches), bit for bit."""
+    from linr_pcgc_amd import engine
+    dev = _dev()
+    scales = [{'coord': s['coord'], 'offset_tensor': None, 'scale_idx': s['scale_idx']} for s in shell['scales']]
+    f = engine.Frame(scales, len(scales), dev, with_arena=False)
+    ref = np.concatenate([s['offset_tensor'] for s in shell['scales']], axis=0)
+    assert np.array_equal(f.offset_feat.cpu().numpy(), ref.astype(np.float32))
+
+
 def test_kmap_rejects_unsorted(pkg):
     from linr_pcgc_amd import ops
     c = torch.tensor([[1, 0, 0], [0, 0, 0]], dtype=torch.int32, device=_dev())
