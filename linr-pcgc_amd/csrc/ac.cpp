@@ -63,21 +63,26 @@ struct RangeEncoder {
 };
 
 struct BitSource {
-    const uint8_t* in; int64_t len; int64_t pos = 0; uint32_t cache = 0; int ncache = 0;
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint64_t buf = 0; int nbuf = 0;    // buf: next bits, MSB-aligned
     BitSource(const uint8_t* i, int64_t l) : in(i), len(l) {}
-    inline void shift_in(uint32_t& value) {
-        if (ncache == 0) {
-            if (pos == len) { value <<= 1; return; }     // past the end: zeros
-            cache = in[pos++]; ncache = 8;
+    // the next n (1..32) bits of the stream, MSB first; zeros past the end
+    inline uint32_t bits(int n) {
+        while (nbuf <= 56) {
+            const uint64_t byte = pos < len ? in[pos] : 0u;
+            ++pos;
+            buf |= byte << (56 - nbuf);
+            nbuf += 8;
         }
-        value = (value << 1) | ((cache >> (ncache - 1)) & 1u);
-        --ncache;
+        const uint32_t v = (uint32_t)(buf >> (64 - n));
+        buf <<= n;
+        nbuf -= n;
+        return v;
     }
 };
 
 struct RangeDecoder {
     uint32_t low = 0, high = 0xFFFFFFFFu, value = 0; BitSource src;
-    RangeDecoder(const uint8_t* i, int64_t l) : src(i, l) { for (int b = 0; b < 32; ++b) src.shift_in(value); }
+    RangeDecoder(const uint8_t* i, int64_t l) : src(i, l) { value = src.bits(32); }
     inline uint32_t target() const {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         return (uint32_t)(uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000u - 1) / span);
@@ -87,24 +92,30 @@ struct RangeDecoder {
         high = (low - 1) + (uint32_t)((span * c_high) >> 16);
         low = low + (uint32_t)((span * c_low) >> 16);
         for (;;) {
-            if (low >= 0x80000000u || high < 0x80000000u) {
-                low <<= 1; high = (high << 1) | 1u;
+            const uint32_t diff = low ^ high;
+            if (diff < 0x80000000u) {
+                // torchac shifts one bit at a time while the top bits of low and high agree; all of those shifts at once
+                int n = diff ? __builtin_clz(diff) : 31;
+                if (n > 31) n = 31;
+                low <<= n;
+                high = (high << n) | ((1u << n) - 1u);
+                value = (value << n) | src.bits(n);
             } else if (low >= 0x40000000u && high < 0xC0000000u) {
                 low = (low << 1) & 0x7FFFFFFFu;
                 high = (high << 1) | 0x80000001u;
                 value -= 0x40000000u;
+                value = (value << 1) | src.bits(1);
             } else {
                 break;
             }
-            src.shift_in(value);
         }
     }
 };
 
 inline uint32_t binary_c1(float p) {
     // float32 arithmetic exactly as torch: (1 - p) * 65534, round half to even, int16 wrap, + 1
-    const float scaled = nearbyintf((1.0f - p) * 65534.0f);
-    return (uint32_t)(((int64_t)scaled + 1) & 0xFFFF);
+    const long scaled = lrintf((1.0f - p) * 65534.0f);      // current rounding mode = to nearest even, like torch.round
+    return (uint32_t)((scaled + 1) & 0xFFFF);
 }
 
 }  // namespace
@@ -125,8 +136,12 @@ extern "C" int linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8
     RangeDecoder dec(in_h, in_len);
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t c1 = binary_c1(prob_h[i]);
-        // torchac's binary search over [0, c1, *] returns symbol 1 iff target >= c1
-        const uint32_t s = dec.target() >= c1 ? 1u : 0u;
+        // torchac's binary search over [0, c1, *] returns symbol 1 iff target >= c1, i.e. iff
+        //   ((value - low + 1) * 2^16 - 1) / span >= c1  <=>  (value - low + 1) * 2^16 > c1 * span
+        //   <=>  value - low + 1 > floor(c1 * span / 2^16)  <=>  value - low >= (c1 * span) >> 16
+        // (integers on the left): the division-free form of the same decision
+        const uint64_t span = (uint64_t)dec.high - (uint64_t)dec.low + 1;
+        const uint32_t s = ((uint64_t)dec.value - (uint64_t)dec.low >= ((span * c1) >> 16)) ? 1u : 0u;
         sym_h[i] = (uint8_t)s;
         if (i == n - 1) break;
         if (s) dec.consume(c1, 0x10000u); else dec.consume(0u, c1);

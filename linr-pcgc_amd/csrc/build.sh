@@ -13,7 +13,7 @@ for f in kmap spconv linear loss_optim net fused; do
   fi
 done
 if [ ! -f _obj/ac.o ] || [ ac.cpp -nt _obj/ac.o ] || [ ../../include/linr_hip.h -nt _obj/ac.o ]; then
-  g++ -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall -c ac.cpp -o _obj/ac.o &
+  g++ -O3 -fno-math-errno -fPIC -std=c++17 -fvisibility=hidden -Wall -c ac.cpp -o _obj/ac.o &
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
