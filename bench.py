@@ -44,24 +44,7 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_roofline(model, gop, iters=50):
-    """Dominant kernel = the 8->8 sparse-conv kernel the executor launches (cconv_mfma_k<8,8,fwd>: compressed kernel
-    map + v_mfma_f32_4x4x1; 17 launches per forward, its transposed twin another 17 per backward).  Timed live with
-    events on the launch stream over `iters` launches on frame 0's full row space, through the C-ABI entry
-    linr_spconv_cmap.  Algorithmic bytes per row: 4*(8+8) feature bytes + 108 neighbour-table bytes
-    (the kernel actually streams the 40 B/row compressed table, so it may exceed 1.0 against this figure one day)."""
-    from linr_pcgc_amd import ops
-    f = gop.frames[0]
-    R = f.rows
-    dev = f.device
-    x = torch.zeros((R + 1, 8), device=dev)
-    x[1:].normal_()
-    out = torch.empty((R, 8), device=dev)
-    w = torch.randn(27, 8, 8, device=dev) * 0.1
-    b = torch.zeros(8, device=dev)
-
-    def go():
-        ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out)
+def _time_launches(go, iters):
     for _ in range(5):
         go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,20 +54,49 @@ def kernel_roofline(model, gop, iters=50):
         go()
     e1.record()
     torch.cuda.synchronize()
-    dur_s = e0.elapsed_time(e1) / 1e3 / iters
+    return e0.elapsed_time(e1) / 1e3 / iters
+
+
+def kernel_roofline(model, gop, iters=50):
+    """Dominant kernel = the top line of the rocprofv3 kernel statistics of this command (profiles/): the 8->8
+    backward-weight kernel spconv_wgrad_mfma_k<2,8> (24 passes over the rows per step, ~20 % of the step).  The second
+    line, the 8->8 convolution cconv_mfma_k<8,8,fwd> (the template behind forward, backward-data and the fused head /
+    Inception variants, ~40 % together), is reported next to it as `conv`.  Both are timed live with events on the
+    launch stream over `iters` launches on frame 0's full row space, through their own C-ABI entries
+    (linr_spconv_wgrad_cmap, linr_spconv_cmap).  Algorithmic bytes per row, both kernels:
+    4*(8+8) feature bytes + 108 neighbour-table bytes (they actually stream the 40 B/row compressed table)."""
+    from linr_pcgc_amd import ops
+    f = gop.frames[0]
+    R = f.rows
+    dev = f.device
+    x = torch.zeros((R + 1, 8), device=dev)
+    x[1:].normal_()
+    g = torch.randn((R, 8), device=dev)
+    out = torch.empty((R, 8), device=dev)
+    w = torch.randn(27, 8, 8, device=dev) * 0.1
+    b = torch.zeros(8, device=dev)
+    slab = torch.empty((512, 27 * 64 + 8), device=dev)
     alg_bytes = R * (4 * (8 + 8) + 108)
-    achieved = alg_bytes / dur_s / 1e9
-    traffic = None
+    traffic = {}
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')          # PMC-derived HBM bytes per launch (see profiles/README)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('cconv_mfma_8x8_fwd_bytes_per_launch')
+            traffic = json.load(open(tpath))
         except Exception:
-            traffic = None
-    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'kernel': 'cconv_mfma_k<8,8,fwd,LOADW=8>', 'rows_per_launch': R,
-            'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': round(dur_s * 1e6, 2)}
+            traffic = {}
+
+    def entry(name, dur_s, key):
+        achieved = alg_bytes / dur_s / 1e9
+        return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic.get(key), 'kernel': name,
+                'rows_per_launch': R, 'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': round(dur_s * 1e6, 2)}
+
+    d_wg = _time_launches(lambda: ops.spconv_wgrad_cmap(x[1:], g, f.nbr, f.nbr_lo, f.nbr_mask, R, 8, 8, slab=slab,
+                                                        reduce=False), iters)
+    d_cv = _time_launches(lambda: ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out), iters)
+    roof = entry('spconv_wgrad_mfma_k<2,8,cmap>', d_wg, 'spconv_wgrad_mfma_8x8_bytes_per_launch')
+    roof['conv'] = entry('cconv_mfma_k<8,8,fwd,LOADW=8>', d_cv, 'cconv_mfma_8x8_fwd_bytes_per_launch')
+    return roof
 
 
 def cpu_baseline(model_sd, gop_info, point_num, sample_rows):

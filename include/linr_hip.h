@@ -97,6 +97,16 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
                      const float* res, int32_t res_ld, const float* act, int32_t act_ld, float* out, int32_t out_ld,
                      uint32_t flags, void* stream);
 
+/* Backward-weight of the same convolution as the executor runs it (spconv_wgrad_mfma_k on the compressed map: lane =
+ * (offset, channel quad), gathered quad x broadcast gradient tile on v_mfma_f32_4x4x1, row order fixed => reproducible).
+ * Writes linr_spconv_wgrad_cmap_blocks() (= 512) per-block partials: slab[b][(27 cin + 1) cout], kernel gradient
+ * [27][cin][cout] first, bias gradient [cout] last; their ascending sum over b is MinkowskiConvolution's kernel / bias
+ * gradient (ME autograd of the call sites above).  `in`: [n][8] floats, 16-byte aligned, zero row at index -1. */
+LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
+LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
+                           const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin, int32_t cout,
+                           float* slab, void* stream);
+
 /* ---- pointwise layers ---------------------------------------------------------------------------------------
  * Replaces ME.MinkowskiConvolution(kernel_size=1) (models/resnet.py:31-37,45-51) and nn.Linear inside
  * PointwiseMLP (models/module_utils.py:42-81).  Element (ci,co) of the weight is W[ci*ws_ci + co*ws_co]:

@@ -480,6 +480,27 @@ extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, con
                              flags, (hipStream_t)stream, nullptr, 1);
 }
 
+// The executor's backward-weight kernel through its own entry: per-block partial sums of
+//   gW[k][ci][co] = sum_r in[nbr_k(r)][ci] gout[r][co],  gb[co] = sum_r gout[r][co]
+// into slab[b * (27 cin + 1) cout + (k cin + ci) cout + co] (bias row last), b < LINR_WG_BLOCKS (512); the caller sums the
+// 512 partials in ascending order (the executor does so for all parameters at once in wgrad_reduce_k).
+extern "C" int64_t linr_spconv_wgrad_cmap_blocks(void) { return LINR_WG_BLOCKS; }
+
+extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
+                                      const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin,
+                                      int32_t cout, float* slab, void* stream) {
+    if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !gout || !nbr || !lo || !mask || !slab) return LINR_EINVAL;
+    if (!linr_aligned16(in)) return LINR_EALIGN;          // lo / mask / ld not 16-byte friendly: the kernel reads the nbr table
+    if (!((cin == 8 && (cout == 8 || cout == 4)) || (cin < 8 && cin >= 1 && cout == 8))) return LINR_EINVAL;
+    if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    const int64_t elems = (int64_t)(27 * cin + 1) * cout;
+    LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
+    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
+                                 lo, mask);
+}
+
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
 int linr_cconv_head_launch(const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                            const float* W, const float* bias, float* c_out, const float* w1, const float* b1,

@@ -455,6 +455,31 @@ def test_cmap_mfma_conv_bit_identical_to_gather_kernel(pkg, shell, cin, cout):
         assert torch.equal(ref_b, got_b)
 
 
+@pytest.mark.parametrize('cin,cout', [(8, 8), (8, 4), (3, 8)])
+def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
+    """linr_spconv_wgrad_cmap (the executor's backward-weight kernel) against autograd of the oracle convolution."""
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    g = torch.Generator().manual_seed(31 * cin + cout)
+    x = torch.randn(n, cin, generator=g)
+    go = torch.randn(n, cout, generator=g)
+    wo = (torch.randn(27, cin, cout, generator=g) * 0.2).requires_grad_()
+    bo = torch.zeros(1, cout, requires_grad=True)
+    onet.conv3(x, torch.from_numpy(sc['nbr']).long(), wo, bo).backward(go)
+    nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
+    lo, mask = ops.kmap_compress(nbr)
+    xb = torch.zeros((n + 1, 8), device=dev)
+    xb[1:, :cin] = x.to(dev)
+    gw, gb = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout)
+    _close(gw, wo.grad, 0, 1e-4 * float(wo.grad.abs().max()) + 1e-6, 'wgrad cmap')
+    _close(gb, bo.grad.reshape(-1), 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bias grad cmap')
+    slab1 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
+    slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
+    assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
+
+
 def test_full_size_frame_properties(pkg):
     """BASELINE config[1] size (784,314 points, 7 scales): size-independent properties instead of the slow oracle:
     determinism, staged == one-shot probabilities, train step lowers the bits, encode -> decode is lossless."""
