@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 EPOCHS = 10          # first_epoch / others_epoch of BASELINE config[1]
+PROF_EVERY = int(os.environ.get('LINR_BENCH_PROF_EVERY', 8))          # live kernel timing samples every 8th timed step
 HBM_PEAK_GBS = 8000.0
 
 
@@ -57,18 +58,22 @@ def _time_launches(go, iters):
     return e0.elapsed_time(e1) / 1e3 / iters
 
 
-def kernel_roofline(model, gop, iters=50):
+def kernel_roofline(model, gop, live, iters=10):
     """Dominant kernel = the top line of the rocprofv3 kernel statistics of this command (profiles/): the 8->8
-    backward-weight kernel spconv_wgrad_mfma_k<2,8> (24 passes over the rows per step, ~20 % of the step).  The second
-    line, the 8->8 convolution cconv_mfma_k<8,8,fwd> (the template behind forward, backward-data and the fused head /
-    Inception variants, ~40 % together), is reported next to it as `conv`.  Both are timed live with events on the
-    launch stream over `iters` launches on frame 0's full row space, through their own C-ABI entries
-    (linr_spconv_wgrad_cmap, linr_spconv_cmap).  Algorithmic bytes per row, both kernels:
-    4*(8+8) feature bytes + 108 neighbour-table bytes (they actually stream the 40 B/row compressed table)."""
+    backward-weight kernel spconv_wgrad_mfma_k<2,8> (24 row passes per step in 5 launches, ~25 % of the step).  The
+    second line, the 8->8 convolution cconv_mfma_k<8,8,fwd> (the template behind forward, backward-data and the fused
+    head / Inception variants, ~40 % together), is reported next to it as `conv`.
+    `avg_launch_us` is measured LIVE over the timed region: the library brackets every launch of the two kernels inside
+    the training steps with a HIP event pair on the launch stream (linr_prof_enable / linr_prof_read), so it is the
+    number rocprofv3's AverageNs of the same command must agree with.  One launch covers `passes_per_launch` row passes
+    (grouped launches).  Algorithmic bytes per row pass, both kernels: 4*(8+8) feature bytes + 108
+    neighbour-table bytes (they actually stream the 40 B/row compressed table).  `single_launch_us`: the same kernel
+    launched alone on frame 0 through its C-ABI entry (linr_spconv_wgrad_cmap / linr_spconv_cmap), for reference."""
     from linr_pcgc_amd import ops
     f = gop.frames[0]
     R = f.rows
     dev = f.device
+    mean_rows = sum(fr.rows for fr in gop.frames) / len(gop.frames)
     x = torch.zeros((R + 1, 8), device=dev)
     x[1:].normal_()
     g = torch.randn((R, 8), device=dev)
@@ -76,26 +81,35 @@ def kernel_roofline(model, gop, iters=50):
     w = torch.randn(27, 8, 8, device=dev) * 0.1
     b = torch.zeros(8, device=dev)
     slab = torch.empty((512, 27 * 64 + 8), device=dev)
-    alg_bytes = R * (4 * (8 + 8) + 108)
     traffic = {}
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')          # PMC-derived HBM bytes per launch (see profiles/README)
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')          # PMC-derived HBM bytes per row pass (see profiles/README)
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath))
         except Exception:
             traffic = {}
 
-    def entry(name, dur_s, key):
-        achieved = alg_bytes / dur_s / 1e9
+    def entry(name, key, live_rec, single_s):
+        tot_ms, launches, passes = live_rec
+        if launches > 0:
+            dur_s = tot_ms / 1e3 / launches
+            ppl = passes / launches
+        else:                                   # executor did not run this kernel (debug switches): fall back to the single launch
+            dur_s, ppl = single_s, 1.0
+        alg = ppl * mean_rows * (4 * (8 + 8) + 108)
+        achieved = alg / dur_s / 1e9
+        tr = traffic.get(key)
         return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic.get(key), 'kernel': name,
-                'rows_per_launch': R, 'alg_bytes_per_launch': alg_bytes, 'avg_launch_us': round(dur_s * 1e6, 2)}
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if tr is None else int(tr * ppl), 'kernel': name,
+                'launches_timed': int(launches), 'passes_per_launch': round(ppl, 3), 'rows_per_pass': round(mean_rows, 1),
+                'alg_bytes_per_launch': int(alg), 'avg_launch_us': round(dur_s * 1e6, 2),
+                'single_launch_us': round(single_s * 1e6, 2)}
 
     d_wg = _time_launches(lambda: ops.spconv_wgrad_cmap(x[1:], g, f.nbr, f.nbr_lo, f.nbr_mask, R, 8, 8, slab=slab,
                                                         reduce=False), iters)
     d_cv = _time_launches(lambda: ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out), iters)
-    roof = entry('spconv_wgrad_mfma_k<2,8,cmap>', d_wg, 'spconv_wgrad_mfma_8x8_bytes_per_launch')
-    roof['conv'] = entry('cconv_mfma_k<8,8,fwd,LOADW=8>', d_cv, 'cconv_mfma_8x8_fwd_bytes_per_launch')
+    roof = entry('spconv_wgrad_mfma_k<2,8,cmap>', 'spconv_wgrad_mfma_8x8_bytes_per_launch', live['wgrad'], d_wg)
+    roof['conv'] = entry('cconv_mfma_k<8,8,fwd,LOADW=8>', 'cconv_mfma_8x8_fwd_bytes_per_launch', live['conv'], d_cv)
     return roof
 
 
@@ -192,13 +206,22 @@ def main():
     opt = FlatAdam(model)
 
     log('warm-up done')
+    from linr_pcgc_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    _lib.check(L.linr_prof_enable(1), 'linr_prof_enable')     # event pairs around the two roofline kernels ...
+    L.linr_prof_enable(0)                                     # ... in every PROF_EVERY-th timed step (a pair costs ~10 us of stream time)
     barrier()
     t0 = time.time()
     acc = torch.zeros(1, dtype=torch.float64, device='cuda')
     epoch_loss = []
     for i in range(args.steps):
         j = i % len(gop)
+        if i % PROF_EVERY == 0:
+            L.linr_prof_enable(2)
         bits = train_step(model, opt, gop.frames[j], gop.point_nums[j])
+        if i % PROF_EVERY == 0:
+            L.linr_prof_enable(0)
         acc += bits / gop.point_nums[j]
         if j == len(gop) - 1:
             opt.clamp_lr(4e-4)
@@ -206,6 +229,11 @@ def main():
             acc.zero_()
     barrier()
     elapsed = time.time() - t0
+    live = {}
+    for kind, name in ((0, 'wgrad'), (1, 'conv')):
+        tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib().linr_prof_read(kind, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)), 'linr_prof_read')
+        live[name] = (tot.value, nl.value, npass.value)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -255,7 +283,7 @@ def main():
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
-        out['roofline'] = kernel_roofline(model, gop)
+        out['roofline'] = kernel_roofline(model, gop, live)
         log('roofline: %s' % out['roofline'])
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_threads())

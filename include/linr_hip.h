@@ -107,6 +107,16 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
                            const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin, int32_t cout,
                            float* slab, void* stream);
 
+/* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
+ * linr_net_forward / _backward / _train_step (kind 0: spconv_wgrad_mfma_k<2,8> on the compressed map; kind 1:
+ * cconv_mfma_k<8,8,forward, plain epilogue>) is bracketed by a HIP event pair on the stream it is launched on.
+ * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
+ * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,
+ * 0 = stop (records are kept).  An event pair costs a few microseconds of stream time, so bench.py samples every 8th
+ * step.  Not thread-safe; 4096 launches in total. */
+LINR_API int linr_prof_enable(int32_t mode);
+LINR_API int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes);
+
 /* ---- pointwise layers ---------------------------------------------------------------------------------------
  * Replaces ME.MinkowskiConvolution(kernel_size=1) (models/resnet.py:31-37,45-51) and nn.Linear inside
  * PointwiseMLP (models/module_utils.py:42-81).  Element (ci,co) of the weight is W[ci*ws_ci + co*ws_co]:

@@ -30,6 +30,8 @@ _PROTOS = {
     'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_spconv_wgrad_cmap_blocks': (ctypes.c_int64, []),
     'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    'linr_prof_enable': (ctypes.c_int, [c_i32]),
+    'linr_prof_read': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr]),
     'linr_kmap_offset_feat': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'linr_kmap_compress': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'linr_spconv_fwd': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32,

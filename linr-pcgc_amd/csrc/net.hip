@@ -9,6 +9,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <vector>
 
 #define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
 #define MAX_SCALES 16
@@ -344,11 +345,75 @@ static int stream_order(hipStream_t from, hipStream_t to) {
     return linr_hip_rc(hipStreamWaitEvent(to, ev, 0));
 }
 
+// ---- live kernel timing for bench.py's roofline (include/linr_hip.h: linr_prof_*) --------------------------------------
+// While enabled, every launch of the two roofline kernels inside the executor (kind 0: spconv_wgrad_mfma_k<2,8>,
+// kind 1: cconv_mfma_k<8,8,fwd,plain epilogue>) is bracketed by an event pair on its own stream; `passes` counts the
+// row passes (groups) of a launch.  Measurement aid only: not thread-safe, nothing is recorded when disabled.
+#define LINR_PROF_MAX 2048
+struct ProfRec { hipEvent_t e0, e1; int passes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof[2];          // used records
+static std::vector<ProfRec> g_prof_free;        // pre-created event pairs (creating events in the hot path costs ~20 us each)
+
+struct ProfScope {
+    hipStream_t s; int kind; bool live;
+    ProfRec r;
+    ProfScope(hipStream_t s_, int kind_, int passes, bool want = true) : s(s_), kind(kind_), live(false) {
+        if (!want || !g_prof_on || g_prof_free.empty()) return;
+        r = g_prof_free.back();
+        g_prof_free.pop_back();
+        r.passes = passes;
+        live = hipEventRecord(r.e0, s) == hipSuccess;
+        if (!live) g_prof_free.push_back(r);
+    }
+    ~ProfScope() {
+        if (!live) return;
+        (void)hipEventRecord(r.e1, s);
+        g_prof[kind].push_back(r);
+    }
+};
+
+extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kept), 1: clear + start, 2: resume
+    g_prof_on = false;
+    if (mode == 0) return 0;
+    if (mode == 1)
+        for (int k = 0; k < 2; ++k) {
+            for (auto& r : g_prof[k]) g_prof_free.push_back(r);
+            g_prof[k].clear();
+        }
+    while (g_prof_free.size() + g_prof[0].size() + g_prof[1].size() < 2 * LINR_PROF_MAX) {
+        ProfRec r;
+        r.passes = 0;
+        if (hipEventCreate(&r.e0) != hipSuccess) break;
+        if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); break; }
+        g_prof_free.push_back(r);
+    }
+    g_prof_on = true;
+    return 0;
+}
+
+extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes) {
+    if (kind < 0 || kind > 1 || !total_ms || !launches || !passes) return LINR_EINVAL;
+    double t = 0.0;
+    int64_t np = 0;
+    for (auto& r : g_prof[kind]) {
+        TRY(linr_hip_rc(hipEventSynchronize(r.e1)));
+        float ms = 0.0f;
+        TRY(linr_hip_rc(hipEventElapsedTime(&ms, r.e0, r.e1)));
+        t += ms;
+        np += r.passes;
+    }
+    *total_ms = t; *launches = (int64_t)g_prof[kind].size(); *passes = np;
+    return 0;
+}
+
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
-    if (c.f->nbr_lo && c.f->nbr_mask)
+    if (c.f->nbr_lo && c.f->nbr_mask) {
+        ProfScope ps(c.s, 1, 1, !bwd && cin == 8 && cout == 8);
         return linr_cconv_launch(bwd, in, in_ld, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld,
                                  act, act_ld, out, out_ld, flags, c.s);
+    }
     return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
                              flags | LINR_PAD_ROW, c.s);
 }
@@ -364,6 +429,7 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
     static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
     TRY(stream_order(c.s, c.ws));
+    ProfScope ps(c.ws, 0, 1, use_mfma && cout == 8 && in_ld >= 8 && wg_cmap() && c.f->nbr_lo);
     if (use_mfma)
         return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
                                      wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
@@ -552,6 +618,7 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
     {   // O[b] = conv3(I; b) + x_glob
         Grp gp = Grp();
         goffs(gp.in, pI, 7); goffs(gp.w, p_bw, 7); goffs(gp.b, p_bb, 7); goffs(gp.out, pO, 7);
+        ProfScope ps(c.s, 1, 7);
         TRY(linr_cconv_launch(false, pI[0], 8, lo, mk, c.nbr_ld, c.R, p_bw[0], p_bb[0], 8, 8, a.O[0], 8, nullptr, 0, a.O[1], 8, 0,
                               c.s, &gp, 7));
     }
@@ -691,6 +758,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
+            ProfScope ps(c.ws, 0, 8, wg_cmap());
             TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? lo : nullptr, mk));
         }
         {   // ... and gO[k] = bwd(gC[k])
@@ -724,6 +792,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pI, 7); goffs(gp.res, p_gO, 7); goffs_i(gp.w, o_bw, 7); goffs_i(gp.b, o_bb, 7);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
+        ProfScope ps(c.ws, 0, 7, wg_cmap());
         TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
@@ -774,6 +843,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         for (int g = 0; g < 7; ++g) gp.e2[g] = g + 1;
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
+        ProfScope ps(c.ws, 0, 7, wg_cmap());
         TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     return 0;
