@@ -101,7 +101,9 @@ class octree_level(nn.Module):
     def forward(self, leaf, qsc=None):
         parent = unique_sorted(torch.div(leaf.to(torch.int64), 2, rounding_mode='floor'))
         off = self.offsets.to(leaf.device)
-        occ = torch.stack([contains(leaf, parent.to(torch.int64) * 2 + off[i]) for i in range(8)], dim=1)
+        # all 8 child lookups of every parent as ONE batched search over the sorted leaf keys
+        q = (parent.to(torch.int64)[:, None, :] * 2 + off[None, :, :]).reshape(-1, 3)
+        occ = contains(leaf, q).reshape(-1, 8)
         return parent, occ
 
     def upper_layer(self, parent_C, occupancy):
@@ -117,8 +119,8 @@ octree_level_obj = octree_level()
 class qscTensor:
     """module_utils.py:155-224 (the members the drivers use): sorted unique coords + 7-neighbour occupancy."""
 
-    def __init__(self, coord, feat=None):
-        self.coord = unique_sorted(coord)
+    def __init__(self, coord, feat=None, presorted=False):
+        self.coord = coord if presorted else unique_sorted(coord)
         self.feat = feat
         self.parent_C = self.occupancy = self.offset_tensor = None
 
@@ -140,14 +142,17 @@ class qscTensor:
     def set_offset_tensor(self, offsets=OFFSETS_INI):
         offs = torch.as_tensor(offsets, dtype=torch.int64, device=self.coord.device)
         c = self.coord.to(torch.int64)
-        self.offset_tensor = torch.stack([contains(self.coord, c + o) for o in offs], dim=1)
+        q = (c[:, None, :] + offs[None, :, :]).reshape(-1, 3)
+        self.offset_tensor = contains(self.coord, q).reshape(-1, offs.shape[0])
 
     def get_offset_tensor(self):
         return self.offset_tensor
 
 
-def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu'):
-    """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3]."""
+def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_offsets=True):
+    """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3].
+    with_offsets=False leaves 'offset_tensor' None: engine.Frame then reads the 7-neighbour occupancy off the kernel map
+    it builds anyway (linr_kmap_offset_feat) and overfit.Gop stores those rows back into the dicts."""
     pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
     cmin = pts.min(dim=0).values
     cur = qscTensor(pts - cmin)
@@ -157,8 +162,9 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu'):
     for s in range(limit):
         cur.set_oct_level()
         parent, occ = cur.get_oct_level()
-        low = qscTensor(parent)
-        low.set_offset_tensor()
+        low = qscTensor(parent, presorted=True)
+        if with_offsets:
+            low.set_offset_tensor()
         info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),
                      'ground_truth': cur.get_coord(), 'scale_idx': s, 'occ': occ,
                      'occ_lst': [occ[:, i:i + 1] for i in range(8)]})

@@ -27,7 +27,7 @@ class Gop:
         self.frames, self.point_nums, self.coord_mins, self.low_xyz, self.infos = [], [], [], [], []
         self.scale_num = scale_num
         for pts in clouds:
-            fr = prepare_frame(pts, self.scale_num, min_point_num, device=device)
+            fr = prepare_frame(pts, self.scale_num, min_point_num, device=device, with_offsets=False)
             if self.scale_num is None:
                 self.scale_num = fr['scale_num']             # frozen from frame 0 (main.py:77-78)
             self.infos.append(fr)
@@ -36,6 +36,9 @@ class Gop:
         from . import engine
         for fr in self.infos:
             f = engine.Frame(fr['all_input_info'], self.model_scale_num, device, validate=True, with_arena=False)
+            for i, sinfo in enumerate(fr['all_input_info']):      # the reference's per-scale dicts carry 'offset_tensor'
+                sinfo['offset_tensor'] = f.offset_feat[f.scale_slice(i)]
+                sinfo['xyzqsc_t'].offset_tensor = sinfo['offset_tensor']
             self.frames.append(f)
             self.point_nums.append(fr['point_num'])
             self.coord_mins.append(fr['coord_data_min'])
