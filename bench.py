@@ -140,7 +140,7 @@ def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
     return {'value': round(EPOCHS * t_step + t_fwd, 3), 'unit': 's/frame', 'cores': torch.get_num_threads(),
             'kind': 'port',
             'sample': '1 overfit step (%.2f s) + 1 forward (%.2f s) of frame 0 (%d rows), x%d epochs; AC not included'
-                      % (t_step, t_fwd, rows, EPOCHS), 'bits_frame0_init': float(bits)}
+                      % (t_step, t_fwd, rows, EPOCHS), 'bits_frame0_init': float(bits.detach())}
 
 
 def log(msg):
@@ -165,12 +165,18 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if os.environ.get('LINR_BENCH_SINGLE_DEVICE'):          # rehearsal of the N > 1 control flow on a 1-GPU box
+        local = 0
     assert torch.cuda.is_available(), 'bench.py needs an MI355X: the coding network has no CPU path'
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL; gloo only for the 1-GPU rehearsal
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     from linr_pcgc_amd import codec, overfit, synthetic
     from linr_pcgc_amd.model_core import FlatAdam
 
