@@ -81,18 +81,40 @@ def decode_one_frame(model, frame_enc_bytes, xyz_low):
     return {'dec_coord': lowx}
 
 
-def decode_gop(model_ori, enc, device='cuda', frames=None):
-    """decoder.decode_one_gop: rebuild the model from model.bin, then every frame from its streams alone."""
+def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1):
+    """decoder.decode_one_gop: rebuild the model from model.bin, then every frame from its streams alone.
+    Frames are independent once the model is known; with workers > 1 they are decoded by a host thread pool, each
+    thread on its own HIP stream (a frame's own chain - 56 stage forwards with a serial range decode in between - cannot
+    be parallelised, but the range decoding of one frame overlaps the stage forwards and copies of the others; the
+    C calls release the GIL)."""
     side = dict(enc['side_info'])
     side['final_bytes'] = enc['model_bin']
     model, _ = Model_Estimate().decompress_model(model_ori, side)
     lows, mins = dec_all_frame_low_xyz(enc['low_enc_bytes'])
-    out = []
-    for i in (range(len(enc['frames'])) if frames is None else frames):
+    todo = list(range(len(enc['frames'])) if frames is None else frames)
+
+    def one(i):
         xyz_low = torch.tensor(lows[i].astype(np.int32), device=device)
         dec = decode_one_frame(model, list(enc['frames'][i]), xyz_low)['dec_coord']
-        out.append(dec + torch.tensor(mins[i], device=device, dtype=torch.int32))
-    return out
+        return dec + torch.tensor(mins[i], device=device, dtype=torch.int32)
+
+    if workers <= 1 or len(todo) <= 1:
+        return [one(i) for i in todo]
+    from concurrent.futures import ThreadPoolExecutor
+    main_stream = torch.cuda.current_stream()
+    dev_index = torch.cuda.current_device()
+
+    def job(i):
+        torch.cuda.set_device(dev_index)
+        st = torch.cuda.Stream()
+        st.wait_stream(main_stream)                 # the decompressed parameters were written on the caller's stream
+        with torch.cuda.stream(st):
+            out = one(i)
+        st.synchronize()
+        return out
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return list(pool.map(job, todo))
 
 
 def write_gop(enc, result_dir):

@@ -196,11 +196,13 @@ class LINR_PCGC_Model(nn.Module):
 
     def _host_buffers(self, rows):
         """Pinned staging buffers of the staged decoder (probabilities down, decoded symbols up), grown on demand."""
-        buf = getattr(self, '_dec_host', None)
+        import threading
+        tls = self.__dict__.setdefault('_dec_tls', threading.local())          # one pair per decoding thread
+        buf = getattr(tls, 'buf', None)
         if buf is None or buf[0].numel() < rows:
             cap = max(rows, 1 << 16)
             buf = (torch.empty(cap, dtype=torch.float32, pin_memory=True), torch.empty(cap, dtype=torch.uint8, pin_memory=True))
-            self._dec_host = buf
+            tls.buf = buf
         return buf
 
     @torch.no_grad()

@@ -61,7 +61,7 @@ def main():
         codec.write_gop(enc, res_dir)
         ok = None
         if args.decode:
-            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), codec.read_gop(res_dir), 'cuda')
+            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), codec.read_gop(res_dir), 'cuda', workers=4)
             ok = all(torch.equal(d, torch.as_tensor(i['ori']).cuda() + torch.tensor(m, device='cuda', dtype=torch.int32))
                      for d, i, m in zip(dec, gop.infos, gop.coord_mins))
         torch.cuda.synchronize()

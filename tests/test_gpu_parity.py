@@ -611,6 +611,21 @@ def test_tiny_and_ragged_frames(pkg, n):
     assert bool(torch.isfinite(grads).all())
 
 
+def test_threaded_gop_decode_equals_serial(pkg):
+    """codec.decode_gop(workers=3): frames decoded concurrently on their own streams give the serial result."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    clouds = [synthetic.sphere_shell(7, 40 + t) for t in range(5)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    serial = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda')
+    threaded = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', workers=3)
+    for i, (a, b) in enumerate(zip(serial, threaded)):
+        assert torch.equal(a, b), i
+        ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
+        assert torch.equal(a, ref)
+
+
 def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
     """main.overfit_enc_dec in miniature: GOP 0 from scratch -> checkpoint -> GOP 1 warm start (model + Adam state) ->
     encode -> reference directory layout on disk -> decode from the files alone -> lossless; model codec round trip."""

@@ -58,3 +58,13 @@ for s_idx in range(len(fb) - 1, -1, -1):
 for k, v in sorted(T.items(), key=lambda kv: -kv[1]):
     print('%-36s %.1f ms' % (k, v * 1e3))
 print('sum %.1f ms' % (sum(T.values()) * 1e3))
+
+# GOP-level decode throughput: 8 frames, serial vs threaded
+clouds = [synthetic.sequence_frame('loot10', t) for t in range(8)]
+gop8 = overfit.Gop(None, clouds, None, 64, 'cuda')
+enc8 = codec.encode_gop(model, overfit.gen_model(gop8.scale_num, 'cuda'), gop8, 8)
+for w in (1, 2, 4, 8):
+    torch.cuda.synchronize(); t0 = time.time()
+    out = codec.decode_gop(overfit.gen_model(gop8.scale_num, 'cuda'), enc8, 'cuda', workers=w)
+    torch.cuda.synchronize()
+    print('decode_gop 8 frames, workers=%d: %.1f ms/frame' % (w, (time.time() - t0) * 1e3 / 8))
