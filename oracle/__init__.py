@@ -17,7 +17,10 @@ Pinning status (see DESIGN.md "Oracle"):
   * weight quantiser: pinned by loot/gop_32_62/70/side_info.json (mu, b, min, max).
   * range coder + Laplace-CDF quirk: pinned by the 35,320-byte model stream implied by
     loot/gop_32_62/70/result.json.
-  * network arithmetic (MinkowskiEngine semantics): PARITY UNPINNED - MinkowskiEngine 0.5.4 is not in
+  * network arithmetic (MinkowskiEngine semantics): PARITY UNPINNED at bit level - MinkowskiEngine 0.5.4 is not in
     /root/reference and not installable here; the restatement follows the reference call sites and
-    MinkowskiEngine's documented semantics.
+    MinkowskiEngine's documented semantics.  Pinned behaviourally by the checkpoint the reference ships
+    (loot/gop_32_62/model.pth -> tests/golden/loot_model_kat.npz): the reference-trained weights predict unseen
+    surfaces (0.96 bits/point) only under the assumed tap order / direction / wiring; each of the 11 other tap
+    conventions gives 6.6-10.8 (tests/test_oracle_golden.py::test_reference_checkpoint_pins_network_semantics).
 """

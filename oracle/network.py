@@ -13,7 +13,8 @@ Reference lines restated:
   InceptionResNet             models/resnet.py:7-60 ; ResNetBlock :146-162 (block_layers == 1: no extra skip)
   PointwiseMLP                models/module_utils.py:42-81
   merge_two_frames (=concat)  models/function_utils.py:58-69
-MinkowskiEngine semantics (third-party, not in tree): SURVEY.md Appendix B.  PARITY UNPINNED for this file.
+MinkowskiEngine semantics (third-party, not in tree): SURVEY.md Appendix B.  PARITY UNPINNED at bit level for this file;
+the tap order / direction / wiring are confirmed by the reference-trained checkpoint (oracle/__init__.py).
 """
 import math
 import torch

@@ -259,6 +259,29 @@ def test_net_forward_matches_oracle(pkg, shell):
     assert torch.equal(probs, probs2) and torch.equal(bits, bits2), 'forward must be bit-reproducible'
 
 
+def test_net_forward_with_reference_trained_weights(pkg, shell, golden_dir):
+    """Parity with the checkpoint the reference ships (loot/gop_32_62/model.pth): trained weights have a far wider
+    dynamic range than the seeded initialisation.  Bits against the oracle, and the reference model must actually predict
+    (the behavioural pin of tests/test_oracle_golden.py, through the HIP path)."""
+    from test_oracle_golden import _reference_state_dict
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    sd = _reference_state_dict(golden_dir)
+    model = LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
+                             'instage': 1})
+    model.load_state_dict(sd)
+    model = model.cuda()
+    frame = model.make_frame(shell['scales'])
+    probs, bits = model.frame_probs(frame)
+    with torch.no_grad():
+        ref = float(onet.frame_bits(sd, onet.to_torch_scales(shell['scales'])))
+    assert abs(float(bits) - ref) <= 1e-5 * ref, (float(bits), ref)
+    assert float(bits) / shell['point_num'] < 1.2
+    mirrored = _reference_state_dict(golden_dir, (0, 1, 2), True)
+    model.load_state_dict(mirrored)
+    _, bits_m = model.frame_probs(frame)
+    assert float(bits_m) > 4.0 * float(bits)
+
+
 def test_net_backward_matches_autograd(pkg, shell):
     from linr_pcgc_amd import engine
     model, sd = _model_and_oracle(pkg, 5)
