@@ -38,27 +38,39 @@ def dec_all_frame_low_xyz(low_byte):
     return [np.frombuffer(c, dtype=np.uint8).reshape(-1, 3) for c in chunks], mins
 
 
-def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=8):
+def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None):
     """encoder.encode_one_gop: quantise the model, then per frame ONE forward over all scales and 8 x scales
     independent arithmetic-coded streams (thread pool)."""
+    if n_threads is None:
+        n_threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 8))
     comp = Model_Estimate().compress_model(model, bitdepth, True, model_ori)
     coded_model = comp['new_model']                      # the de-quantised model is what codes the geometry
     side_info = {'mu': comp['mu'], 'b': comp['b'], 'min_param': comp['min_param'], 'max_param': comp['max_param'],
                  'enc_mode': comp['enc_mode'], 'bitdepth': bitdepth}
-    frames_bytes, bits_est = [], 0.0
-    for f in gop.frames:
-        probs, bits = coded_model.frame_probs(f)
-        bits_est += float(bits)
-        p_host = probs.cpu().numpy()
-        occ_host = f.occ.t().contiguous().cpu().numpy().astype(np.uint8)
+    # Two-stage pipeline: the GPU forward + D2H of frame i+1 runs while a host thread range-codes frame i (the coder's C
+    # call releases the GIL and fans the 8 x scales independent streams out over n_threads).
+    from concurrent.futures import ThreadPoolExecutor
+
+    def code(p_host, occ_host, row_off, n_scales):
         ps, ss = [], []
-        for i in range(f.n_scales):
-            sl = f.scale_slice(i)
+        for i in range(n_scales):
+            a, b = int(row_off[i]), int(row_off[i + 1])
             for k in range(8):
-                ps.append(p_host[k, sl])
-                ss.append(occ_host[k, sl])
+                ps.append(p_host[k, a:b])
+                ss.append(occ_host[k, a:b])
         streams = encode_streams(ps, ss, n_threads)
-        frames_bytes.append([pack_bitstream(streams[8 * i:8 * i + 8]) for i in range(f.n_scales)])
+        return [pack_bitstream(streams[8 * i:8 * i + 8]) for i in range(n_scales)]
+
+    jobs, bits_dev = [], []
+    with ThreadPoolExecutor(max_workers=1) as coder:
+        for f in gop.frames:
+            probs, bits = coded_model.frame_probs(f)
+            bits_dev.append(bits)
+            p_host = probs.cpu().numpy()                                        # synchronises this frame only
+            occ_host = f.occ.t().to(torch.uint8).contiguous().cpu().numpy()      # cast on the GPU: 1 byte per symbol over PCIe
+            jobs.append(coder.submit(code, p_host, occ_host, f.row_off, f.n_scales))
+        frames_bytes = [j.result() for j in jobs]
+    bits_est = float(torch.stack(bits_dev).sum())
     low = enc_all_frame_low_xyz(gop)
     points = sum(gop.point_nums)
     occ_bits = 8 * sum(len(b) for fb in frames_bytes for b in fb)
