@@ -32,6 +32,40 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.linr_abi_version() == _lib.ABI_VERSION
 
 
+def test_c_abi_argument_checks(lib):
+    """Every entry validates its arguments before it touches the device: bad sizes / NULLs / short or misaligned workspaces
+    come back as LINR_EINVAL (-1) / LINR_ENOSPC (-2) / LINR_EALIGN (-3), with nothing launched (so this runs without a GPU)."""
+    import ctypes
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    # kernel map
+    assert lib.linr_kmap_build(p16, -1, p16, 8, 0, p16, 1024, None) == -1                  # n < 0
+    assert lib.linr_kmap_build(p16, 8, p16, 4, 0, p16, 1024, None) == -1                   # ld < n
+    assert lib.linr_kmap_build(p16, 8, p16, 8, 4, p16, 1024, None) == -1                   # row_base + n > ld
+    assert lib.linr_kmap_build(None, 8, p16, 8, 0, p16, 1024, None) == -1                  # NULL coords
+    assert lib.linr_kmap_build(p16, 8, p16, 8, 0, p16, 8, None) == -2                      # workspace too small
+    assert lib.linr_kmap_build(p16, 8, p16, 8, 0, p16 + 4, 1024, None) == -3               # workspace not 8-byte aligned
+    assert lib.linr_kmap_build(p16, 0, p16, 0, 0, None, 0, None) == 0                      # empty input is fine
+    assert lib.linr_kmap_offset_feat(p16, 4, 0, 8, p16, None) == -1
+    # convolutions
+    assert lib.linr_spconv_fwd(p16, 4, p16, 16, 16, p16, p16, 8, 8, None, 0, p16, 8, 0, None) == -1      # in_ld < cin
+    assert lib.linr_spconv_cmap(0, p16, 5, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -1   # ld 5
+    assert lib.linr_spconv_cmap(0, p16 + 4, 8, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -3
+    assert lib.linr_spconv_wgrad_cmap(p16, 8, p16, 8, p16, p16, p16, 16, 16, 8, 5, p16, None) == -1                    # cout 5
+    assert lib.linr_spconv_bwd_weight(p16, 8, p16, 8, p16, 16, 16, 8, 8, p16, p16, 0, p16, 16, None) == -2             # ws short
+    # whole network: NULL frame / parameters, stage range
+    assert lib.linr_net_forward(None, p16, p16, 4096, 0, 8, None, None, None) == -1
+    assert lib.linr_net_train_step(None, p16, p16, 4096, 1.0, None, None, 0.01, 1.0, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
+    assert lib.linr_param_count(0) < 0 or lib.linr_param_count(0) == 0
+    assert lib.linr_param_count(7) == 54712
+    # range coder: capacity / NULL checks
+    assert lib.linr_ac_encode_binary(None, None, 4, p16, 64) == -1
+    assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
+    tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.linr_prof_read(2, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
+
+
 def test_param_count_matches_reference_checkpoint(lib, golden_dir):
     g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
     assert lib.linr_param_count(7) == len(g['flat']) == 54712

@@ -87,6 +87,13 @@ def test_kmap_rejects_unsorted(pkg):
         ops.kmap_build(c)
     with pytest.raises(ValueError):
         ops.kmap_build(torch.tensor([[0, 0, 0], [0, 0, 0]], dtype=torch.int32, device=_dev()))
+    with pytest.raises(ValueError):                                      # coordinate range is [0, 2^20)
+        ops.kmap_build(torch.tensor([[0, 0, 0], [0, 0, 1 << 20]], dtype=torch.int32, device=_dev()))
+    with pytest.raises(ValueError):
+        ops.kmap_build(torch.tensor([[-1, 0, 0], [0, 0, 0]], dtype=torch.int32, device=_dev()))
+    top = (1 << 20) - 1                                                  # the largest legal coordinate still maps
+    nbr = ops.kmap_build(torch.tensor([[top, top, top - 1], [top, top, top]], dtype=torch.int32, device=_dev()))
+    assert nbr[13].tolist() == [0, 1] and nbr[22, 0].item() == 1 and nbr[4, 1].item() == 0
 
 
 # ---- sparse convolution -------------------------------------------------------------------------------------------------
