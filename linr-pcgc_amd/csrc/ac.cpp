@@ -120,31 +120,131 @@ inline uint32_t binary_c1(float p) {
 
 }  // namespace
 
+// ---- binary fast path ---------------------------------------------------------------------------------------------------
+// Same coder, specialised: with cdf = [0, c1, 2^16] the interval update is  t = (span * c1) >> 16;  symbol 1: low += t
+// (high = low - 1 + span is unchanged), symbol 0: high = low + t - 1.  Renormalisation shifts all leading bits on which
+// low and high agree at once (torchac emits them one by one; the first one is followed by the pending complement bits),
+// c1 is computed for a block of symbols at a time (vectorisable, off the serial dependency chain), and the symbol
+// selects are branch-free (the symbol is the one thing the branch predictor cannot know).
+namespace {
+
+struct BitSinkFast {
+    uint8_t* out; int64_t cap; int64_t len = 0; uint64_t acc = 0; int nacc = 0;       // nacc < 8 between calls
+    BitSinkFast(uint8_t* o, int64_t c) : out(o), cap(c) {}
+    inline void put_bits(uint32_t v, int n) {             // n in 0..32, v < 2^n
+        acc = (acc << n) | v;
+        nacc += n;
+        while (nacc >= 8) {
+            nacc -= 8;
+            if (len < cap) out[len] = (uint8_t)(acc >> nacc);
+            ++len;
+        }
+    }
+    inline void put_run(uint32_t bit, uint64_t count) {
+        const uint32_t word = bit ? 0xFFFFFFFFu : 0u;
+        while (count >= 32) { put_bits(word, 32); count -= 32; }
+        if (count) put_bits(word >> (32 - (int)count), (int)count);
+    }
+    inline void finish() { if (nacc) put_bits(0, 8 - nacc); }
+};
+
+constexpr int AC_CHUNK = 256;
+
+inline void c1_block(const float* p, int n, uint32_t* c1) {
+    for (int i = 0; i < n; ++i) c1[i] = binary_c1(p[i]);
+}
+
+}  // namespace
+
 extern "C" int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym_h, int64_t n, uint8_t* out_h, int64_t cap) {
     if (n < 0 || cap < 0 || (n > 0 && (!prob_h || !sym_h)) || (cap > 0 && !out_h)) return LINR_EINVAL;
-    RangeEncoder enc(out_h, cap);
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t c1 = binary_c1(prob_h[i]);
-        if (sym_h[i]) enc.encode(c1, 0x10000u); else enc.encode(0u, c1);
+    BitSinkFast sink(out_h, cap);
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint64_t pending = 0;
+    uint32_t c1[AC_CHUNK];
+    for (int64_t base = 0; base < n; base += AC_CHUNK) {
+        const int m = (int)(n - base < AC_CHUNK ? n - base : AC_CHUNK);
+        c1_block(prob_h + base, m, c1);
+        for (int i = 0; i < m; ++i) {
+            const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+            const uint32_t t = (uint32_t)((span * c1[i]) >> 16);
+            const uint32_t one = sym_h[base + i] ? 0xFFFFFFFFu : 0u;
+            const uint32_t lt = low + t;
+            high = (high & one) | ((lt - 1u) & ~one);
+            low = (lt & one) | (low & ~one);
+            for (;;) {
+                const uint32_t diff = low ^ high;
+                if (diff < 0x80000000u) {
+                    int k = diff ? __builtin_clz(diff) : 31;            // leading bits shared by low and high (>= 1)
+                    if (k > 31) k = 31;
+                    const uint32_t first = low >> 31;
+                    if (pending) {
+                        sink.put_bits(first, 1);
+                        sink.put_run(first ^ 1u, pending);
+                        pending = 0;
+                        if (k > 1) sink.put_bits((low << 1) >> (33 - k), k - 1);
+                    } else {
+                        sink.put_bits(low >> (32 - k), k);
+                    }
+                    low <<= k;
+                    high = (high << k) | ((1u << k) - 1u);
+                } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                    ++pending;
+                    low = (low << 1) & 0x7FFFFFFFu;
+                    high = (high << 1) | 0x80000001u;
+                } else {
+                    break;
+                }
+            }
+        }
     }
-    const int64_t len = enc.finish();
-    return len <= cap ? len : (int64_t)LINR_ENOSPC;
+    ++pending;
+    const uint32_t last = low < 0x40000000u ? 0u : 1u;
+    sink.put_bits(last, 1);
+    sink.put_run(last ^ 1u, pending);
+    sink.finish();
+    return sink.len <= cap ? sink.len : (int64_t)LINR_ENOSPC;
 }
 
 extern "C" int linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h) {
     if (n < 0 || in_len < 0 || (n > 0 && (!prob_h || !sym_h)) || (in_len > 0 && !in_h)) return LINR_EINVAL;
-    RangeDecoder dec(in_h, in_len);
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t c1 = binary_c1(prob_h[i]);
-        // torchac's binary search over [0, c1, *] returns symbol 1 iff target >= c1, i.e. iff
-        //   ((value - low + 1) * 2^16 - 1) / span >= c1  <=>  (value - low + 1) * 2^16 > c1 * span
-        //   <=>  value - low + 1 > floor(c1 * span / 2^16)  <=>  value - low >= (c1 * span) >> 16
-        // (integers on the left): the division-free form of the same decision
-        const uint64_t span = (uint64_t)dec.high - (uint64_t)dec.low + 1;
-        const uint32_t s = ((uint64_t)dec.value - (uint64_t)dec.low >= ((span * c1) >> 16)) ? 1u : 0u;
-        sym_h[i] = (uint8_t)s;
-        if (i == n - 1) break;
-        if (s) dec.consume(c1, 0x10000u); else dec.consume(0u, c1);
+    BitSource src(in_h, in_len);
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = src.bits(32);
+    uint32_t c1[AC_CHUNK];
+    for (int64_t base = 0; base < n; base += AC_CHUNK) {
+        const int m = (int)(n - base < AC_CHUNK ? n - base : AC_CHUNK);
+        c1_block(prob_h + base, m, c1);
+        for (int i = 0; i < m; ++i) {
+            // torchac's binary search over [0, c1, *] returns symbol 1 iff target >= c1, i.e. iff
+            //   ((value - low + 1) * 2^16 - 1) / span >= c1  <=>  (value - low + 1) * 2^16 > c1 * span
+            //   <=>  value - low + 1 > floor(c1 * span / 2^16)  <=>  value - low >= (c1 * span) >> 16 = t
+            const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
+            const uint32_t t = (uint32_t)((span * c1[i]) >> 16);
+            const uint32_t s = (value - low >= t) ? 1u : 0u;
+            sym_h[base + i] = (uint8_t)s;
+            if (base + i == n - 1) break;                   // torchac does not renormalise after the last symbol
+            const uint32_t one = 0u - s;
+            const uint32_t lt = low + t;
+            high = (high & one) | ((lt - 1u) & ~one);
+            low = (lt & one) | (low & ~one);
+            for (;;) {
+                const uint32_t diff = low ^ high;
+                if (diff < 0x80000000u) {
+                    int k = diff ? __builtin_clz(diff) : 31;
+                    if (k > 31) k = 31;
+                    low <<= k;
+                    high = (high << k) | ((1u << k) - 1u);
+                    value = (value << k) | src.bits(k);
+                } else if (low >= 0x40000000u && high < 0xC0000000u) {
+                    low = (low << 1) & 0x7FFFFFFFu;
+                    high = (high << 1) | 0x80000001u;
+                    value -= 0x40000000u;
+                    value = (value << 1) | src.bits(1);
+                } else {
+                    break;
+                }
+            }
+        }
     }
     return 0;
 }
