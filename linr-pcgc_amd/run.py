@@ -38,11 +38,17 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if os.environ.get('LINR_BENCH_SINGLE_DEVICE'):          # rehearsal of the multi-rank flow on a 1-GPU box (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     groups = gop_parallel.split_gops(args.frames, args.gop)
 
     def make_opt(model):
