@@ -261,12 +261,20 @@ def main():
         codec_s = float(t)
     codec_s_per_frame = codec_s / len(gop)
     log('encode leg: %.3f s/frame, bpp %.4f' % (codec_s_per_frame, enc['bpp']['bpp_all']))
+    # decode check (outside the metric): frames 0..3 from the streams alone, 4 frames in flight; the first call also pays
+    # for the pinned staging buffers, so the timing is taken on a second pass
+    nd = min(4, len(gop))
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
+    lossless = True
+    for i in range(nd):
+        ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
+        lossless = lossless and bool(torch.equal(dec[i], ref))
+    torch.cuda.synchronize()
     t0 = time.time()
-    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=[0])
-    decode_s = time.time() - t0
-    ref0 = torch.as_tensor(gop.infos[0]['ori']).cuda() + torch.tensor(gop.coord_mins[0], device='cuda', dtype=torch.int32)
-    lossless = bool(torch.equal(dec[0], ref0))
-    log('decode frame 0: %.2f s, lossless=%s' % (decode_s, lossless))
+    codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
+    torch.cuda.synchronize()
+    decode_s = (time.time() - t0) / nd
+    log('decode frames 0..%d: %.3f s/frame, lossless=%s' % (nd - 1, decode_s, lossless))
 
     overfit_s_per_frame = EPOCHS * ms_per_step / 1e3
     value = (overfit_s_per_frame + codec_s_per_frame) / world
@@ -283,9 +291,9 @@ def main():
                           'frames_per_gpu': len(gop), 'epochs': EPOCHS, 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
                'bits_per_point': round(enc['bpp']['bpp_all'], 5),
                'bpp_components': {k: round(v, 6) for k, v in enc['bpp'].items()},
-               'lossless_decode_frame0': lossless,
+               'lossless_decode_frames0to3': lossless,
                'components_s_per_frame': {'overfit': round(overfit_s_per_frame, 5), 'codec_fwd_ac_modelcomp': round(codec_s_per_frame, 5),
-                                          'decode_frame0_s': round(decode_s, 3)},
+                                          'decode_s_per_frame_4_in_flight': round(decode_s, 4)},
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
