@@ -11,13 +11,14 @@ import time
 
 import torch
 
-from . import codec, gop_parallel, overfit, synthetic
+from . import codec, gop_parallel, overfit, ply, synthetic
 from .model_core import FlatAdam
 
 
 def parse():
     ap = argparse.ArgumentParser('linr_pcgc_amd.run')
     ap.add_argument('--config', default='loot10')
+    ap.add_argument('--input-glob', default=None, help="PLY / npy frames of a real sequence (sorted by name), e.g. '/data/loot/Ply/*.ply'; replaces --config")
     ap.add_argument('--frames', type=int, default=32)
     ap.add_argument('--gop', type=int, default=32)
     ap.add_argument('--first-epoch', type=int, default=10)
@@ -49,14 +50,24 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
+    files = None
+    if args.input_glob:
+        import glob
+        files = sorted(glob.glob(args.input_glob))[:args.frames]
+        if not files:
+            raise ValueError('no file matches %s' % args.input_glob)
+        args.frames = len(files)
     groups = gop_parallel.split_gops(args.frames, args.gop)
+
+    def load_frame(t):
+        return ply.read_points(files[t]) if files is not None else synthetic.sequence_frame(args.config, t)
 
     def make_opt(model):
         return FlatAdam(model, lr=args.learning_rate, weight_decay=args.decay_rate, step_size=args.step_size, gamma=args.gamma)
 
     def run_gop(group, epochs, ckpt):
         t0 = time.time()
-        gop = overfit.Gop(None, [synthetic.sequence_frame(args.config, t) for t in group], None, 64, 'cuda')
+        gop = overfit.Gop(None, [load_frame(t) for t in group], None, 64, 'cuda')
         model = overfit.gen_model(gop.scale_num, 'cuda', seed=args.seed)
         opt = make_opt(model)
         if ckpt is not None:

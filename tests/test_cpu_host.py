@@ -209,3 +209,30 @@ def test_flat_adam_state_dict_roundtrip():
     for i in range(1, 100):
         opt2.scheduler_step()
     assert abs(opt2.lr - 0.00731 * 0.992 ** 3) < 1e-12          # StepLR(32, 0.992) stepped per frame
+
+
+@pytest.mark.parametrize('binary', [True, False])
+def test_ply_reader(tmp_path, binary):
+    """read_ply_o3d replacement (custom_dataset.py:9-14): x, y, z from ascii / binary PLY with extra vertex properties."""
+    from linr_pcgc_amd import ply
+    rng = np.random.default_rng(4)
+    xyz = rng.integers(0, 1024, size=(257, 3))
+    path = str(tmp_path / 'a.ply')
+    ply.write_ply_xyz(path, xyz, binary=binary)
+    assert np.array_equal(ply.read_points(path), xyz)
+    # a vertex element with colours and a face element behind it, big endian
+    path2 = str(tmp_path / 'b.ply')
+    rec = np.zeros(5, dtype=[('x', '>f8'), ('red', 'u1'), ('y', '>f8'), ('z', '>f8'), ('green', 'u1')])
+    rec['x'], rec['y'], rec['z'] = [1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [11, 12, 13, 14, 15]
+    with open(path2, 'wb') as f:
+        f.write(b'ply\nformat binary_big_endian 1.0\nelement vertex 5\nproperty double x\nproperty uchar red\n'
+                b'property double y\nproperty double z\nproperty uchar green\nelement face 0\n'
+                b'property list uchar int vertex_indices\nend_header\n')
+        f.write(rec.tobytes())
+    got = ply.read_points(path2)
+    assert got.tolist() == [[1, 6, 11], [2, 7, 12], [3, 8, 13], [4, 9, 14], [5, 10, 15]]
+    np.save(str(tmp_path / 'c.npy'), xyz)
+    assert np.array_equal(ply.read_points(str(tmp_path / 'c.npy')), xyz)
+    with pytest.raises(ValueError):
+        open(str(tmp_path / 'd.ply'), 'wb').write(b'plx\n')
+        ply.read_points(str(tmp_path / 'd.ply'))
