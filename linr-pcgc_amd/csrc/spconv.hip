@@ -279,8 +279,7 @@ template <int XQ, int COUT, bool PAD, bool VIDX>
 __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_k(
     const float* __restrict__ in, int in_ld, const float* __restrict__ gout, int gout_ld,
     const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n, LinrWgradDst d) {
-    constexpr int CIN = 4 * XQ;
-    constexpr int NI = 27 * XQ;
+    constexpr int NI = 27 * XQ;            // lanes in use: one per (offset, input-channel quad)
     constexpr int NA = 4 * COUT;
     __shared__ float sacc[64 * (NA + 1)];
     const int lane = threadIdx.x & 63;
