@@ -376,19 +376,22 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
         const float p = 1.0f / (1.0f + expf(-z));
         if (live) hd.p_out[row] = p;
         if (hd.partial != nullptr) {          // wave-uniform (kernel argument)
-            __shared__ double sred[LINR_CONV_BLOCK];
+            __shared__ double sred[LINR_CONV_BLOCK / 64];
             double nats = 0.0;
             if (live) {
                 const float t = hd.target[row * hd.target_ld];
                 nats = (double)((t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f));
             }
-            sred[threadIdx.x] = nats;
+            // fixed shuffle tree inside the wave, then the waves in order => bit-reproducible
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) nats += __shfl_xor(nats, d, 64);
+            if (lane == 0) sred[threadIdx.x >> 6] = nats;
             __syncthreads();
-            for (int s2 = LINR_CONV_BLOCK / 2; s2 > 0; s2 >>= 1) {
-                if ((int)threadIdx.x < s2) sred[threadIdx.x] += sred[threadIdx.x + s2];
-                __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = sred[0];
+                for (int w = 1; w < LINR_CONV_BLOCK / 64; ++w) tot += sred[w];
+                hd.partial[blockIdx.x] = tot;
             }
-            if (threadIdx.x == 0) hd.partial[blockIdx.x] = sred[0];
         }
         return;
     } else {
