@@ -168,6 +168,7 @@ def main():
     if os.environ.get('LINR_BENCH_SINGLE_DEVICE'):          # rehearsal of the N > 1 control flow on a 1-GPU box
         local = 0
     assert torch.cuda.is_available(), 'bench.py needs an MI355X: the coding network has no CPU path'
+    torch.set_num_threads(host_threads())          # torch CPU ops otherwise fan out over every core of the node, per rank
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
