@@ -63,6 +63,12 @@ LINR_API int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n, i
  * offsets of glob_params.py:3) read off the kernel map: out[j*7 + i] = 1.0f if neighbour i of voxel row_base + j exists.
  * Replaces 7 QuickSearchCoord.search calls per scale in decoder.decode_one_frame (decoder.py:160-166). */
 LINR_API int linr_kmap_offset_feat(const int32_t* nbr, int64_t ld, int64_t row_base, int64_t n, float* out, void* stream);
+/* Child occupancy of an octree level (octree_level.forward, models/module_utils.py:86-110; the 8 x [N,1] `occ_lst` of
+ * datautils/custom_dataset.py:201-206): child [m,3] int32 sorted x-major and unique, parent [n,3] = the sorted unique
+ * floor(child / 2); writes occ[j*8 + 4dx+2dy+dz] = 1.0f iff child 2*parent[j]+(dx,dy,dz) exists.  Same sorted-key binary
+ * search as the kernel map; ws: linr_kmap_workspace_bytes(m) bytes, 8-byte aligned. */
+LINR_API int linr_octree_occupancy(const int32_t* child, int64_t m, const int32_t* parent, int64_t n, float* occ, void* ws,
+                          size_t ws_bytes, void* stream);
 /* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
 LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
 

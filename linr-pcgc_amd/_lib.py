@@ -32,6 +32,7 @@ _PROTOS = {
     'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'linr_prof_enable': (ctypes.c_int, [c_i32]),
     'linr_prof_read': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr]),
+    'linr_octree_occupancy': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'linr_kmap_offset_feat': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'linr_kmap_compress': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'linr_spconv_fwd': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32,

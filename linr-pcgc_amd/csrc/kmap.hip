@@ -93,3 +93,41 @@ extern "C" int linr_kmap_offset_feat(const int32_t* nbr, int64_t ld, int64_t row
     kmap_offset_feat_k<<<linr_grid(n * 7, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, ld, row_base, n, out);
     return linr_launch_rc();
 }
+
+// Child occupancy of every parent voxel (octree_level.forward, models/module_utils.py:86-110): occ[j][4dx+2dy+dz] = 1 if
+// child 2*parent[j] + (dx,dy,dz) is in the sorted child list.  The two dz children of a (dx,dy) pair are adjacent in the
+// x-major list: 4 searches per parent, the same primitive as the kernel map.
+__global__ __launch_bounds__(LINR_BLOCK) void octree_occ_k(const long long* __restrict__ keys, int64_t m,
+                                                           const int32_t* __restrict__ parent, int64_t n,
+                                                           float* __restrict__ occ) {
+    const int64_t idx = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (idx >= 4 * n) return;
+    const int q = (int)(idx / n);            // (dx,dy) pair: consecutive threads -> consecutive parents
+    const int64_t j = idx - (int64_t)q * n;
+    const int dx = q >> 1, dy = q & 1;
+    const long long key0 = linr_key(2 * parent[3 * j] + dx, 2 * parent[3 * j + 1] + dy, 2 * parent[3 * j + 2]);
+    int64_t lo = 0, hi = m;                  // lower_bound(key0)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key0) lo = mid + 1; else hi = mid;
+    }
+    const bool h0 = lo < m && keys[lo] == key0;
+    if (h0) ++lo;
+    const bool h1 = lo < m && keys[lo] == key0 + 1;
+    occ[j * 8 + 4 * dx + 2 * dy] = h0 ? 1.0f : 0.0f;
+    occ[j * 8 + 4 * dx + 2 * dy + 1] = h1 ? 1.0f : 0.0f;
+}
+
+extern "C" int linr_octree_occupancy(const int32_t* child, int64_t m, const int32_t* parent, int64_t n, float* occ, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    if (m < 0 || n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!parent || !occ || (m > 0 && (!child || !ws))) return LINR_EINVAL;
+    if (ws_bytes < linr_kmap_workspace_bytes(m)) return LINR_ENOSPC;
+    if (((uintptr_t)ws) & 7u) return LINR_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    long long* keys = (long long*)ws;
+    if (m > 0) kmap_keys_k<<<linr_grid(m, LINR_BLOCK), LINR_BLOCK, 0, s>>>(child, m, keys);
+    octree_occ_k<<<linr_grid(4 * n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(keys, m, parent, n, occ);
+    return linr_launch_rc();
+}

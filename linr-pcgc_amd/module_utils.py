@@ -100,6 +100,9 @@ class octree_level(nn.Module):
 
     def forward(self, leaf, qsc=None):
         parent = unique_sorted(torch.div(leaf.to(torch.int64), 2, rounding_mode='floor'))
+        if leaf.is_cuda and leaf.dtype == torch.int32:        # GPU: the kernel map's sorted-key search (linr_octree_occupancy)
+            from . import ops
+            return parent, ops.octree_occupancy(leaf.contiguous(), parent.contiguous())
         off = self.offsets.to(leaf.device)
         # all 8 child lookups of every parent as ONE batched search over the sorted leaf keys
         q = (parent.to(torch.int64)[:, None, :] * 2 + off[None, :, :]).reshape(-1, 3)

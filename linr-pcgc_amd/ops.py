@@ -200,3 +200,16 @@ def spconv_wgrad_cmap(x, gout, nbr, lo, mask, n, cin, cout, slab=None, reduce=Tr
         return slab
     tot = slab.sum(dim=0)
     return tot[:27 * cin * cout].view(27, cin, cout), tot[27 * cin * cout:]
+
+
+def octree_occupancy(child, parent):
+    """occ float32 [N,8] of the parents (sorted unique floor(child/2)) of a sorted unique child list (int32 [M,3])."""
+    _dev(child, torch.int32, 'child')
+    _dev(parent, torch.int32, 'parent')
+    L = _lib.lib()
+    m, n = child.shape[0], parent.shape[0]
+    occ = torch.empty((n, 8), dtype=torch.float32, device=child.device)
+    ws = torch.empty(max(L.linr_kmap_workspace_bytes(m), 8), dtype=torch.uint8, device=child.device)
+    check(L.linr_octree_occupancy(child.data_ptr(), m, parent.data_ptr(), n, occ.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          'linr_octree_occupancy')
+    return occ

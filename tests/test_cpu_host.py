@@ -48,6 +48,8 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_kmap_build(p16, 8, p16, 8, 0, p16 + 4, 1024, None) == -3               # workspace not 8-byte aligned
     assert lib.linr_kmap_build(p16, 0, p16, 0, 0, None, 0, None) == 0                      # empty input is fine
     assert lib.linr_kmap_offset_feat(p16, 4, 0, 8, p16, None) == -1
+    assert lib.linr_octree_occupancy(p16, 8, p16, 4, p16, p16, 8, None) == -2                # workspace too small
+    assert lib.linr_octree_occupancy(p16, -1, p16, 4, p16, p16, 1024, None) == -1
     # convolutions
     assert lib.linr_spconv_fwd(p16, 4, p16, 16, 16, p16, p16, 8, 8, None, 0, p16, 8, 0, None) == -1      # in_ld < cin
     assert lib.linr_spconv_cmap(0, p16, 5, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -1   # ld 5

@@ -70,6 +70,22 @@ def test_kmap_bit_exact(pkg, shell, case):
     assert (nbr.t().cpu().numpy() == ref).all()
 
 
+def test_octree_occupancy_kernel_matches_golden(pkg, golden_dir):
+    """linr_octree_occupancy against the fixtures the reference's own octree_level produced (bit-exact)."""
+    from linr_pcgc_amd import ops
+    dev = _dev()
+    for name in ('octree_random64.npz', 'octree_shell128.npz'):
+        g = np.load(os.path.join(golden_dir, name))
+        child = torch.from_numpy(g['ori'].astype(np.int32)).to(dev)
+        for s in range(int(g['scale_num'])):
+            parent = torch.from_numpy(g['s%d_coord' % s].astype(np.int32)).to(dev)
+            occ = ops.octree_occupancy(child.contiguous(), parent.contiguous())
+            assert np.array_equal(occ.cpu().numpy(), g['s%d_occ' % s].astype(np.float32)), (name, s)
+            child = parent
+    empty = ops.octree_occupancy(torch.zeros((0, 3), dtype=torch.int32, device=dev), torch.zeros((0, 3), dtype=torch.int32, device=dev))
+    assert empty.shape == (0, 8)
+
+
 def test_offset_features_from_kernel_map(pkg, shell):
     """linr_kmap_offset_feat == qscTensor.set_offset_tensor (the reference's 7 coordinate searches), bit for bit."""
     from linr_pcgc_amd import engine
