@@ -99,8 +99,10 @@ def kernel_roofline(model, gop, live, iters=10):
         alg = ppl * mean_rows * (4 * (8 + 8) + 108)
         achieved = alg / dur_s / 1e9
         tr = traffic.get(key)
+        tflops = ppl * mean_rows * 2 * 27 * 8 * 8 / dur_s / 1e12       # dense-27 flops the kernel executes on the matrix cores
         return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None if tr is None else int(tr * ppl), 'kernel': name,
+                'mfma_f32_view': {'achieved_tflops': round(tflops, 1), 'peak_tflops': 157.3, 'frac': round(tflops / 157.3, 4)},
                 'launches_timed': int(launches), 'passes_per_launch': round(ppl, 3), 'rows_per_pass': round(mean_rows, 1),
                 'alg_bytes_per_launch': int(alg), 'avg_launch_us': round(dur_s * 1e6, 2),
                 'single_launch_us': round(single_s * 1e6, 2)}
