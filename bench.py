@@ -164,6 +164,14 @@ def host_threads():
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks the way the driver does (child process; nothing has touched
+        # the GPU yet) and pass its exit code on
+        import subprocess
+        port = os.environ.get('MASTER_PORT', '29533')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
