@@ -11,6 +11,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle issues tens of thousands of small torch ops; on a 256-core GPU host each of them would fan out over
+    # every core (measured 10x slower than 8 threads)
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(8, n)))
 
 
 @pytest.fixture(scope='session')
