@@ -362,6 +362,34 @@ def test_more_scales_than_one_grouped_launch(pkg):
     _close(grads, gref, 1e-3, 1e-4 * float(gref.abs().max()), 'gradients with %d scales' % S)
 
 
+def test_executor_without_compressed_map(pkg, shell):
+    """linr_frame.nbr_lo / nbr_mask are optional: without them the executor runs the generic op-level kernels layer by
+    layer (no fused epilogues, no grouped launches).  Same per-row fmaf chains => same probabilities; gradients agree to
+    rounding (different partial-sum tiling)."""
+    import copy
+    from linr_pcgc_amd import engine
+    model, _ = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    flat = model.flat_parameters()
+    probs, bits = model.frame_probs(frame)
+    grads = torch.zeros_like(flat)
+    engine.net_forward(frame, flat, 0, 8, None, torch.zeros(1, dtype=torch.float64, device='cuda'))
+    engine.net_backward(frame, flat, grads, 1.0 / shell['point_num'])
+    plain = copy.copy(frame)
+    plain._c = type(frame._c)(rows=frame._c.rows, n_scales=frame._c.n_scales, model_scale_num=frame._c.model_scale_num,
+                              row_off_h=frame._c.row_off_h, scale_idx_h=frame._c.scale_idx_h, nbr=frame._c.nbr,
+                              nbr_ld=frame._c.nbr_ld, nbr_lo=None, nbr_mask=None, offset_feat=frame._c.offset_feat,
+                              occ=frame._c.occ)
+    probs2 = torch.empty_like(probs)
+    bits2 = torch.zeros(1, dtype=torch.float64, device='cuda')
+    engine.net_forward(plain, flat, 0, 8, probs2, bits2)
+    assert torch.equal(probs, probs2), float((probs - probs2).abs().max())
+    assert abs(float(bits) - float(bits2)) <= 1e-9 * float(bits)
+    grads2 = torch.zeros_like(flat)
+    engine.net_backward(plain, flat, grads2, 1.0 / shell['point_num'])
+    _close(grads2, grads, 1e-4, 1e-6 * float(grads.abs().max()), 'gradients of the generic executor path')
+
+
 def test_multiscale_batch_equals_per_scale(pkg, shell):
     """Batching all scales into one row space must not change any row's arithmetic (bitwise)."""
     model, _ = _model_and_oracle(pkg, 5)
