@@ -34,7 +34,7 @@ class Frame:
         self.n_scales = len(scales)
         R = self.rows
         self.nbr_ld = (R + 63) // 64 * 64          # padded leading dimension: 16-byte aligned index rows
-        self.nbr = torch.empty((27, self.nbr_ld), dtype=torch.int32, device=device)
+        self.nbr = torch.full((27, self.nbr_ld), -1, dtype=torch.int32, device=device)     # padding columns: no neighbour
         self.offset_feat = torch.empty((R, 7), dtype=torch.float32, device=device)
         self.occ = torch.zeros((R, 8), dtype=torch.float32, device=device)
         for i, s in enumerate(scales):
@@ -52,8 +52,8 @@ class Frame:
                 self.occ[r0:r1] = torch.cat([torch.as_tensor(o).reshape(-1, 1) for o in s['occ_lst']], dim=1).to(
                     device=device, dtype=torch.float32)
         # compressed kernel map (9 column bases + 27-bit mask per row) used by the network executor
-        self.nbr_lo = torch.empty((9, self.nbr_ld), dtype=torch.int32, device=device)
-        self.nbr_mask = torch.empty((self.nbr_ld,), dtype=torch.int32, device=device)
+        self.nbr_lo = torch.zeros((9, self.nbr_ld), dtype=torch.int32, device=device)
+        self.nbr_mask = torch.zeros((self.nbr_ld,), dtype=torch.int32, device=device)      # padding columns: empty masks
         check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
                                             self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
         self.arena = None

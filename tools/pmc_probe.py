@@ -16,5 +16,5 @@ b = torch.zeros(1, 8, device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
     ops.spconv_fwd(x[1:], f.nbr, w, b, out=out, pad_row=True)
     ops.spconv_bwd_data(go[1:], f.nbr, w, out=out, pad_row=True)
-    ops.spconv_bwd_weight(x[1:], go[1:], f.nbr, 8, 8)
+    ops.spconv_bwd_weight(x[1:], go[1:], f.nbr[:, :R], 8, 8)
 torch.cuda.synchronize()

@@ -35,9 +35,9 @@ def timeit(fn):
 
 
 print('rows', R)
-print('wgrad 8x8 mfma (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr, 8, 8, pad_row=True)))
-print('wgrad 8x4 mfma (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr, 8, 4, pad_row=True)))
-print('wgrad 8x8 valu (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr, 8, 8)))
+print('wgrad 8x8 mfma (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr[:, :R], 8, 8, pad_row=True)))
+print('wgrad 8x4 mfma (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr[:, :R], 8, 4, pad_row=True)))
+print('wgrad 8x8 valu (+reduce) %.1f us' % timeit(lambda: ops.spconv_bwd_weight(x[1:], go[1:], f.nbr[:, :R], 8, 8)))
 print('conv fwd 8x8 cmap        %.1f us' % timeit(lambda: ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out)))
 # the executor's variant: compressed map indices (through one training step's kernels is the only C-ABI route, so time
 # the whole backward here instead)
