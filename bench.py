@@ -314,7 +314,7 @@ def main():
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
-        out['roofline'] = kernel_roofline(model, gop, live)
+        out['roofline'] = None if os.environ.get('LINR_SKIP_ROOFLINE') else kernel_roofline(model, gop, live)
         log('roofline: %s' % out['roofline'])
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_threads())
