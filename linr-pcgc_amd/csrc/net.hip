@@ -407,6 +407,13 @@ extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches,
     return 0;
 }
 
+// grouped launches need the matrix-core conv kernel (the VALU fallback of LINR_CONV_MFMA=0 is a single-layer kernel)
+static bool grouped_enabled() {
+    static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
+    static const int conv_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;
+    return batched != 0 && conv_mfma != 0;
+}
+
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
     if (c.f->nbr_lo && c.f->nbr_mask) {
@@ -676,7 +683,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         }
         TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
     }
-    static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
+    const bool batched = grouped_enabled();
     if (batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask) return forward_batched(c, probs, bits_acc);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
@@ -859,7 +866,7 @@ static int backward_core(Ctx& c, float gscale) {
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));
-    static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
+    const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
     if (grouped) TRY(backward_batched(c, gz_scale));
     for (int k = grouped ? -1 : 7; k >= 0; --k) {
