@@ -165,7 +165,7 @@ LINR_API int linr_adam_step(float* params, const float* grads, float* exp_avg, f
  * Replaces LINR_PCGC_Model.logic_core/forward (models/model_core.py:38-81) + CNP.forward
  * (models/upsample.py:163-217) and the autograd backward that main.py:315-316 runs. */
 typedef struct linr_frame {
-    int64_t rows;                 /* total rows over all scales                                             */
+    int64_t rows;                 /* total rows over all scales, < 2^27 - 1 (32-bit byte offsets of the gathers)  */
     int32_t n_scales;             /* scales present in this frame (<= model scale_num)                      */
     int32_t model_scale_num;      /* LINR_PCGC_Model scale_num (fixes the parameter layout)                 */
     const int64_t* row_off_h;     /* HOST [n_scales+1] first row of each scale                              */

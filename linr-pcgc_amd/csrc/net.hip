@@ -530,7 +530,8 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     if (!f || !params || !arena) return LINR_EINVAL;
     if (f->rows < 0 || f->n_scales < 1 || f->n_scales > MAX_SCALES || !f->row_off_h || !f->scale_idx_h) return LINR_EINVAL;
     if (f->rows > 0 && (!f->nbr || !f->offset_feat || !f->occ)) return LINR_EINVAL;
-    if (f->rows > INT32_MAX - 1 || f->nbr_ld < f->rows) return LINR_EINVAL;
+    // the conv kernels address gathered rows with 32-bit byte offsets: (rows + 1) * 32 B must stay below 2^32
+    if (f->rows >= ((int64_t)1 << 27) - 1 || f->nbr_ld < f->rows) return LINR_EINVAL;
     if (!make_layout(c.L, f->model_scale_num)) return LINR_EINVAL;
     if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
     for (int s = 0; s < f->n_scales; ++s) {
