@@ -717,6 +717,26 @@ def test_tiny_and_ragged_frames(pkg, n):
     assert bool(torch.isfinite(grads).all())
 
 
+def test_overfit_is_run_to_run_deterministic(pkg):
+    """No float atomics, fixed reduction orders: two overfits of the same GOP from the same seed end in the same bits
+    (parameters, Adam moments, bitstreams)."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sphere_shell(7, 40 + t) for t in range(3)]
+    runs = []
+    for _ in range(2):
+        gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+        model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+        opt = FlatAdam(model)
+        losses = overfit.overfit_gop(model, opt, gop, 4)
+        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+        runs.append((model.flat_parameters().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), losses, enc))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3]
+    assert a[4]['frames'] == b[4]['frames'] and a[4]['model_bin'] == b[4]['model_bin']
+
+
 def test_threaded_gop_decode_equals_serial(pkg):
     """codec.decode_gop(workers=3): frames decoded concurrently on their own streams give the serial result."""
     from linr_pcgc_amd import codec, overfit, synthetic
