@@ -252,7 +252,7 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
     for (int h = 0; h < GOUT / 4; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[h][j] = (bias != nullptr) ? bias[4 * h + j] : 0.0f;
-    constexpr int PF = 3;
+    constexpr int PF = 4;
     float x[PF + 1][LOADW];
     // the offset loop; SRC = 0: rows from global memory (per-lane gathers), SRC = 1: rows from the LDS windows.
     // Left to itself hipcc waits (vmcnt(0)) right after every 16-byte gather - 54 serial round trips per wave.  The loop
