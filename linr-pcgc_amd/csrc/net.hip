@@ -290,19 +290,30 @@ __global__ void sce_emb_grad_k(const float* __restrict__ gb1, const float* __res
     }
 }
 
-// gsum[p] = sum_b big[b][p] in a fixed association (8 interleaved partial sums, ascending b) => bit-reproducible
+// gsum[p] = sum_b big[b][p] in a fixed association (RED_SPLIT threads per parameter, each 8 interleaved partial sums over
+// its quarter of the slab rows in ascending order, quarters added in order) => bit-reproducible.  One thread per
+// parameter alone would be 214 blocks of latency-bound streaming on 256 CUs.
+#define RED_SPLIT 4       // threads per parameter: each sums nblocks / RED_SPLIT slab rows
 __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
                                                              float* __restrict__ gsum) {
-    const int64_t p = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (p >= total) return;
-    float a[8];
+    __shared__ float part[RED_SPLIT][LINR_BLOCK / RED_SPLIT];
+    const int lp = threadIdx.x % (LINR_BLOCK / RED_SPLIT), q = threadIdx.x / (LINR_BLOCK / RED_SPLIT);
+    const int64_t p = (int64_t)blockIdx.x * (LINR_BLOCK / RED_SPLIT) + lp;
+    float s = 0.0f;
+    if (p < total) {
+        float a[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = 0.0f;
-    for (int b = 0; b < nblocks; b += 8) {
+        for (int i = 0; i < 8; ++i) a[i] = 0.0f;
+        const int per = nblocks / RED_SPLIT;                 // nblocks is a multiple of 8 * RED_SPLIT
+        for (int b = q * per; b < (q + 1) * per; b += 8) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] += big[(int64_t)(b + i) * total + p];
+            for (int i = 0; i < 8; ++i) a[i] += big[(int64_t)(b + i) * total + p];
+        }
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
-    gsum[p] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    part[q][lp] = s;
+    __syncthreads();
+    if (q == 0 && p < total) gsum[p] = ((part[0][lp] + part[1][lp]) + part[2][lp]) + part[3][lp];
 }
 
 struct Ctx {
@@ -928,7 +939,7 @@ static int backward_core(Ctx& c, float gscale) {
     }
     // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
     TRY(stream_order(c.ws, c.s));
-    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
+    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
     if (ns > 0) {
         EmbArgs ea;
         for (int j = 0; j < ns; ++j) {
