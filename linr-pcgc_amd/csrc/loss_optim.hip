@@ -35,19 +35,23 @@ __global__ __launch_bounds__(LINR_BLOCK) void bce_bits_fwd_k(const float* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = sred[0];
 }
 
-// one block; thread t sums partials t, t+256, ... then a fixed LDS tree: the association is fixed => bit-reproducible
-__global__ __launch_bounds__(LINR_BLOCK) void bce_bits_finish_k(const double* __restrict__ partial, int nblocks,
-                                                                double* __restrict__ bits_acc) {
-    __shared__ double sred[LINR_BLOCK];
+// one block of 1024 threads; thread t sums partials t, t+1024, ..., then a fixed shuffle tree per wave and the 16 waves in
+// order: the association is fixed => bit-reproducible
+#define BITS_FINISH_THREADS 1024
+__global__ __launch_bounds__(BITS_FINISH_THREADS) void bce_bits_finish_k(const double* __restrict__ partial, int nblocks,
+                                                                        double* __restrict__ bits_acc) {
+    __shared__ double sred[BITS_FINISH_THREADS / 64];
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += LINR_BLOCK) s += partial[b];
-    sred[threadIdx.x] = s;
+    for (int b = threadIdx.x; b < nblocks; b += BITS_FINISH_THREADS) s += partial[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int h = LINR_BLOCK / 2; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) sred[threadIdx.x] += sred[threadIdx.x + h];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sred[0];
+        for (int w = 1; w < BITS_FINISH_THREADS / 64; ++w) t += sred[w];
+        *bits_acc += t * 1.4426950408889634;   // 1 / ln 2
     }
-    if (threadIdx.x == 0) *bits_acc += sred[0] * 1.4426950408889634;   // 1 / ln 2
 }
 
 // torch: binary_cross_entropy_backward  g_p = g * (p - t) / max((1-p)*p, 1e-12), then sigmoid backward * p*(1-p)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void bce_bits_bwd_k(const float* __rest
 }
 
 int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s) {
-    bce_bits_finish_k<<<1, LINR_BLOCK, 0, s>>>(partial, count, bits_acc);
+    bce_bits_finish_k<<<1, BITS_FINISH_THREADS, 0, s>>>(partial, count, bits_acc);
     return linr_launch_rc();
 }
 
@@ -81,7 +85,7 @@ extern "C" int linr_bce_bits_fwd(const float* z, const float* target, int32_t ta
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)linr_grid(n, BCE_ROWS_PER_BLOCK);
     bce_bits_fwd_k<<<nb, LINR_BLOCK, 0, s>>>(z, target, target_ld, n, p, (double*)ws);
-    bce_bits_finish_k<<<1, LINR_BLOCK, 0, s>>>((const double*)ws, nb, bits_acc);
+    bce_bits_finish_k<<<1, BITS_FINISH_THREADS, 0, s>>>((const double*)ws, nb, bits_acc);
     return linr_launch_rc();
 }
 
