@@ -842,6 +842,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
     const int gl = DUAL ? (lane & 31) : lane;
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
+    const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);      // live components per quad (>= 4: all)
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
         if (IDX >= 1 && g0r + 8 <= n) {
@@ -884,10 +885,12 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
             static_for<HB>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 constexpr int ab = u * HB + h;           // the block holding g[row u][4h .. 4h+3]
+                // first convs of the outter blocks (cin_valid = 1..7): component c of a quad is input channel >= c, so it
+                // is dead in BOTH quads once c >= cin_valid (wave-uniform: cin_valid is a kernel argument)
                 acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
-                acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
-                acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
-                acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
             });
         });
     }
