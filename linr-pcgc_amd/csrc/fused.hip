@@ -786,7 +786,9 @@ int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* m
 // holds g[row u][4h .. 4h+3] and ABID selects it - no per-row gradient loads, no shuffles.  Register i of accumulator
 // (c, h) on a lane is gW[k][4q + c][4h + i] of the lane's own pair.  DUAL (the two 4->4 convs of an Inception block):
 // lanes 0..31 are conv 0, lanes 32..63 conv 1, each half loads its own gradient matrix and CBSZ = 3 keeps them apart.
-// Pair k == 27 is the bias pseudo-pair (x = (1,0,0,0)).  K = 1 keeps exact fp32 FMAs in row order.
+// The bias gradient is the column sum of the same gradient tiles (each lane adds up the element it loads; a fixed shuffle
+// tree and the waves in order finish it) - no per-row selects in the loop: VALU instructions run on the same FMA units as
+// the f32 MFMAs, so every one of them is paid for.  K = 1 keeps exact fp32 FMAs in row order.
 struct WgradSrc {
     const float* in; int in_ld;           // gathered matrix (quad q at column 4q)
     const float* g0; int g0_ld;           // output gradient (DUAL: of conv 0)
@@ -817,9 +819,8 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = DUAL ? (lane >> 5) : (XQ == 2 ? (lane & 1) : 0);
-    const int kk = DUAL ? (lane & 31) : (XQ == 2 ? (lane >> 1) : lane);          // 27 == bias pseudo-pair, > 27 idle
+    const int kk = DUAL ? (lane & 31) : (XQ == 2 ? (lane >> 1) : lane);          // >= 27: idle lanes
     const bool live = kk < 27;
-    const bool biasl = kk == 27;
     const int k = live ? kk : 26;
     f32x4 acc[4][HB];
 #pragma unroll
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int gl = DUAL ? (lane & 31) : lane;
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
     const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);      // live components per quad (>= 4: all)
+    float bsum = 0.0f;
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
         if (IDX >= 1 && g0r + 8 <= n) {
@@ -878,8 +880,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[u] + 1) * rowbytes);
-            if (!live) x[u] = make_float4(biasl ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
         }
+        bsum += gv;                      // bias gradient: column sums of the gradient rows (lanes beyond the 27 offsets
+                                         // gather offset 26's rows again; their products are never written)
         static_for<8>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             static_for<HB>([&](auto hc) {
@@ -910,11 +913,27 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         }
         __syncthreads();
     }
+    // bias gradient: lane l holds the partial column sum of channel gc over rows gu, gu + 8, ...: add the 8 row phases with
+    // a fixed xor tree, then the waves in order
+    __shared__ float sbias[WG_WAVES][16];
+    {
+        float t = bsum;
+#pragma unroll
+        for (int m = COUT; m < 8 * COUT; m <<= 1) t += __shfl_xor(t, m, 64);
+        const int slot = DUAL ? ((lane >> 5) * 4 + (lane & 3)) : (lane % COUT);          // lanes 0..COUT-1 (and 32..35 for DUAL)
+        if ((lane & 31) < COUT && (DUAL || lane < 32)) sbias[wave][slot] = t;
+        __syncthreads();
+    }
     if (wave == 0) {
         // register i of accumulator (c, h)  <->  pair (kk, q), input channel 4q + c, output channel 4h + i
         float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+        if (lane < (DUAL ? 8 : COUT)) {
+            float t = sbias[0][lane];
+            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][lane];
+            if (DUAL) dst[(lane < 4 ? d.b_off : dd.b_off1) + (lane & 3)] = t;
+            else dst[d.b_off + lane] = t;
+        }
         const int64_t w_off = (DUAL && q) ? dd.w_off1 : d.w_off;
-        const int64_t b_off = (DUAL && q) ? dd.b_off1 : d.b_off;
         const int cinv = DUAL ? 4 : d.cin_valid;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -925,11 +944,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
                 for (int i = 0; i < 4; ++i) {
                     const float v = mine[(c * HB + h) * 4 + i];
                     const int co = 4 * h + i;
-                    if (live) {
-                        if (ci < cinv) dst[w_off + (kk * cinv + ci) * COUT + co] = v;
-                    } else if (biasl && c == 0 && (XQ == 1 || DUAL || q == 0)) {
-                        dst[b_off + co] = v;
-                    }
+                    if (live && ci < cinv) dst[w_off + (kk * cinv + ci) * COUT + co] = v;
                 }
         }
     }
