@@ -107,14 +107,16 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
  * (offset, channel quad), gathered quad x broadcast gradient tile on v_mfma_f32_4x4x1, row order fixed => reproducible).
  * Writes linr_spconv_wgrad_cmap_blocks() (= 512) per-block partials: slab[b][(27 cin + 1) cout], kernel gradient
  * [27][cin][cout] first, bias gradient [cout] last; their ascending sum over b is MinkowskiConvolution's kernel / bias
- * gradient (ME autograd of the call sites above).  `in`: [n][8] floats, 16-byte aligned, zero row at index -1. */
+ * gradient (ME autograd of the call sites above).  `in`: [n][8] floats, 16-byte aligned, zero row at index -1.
+ * lo / mask: the compressed map, or both NULL to take the indices from nbr[27][ld] (what the executor does by default:
+ * 108 instead of 40 index bytes per row, but no decode instructions). */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
                            const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin, int32_t cout,
                            float* slab, void* stream);
 
 /* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
- * linr_net_forward / _backward / _train_step (kind 0: spconv_wgrad_mfma_k<2,8> on the compressed map; kind 1:
+ * linr_net_forward / _backward / _train_step (kind 0: spconv_wgrad_mfma_k<2,8>; kind 1:
  * cconv_mfma_k<8,8,forward, plain epilogue>) is bracketed by a HIP event pair on the stream it is launched on.
  * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,

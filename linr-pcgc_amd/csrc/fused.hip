@@ -494,7 +494,7 @@ extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const floa
                                       int32_t cout, float* slab, void* stream) {
     if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
     if (n == 0) return 0;
-    if (!in || !gout || !nbr || !lo || !mask || !slab) return LINR_EINVAL;
+    if (!in || !gout || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;     // lo / mask NULL: indices from nbr
     if (!linr_aligned16(in)) return LINR_EALIGN;          // lo / mask / ld not 16-byte friendly: the kernel reads the nbr table
     if (!((cin == 8 && (cout == 8 || cout == 4)) || (cin < 8 && cin >= 1 && cout == 8))) return LINR_EINVAL;
     if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;

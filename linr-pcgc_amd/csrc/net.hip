@@ -436,9 +436,11 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
                              flags | LINR_PAD_ROW, c.s);
 }
 
-// LINR_WGRAD_CMAP=0: weight-gradient kernels read the full nbr[27][ld] table instead of the compressed map
+// LINR_WGRAD_CMAP=1: weight-gradient kernels decode the compressed map instead of reading the full nbr[27][ld] table.
+// The table costs 108 instead of 40 index bytes per row, the decode ~5 VALU instructions per index - and VALU
+// instructions share the FMA units with the f32 MFMAs: the table is 0.7 % faster end to end (same-box A/B).
 static bool wg_cmap() {
-    static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 1;
+    static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 0;
     return v != 0;
 }
 
@@ -447,7 +449,7 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
     static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
     TRY(stream_order(c.s, c.ws));
-    ProfScope ps(c.ws, 0, 1, use_mfma && cout == 8 && in_ld >= 8 && wg_cmap() && c.f->nbr_lo);
+    ProfScope ps(c.ws, 0, 1, use_mfma && cout == 8 && in_ld >= 8);
     if (use_mfma)
         return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
                                      wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
@@ -777,7 +779,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
-            ProfScope ps(c.ws, 0, 8, wg_cmap());
+            ProfScope ps(c.ws, 0, 8);
             TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? lo : nullptr, mk));
         }
         {   // ... and gO[k] = bwd(gC[k])
@@ -811,7 +813,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pI, 7); goffs(gp.res, p_gO, 7); goffs_i(gp.w, o_bw, 7); goffs_i(gp.b, o_bb, 7);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, 7, wg_cmap());
+        ProfScope ps(c.ws, 0, 7);
         TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
@@ -862,7 +864,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         for (int g = 0; g < 7; ++g) gp.e2[g] = g + 1;
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, 7, wg_cmap());
+        ProfScope ps(c.ws, 0, 7);
         TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
     }
     return 0;

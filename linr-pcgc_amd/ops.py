@@ -186,15 +186,15 @@ def spconv_cmap(x, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None
 
 
 def spconv_wgrad_cmap(x, gout, nbr, lo, mask, n, cin, cout, slab=None, reduce=True):
-    """The executor's backward-weight kernel (compressed map + MFMA).  x: view buf[1:] of a [n+1, 8] buffer whose row 0 is
-    zero.  Returns (gW [27,cin,cout], gb [cout]) summed over the per-block partials, or the raw slab with reduce=False."""
+    """The executor's backward-weight kernel (MFMA; indices from the compressed map, or from nbr when lo and mask are
+    None - the executor's default).  x: view buf[1:] of a [n+1, 8] buffer whose row 0 is zero.  Returns (gW [27,cin,cout], gb [cout]) summed over the per-block partials, or the raw slab with reduce=False."""
     L = _lib.lib()
     nb = int(L.linr_spconv_wgrad_cmap_blocks())
     elems = (27 * cin + 1) * cout
     if slab is None:
         slab = torch.empty((nb, elems), dtype=torch.float32, device=x.device)
-    check(L.linr_spconv_wgrad_cmap(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(), lo.data_ptr(),
-                                   mask.data_ptr(), lo.stride(0), n, cin, cout, slab.data_ptr(), _stream()),
+    check(L.linr_spconv_wgrad_cmap(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(), _ptr(lo),
+                                   _ptr(mask), nbr.stride(0), n, cin, cout, slab.data_ptr(), _stream()),
           'linr_spconv_wgrad_cmap')
     if not reduce:
         return slab

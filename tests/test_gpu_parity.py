@@ -501,8 +501,8 @@ def test_grouped_launches_bitwise_equal_stage_by_stage(pkg, golden_dir, tmp_path
     script = os.path.join(os.path.dirname(__file__), '_dump_net.py')
     golden = os.path.join(golden_dir, 'octree_shell128.npz')
     res = {}
-    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_SCE_FUSED': '1', 'LINR_WGRAD_CMAP': '1'}),
-                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '0'})):
+    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_SCE_FUSED': '1', 'LINR_WGRAD_CMAP': '0'}),
+                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1'})):
         out = str(tmp_path / (tag + '.npz'))
         subprocess.run([sys.executable, script, golden, out], check=True, env=dict(os.environ, **env), timeout=600)
         res[tag] = np.load(out)
@@ -581,6 +581,8 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     gw, gb = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout)
     _close(gw, wo.grad, 0, 1e-4 * float(wo.grad.abs().max()) + 1e-6, 'wgrad cmap')
     _close(gb, bo.grad.reshape(-1), 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bias grad cmap')
+    gw_t, gb_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, None, None, n, cin, cout)      # indices from the nbr table
+    assert torch.equal(gw_t, gw) and torch.equal(gb_t, gb)
     slab1 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
     slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
