@@ -39,6 +39,11 @@ extern "C" int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n,
 template <bool BWD>
 __device__ __forceinline__ void decode_offsets(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                int64_t ld, int64_t row, uint32_t rowbytes, uint32_t (&off)[27]) {
+    if (mask == nullptr) {            // `lo` is the full table nbr[27][ld]: no decode arithmetic, 27 coalesced index loads
+#pragma unroll
+        for (int k = 0; k < 27; ++k) off[BWD ? 26 - k : k] = (uint32_t)(lo[(int64_t)k * ld + row] + 1) * rowbytes;
+        return;
+    }
     const uint32_t m = mask[row];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {

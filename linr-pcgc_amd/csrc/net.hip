@@ -418,6 +418,15 @@ extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches,
     return 0;
 }
 
+// Index source of the conv kernels (cconv_mfma_k and friends): LINR_CONV_TABLE=1 hands them the full nbr[27][ld] table
+// (mask == NULL selects the table decode in decode_offsets) instead of the compressed map.
+static bool conv_table() {
+    static const int v = getenv("LINR_CONV_TABLE") ? atoi(getenv("LINR_CONV_TABLE")) : 0;
+    return v != 0;
+}
+static const int32_t* clo(const Ctx& c) { return conv_table() ? c.f->nbr : c.f->nbr_lo; }
+static const uint32_t* cmk(const Ctx& c) { return conv_table() ? nullptr : c.f->nbr_mask; }
+
 // grouped launches need the matrix-core conv kernel (the VALU fallback of LINR_CONV_MFMA=0 is a single-layer kernel)
 static bool grouped_enabled() {
     static const int batched = getenv("LINR_BATCHED") ? atoi(getenv("LINR_BATCHED")) : 1;
@@ -429,7 +438,7 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
     if (c.f->nbr_lo && c.f->nbr_mask) {
         ProfScope ps(c.s, 1, 1, !bwd && cin == 8 && cout == 8);
-        return linr_cconv_launch(bwd, in, in_ld, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld,
+        return linr_cconv_launch(bwd, in, in_ld, clo(c), cmk(c), c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld,
                                  act, act_ld, out, out_ld, flags, c.s);
     }
     return linr_conv3_launch(bwd, in, in_ld, c.f->nbr, c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld, act, act_ld, out, out_ld,
@@ -479,9 +488,9 @@ static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     if (c.f->nbr_lo && c.f->nbr_mask) {
         // Inception block in two launches (csrc/fused.hip): [conv0_0 | conv1_0 centre tap] -> H, then the two 4->4 convs
         // as one pass with conv1_2 and the residual in the epilogue -> M, I
-        TRY(linr_conv_pw_fwd_launch(a.A[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c00_b, P + bp.c10_w,
+        TRY(linr_conv_pw_fwd_launch(a.A[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c00_w, P + bp.c00_b, P + bp.c10_w,
                                     P + bp.c10_b, a.H[b], c.s));
-        TRY(linr_dual44_fwd_launch(a.H[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c01_b, P + bp.c11_w,
+        TRY(linr_dual44_fwd_launch(a.H[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c01_w, P + bp.c01_b, P + bp.c11_w,
                                    P + bp.c11_b, a.A[b], P + bp.c12_w, P + bp.c12_b, a.M[b], a.I[b], c.s));
     } else {
     // path 0: H[:,0:4] = relu(conv3 8->4 (A));  path 1: H[:,4:8] = relu(A @ conv1_0)
@@ -505,16 +514,16 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
     TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
     if (c.f->nbr_lo && c.f->nbr_mask) {
         // fused backward (csrc/fused.hip): gI (+ gM in the epilogue) -> dual 4->4 backward -> gA with both side paths
-        TRY(linr_conv_bwd_gm_launch(gO, c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI[b], a.gM[b], c.s));
+        TRY(linr_conv_bwd_gm_launch(gO, clo(c), cmk(c), c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI[b], a.gM[b], c.s));
         TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI[b], 8, a.gM[b], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
                                     bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap() ? c.f->nbr_lo : nullptr,
                                     c.f->nbr_mask));
-        TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
+        TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
         TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
         TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
-        TRY(linr_conv_bwd_ga_launch(a.gH[b], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI[b], a.A[b], a.gA[b], c.s));
+        TRY(linr_conv_bwd_ga_launch(a.gH[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI[b], a.A[b], a.gA[b], c.s));
     } else {
     TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI[b], 8, 0));
     // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
@@ -594,8 +603,8 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
-    const int32_t* lo = c.f->nbr_lo;
-    const uint32_t* mk = c.f->nbr_mask;
+    const int32_t* lo = clo(c);
+    const uint32_t* mk = cmk(c);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     const float *pA[7], *pH[7], *pM[7], *pI[7], *pO[7], *p_ab[7], *p_c00w[7], *p_c00b[7], *p_c10w[7], *p_c10b[7], *p_c01w[7],
         *p_c01b[7], *p_c11w[7], *p_c11b[7], *p_c12w[7], *p_c12b[7], *p_bw[7], *p_bb[7];
@@ -707,7 +716,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         if (c.f->nbr_lo && c.f->nbr_mask) {
             // prune conv + MLP + sigmoid + BCE partials in one launch (csrc/fused.hip)
             double* part = bits_acc ? (double*)a.slab + (int64_t)k * nblk : nullptr;
-            TRY(linr_cconv_head_launch(a.O[k], c.f->nbr_lo, c.f->nbr_mask, c.nbr_ld, c.R, P + c.L.pr_w[k], P + c.L.pr_b[k],
+            TRY(linr_cconv_head_launch(a.O[k], clo(c), cmk(c), c.nbr_ld, c.R, P + c.L.pr_w[k], P + c.L.pr_b[k],
                                        a.C[k], P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], P + c.L.h2_b[k],
                                        a.OCC + k, 8, a.P[k], part, c.s));
             if (bits_acc) fused_bits = true;
@@ -754,8 +763,8 @@ static int backward_batched(Ctx& c, float gz_scale) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
-    const int32_t* lo = c.f->nbr_lo;
-    const uint32_t* mk = c.f->nbr_mask;
+    const int32_t* lo = clo(c);
+    const uint32_t* mk = cmk(c);
     {
         const float *hC[8], *hP[8], *hO[8], *h_gC[8], *h_gO[8], *h_prw[8], *h_w1[8], *h_b1[8], *h_w2[8];
         int64_t o_w1[8], o_b1[8], o_w2[8], o_b2[8], o_prw[8], o_prb[8];
@@ -780,7 +789,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
             ProfScope ps(c.ws, 0, 8);
-            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? lo : nullptr, mk));
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
         }
         {   // ... and gO[k] = bwd(gC[k])
             Grp gp = Grp();
@@ -814,7 +823,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
@@ -835,7 +844,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
+                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
         Grp gq = Grp();
         goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
         goffs(gq.act, pH, 7);
@@ -846,7 +855,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
         Grp gq = Grp();
         goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
@@ -865,7 +874,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? lo : nullptr, mk));
+        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
     }
     return 0;
 }
