@@ -452,6 +452,12 @@ static bool wg_cmap() {
     static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 0;
     return v != 0;
 }
+// ... except the 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row), where the decode is hidden
+// and the smaller index stream wins (LINR_WGRAD_CMAP4=0 gives them the table as well)
+static bool wg_cmap4() {
+    static const int v = getenv("LINR_WGRAD_CMAP4") ? atoi(getenv("LINR_WGRAD_CMAP4")) : 1;
+    return v != 0;
+}
 
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
@@ -461,7 +467,7 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
     ProfScope ps(c.ws, 0, 1, use_mfma && cout == 8 && in_ld >= 8);
     if (use_mfma)
         return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
-                                     wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
+                                     (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
     return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
                                     LINR_PAD_ROW, c.ws);
 }
@@ -518,7 +524,7 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
         TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI[b], 8, a.gM[b], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
-                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap() ? c.f->nbr_lo : nullptr,
+                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
                                     c.f->nbr_mask));
         TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
         TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
@@ -844,7 +850,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
+                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
         Grp gq = Grp();
         goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
         goffs(gq.act, pH, 7);
@@ -855,7 +861,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask));
         Grp gq = Grp();
         goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
