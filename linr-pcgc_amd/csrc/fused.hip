@@ -6,7 +6,7 @@
 // becomes 13.5 MB, i.e. one XCD's share (1.7 MB) stays L2-resident across the ~140 conv passes of a training step.
 #include "common.h"
 #include <stdlib.h>
-#define WG_WAVES 8
+#define WG_WAVES 4          // waves per block of the MFMA weight-gradient kernels (same-box A/B: 2 -> 2.765, 4 -> 2.574, 8 -> 2.596 ms/step)
 
 __global__ __launch_bounds__(LINR_BLOCK) void kmap_compress_k(const int32_t* __restrict__ nbr, int64_t nbr_ld, int64_t n,
                                                               int32_t* __restrict__ lo, uint32_t* __restrict__ mask,
