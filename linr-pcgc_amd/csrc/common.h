@@ -37,7 +37,7 @@ struct LinrLinDst {      // pointwise layers: element (ci,co) at w_off + ci*ws_c
     int ws_ci, ws_co;
     int64_t b_off;
 };
-#define LINR_WG_BLOCKS 512   // persistent blocks of every weight-gradient kernel (2 per CU x 8 waves)
+#define LINR_WG_BLOCKS 512   // persistent blocks of every weight-gradient kernel (2 per CU; sweep: tools/wg_blocks_sweep.sh)
 
 // Grouped launches: independent layers of equal shape (the 7 outter blocks, the 8 occupancy heads, whose inputs are the
 // ground-truth occupancy and x_glob during overfitting / encoding) run as ONE launch with gridDim.y = groups.  Group g adds
