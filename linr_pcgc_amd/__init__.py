@@ -1,4 +1,4 @@
-"""linr-pcgc_amd: MI355X-native (gfx950) coding network for LINR-PCGC.
+"""linr_pcgc_amd: MI355X-native (gfx950) coding network for LINR-PCGC.
 
 Host side is Python on PyTorch-ROCm and mirrors the reference's operator surface (models/model_core.py,
 models/upsample.py, models/resnet.py, models/module_utils.py, models/function_utils.py); all arithmetic of the hot path

@@ -82,7 +82,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise LinrError('%s not found: build it with linr-pcgc_amd/csrc/build.sh (or __graft_entry__.build()); '
+            raise LinrError('%s not found: build it with linr_pcgc_amd/csrc/build.sh (or __graft_entry__.build()); '
                             'there is no CPU / PyTorch fallback for the coding network' % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():

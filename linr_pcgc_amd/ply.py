@@ -63,7 +63,7 @@ def read_points(path):
 def write_ply_xyz(path, xyz, binary=True):
     """Minimal writer (tests, exporting decoded frames): float x y z like open3d's write_point_cloud."""
     xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
-    header = 'ply\nformat %s 1.0\ncomment linr-pcgc_amd\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n' \
+    header = 'ply\nformat %s 1.0\ncomment linr_pcgc_amd\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n' \
         % ('binary_little_endian' if binary else 'ascii', xyz.shape[0])
     with open(path, 'wb') as f:
         f.write(header.encode('ascii'))

@@ -1,7 +1,7 @@
 """CPU oracle for the LINR-PCGC hot path.  TEST INFRASTRUCTURE ONLY.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-this package.  The product (``linr-pcgc_amd/``) never imports it and has no CPU fallback.
+this package.  The product (``linr_pcgc_amd/``) never imports it and has no CPU fallback.
 
 Contents
   octree.py       numpy restatement of the per-frame multi-scale prep (custom_dataset.py:259-355)

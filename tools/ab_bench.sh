@@ -6,7 +6,7 @@ F=$1; A=$2; B=$3
 b(){ (cd $R && LINR_SKIP_ROOFLINE=1 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"); }
 for arm in A B A B; do
   src=$A; [ $arm = B ] && src=$B
-  cp $R/$src $R/linr-pcgc_amd/csrc/$F
-  (cd $R && bash linr-pcgc_amd/csrc/build.sh > /dev/null 2>&1)
+  cp $R/$src $R/linr_pcgc_amd/csrc/$F
+  (cd $R && bash linr_pcgc_amd/csrc/build.sh > /dev/null 2>&1)
   echo "$arm ($src): $(b) $(b)"
 done
