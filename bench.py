@@ -5,10 +5,19 @@ first_epoch = 10, one GOP per GPU (no data-path collective).
 
 A step = one frame-epoch of the per-GOP overfit (forward + backward + fused Adam + StepLR on one frame), the unit the
 reference logs as train_time_avg (loot/info.log).  The K timed steps walk the GOP's frames in the reference's order
-(main.py:297-321).  After the timed region the codec leg (model compression, one inference forward + D2H + range coding
-per frame) is timed separately, one frame is decoded and checked bit-exact, and
-    value = epochs * step_time + codec_time_per_frame     [s/frame, whole job: divided by the number of GPUs]
-With the defaults (K = 320 = 10 epochs x 32 frames) the timed region IS config[1]'s overfit.
+(main.py:297-321); `ms_per_step` is their mean.  Whatever K is, the overfit is then carried on to its full
+epochs x frames steps (timed as a second region), so `bits_per_point` and `value` always describe the SAME complete
+training:
+    value = (full overfit wall / frames) + codec_time_per_frame     [s/frame, whole job: divided by the number of GPUs]
+The codec leg (model compression, one inference forward + D2H + range coding + stream files per frame) is timed
+separately, frames are decoded and checked bit-exact.  Warm-up runs the exact timed-loop body (live kernel timing and
+loss accumulation included) and the state is reset in place, so nothing idles the GPU between warm-up and t0; every
+timed step also gets a HIP event so the log shows the per-step spread.
+
+After the headline the BASELINE config[2] flow (300 frames, GOP 32, GOP 0 as serial prefix, GOPs sharded over the GPUs
+with no collective) runs once for real and is reported as `sequence` (whole-sequence wall, phase-B efficiency, ideal
+bound); `--sequence` makes that run the headline (strong scaling).  On one GPU the full-size oracle gradient that the
+CPU baseline computes anyway is compared with the HIP forward/backward tensor by tensor.
 
     python bench.py --gpus 1 --steps 320 --warmup 32
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -41,6 +50,11 @@ def parse():
     ap.add_argument('--config', default='loot10', help='synthetic sequence (linr_pcgc_amd.synthetic.CONFIGS)')
     ap.add_argument('--gop', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sequence', action='store_true', help='headline = the whole BASELINE config[2] sequence (strong scaling)')
+    ap.add_argument('--no-sequence', action='store_true', help='skip the config[2] sequence leg after the headline')
+    ap.add_argument('--seq-frames', type=int, default=300)
+    ap.add_argument('--seq-epochs', type=int, default=EPOCHS)
+    ap.add_argument('--seq-decode-frames', type=int, default=1, help='frames per GOP decoded and checked in the sequence leg')
     ap.add_argument('--cpu-sample-rows', type=int, default=0, help='0 = whole frame 0')
     return ap.parse_args()
 
@@ -117,11 +131,11 @@ def kernel_roofline(model, gop, live, iters=10):
 
 def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
     """The CPU oracle ("port": ME/torchac are not installable, the reference has no CPU path) on the host cores:
-    one overfit step (forward + autograd backward + Adam) + one inference forward on frame 0."""
+    one overfit step (forward + autograd backward + Adam) + one inference forward on frame 0.
+    Also returns the oracle's bits and per-tensor gradients of that step for the full-size parity check."""
     from oracle import network as onet
     scales = []
     for s in gop_info['all_input_info']:
-        n = s['coord'].shape[0]
         scales.append({'coord': s['coord'].cpu().numpy(), 'occ': s['occ'].cpu().numpy(),
                        'offset_tensor': s['offset_tensor'].cpu().numpy(), 'scale_idx': s['scale_idx']})
     rows = sum(len(s['coord']) for s in scales)
@@ -133,16 +147,54 @@ def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
     bits = onet.frame_bits(sd, tsc)
     (bits / point_num).backward()
     g = torch.cat([t.grad.reshape(-1) for t in sd.values()])
-    onet.adam_step(flat_p, g, m, v, 1, 0.01)
+    grads = {k: t.grad.detach().clone() for k, t in sd.items()}
+    onet.adam_step(flat_p, g.clone(), m, v, 1, 0.01)
     t_step = time.time() - t0
     with torch.no_grad():
         t0 = time.time()
         onet.frame_bits({k: v.detach() for k, v in sd.items()}, tsc)
         t_fwd = time.time() - t0
-    return {'value': round(EPOCHS * t_step + t_fwd, 3), 'unit': 's/frame', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': '1 overfit step (%.2f s) + 1 forward (%.2f s) of frame 0 (%d rows), x%d epochs; AC not included'
-                      % (t_step, t_fwd, rows, EPOCHS), 'bits_frame0_init': float(bits.detach())}
+    out = {'value': round(EPOCHS * t_step + t_fwd, 3), 'unit': 's/frame', 'cores': torch.get_num_threads(),
+           'kind': 'port',
+           'sample': '1 overfit step (%.2f s) + 1 forward (%.2f s) of frame 0 (%d rows), x%d epochs; AC not included'
+                     % (t_step, t_fwd, rows, EPOCHS), 'bits_frame0_init': float(bits.detach())}
+    return out, float(bits.detach()), grads
+
+
+# full-size parity (frame 0, 336 k rows, initial parameters): HIP forward/backward against the oracle step the CPU baseline
+# runs anyway.  bits: relative 1e-5; gradients PER TENSOR: max |d| <= 1e-4 * max |g| of that tensor
+# + 1e-9 (fp32 sums of 336 k rows in two different orders).
+PARITY_BITS_RTOL = 1e-5
+PARITY_GRAD_RTOL = 1e-4
+
+
+def full_size_parity(model_sd, frame, point_num, oracle_bits, oracle_grads, scale_num):
+    from linr_pcgc_amd import engine, overfit
+    model = overfit.gen_model(scale_num, 'cuda')
+    model.load_state_dict(model_sd)
+    bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+    engine.net_forward(frame, model.flat_parameters(), 0, 8, None, bits)
+    flat_g = torch.zeros_like(model.flat_parameters())
+    engine.net_backward(frame, model.flat_parameters(), flat_g, 1.0 / float(point_num))
+    torch.cuda.synchronize()
+    got_bits = float(bits)
+    worst, worst_name, off = 0.0, '', 0
+    flat_g = flat_g.cpu()
+    for name, p in model.state_dict().items():
+        n = p.numel()
+        g_hip = flat_g[off:off + n].view(p.shape)
+        g_ref = oracle_grads[name]
+        off += n
+        gmax = float(g_ref.abs().max())
+        err = float((g_hip - g_ref).abs().max())
+        rel = err / (gmax + 1e-30) if gmax > 0 else (0.0 if err <= 1e-9 else float('inf'))
+        if err > 1e-9 and rel > worst:
+            worst, worst_name = rel, name
+    bits_rel = abs(got_bits - oracle_bits) / abs(oracle_bits)
+    ok = bits_rel <= PARITY_BITS_RTOL and worst <= PARITY_GRAD_RTOL
+    return {'ok': bool(ok), 'bits_hip': got_bits, 'bits_oracle': oracle_bits, 'bits_rel_err': bits_rel,
+            'grad_worst_rel_err_per_tensor': worst, 'grad_worst_tensor': worst_name, 'tensors': len(oracle_grads),
+            'tolerance': {'bits_rel': PARITY_BITS_RTOL, 'grad_rel_to_own_tensor_max': PARITY_GRAD_RTOL}}
 
 
 def log(msg):
@@ -160,6 +212,37 @@ def host_threads():
     except AttributeError:
         n = os.cpu_count() or 1
     return max(1, min(n, 16))
+
+
+def sequence_leg(args, rank, world, dist):
+    """BASELINE config[2] for real: seq_frames frames in GOPs of args.gop, GOP 0 from scratch on rank 0, the other GOPs
+    warm-started from its checkpoint and dealt over the ranks (static longest-first deal so that every input is staged in
+    HBM before the timed region starts), each GOP overfitted, encoded to files and spot-decoded.  Strong scaling: the
+    work is fixed, `sec_per_frame` = whole-sequence wall / frames."""
+    import shutil
+    import tempfile
+    from linr_pcgc_amd import run as seq_run
+    out_dir = None
+    if rank == 0:
+        out_dir = tempfile.mkdtemp(prefix='linr_seq_')
+    if dist is not None:
+        box = [out_dir]
+        dist.broadcast_object_list(box, src=0)
+        out_dir = box[0]
+    sargs = seq_run.parse(['--config', args.config, '--frames', str(args.seq_frames), '--gop', str(args.gop),
+                           '--first-epoch', str(args.seq_epochs), '--others-epoch', str(args.seq_epochs), '--out', out_dir,
+                           '--decode'])
+    try:
+        summary, _ = seq_run.run_sequence_job(sargs, rank, world, dist, stage_all=True, decode_frames=args.seq_decode_frames)
+    finally:
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    summary['workload'] = ('BASELINE config[2] stand-in: synthetic %s, %d frames, GOP %d, first_epoch=others_epoch=%d, GOP 0 serial '
+                           'prefix then GOPs over %d GPU(s), no collective; %d frame(s) per GOP decoded and compared'
+                           % (args.config, args.seq_frames, args.gop, args.seq_epochs, world, args.seq_decode_frames))
+    return summary
 
 
 def main():
@@ -182,23 +265,12 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL; gloo only for the 1-GPU rehearsal
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend)
-    from linr_pcgc_amd import codec, overfit, synthetic
-    from linr_pcgc_amd.model_core import FlatAdam
-
-    # rank r owns GOP r of the sequence: frames [gop*r, gop*(r+1))  (GOPs are independent: no collective)
-    t_setup = time.time()
-    clouds = [synthetic.sequence_frame(args.config, rank * args.gop + t) for t in range(args.gop)]
-    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
-    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
-    init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    setup_s = time.time() - t_setup
-    log('setup done: %d frames, frame0 %d points / %d rows, %d scales' % (len(gop), gop.point_nums[0], gop.frames[0].rows, gop.scale_num))
+        from linr_pcgc_amd.run import init_dist
+        dist = init_dist(local)
+    from linr_pcgc_amd import _lib, codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    import ctypes
+    L = _lib.lib()
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,58 +278,112 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up on a throw-away copy of the optimiser state so the timed steps start from the seeded initialisation
-    from linr_pcgc_amd.model_core import train_step
+    if args.sequence:
+        # headline = the whole sequence (strong scaling); a short ramp so the first GOP does not start at idle clocks
+        seq = sequence_leg(args, rank, world, dist)
+        if rank == 0:
+            out = {'metric': 'encode_sec_per_frame', 'value': seq['sec_per_frame'], 'unit': 's/frame', 'n_gpus': world,
+                   'steps': args.seq_frames * args.seq_epochs, 'warmup': 0,
+                   'ms_per_step': round(seq['wall_s'] * 1e3 / (args.seq_frames * args.seq_epochs), 4),
+                   'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                   'config': {'workload': seq['workload'], 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
+                   'bits_per_point': seq['bits_per_point'], 'sequence': seq, 'roofline': None, 'cpu_baseline': None}
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # rank r owns GOP r of the sequence: frames [gop*r, gop*(r+1))  (GOPs are independent: no collective)
+    t_setup = time.time()
+    clouds = [synthetic.sequence_frame_device(args.config, rank * args.gop + t, 'cuda') for t in range(args.gop)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    del clouds
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    init_flat = model.flat_parameters().detach().clone()           # device copy: the reset before t0 is one D2D copy
+    setup_s = time.time() - t_setup
+    log('setup done: %d frames, frame0 %d points / %d rows, %d scales' % (len(gop), gop.point_nums[0], gop.frames[0].rows, gop.scale_num))
+
     opt = FlatAdam(model)
+    total_steps = EPOCHS * len(gop)
+    # everything the timed loop touches exists before the ramp: the event pool of the live kernel timing, the float64
+    # accumulators and their (lazily loaded) torch kernels, the per-step events
+    _lib.check(L.linr_prof_enable(1), 'linr_prof_enable')     # creates the event pairs ...
+    L.linr_prof_enable(0)                                     # ... and stops; sampled steps switch it on (mode 2)
+    acc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    epoch_loss = []
+
+    def body(i, sample):
+        """One iteration of the timed loop - warm-up and ramp run exactly this."""
+        j = i % len(gop)
+        if sample:
+            L.linr_prof_enable(2)
+        bits = train_step(model, opt, gop.frames[j], gop.point_nums[j])
+        if sample:
+            L.linr_prof_enable(0)
+        acc.add_(bits / gop.point_nums[j])
+        if j == len(gop) - 1:
+            opt.clamp_lr(4e-4)
+            epoch_loss.append(acc.clone())
+            acc.zero_()
+
     # a fresh box starts at idle clocks (sclk level 1): ramp the device with ~1 s of the same steps before the W warm-up
     # steps, otherwise the first few hundred timed steps run ~10 % slow (measured: 3.22 vs 2.92 ms/step)
     t_ramp, i_ramp = time.time(), 0
     while time.time() - t_ramp < args.ramp_s:
         for _ in range(32):
-            train_step(model, opt, gop.frames[i_ramp % len(gop)], gop.point_nums[i_ramp % len(gop)])
+            body(i_ramp, i_ramp % PROF_EVERY == 0)
             i_ramp += 1
         torch.cuda.synchronize()
     for i in range(args.warmup):
-        train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)])
-    model.load_state_dict(init_sd)
-    opt = FlatAdam(model)
-
-    log('warm-up done')
-    from linr_pcgc_amd import _lib
-    import ctypes
-    L = _lib.lib()
-    _lib.check(L.linr_prof_enable(1), 'linr_prof_enable')     # event pairs around the two roofline kernels ...
-    L.linr_prof_enable(0)                                     # ... in every PROF_EVERY-th timed step (a pair costs ~10 us of stream time)
+        body(i, i % PROF_EVERY == 0)
+    # reset to the seeded initialisation IN PLACE (one D2D copy + three memsets on the stream; nothing is allocated and
+    # the host does not wait), drop the warm-up's samples
+    model.flat_parameters().copy_(init_flat)
+    opt.reset()
+    acc.zero_()
+    epoch_loss.clear()
+    barrier()
+    L.linr_prof_enable(1)                                     # clears the records (the events are reused, none is created)
+    L.linr_prof_enable(0)
+    log('warm-up done (%d ramp + %d warm-up steps)' % (i_ramp, args.warmup))
     barrier()
     t0 = time.time()
-    acc = torch.zeros(1, dtype=torch.float64, device='cuda')
-    epoch_loss = []
+    step_ev[0].record()
     for i in range(args.steps):
-        j = i % len(gop)
-        if i % PROF_EVERY == 0:
-            L.linr_prof_enable(2)
-        bits = train_step(model, opt, gop.frames[j], gop.point_nums[j])
-        if i % PROF_EVERY == 0:
-            L.linr_prof_enable(0)
-        acc += bits / gop.point_nums[j]
-        if j == len(gop) - 1:
-            opt.clamp_lr(4e-4)
-            epoch_loss.append(acc.clone())
-            acc.zero_()
+        body(i, i % PROF_EVERY == 0)
+        step_ev[i + 1].record()
     barrier()
     elapsed = time.time() - t0
+    per_step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     live = {}
     for kind, name in ((0, 'wgrad'), (1, 'conv')):
         tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
-        _lib.check(_lib.lib().linr_prof_read(kind, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)), 'linr_prof_read')
+        _lib.check(L.linr_prof_read(kind, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)), 'linr_prof_read')
         live[name] = (tot.value, nl.value, npass.value)
+    # carry the overfit on to its full length (second timed region) so that bits/point and value describe one training
+    rest = max(0, total_steps - args.steps)
+    barrier()
+    t1 = time.time()
+    for i in range(args.steps, args.steps + rest):
+        body(i, False)
+    barrier()
+    rest_s = time.time() - t1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed, rest_s], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed, rest_s = float(t[0]), float(t[1])
     ms_per_step = elapsed * 1e3 / args.steps
+    steps_done = args.steps + rest
+    full_overfit_s = (elapsed + rest_s) * (total_steps / float(steps_done))       # steps > total: scaled back to one overfit
     losses = [float(x) / len(gop) for x in epoch_loss]
-    log('timed %d steps: %.3f ms/step, epoch losses %s' % (args.steps, ms_per_step, ['%.4f' % x for x in losses]))
+    srt = sorted(per_step_ms)
+    step_stats = {'min': round(srt[0], 4), 'median': round(srt[len(srt) // 2], 4), 'max': round(srt[-1], 4),
+                  'first8': [round(x, 3) for x in per_step_ms[:8]], 'sum_over_wall': round(sum(per_step_ms) / (elapsed * 1e3), 4)}
+    log('timed %d steps: %.3f ms/step (events: min %.3f median %.3f max %.3f); full overfit %d steps %.3f s; epoch losses %s'
+        % (args.steps, ms_per_step, srt[0], srt[len(srt) // 2], srt[-1], steps_done, elapsed + rest_s, ['%.4f' % x for x in losses]))
 
     # codec leg (outside the K timed steps): model compression + per-frame forward + D2H + AC + the bitstream files of
     # encoder.py:13-18,81-118 (T_write of the metric), then the lossless check
@@ -293,7 +419,7 @@ def main():
     decode_s = (time.time() - t0) / nd
     log('decode frames 0..%d: %.3f s/frame, lossless=%s' % (nd - 1, decode_s, lossless))
 
-    overfit_s_per_frame = EPOCHS * ms_per_step / 1e3
+    overfit_s_per_frame = full_overfit_s / len(gop)
     value = (overfit_s_per_frame + codec_s_per_frame) / world
 
     out = None
@@ -307,8 +433,14 @@ def main():
                                       % (args.config, gop.point_nums[0], gop.frames[0].rows, gop.scale_num, len(gop), EPOCHS),
                           'frames_per_gpu': len(gop), 'epochs': EPOCHS, 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
                'bits_per_point': round(enc['bpp']['bpp_all'], 5),
+               'bits_per_point_after_steps': steps_done,
                'bpp_components': {k: round(v, 6) for k, v in enc['bpp'].items()},
                'lossless_decode_frames0to3': lossless,
+               'full_overfit': {'steps': steps_done, 'seconds': round(elapsed + rest_s, 4),
+                                'ms_per_step': round((elapsed + rest_s) * 1e3 / steps_done, 4),
+                                'note': 'value and bits_per_point both come from this complete %d-epoch overfit; ms_per_step is '
+                                        'the mean of its first `steps` steps' % EPOCHS},
+               'per_step_ms_hip_events': step_stats,
                'components_s_per_frame': {'overfit': round(overfit_s_per_frame, 5), 'codec_modelcomp_fwd_ac_write': round(codec_s_per_frame, 5),
                                           'decode_s_per_frame_4_in_flight': round(decode_s, 4)},
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
@@ -316,18 +448,36 @@ def main():
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
         out['roofline'] = None if os.environ.get('LINR_SKIP_ROOFLINE') else kernel_roofline(model, gop, live)
         log('roofline: %s' % out['roofline'])
+    parity_ok = True
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_threads())
             log('cpu baseline on %d threads ...' % host_threads())
-            out['cpu_baseline'] = cpu_baseline(init_sd, gop.infos[0], gop.point_nums[0], args.cpu_sample_rows)
+            out['cpu_baseline'], o_bits, o_grads = cpu_baseline(init_sd, gop.infos[0], gop.point_nums[0], args.cpu_sample_rows)
+            out['full_size_parity'] = full_size_parity(init_sd, gop.frames[0], gop.point_nums[0], o_bits, o_grads, gop.scale_num)
+            parity_ok = out['full_size_parity']['ok']
+            log('full-size parity vs oracle: %s' % out['full_size_parity'])
         else:
             out['cpu_baseline'] = None
+    # free the headline's GOP before the sequence leg stages its own frames
+    del gop, enc, dec
+    torch.cuda.empty_cache()
+    seq = None
+    if not args.no_sequence:
+        try:
+            seq = sequence_leg(args, rank, world, dist)
+            log('sequence leg: %s' % seq)
+        except Exception as e:          # the headline above is already measured: report the failure instead of losing the line
+            seq = {'error': repr(e)}
+            log('sequence leg failed: %r' % (e,))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out['sequence'] = seq
         assert lossless, 'decoded geometry differs from the input'
         print(json.dumps(out))
+        assert parity_ok, 'HIP forward/backward differs from the CPU oracle at full size: %s' % out.get('full_size_parity')
 
 
 if __name__ == '__main__':

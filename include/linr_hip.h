@@ -6,7 +6,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _h (host); the caller (PyTorch's caching
- *     allocator) owns all memory; nothing is allocated, freed or retained across calls.
+ *     allocator) owns all memory; nothing is allocated, freed or retained across calls.  The library keeps no mutable
+ *     global state on the data path: calls on different streams may run from different host threads (the GOP decoder
+ *     does).  The two optional process-wide aids - the live kernel timing of linr_prof_* and the auxiliary
+ *     weight-gradient stream of LINR_WGRAD_STREAM=1 - are mutex-guarded.
  *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no host synchronisation.
  *   - return value: 0 on success, >0 = hipError_t, <0 = argument error (LINR_E*).  No exceptions cross.
  *   - feature matrices are row-major float32 [rows, ld] with an explicit leading dimension `*_ld` so that a
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 1
+#define LINR_ABI_VERSION 2
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -40,9 +43,12 @@ extern "C" {
                                 absent neighbours are read from it instead of being branched around      */
 
 LINR_API int linr_abi_version(void);
-/* number of float parameters of LINR_PCGC_Model(scale_num, hidden=8, block_layers=1, outstage=8, instage=1)
- * in parameters() order (models/model_core.py:31-35, models/upsample.py:43-76).  54,712 for scale_num = 7. */
-LINR_API int64_t linr_param_count(int32_t scale_num);
+/* number of float parameters of LINR_PCGC_Model(scale_num, hidden=8, block_layers, outstage=8, instage=1)
+ * in parameters() order (models/model_core.py:31-35, models/upsample.py:43-76; block_layers = main.py:521, the
+ * Inception layers of block_in's ResNetBlock, 1..4 - the outter blocks always have one, upsample.py:72-76).
+ * 54,712 for scale_num = 7, block_layers = 1.  hidden_channel_conv (main.py:520) is fixed at 8: the kernels are
+ * specialised for 8-wide rows. */
+LINR_API int64_t linr_param_count(int32_t scale_num, int32_t block_layers);
 
 /* ---- kernel map -------------------------------------------------------------------------------------------
  * Replaces MinkowskiEngine's CoordinateManager insert + kernel-map generation that every ME.SparseTensor /
@@ -121,7 +127,7 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
  * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,
  * 0 = stop (records are kept).  An event pair costs a few microseconds of stream time, so bench.py samples every 8th
- * step.  Not thread-safe; 4096 launches in total. */
+ * step.  Mutex-guarded; 2048 launches in total. */
 LINR_API int linr_prof_enable(int32_t mode);
 LINR_API int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes);
 
@@ -170,6 +176,8 @@ typedef struct linr_frame {
     int64_t rows;                 /* total rows over all scales, < 2^27 - 1 (32-bit byte offsets of the gathers)  */
     int32_t n_scales;             /* scales present in this frame (<= model scale_num)                      */
     int32_t model_scale_num;      /* LINR_PCGC_Model scale_num (fixes the parameter layout)                 */
+    int32_t block_layers;         /* Inception layers of block_in (main.py:521); 0 is read as 1              */
+    int32_t reserved_;
     const int64_t* row_off_h;     /* HOST [n_scales+1] first row of each scale                              */
     const int32_t* scale_idx_h;   /* HOST [n_scales]  which scale embedding / scale MLP each scale uses     */
     const int32_t* nbr;           /* [27][nbr_ld] kernel map with global row ids                            */
@@ -180,7 +188,7 @@ typedef struct linr_frame {
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
 } linr_frame;
 
-LINR_API size_t linr_net_arena_bytes(int64_t rows);
+LINR_API size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers);
 /* stages [stage_begin, stage_end) of the 8-stage head; stage_begin == 0 also runs scale context + block_in.
  * The encoder calls (0, 8); the decoder calls (k, k+1) after writing decoded occupancy column k-1 into
  * frame->occ, which executes the identical launches => bitwise identical probabilities (models/upsample.py:249-295).
@@ -194,10 +202,14 @@ LINR_API int linr_net_backward(const linr_frame* f, const float* params, float* 
 
 /* One iteration of main.py:305-321 in a single call: forward (bits added into bits_acc), backward of
  * gscale * bits (gscale = 1/point_num), deterministic gradient reduction and the fused Adam update of `params`
- * (hyper-parameters as in linr_adam_step).  Nothing synchronises with the host. */
+ * (torch.optim.Adam with L2 weight decay; `step` = this update's 1-based count, bias corrections computed in double).
+ * scale_steps_h: HOST [model_scale_num] 1-based step counts of the per-scale context MLPs, or NULL.  With it the
+ * update follows torch.optim.Adam's handling of parameters without a gradient: the MLP of a scale this frame does not
+ * contain (custom_dataset.py:325) is skipped entirely and the others use their own step count; NULL updates every
+ * parameter with `step` (a zero gradient still decays weights and moments).  Nothing synchronises with the host. */
 LINR_API int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
-                        float* exp_avg, float* exp_avg_sq, double step_size, double bc2_sqrt, double beta1,
-                        double beta2, double eps, double weight_decay, double* bits_acc, void* stream);
+                        float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
+                        double beta1, double beta2, double eps, double weight_decay, double* bits_acc, void* stream);
 
 /* ---- arithmetic-coder feed (host side) -----------------------------------------------------------------------
  * Replaces torchac.encode_float_cdf / decode_float_cdf as used by BinaryArithmeticCoding

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblinr_hip.so')
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -17,14 +17,15 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
 class LinrFrame(ctypes.Structure):
     """struct linr_frame (include/linr_hip.h)."""
-    _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('row_off_h', c_ptr),
+    _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('block_layers', c_i32),
+                ('reserved_', c_i32), ('row_off_h', c_ptr),
                 ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('nbr_lo', c_ptr), ('nbr_mask', c_ptr),
                 ('offset_feat', c_ptr), ('occ', c_ptr)]
 
 
 _PROTOS = {
     'linr_abi_version': (ctypes.c_int, []),
-    'linr_param_count': (c_i64, [c_i32]),
+    'linr_param_count': (c_i64, [c_i32, c_i32]),
     'linr_kmap_workspace_bytes': (c_size, [c_i64]),
     'linr_kmap_build': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
@@ -56,12 +57,12 @@ _PROTOS = {
     'linr_bce_bits_bwd': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_i64, c_f32, c_ptr, c_ptr]),
     'linr_adam_step': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_f64,
                                       c_ptr]),
-    'linr_net_arena_bytes': (c_size, [c_i64]),
+    'linr_net_arena_bytes': (c_size, [c_i64, c_i32]),
     'linr_net_forward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr,
                                         c_ptr]),
     'linr_net_backward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr]),
     'linr_net_train_step': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr, c_f64,
-                                           c_f64, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
+                                           c_i64, c_ptr, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
     'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),

@@ -37,6 +37,17 @@ struct LinrLinDst {      // pointwise layers: element (ci,co) at w_off + ci*ws_c
     int ws_ci, ws_co;
     int64_t b_off;
 };
+// per-range Adam schedule (csrc/loss_optim.hip: adam_k); 16 = MAX_SCALES of the executor
+struct LinrAdamRanges {
+    int count;               // 0: none
+    int64_t begin, len;      // range r = [begin + r*len, begin + (r+1)*len)
+    int active[16];
+    float step_size[16], bc2_sqrt[16];
+};
+__attribute__((visibility("hidden")))
+int linr_adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double step_size,
+                     double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,
+                     const LinrAdamRanges* rg, hipStream_t s);
 #define LINR_WG_BLOCKS 512   // persistent blocks of every weight-gradient kernel (2 per CU; sweep: tools/wg_blocks_sweep.sh)
 
 // Grouped launches: independent layers of equal shape (the 7 outter blocks, the 8 occupancy heads, whose inputs are the
@@ -103,7 +114,7 @@ int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* 
                             const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s,
+                            const float* w10, const float* gI, const float* A, float* gA, unsigned flags, hipStream_t s,
                             const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* P,

@@ -675,15 +675,16 @@ int linr_conv_bwd_gm_launch(const float* gO, const int32_t* lo, const uint32_t* 
     return linr_launch_rc();
 }
 
-// gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
+// gA = (bwd(gH[:,0:4]; W00) + gI (+ old gA: LINR_ACCUM) + gH[:,4:8] @ W10^T) (* (A > 0): LINR_RELU_MASK)
 int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w00,
-                            const float* w10, const float* gI, const float* A, float* gA, hipStream_t s, const Grp* gp,
-                            int ngroups) {
+                            const float* w10, const float* gI, const float* A, float* gA, unsigned flags, hipStream_t s,
+                            const Grp* gp, int ngroups) {
     if (n == 0) return 0;
+    if ((flags & LINR_RELU_MASK) && !A) return LINR_EINVAL;
     const Grp g0 = gp ? *gp : Grp();
     PwArgs pw = {w10, nullptr, gH, nullptr};
     cconv_mfma_k<4, 8, true, 4, 4><<<dim3(linr_grid(n, LINR_CONV_BLOCK), ngroups), LINR_CONV_BLOCK, 0, s>>>(
-        gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8, gA, 8, LINR_RELU_MASK, HeadArgs(), pw, g0);
+        gH, 8, lo, mask, ld, n, w00, nullptr, gI, 8, A, 8, gA, 8, flags & (LINR_RELU_MASK | LINR_ACCUM), HeadArgs(), pw, g0);
     return linr_launch_rc();
 }
 

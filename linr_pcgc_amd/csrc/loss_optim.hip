@@ -99,12 +99,23 @@ extern "C" int linr_bce_bits_bwd(const float* p, const float* target, int32_t ta
 }
 
 // torch.optim.Adam single-tensor update (amsgrad=False, maximize=False), L2 weight decay folded into the gradient.
+// Optional per-range schedule (LinrAdamRanges): torch.optim.Adam skips a parameter whose .grad is None and keeps a step
+// counter per parameter.  The scale-context MLP of a scale that a frame does not contain (custom_dataset.py:325 stops
+// early on min_point_num) gets no gradient in the reference (zero_grad(set_to_none=True) is torch 2's default), so its
+// 392 parameters are left untouched on that frame - no weight decay, no moment decay - and their bias corrections follow
+// their own step count.  Range r covers [begin + r*len, begin + (r+1)*len); everything outside uses the global scalars.
 __global__ __launch_bounds__(LINR_BLOCK) void adam_k(float* __restrict__ params, const float* __restrict__ grads,
                                                      float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                      float step_size, float bc2_sqrt, float beta1, float omb1, float beta2,
-                                                     float omb2, float eps, float wd) {
+                                                     float omb2, float eps, float wd, LinrAdamRanges rg) {
     const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (i >= n) return;
+    if (rg.count > 0 && i >= rg.begin && i < rg.begin + (int64_t)rg.count * rg.len) {
+        const int r = (int)((i - rg.begin) / rg.len);
+        if (!rg.active[r]) return;
+        step_size = rg.step_size[r];
+        bc2_sqrt = rg.bc2_sqrt[r];
+    }
     const float p = params[i];
     const float g = fmaf(wd, p, grads[i]);
     const float mi = m[i] * beta1 + omb1 * g;           // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
@@ -115,14 +126,23 @@ __global__ __launch_bounds__(LINR_BLOCK) void adam_k(float* __restrict__ params,
     params[i] = p - step_size * (mi / denom);
 }
 
-extern "C" int linr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                              double step_size, double bc2_sqrt, double beta1, double beta2, double eps,
-                              double weight_decay, void* stream) {
+int linr_adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double step_size,
+                     double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,
+                     const LinrAdamRanges* rg, hipStream_t s) {
     if (n < 0) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return LINR_EINVAL;
-    adam_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(
+    LinrAdamRanges none;
+    none.count = 0; none.begin = 0; none.len = 1;
+    adam_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(
         params, grads, exp_avg, exp_avg_sq, n, (float)step_size, (float)bc2_sqrt, (float)beta1, (float)(1.0 - beta1),
-        (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+        (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, rg ? *rg : none);
     return linr_launch_rc();
+}
+
+extern "C" int linr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              double step_size, double bc2_sqrt, double beta1, double beta2, double eps,
+                              double weight_decay, void* stream) {
+    return linr_adam_launch(params, grads, exp_avg, exp_avg_sq, n, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay,
+                            nullptr, (hipStream_t)stream);
 }

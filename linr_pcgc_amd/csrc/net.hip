@@ -10,24 +10,32 @@
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
+#include <mutex>
+#include <atomic>
 
 #define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
 #define MAX_SCALES 16
 
 // ---- parameter layout (reference parameters() order) ------------------------------------------------------------
+#define MAX_BL 4              // block_layers of block_in (main.py:521 default 1; the outter blocks always have 1, upsample.py:72-76)
+struct IncP {                 // one InceptionResNet layer (models/resnet.py:7-60)
+    int64_t c00_w, c00_b;     // conv0_0  conv3 8->4
+    int64_t c01_w, c01_b;     // conv0_1  conv3 4->4
+    int64_t c10_w, c10_b;     // conv1_0  1x1 8->4   kernel [8][4]
+    int64_t c11_w, c11_b;     // conv1_1  conv3 4->4
+    int64_t c12_w, c12_b;     // conv1_2  1x1 4->4   kernel [4][4]
+};
 struct BlockP {
     int cin;
-    int64_t a_w, a_b;        // .0   conv3 cin->8
-    int64_t c00_w, c00_b;    // .2.layers.0.conv0_0  conv3 8->4
-    int64_t c01_w, c01_b;    // conv0_1  conv3 4->4
-    int64_t c10_w, c10_b;    // conv1_0  1x1 8->4   kernel [8][4]
-    int64_t c11_w, c11_b;    // conv1_1  conv3 4->4
-    int64_t c12_w, c12_b;    // conv1_2  1x1 4->4   kernel [4][4]
-    int64_t b_w, b_b;        // .3   conv3 8->8
+    int nl;                   // Inception layers of the ResNetBlock (.2.layers.0 .. nl-1)
+    int64_t a_w, a_b;         // .0   conv3 cin->8
+    IncP inc[MAX_BL];
+    int64_t b_w, b_b;         // .3   conv3 8->8
 };
 
 struct Layout {
     int S;
+    int BL;                                        // block_layers of block_in
     int64_t emb;                                   // [S][8]
     int64_t m0_w[MAX_SCALES], m0_b[MAX_SCALES];    // Linear(15,16): weight [16][15]
     int64_t m2_w[MAX_SCALES], m2_b[MAX_SCALES];    // Linear(16,8):  weight [8][16]
@@ -40,42 +48,47 @@ struct Layout {
 
 static int64_t take(int64_t& cur, int64_t n) { int64_t o = cur; cur += n; return o; }
 
-static void layout_block(BlockP& b, int cin, int64_t& cur) {
+static void layout_block(BlockP& b, int cin, int nl, int64_t& cur) {
     b.cin = cin;
+    b.nl = nl;
     b.a_w = take(cur, 27 * cin * 8);  b.a_b = take(cur, 8);
-    b.c00_w = take(cur, 27 * 8 * 4);  b.c00_b = take(cur, 4);
-    b.c01_w = take(cur, 27 * 4 * 4);  b.c01_b = take(cur, 4);
-    b.c10_w = take(cur, 8 * 4);       b.c10_b = take(cur, 4);
-    b.c11_w = take(cur, 27 * 4 * 4);  b.c11_b = take(cur, 4);
-    b.c12_w = take(cur, 4 * 4);       b.c12_b = take(cur, 4);
+    for (int l = 0; l < nl; ++l) {
+        IncP& q = b.inc[l];
+        q.c00_w = take(cur, 27 * 8 * 4);  q.c00_b = take(cur, 4);
+        q.c01_w = take(cur, 27 * 4 * 4);  q.c01_b = take(cur, 4);
+        q.c10_w = take(cur, 8 * 4);       q.c10_b = take(cur, 4);
+        q.c11_w = take(cur, 27 * 4 * 4);  q.c11_b = take(cur, 4);
+        q.c12_w = take(cur, 4 * 4);       q.c12_b = take(cur, 4);
+    }
     b.b_w = take(cur, 27 * 8 * 8);    b.b_b = take(cur, 8);
 }
 
-static bool make_layout(Layout& L, int S) {
-    if (S < 1 || S > MAX_SCALES) return false;
+static bool make_layout(Layout& L, int S, int BL = 1) {
+    if (S < 1 || S > MAX_SCALES || BL < 1 || BL > MAX_BL) return false;
     L.S = S;
+    L.BL = BL;
     int64_t cur = 0;
     L.emb = take(cur, (int64_t)S * 8);
     for (int s = 0; s < S; ++s) {
         L.m0_w[s] = take(cur, 16 * 15); L.m0_b[s] = take(cur, 16);
         L.m2_w[s] = take(cur, 8 * 16);  L.m2_b[s] = take(cur, 8);
     }
-    layout_block(L.block_in, 8, cur);
+    layout_block(L.block_in, 8, BL, cur);
     for (int k = 0; k < 8; ++k) {
         L.h0_w[k] = take(cur, 24 * 8); L.h0_b[k] = take(cur, 24);
         L.h2_w[k] = take(cur, 24);     L.h2_b[k] = take(cur, 1);
     }
     for (int k = 0; k < 8; ++k) { L.pr_w[k] = take(cur, 27 * 8 * 8); L.pr_b[k] = take(cur, 8); }
-    for (int k = 0; k < 7; ++k) layout_block(L.outter[k], k + 1, cur);
+    for (int k = 0; k < 7; ++k) layout_block(L.outter[k], k + 1, 1, cur);
     L.total = cur;
     return true;
 }
 
 extern "C" int linr_abi_version(void) { return LINR_ABI_VERSION; }
 
-extern "C" int64_t linr_param_count(int32_t scale_num) {
+extern "C" int64_t linr_param_count(int32_t scale_num, int32_t block_layers) {
     Layout L;
-    return make_layout(L, scale_num) ? L.total : (int64_t)LINR_EINVAL;
+    return make_layout(L, scale_num, block_layers) ? L.total : (int64_t)LINR_EINVAL;
 }
 
 // ---- arena ------------------------------------------------------------------------------------------------------
@@ -89,6 +102,8 @@ struct Arena {
     // forward (saved for backward)
     float *MIX, *HID, *X0, *OCC;
     float *A[8], *H[8], *M[8], *I[8], *O[8];
+    float *Hx[MAX_BL - 1], *Mx[MAX_BL - 1], *Ix[MAX_BL - 1];        // Inception layers 1.. of block_in (block_layers > 1)
+    float *gIx[MAX_BL - 1], *gMx[MAX_BL - 1], *gHx[MAX_BL - 1];
     float *C[8], *HH[8], *Z[8], *P[8];
     // backward scratch
     float *gZ, *gHH, *gXG, *gX0, *gHID;
@@ -114,7 +129,7 @@ static size_t slab_need(int64_t rows) {
     return (a > b ? a : b) + 64;
 }
 
-static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
+static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params, int block_layers = 1) {
     a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
     a.MIX = arena_mat(a, 16); a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
     for (int b = 0; b < 8; ++b) {
@@ -129,6 +144,13 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
         a.gC[i] = arena_mat(a, 8); a.gO[i] = arena_mat(a, 8); a.gI[i] = arena_mat(a, 8); a.gA[i] = arena_mat(a, 8);
         a.gH[i] = arena_mat(a, 8); a.gM[i] = arena_mat(a, 4);
     }
+    for (int l = 0; l + 1 < MAX_BL; ++l) {
+        a.Hx[l] = a.Mx[l] = a.Ix[l] = a.gIx[l] = a.gMx[l] = a.gHx[l] = nullptr;
+        if (l + 1 < block_layers) {
+            a.Hx[l] = arena_mat(a, 8); a.Mx[l] = arena_mat(a, 4); a.Ix[l] = arena_mat(a, 8);
+            a.gIx[l] = arena_mat(a, 8); a.gMx[l] = arena_mat(a, 4); a.gHx[l] = arena_mat(a, 8);
+        }
+    }
     a.n_params = n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;
     a.GSUM = base ? base + a.cur : nullptr; a.cur += (n_params + 15) & ~(int64_t)15;
@@ -140,12 +162,14 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params) {
     a.cur += (int64_t)((a.slab_bytes + 3) / 4);
 }
 
-extern "C" size_t linr_net_arena_bytes(int64_t rows) {
+extern "C" size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers) {
     if (rows < 0) return 0;
+    if (block_layers < 1) block_layers = 1;
+    if (block_layers > MAX_BL) return 0;
     Arena a;
     Layout L;
-    make_layout(L, MAX_SCALES);                               // sized for the largest model: the arena is model-agnostic
-    make_arena(a, rows, nullptr, L.total);
+    make_layout(L, MAX_SCALES, block_layers);                 // sized for the largest scale_num: one arena serves any model of this depth
+    make_arena(a, rows, nullptr, L.total, block_layers);
     return (size_t)a.cur * sizeof(float) + 64;
 }
 
@@ -333,8 +357,10 @@ static hipStream_t g_aux = nullptr;
 static hipEvent_t g_ev[64];
 static int g_ev_next = 0;
 static bool g_aux_ok = false;
+static std::mutex g_aux_mu;          // the pool is process-wide; executor calls may come from several host threads
 
 static bool aux_init() {
+    std::lock_guard<std::mutex> lk(g_aux_mu);
     if (g_aux_ok) return true;
     // off by default: since the layers run as grouped launches every kernel fills the chip on its own and a second stream
     // only adds contention (measured 3.02 ms/step with it, 2.83 without); LINR_WGRAD_STREAM=1 turns it on
@@ -350,6 +376,7 @@ static bool aux_init() {
 // everything issued on `from` so far happens-before whatever is issued on `to` next
 static int stream_order(hipStream_t from, hipStream_t to) {
     if (from == to) return 0;
+    std::lock_guard<std::mutex> lk(g_aux_mu);
     hipEvent_t ev = g_ev[g_ev_next];
     g_ev_next = (g_ev_next + 1) & 63;
     TRY(linr_hip_rc(hipEventRecord(ev, from)));
@@ -359,10 +386,11 @@ static int stream_order(hipStream_t from, hipStream_t to) {
 // ---- live kernel timing for bench.py's roofline (include/linr_hip.h: linr_prof_*) --------------------------------------
 // While enabled, every launch of the two roofline kernels inside the executor (kind 0: spconv_wgrad_mfma_k<2,8>,
 // kind 1: cconv_mfma_k<8,8,fwd,plain epilogue>) is bracketed by an event pair on its own stream; `passes` counts the
-// row passes (groups) of a launch.  Measurement aid only: not thread-safe, nothing is recorded when disabled.
+// row passes (groups) of a launch.  Measurement aid only: mutex-guarded, nothing is recorded (and no lock is taken) when disabled.
 #define LINR_PROF_MAX 2048
 struct ProfRec { hipEvent_t e0, e1; int passes; };
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;                    // guards the two vectors below
 static std::vector<ProfRec> g_prof[2];          // used records
 static std::vector<ProfRec> g_prof_free;        // pre-created event pairs (creating events in the hot path costs ~20 us each)
 
@@ -370,7 +398,9 @@ struct ProfScope {
     hipStream_t s; int kind; bool live;
     ProfRec r;
     ProfScope(hipStream_t s_, int kind_, int passes, bool want = true) : s(s_), kind(kind_), live(false) {
-        if (!want || !g_prof_on || g_prof_free.empty()) return;
+        if (!want || !g_prof_on.load(std::memory_order_relaxed)) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_free.empty()) return;
         r = g_prof_free.back();
         g_prof_free.pop_back();
         r.passes = passes;
@@ -380,6 +410,7 @@ struct ProfScope {
     ~ProfScope() {
         if (!live) return;
         (void)hipEventRecord(r.e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof[kind].push_back(r);
     }
 };
@@ -387,6 +418,7 @@ struct ProfScope {
 extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kept), 1: clear + start, 2: resume
     g_prof_on = false;
     if (mode == 0) return 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (mode == 1)
         for (int k = 0; k < 2; ++k) {
             for (auto& r : g_prof[k]) g_prof_free.push_back(r);
@@ -405,6 +437,7 @@ extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kep
 
 extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes) {
     if (kind < 0 || kind > 1 || !total_ms || !launches || !passes) return LINR_EINVAL;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     double t = 0.0;
     int64_t np = 0;
     for (auto& r : g_prof[kind]) {
@@ -486,29 +519,47 @@ static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, i
     return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, LINR_WG_BLOCKS, c.ws);
 }
 
-// make_block: conv3(cin->8)+ReLU -> Inception -> conv3(8->8) (+ res)
+// Per-layer matrices of block slot b (0 = block_in, 1..7 = outter blocks): layer 0 uses the slot's own H/M/I, the extra
+// Inception layers of block_in (block_layers > 1, models/resnet.py:156-162) the Hx/Mx/Ix sets.
+struct LayerBufs { float *H, *M, *I, *gI, *gM, *gH; };
+static LayerBufs layer_bufs(Arena& a, int b, int l) {
+    if (l == 0) return {a.H[b], a.M[b], a.I[b], a.gI[b], a.gM[b], a.gH[b]};
+    return {a.Hx[l - 1], a.Mx[l - 1], a.Ix[l - 1], a.gIx[l - 1], a.gMx[l - 1], a.gHx[l - 1]};
+}
+
+// make_block (models/upsample.py:88-97): conv3(cin->8)+ReLU -> ResNetBlock(nl x Inception, extra skip if nl > 1) ->
+// conv3(8->8) (+ res)
 static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b, const float* res) {
     Arena& a = c.A;
     const float* P = c.P;
     TRY(conv3(c, false, in, in_ld, P + bp.a_w, P + bp.a_b, bp.cin, 8, nullptr, 0, nullptr, 0, a.A[b], 8, LINR_RELU));
-    if (c.f->nbr_lo && c.f->nbr_mask) {
-        // Inception block in two launches (csrc/fused.hip): [conv0_0 | conv1_0 centre tap] -> H, then the two 4->4 convs
-        // as one pass with conv1_2 and the residual in the epilogue -> M, I
-        TRY(linr_conv_pw_fwd_launch(a.A[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c00_w, P + bp.c00_b, P + bp.c10_w,
-                                    P + bp.c10_b, a.H[b], c.s));
-        TRY(linr_dual44_fwd_launch(a.H[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c01_w, P + bp.c01_b, P + bp.c11_w,
-                                   P + bp.c11_b, a.A[b], P + bp.c12_w, P + bp.c12_b, a.M[b], a.I[b], c.s));
-    } else {
-    // path 0: H[:,0:4] = relu(conv3 8->4 (A));  path 1: H[:,4:8] = relu(A @ conv1_0)
-    TRY(conv3(c, false, a.A[b], 8, P + bp.c00_w, P + bp.c00_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b], 8, LINR_RELU));
-    TRY(linear(c, a.A[b], 8, c.R, P + bp.c10_w, 4, 1, P + bp.c10_b, 8, 4, nullptr, 0, nullptr, 0, a.H[b] + 4, 8, LINR_RELU));
-    // I[:,0:4] = conv3 4->4 (H0) + A[:,0:4]
-    TRY(conv3(c, false, a.H[b], 8, P + bp.c01_w, P + bp.c01_b, 4, 4, a.A[b], 8, nullptr, 0, a.I[b], 8, 0));
-    // M = relu(conv3 4->4 (H1)); I[:,4:8] = M @ conv1_2 + A[:,4:8]
-    TRY(conv3(c, false, a.H[b] + 4, 8, P + bp.c11_w, P + bp.c11_b, 4, 4, nullptr, 0, nullptr, 0, a.M[b], 4, LINR_RELU));
-    TRY(linear(c, a.M[b], 4, c.R, P + bp.c12_w, 4, 1, P + bp.c12_b, 4, 4, a.A[b] + 4, 8, nullptr, 0, a.I[b] + 4, 8, 0));
+    const float* X = a.A[b];                          // input of the current Inception layer
+    for (int l = 0; l < bp.nl; ++l) {
+        const IncP& q = bp.inc[l];
+        const LayerBufs t = layer_bufs(a, b, l);
+        if (c.f->nbr_lo && c.f->nbr_mask) {
+            // Inception layer in two launches (csrc/fused.hip): [conv0_0 | conv1_0 centre tap] -> H, then the two 4->4 convs
+            // as one pass with conv1_2 and the residual in the epilogue -> M, I
+            TRY(linr_conv_pw_fwd_launch(X, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c00_w, P + q.c00_b, P + q.c10_w,
+                                        P + q.c10_b, t.H, c.s));
+            TRY(linr_dual44_fwd_launch(t.H, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c01_w, P + q.c01_b, P + q.c11_w,
+                                       P + q.c11_b, X, P + q.c12_w, P + q.c12_b, t.M, t.I, c.s));
+        } else {
+            // path 0: H[:,0:4] = relu(conv3 8->4 (X));  path 1: H[:,4:8] = relu(X @ conv1_0)
+            TRY(conv3(c, false, X, 8, P + q.c00_w, P + q.c00_b, 8, 4, nullptr, 0, nullptr, 0, t.H, 8, LINR_RELU));
+            TRY(linear(c, X, 8, c.R, P + q.c10_w, 4, 1, P + q.c10_b, 8, 4, nullptr, 0, nullptr, 0, t.H + 4, 8, LINR_RELU));
+            // I[:,0:4] = conv3 4->4 (H0) + X[:,0:4]
+            TRY(conv3(c, false, t.H, 8, P + q.c01_w, P + q.c01_b, 4, 4, X, 8, nullptr, 0, t.I, 8, 0));
+            // M = relu(conv3 4->4 (H1)); I[:,4:8] = M @ conv1_2 + X[:,4:8]
+            TRY(conv3(c, false, t.H + 4, 8, P + q.c11_w, P + q.c11_b, 4, 4, nullptr, 0, nullptr, 0, t.M, 4, LINR_RELU));
+            TRY(linear(c, t.M, 4, c.R, P + q.c12_w, 4, 1, P + q.c12_b, 4, 4, X + 4, 8, nullptr, 0, t.I + 4, 8, 0));
+        }
+        X = t.I;
     }
-    TRY(conv3(c, false, a.I[b], 8, P + bp.b_w, P + bp.b_b, 8, 8, res, 8, nullptr, 0, a.O[b], 8, 0));
+    float* Il = layer_bufs(a, b, bp.nl - 1).I;
+    if (bp.nl > 1)           // ResNetBlock.forward: out += x when it chains more than one layer (resnet.py:160-161)
+        axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.A[b], c.R * 8, Il, 1);
+    TRY(conv3(c, false, Il, 8, P + bp.b_w, P + bp.b_b, 8, 8, res, 8, nullptr, 0, a.O[b], 8, 0));
     return 0;
 }
 
@@ -516,37 +567,57 @@ static int block_fwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
 static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b, const float* gO, float* gin) {
     Arena& a = c.A;
     const float* P = c.P;
-    // O = conv3(I; b)
-    TRY(conv3_wgrad(c, a.I[b], 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
-    if (c.f->nbr_lo && c.f->nbr_mask) {
-        // fused backward (csrc/fused.hip): gI (+ gM in the epilogue) -> dual 4->4 backward -> gA with both side paths
-        TRY(linr_conv_bwd_gm_launch(gO, clo(c), cmk(c), c.nbr_ld, c.R, P + bp.b_w, P + bp.c12_w, a.M[b], a.gI[b], a.gM[b], c.s));
-        TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_dual44(a.H[b], a.gI[b], 8, a.gM[b], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, bp.c01_w, bp.c01_b,
-                                    bp.c11_w, bp.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
-                                    c.f->nbr_mask));
-        TRY(linr_dual44_bwd_launch(a.gI[b], a.gM[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c01_w, P + bp.c11_w, a.H[b], a.gH[b], c.s));
-        TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
-        TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
-        TRY(linr_conv_bwd_ga_launch(a.gH[b], clo(c), cmk(c), c.nbr_ld, c.R, P + bp.c00_w, P + bp.c10_w, a.gI[b], a.A[b], a.gA[b], c.s));
-    } else {
-    TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gI[b], 8, 0));
-    // I[:,4:8] = M @ c12 + b12 + A[:,4:8]
-    TRY(linear_wgrad(c, a.M[b], 4, a.gI[b] + 4, 8, c.R, 4, 4, bp.c12_w, 4, 1, bp.c12_b));
-    TRY(linear(c, a.gI[b] + 4, 8, c.R, P + bp.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, a.M[b], 4, a.gM[b], 4, LINR_RELU_MASK));
-    // I[:,0:4] = conv3(H0; c01) + A[:,0:4]
-    TRY(conv3_wgrad(c, a.H[b], 8, a.gI[b], 8, 4, 4, bp.c01_w, bp.c01_b));
-    TRY(conv3(c, true, a.gI[b], 8, P + bp.c01_w, nullptr, 4, 4, nullptr, 0, a.H[b], 8, a.gH[b], 8, LINR_RELU_MASK));
-    // M = relu(conv3(H1; c11))
-    TRY(conv3_wgrad(c, a.H[b] + 4, 8, a.gM[b], 4, 4, 4, bp.c11_w, bp.c11_b));
-    TRY(conv3(c, true, a.gM[b], 4, P + bp.c11_w, nullptr, 4, 4, nullptr, 0, a.H[b] + 4, 8, a.gH[b] + 4, 8, LINR_RELU_MASK));
-    // H0 = relu(conv3(A; c00)), H1 = relu(A @ c10); gA = gI (residual) + both paths, masked by A > 0
-    TRY(conv3_wgrad(c, a.A[b], 8, a.gH[b], 8, 8, 4, bp.c00_w, bp.c00_b));
-    TRY(linear_wgrad(c, a.A[b], 8, a.gH[b] + 4, 8, c.R, 8, 4, bp.c10_w, 4, 1, bp.c10_b));
-    TRY(conv3(c, true, a.gH[b], 8, P + bp.c00_w, nullptr, 8, 4, a.gI[b], 8, nullptr, 0, a.gA[b], 8, 0));
-    TRY(linear(c, a.gH[b] + 4, 8, c.R, P + bp.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, a.A[b], 8, a.gA[b], 8,
-               LINR_ACCUM | LINR_RELU_MASK));
+    const bool cm = c.f->nbr_lo && c.f->nbr_mask;
+    const int nl = bp.nl;
+    const LayerBufs last = layer_bufs(a, b, nl - 1);
+    // O = conv3(I_last; b)
+    TRY(conv3_wgrad(c, last.I, 8, gO, 8, 8, 8, bp.b_w, bp.b_b));
+    for (int l = nl - 1; l >= 0; --l) {
+        const IncP& q = bp.inc[l];
+        const LayerBufs t = layer_bufs(a, b, l);
+        const float* X = l == 0 ? a.A[b] : layer_bufs(a, b, l - 1).I;         // the layer's input
+        float* gX = l == 0 ? a.gA[b] : layer_bufs(a, b, l - 1).gI;           // where its input gradient goes
+        // gI of this layer: from the block's tail conv (last layer) or written by layer l+1 as its input gradient
+        if (l == nl - 1) {
+            if (cm) {   // gI = bwd(gO; Wb) with gM = (gI[:,4:8] @ W12^T) * (M > 0) in the epilogue (csrc/fused.hip)
+                TRY(linr_conv_bwd_gm_launch(gO, clo(c), cmk(c), c.nbr_ld, c.R, P + bp.b_w, P + q.c12_w, t.M, t.gI, t.gM, c.s));
+            } else {
+                TRY(conv3(c, true, gO, 8, P + bp.b_w, nullptr, 8, 8, nullptr, 0, nullptr, 0, t.gI, 8, 0));
+            }
+        }
+        if (!(cm && l == nl - 1))   // I[:,4:8] = M @ c12 + b12 + X[:,4:8]  =>  gM = (gI[:,4:8] @ W12^T) * (M > 0)
+            TRY(linear(c, t.gI + 4, 8, c.R, P + q.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, t.M, 4, t.gM, 4, LINR_RELU_MASK));
+        TRY(linear_wgrad(c, t.M, 4, t.gI + 4, 8, c.R, 4, 4, q.c12_w, 4, 1, q.c12_b));
+        if (cm) {
+            TRY(stream_order(c.s, c.ws));
+            TRY(linr_conv3_wgrad_dual44(t.H, t.gI, 8, t.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, q.c01_w, q.c01_b,
+                                        q.c11_w, q.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
+                                        c.f->nbr_mask));
+            TRY(linr_dual44_bwd_launch(t.gI, t.gM, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c01_w, P + q.c11_w, t.H, t.gH, c.s));
+        } else {
+            // I[:,0:4] = conv3(H0; c01) + X[:,0:4]
+            TRY(conv3_wgrad(c, t.H, 8, t.gI, 8, 4, 4, q.c01_w, q.c01_b));
+            TRY(conv3(c, true, t.gI, 8, P + q.c01_w, nullptr, 4, 4, nullptr, 0, t.H, 8, t.gH, 8, LINR_RELU_MASK));
+            // M = relu(conv3(H1; c11))
+            TRY(conv3_wgrad(c, t.H + 4, 8, t.gM, 4, 4, 4, q.c11_w, q.c11_b));
+            TRY(conv3(c, true, t.gM, 4, P + q.c11_w, nullptr, 4, 4, nullptr, 0, t.H + 4, 8, t.gH + 4, 8, LINR_RELU_MASK));
+        }
+        // H0 = relu(conv3(X; c00)), H1 = relu(X @ c10)
+        TRY(conv3_wgrad(c, X, 8, t.gH, 8, 8, 4, q.c00_w, q.c00_b));
+        TRY(linear_wgrad(c, X, 8, t.gH + 4, 8, c.R, 8, 4, q.c10_w, 4, 1, q.c10_b));
+        // input gradient: gX = bwd(gH[:,0:4]; W00) + gI (the layer's own residual) + gH[:,4:8] @ W10^T; layer 0's input is
+        // A = relu(.) so it is masked by (A > 0), after the ResNetBlock's extra skip (nl > 1: + gI of the last layer)
+        const bool skip = (l == 0 && nl > 1);
+        if (skip)
+            TRY(linr_hip_rc(hipMemcpyAsync(gX, last.gI, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+        if (cm) {
+            TRY(linr_conv_bwd_ga_launch(t.gH, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c00_w, P + q.c10_w, t.gI, l == 0 ? a.A[b] : nullptr,
+                                        gX, (l == 0 ? LINR_RELU_MASK : 0u) | (skip ? LINR_ACCUM : 0u), c.s));
+        } else {
+            TRY(conv3(c, true, t.gH, 8, P + q.c00_w, nullptr, 8, 4, t.gI, 8, nullptr, 0, gX, 8, skip ? LINR_ACCUM : 0u));
+            TRY(linear(c, t.gH + 4, 8, c.R, P + q.c10_w, 1, 4, nullptr, 4, 8, nullptr, 0, l == 0 ? a.A[b] : nullptr, 8, gX, 8,
+                       LINR_ACCUM | (l == 0 ? LINR_RELU_MASK : 0u)));
+        }
     }
     // A = relu(conv3(in; a))
     TRY(conv3_wgrad(c, in, in_ld, a.gA[b], 8, bp.cin, 8, bp.a_w, bp.a_b));
@@ -560,19 +631,19 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     if (f->rows > 0 && (!f->nbr || !f->offset_feat || !f->occ)) return LINR_EINVAL;
     // the conv kernels address gathered rows with 32-bit byte offsets: (rows + 1) * 32 B must stay below 2^32
     if (f->rows >= ((int64_t)1 << 27) - 1 || f->nbr_ld < f->rows) return LINR_EINVAL;
-    if (!make_layout(c.L, f->model_scale_num)) return LINR_EINVAL;
+    if (!make_layout(c.L, f->model_scale_num, f->block_layers < 1 ? 1 : f->block_layers)) return LINR_EINVAL;
     if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
     for (int s = 0; s < f->n_scales; ++s) {
         if (f->row_off_h[s + 1] < f->row_off_h[s]) return LINR_EINVAL;
         if (f->scale_idx_h[s] < 0 || f->scale_idx_h[s] >= f->model_scale_num) return LINR_EINVAL;
     }
-    if (arena_bytes < linr_net_arena_bytes(f->rows)) return LINR_ENOSPC;
+    if (arena_bytes < linr_net_arena_bytes(f->rows, c.L.BL)) return LINR_ENOSPC;
     if (!linr_aligned16(arena)) return LINR_EALIGN;
     c.f = f;
     c.P = (const float*)params;
     c.R = f->rows;
     c.nbr_ld = f->nbr_ld;
-    make_arena(c.A, f->rows, (float*)arena, c.L.total);
+    make_arena(c.A, f->rows, (float*)arena, c.L.total, c.L.BL);
     return 0;
 }
 
@@ -617,9 +688,9 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
     for (int g = 0; g < 7; ++g) {
         const BlockP& bp = L.outter[g];
         pA[g] = a.A[g + 1]; pH[g] = a.H[g + 1]; pM[g] = a.M[g + 1]; pI[g] = a.I[g + 1]; pO[g] = a.O[g + 1];
-        p_ab[g] = P + bp.a_b; p_c00w[g] = P + bp.c00_w; p_c00b[g] = P + bp.c00_b; p_c10w[g] = P + bp.c10_w; p_c10b[g] = P + bp.c10_b;
-        p_c01w[g] = P + bp.c01_w; p_c01b[g] = P + bp.c01_b; p_c11w[g] = P + bp.c11_w; p_c11b[g] = P + bp.c11_b;
-        p_c12w[g] = P + bp.c12_w; p_c12b[g] = P + bp.c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
+        p_ab[g] = P + bp.a_b; p_c00w[g] = P + bp.inc[0].c00_w; p_c00b[g] = P + bp.inc[0].c00_b; p_c10w[g] = P + bp.inc[0].c10_w; p_c10b[g] = P + bp.inc[0].c10_b;
+        p_c01w[g] = P + bp.inc[0].c01_w; p_c01b[g] = P + bp.inc[0].c01_b; p_c11w[g] = P + bp.inc[0].c11_w; p_c11b[g] = P + bp.inc[0].c11_b;
+        p_c12w[g] = P + bp.inc[0].c12_w; p_c12b[g] = P + bp.inc[0].c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
     }
     {   // first conv of every outter block: A[b] = relu(conv3(occ[:, :b]; a) + a_b), one shared gather (csrc/fused.hip)
         static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
@@ -817,11 +888,11 @@ static int backward_batched(Ctx& c, float gz_scale) {
         const int b = g + 1;
         pA[g] = a.A[b]; pH[g] = a.H[b]; pM[g] = a.M[b]; pI[g] = a.I[b]; p_gO[g] = a.gO[b]; p_gI[g] = a.gI[b]; p_gM[g] = a.gM[b];
         p_gH[g] = a.gH[b]; p_gA[g] = a.gA[b];
-        p_bw[g] = P + bp.b_w; p_c12w[g] = P + bp.c12_w; p_c01w[g] = P + bp.c01_w; p_c11w[g] = P + bp.c11_w;
-        p_c00w[g] = P + bp.c00_w; p_c10w[g] = P + bp.c10_w;
-        o_bw[g] = bp.b_w; o_bb[g] = bp.b_b; o_c12w[g] = bp.c12_w; o_c12b[g] = bp.c12_b; o_c01w[g] = bp.c01_w; o_c01b[g] = bp.c01_b;
-        o_c11w[g] = bp.c11_w; o_c11b[g] = bp.c11_b; o_c00w[g] = bp.c00_w; o_c00b[g] = bp.c00_b; o_c10w[g] = bp.c10_w;
-        o_c10b[g] = bp.c10_b; o_aw[g] = bp.a_w; o_ab[g] = bp.a_b;
+        p_bw[g] = P + bp.b_w; p_c12w[g] = P + bp.inc[0].c12_w; p_c01w[g] = P + bp.inc[0].c01_w; p_c11w[g] = P + bp.inc[0].c11_w;
+        p_c00w[g] = P + bp.inc[0].c00_w; p_c10w[g] = P + bp.inc[0].c10_w;
+        o_bw[g] = bp.b_w; o_bb[g] = bp.b_b; o_c12w[g] = bp.inc[0].c12_w; o_c12b[g] = bp.inc[0].c12_b; o_c01w[g] = bp.inc[0].c01_w; o_c01b[g] = bp.inc[0].c01_b;
+        o_c11w[g] = bp.inc[0].c11_w; o_c11b[g] = bp.inc[0].c11_b; o_c00w[g] = bp.inc[0].c00_w; o_c00b[g] = bp.inc[0].c00_b; o_c10w[g] = bp.inc[0].c10_w;
+        o_c10b[g] = bp.inc[0].c10_b; o_aw[g] = bp.a_w; o_ab[g] = bp.a_b;
     }
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
@@ -871,7 +942,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         Grp gp = Grp();
         goffs(gp.in, p_gH, 7); goffs(gp.w, p_c00w, 7); goffs(gp.res, p_gI, 7); goffs(gp.act, pA, 7); goffs(gp.out, p_gA, 7);
         goffs(gp.e0, p_c10w, 7); goffs(gp.e1, p_gH, 7);
-        TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[1], c.s, &gp, 7));
+        TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[1], LINR_RELU_MASK, c.s, &gp, 7));
     }
     {   // A = relu(conv3(occ[:, :b]; a)): weight gradient on the first b channels of the occupancy rows
         Grp gp = Grp();
@@ -981,15 +1052,33 @@ extern "C" int linr_net_backward(const linr_frame* f, const float* params, float
 }
 
 extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
-                                   float* exp_avg, float* exp_avg_sq, double step_size, double bc2_sqrt, double beta1,
-                                   double beta2, double eps, double weight_decay, double* bits_acc, void* stream) {
-    if (!exp_avg || !exp_avg_sq || !bits_acc) return LINR_EINVAL;
+                                   float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
+                                   double beta1, double beta2, double eps, double weight_decay, double* bits_acc,
+                                   void* stream) {
+    if (!exp_avg || !exp_avg_sq || !bits_acc || step < 1) return LINR_EINVAL;
     TRY(linr_net_forward(f, params, arena, arena_bytes, 0, 8, nullptr, bits_acc, stream));
     Ctx c;
     TRY(check_frame(f, params, arena, arena_bytes, c));
     c.s = (hipStream_t)stream;
     if (c.R == 0) return 0;
     TRY(backward_core(c, gscale));
-    return linr_adam_step(params, c.A.GSUM, exp_avg, exp_avg_sq, c.L.total, step_size, bc2_sqrt, beta1, beta2, eps,
-                          weight_decay, stream);
+    // bias corrections in double, like torch.optim.Adam's Python scalars
+    LinrAdamRanges rg;
+    rg.count = 0; rg.begin = c.L.m0_w[0]; rg.len = c.L.S > 1 ? c.L.m0_w[1] - c.L.m0_w[0] : c.L.block_in.a_w - c.L.m0_w[0];
+    if (scale_steps_h) {
+        rg.count = c.L.S;
+        for (int s = 0; s < c.L.S; ++s) { rg.active[s] = 0; rg.step_size[s] = 0.0f; rg.bc2_sqrt[s] = 1.0f; }
+        for (int j = 0; j < f->n_scales; ++j) {
+            if (f->row_off_h[j + 1] <= f->row_off_h[j]) continue;
+            const int si = f->scale_idx_h[j];
+            const int64_t t = scale_steps_h[si];
+            if (t < 1) return LINR_EINVAL;
+            rg.active[si] = 1;
+            rg.step_size[si] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+            rg.bc2_sqrt[si] = (float)sqrt(1.0 - pow(beta2, (double)t));
+        }
+    }
+    return linr_adam_launch(params, c.A.GSUM, exp_avg, exp_avg_sq, c.L.total, lr / (1.0 - pow(beta1, (double)step)),
+                            sqrt(1.0 - pow(beta2, (double)step)), beta1, beta2, eps, weight_decay,
+                            scale_steps_h ? &rg : nullptr, c.s);
 }

@@ -16,7 +16,7 @@ from ._lib import check
 class Frame:
     """All scales of one frame on the GPU: kernel map, 7-neighbour features, child occupancy, activation arena."""
 
-    def __init__(self, scales, model_scale_num, device='cuda', validate=True, with_arena=True):
+    def __init__(self, scales, model_scale_num, device='cuda', validate=True, with_arena=True, block_layers=1):
         """scales: list of dicts {'coord' int32 [N,3] sorted x-major, 'offset_tensor' [N,7] float (None: derived from the
         kernel map),
         'occ' [N,8] float or 'occ_lst' 8 x [N,1], 'scale_idx'} - the per-scale network inputs of
@@ -26,6 +26,7 @@ class Frame:
             raise _lib.LinrError('Frame needs a GPU device: the coding network has no CPU path')
         self.device = device
         self.model_scale_num = int(model_scale_num)
+        self.block_layers = int(block_layers)
         ns = [int(s['coord'].shape[0]) for s in scales]
         self.row_off = np.zeros(len(scales) + 1, dtype=np.int64)
         self.row_off[1:] = np.cumsum(ns)
@@ -60,13 +61,14 @@ class Frame:
         if with_arena:
             self.alloc_arena()
         self._c = _lib.LinrFrame(rows=R, n_scales=self.n_scales, model_scale_num=self.model_scale_num,
+                                 block_layers=self.block_layers, reserved_=0,
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
                                  occ=self.occ.data_ptr())
 
     def alloc_arena(self):
-        nbytes = _lib.lib().linr_net_arena_bytes(self.rows)
+        nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)
         self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def cref(self):
@@ -96,12 +98,13 @@ def net_backward(frame, flat_params, flat_grads, gscale, arena=None):
 
 
 def net_train_step(frame, flat_params, exp_avg, exp_avg_sq, gscale, step, lr, beta1, beta2, eps, weight_decay, bits,
-                   arena=None):
-    """linr_net_train_step: forward + backward + deterministic gradient reduction + fused Adam in one call."""
+                   arena=None, scale_steps=None):
+    """linr_net_train_step: forward + backward + deterministic gradient reduction + fused Adam in one call.
+    scale_steps: int64 numpy array [model_scale_num] of the per-scale context MLPs' 1-based step counts (torch.optim.Adam
+    semantics for scales a frame does not contain), or None = every parameter uses `step`."""
     arena = frame.arena if arena is None else arena
-    bc1 = 1.0 - beta1 ** step
-    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
     check(_lib.lib().linr_net_train_step(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(),
-                                         float(gscale), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), lr / bc1, bc2_sqrt,
+                                         float(gscale), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), float(lr), int(step),
+                                         None if scale_steps is None else scale_steps.ctypes.data,
                                          beta1, beta2, eps, weight_decay, bits.data_ptr(), _stream()),
           'linr_net_train_step')

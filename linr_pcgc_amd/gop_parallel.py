@@ -2,11 +2,17 @@
 
 main.py:83-104 splits the sequence into GOPs; GOP 0 trains from scratch and every later GOP warm-starts from GOP 0's
 model + optimiser state (main.py:99-104,241-248), so GOP 0 is a serial prefix and GOPs 1..G-1 are independent.
-Phase A: rank 0 overfits GOP 0 and writes ``model.pth``; phase B: GOPs 1..G-1 are dealt to the ranks (longest first,
-round-robin), each rank overfits + encodes its own GOPs.  The only cross-rank traffic is the checkpoint file and a
-barrier / MAX-reduce of wall times for reporting (torch.distributed: RCCL on GPUs, gloo in the CPU tests).
+Phase A: rank 0 overfits GOP 0 and writes ``model.pth`` while every other rank already stages its first GOP (octrees,
+kernel maps, resident in HBM).  Phase B: GOPs 1..G-1 are handed out longest first - either a fixed round-robin deal
+(``schedule='static'``: deterministic, what bench.py uses so that all inputs are resident before the timed region) or
+a pull from a shared queue (``schedule='pull'``: a rank claims the next GOP whenever it is free, rank 0 joins after
+GOP 0; the queue is a directory of O_EXCL claim files, so it needs no collective either).  The only cross-rank traffic
+is the checkpoint file; ``torch.distributed`` (RCCL on GPUs, gloo in the CPU tests) is used for a start-up barrier and
+the MAX-reduce of wall times.  Waiting for the checkpoint is a host-side file poll, never a pending collective, so a
+long first_epoch cannot trip the NCCL watchdog.
 """
 import os
+import shutil
 import time
 
 import torch
@@ -21,12 +27,16 @@ def gop_name(group):
     return 'gop_%d_%d' % (group[0], group[-1])
 
 
+def phase_b_order(groups):
+    """GOPs 1..G-1, longest first (stable)."""
+    return sorted(range(1, len(groups)), key=lambda g: (-len(groups[g]), g))
+
+
 def assign_gops(groups, world):
-    """Phase-B assignment: GOPs 1..G-1 sorted by length (desc, stable) and dealt round-robin.  Returns a list of
-    per-rank lists of GOP indices.  Deterministic, identical on every rank."""
-    order = sorted(range(1, len(groups)), key=lambda g: (-len(groups[g]), g))
+    """Static phase-B assignment: phase_b_order dealt round-robin.  Returns a list of per-rank lists of GOP indices.
+    Deterministic, identical on every rank."""
     per_rank = [[] for _ in range(world)]
-    for i, g in enumerate(order):
+    for i, g in enumerate(phase_b_order(groups)):
         per_rank[i % world].append(g)
     return per_rank
 
@@ -39,37 +49,113 @@ def ideal_speedup(groups, world):
     return total / float(len(groups[0]) + phase_b)
 
 
-def wait_for_file(path, timeout_s=3600.0, poll_s=0.05):
+def wait_for_file(path, timeout_s=24 * 3600.0, poll_s=0.02, alive=None):
+    """Host-side poll for the GOP-0 checkpoint.  `alive`: optional callable returning False when rank 0 is known to have
+    failed (its error marker exists) - the wait then raises instead of hanging."""
     t0 = time.time()
     while not os.path.exists(path):
+        if alive is not None and not alive():
+            raise RuntimeError('rank 0 failed before writing %s' % path)
         if time.time() - t0 > timeout_s:
             raise TimeoutError('checkpoint %s did not appear' % path)
         time.sleep(poll_s)
 
 
-def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=None):
-    """Drives the two phases.  first_fn(group) -> checkpoint object (GOP 0, rank 0 only);
-    other_fn(group, checkpoint) -> result for GOPs >= 1.  Returns {gop_index: result} of THIS rank.
-    The checkpoint crosses ranks through ``work_dir/<gop_0>/model.pth`` (atomic rename), like the reference."""
+def _claim(claim_dir, g, rank):
+    """Atomically take GOP g from the shared queue (True if this rank got it)."""
+    try:
+        fd = os.open(os.path.join(claim_dir, 'gop_%d' % g), os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+    except FileExistsError:
+        return False
+    os.write(fd, ('%d\n' % rank).encode())
+    os.close(fd)
+    return True
+
+
+def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=None, prepare_fn=None, schedule='static',
+                 prepared=None):
+    """Drives the two phases.  first_fn(group[, prepared]) -> checkpoint object (GOP 0, rank 0 only);
+    other_fn(group, checkpoint[, prepared]) -> result for GOPs >= 1.  prepare_fn(group) (optional) stages a GOP's
+    inputs (octrees / kernel maps in HBM) and its return value is handed to first_fn / other_fn as `prepared`; ranks
+    >= 1 call it for their first GOP BEFORE the checkpoint exists (phase-A overlap).  `prepared`: {gop index: object}
+    already staged by the caller (bench.py stages everything before its timed region).
+    Returns {gop_index: result} of THIS rank.  The checkpoint crosses ranks through
+    ``work_dir/<gop_0>/model.pth`` (atomic rename), like the reference.  With `dist`, rank 0 clears stale state of an
+    earlier run in work_dir behind a start-up barrier; without it the caller must pass a fresh directory."""
+    if schedule not in ('static', 'pull'):
+        raise ValueError('schedule must be static or pull')
+    prepared = dict(prepared or {})
     results = {}
     ck_dir = os.path.join(work_dir, gop_name(groups[0]))
     ck_path = os.path.join(ck_dir, 'model.pth')
+    claim_dir = os.path.join(work_dir, 'claims')
+    err_path = os.path.join(work_dir, 'rank0_failed')
     if rank == 0:
+        if dist is not None and world > 1:
+            for stale in (ck_path, err_path):
+                if os.path.exists(stale):
+                    os.remove(stale)
+            shutil.rmtree(claim_dir, ignore_errors=True)
         os.makedirs(ck_dir, exist_ok=True)
-        ckpt = first_fn(groups[0])
+        os.makedirs(claim_dir, exist_ok=True)
+    if dist is not None and world > 1:
+        dist.barrier()                                   # start-up only: nothing long-running is pending behind it
+    os.makedirs(claim_dir, exist_ok=True)
+
+    def staged(g):
+        if g not in prepared and prepare_fn is not None:
+            prepared[g] = prepare_fn(groups[g])
+        return prepared.pop(g, None)
+
+    def call(fn, *a):
+        p = staged(a[-1])
+        args = a[:-1]
+        return fn(*args, p) if (prepare_fn is not None or p is not None) else fn(*args)
+
+    order = phase_b_order(groups)
+    static_mine = assign_gops(groups, world)[rank]
+    first_claim = None
+    if rank == 0:
+        try:
+            ckpt = call(first_fn, groups[0], 0)
+        except BaseException:
+            open(err_path, 'w').close()                  # lets the waiting ranks fail instead of hanging
+            raise
         results[0] = ckpt.get('result') if isinstance(ckpt, dict) else None
         tmp = ck_path + '.tmp.%d' % os.getpid()
         torch.save(ckpt, tmp)
         os.replace(tmp, ck_path)
-    if dist is not None and world > 1:
-        dist.barrier()
     else:
-        wait_for_file(ck_path)
-    mine = assign_gops(groups, world)[rank]
-    if mine:
-        ckpt = torch.load(ck_path, map_location='cpu', weights_only=False)
-        for g in mine:
-            results[g] = other_fn(groups[g], ckpt)
+        # phase-A overlap: stage this rank's first GOP while rank 0 still trains GOP 0
+        if schedule == 'static':
+            first_claim = static_mine[0] if static_mine else None
+        else:
+            first_claim = next((g for g in order if _claim(claim_dir, g, rank)), None)
+        if first_claim is not None and prepare_fn is not None and first_claim not in prepared:
+            prepared[first_claim] = prepare_fn(groups[first_claim])
+        wait_for_file(ck_path, alive=lambda: not os.path.exists(err_path))
+    ckpt = None
+
+    def load():
+        return torch.load(ck_path, map_location='cpu', weights_only=False)
+
+    if schedule == 'static':
+        todo = static_mine
+        if todo:
+            ckpt = load()
+        for g in todo:
+            results[g] = call(other_fn, groups[g], ckpt, g)
+    else:
+        g = first_claim
+        while True:
+            if g is None:
+                g = next((h for h in order if _claim(claim_dir, h, rank)), None)
+                if g is None:
+                    break
+            if ckpt is None:
+                ckpt = load()
+            results[g] = call(other_fn, groups[g], ckpt, g)
+            g = None
     return results
 
 
@@ -79,4 +165,12 @@ def max_over_ranks(value, dist=None, device='cpu'):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def sum_over_ranks(value, dist=None, device='cpu'):
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t)

@@ -46,8 +46,11 @@ class _NetBits(torch.autograd.Function):
 
 
 class LINR_PCGC_Model(nn.Module):
-    """models/model_core.py:19-37.  inargs: scale_num, in_channel (=7), hidden_channel_conv (=8), block_layers (=1),
-    outstage (=8), instage (=1) - the only configuration main.py:97,218 can build."""
+    """models/model_core.py:19-37.  inargs: scale_num, in_channel (=7), hidden_channel_conv (=8), block_layers (1..4),
+    outstage (=8), instage (=1).  outstage / instage / in_channel are hard-coded by the reference's drivers
+    (main.py:97,218); block_layers is its live --block_layers flag (main.py:521: the Inception layers of block_in's
+    ResNetBlock, with the extra skip of models/resnet.py:160-161 when > 1).  hidden_channel_conv (main.py:520) is NOT
+    supported at other widths: every kernel is specialised for 8-wide feature rows."""
 
     def __init__(self, inargs):
         super().__init__()
@@ -55,9 +58,15 @@ class LINR_PCGC_Model(nn.Module):
         in_channel = int(inargs['in_channel'])
         hidden = int(inargs['hidden_channel_conv'])
         block_layers = int(inargs['block_layers'])
-        if in_channel != 7 or hidden != 8 or block_layers != 1 or inargs['outstage'] != 8 or inargs['instage'] != 1:
-            raise ValueError('the gfx950 engine is specialised for in_channel=7, hidden_channel_conv=8, block_layers=1, '
-                             'outstage=8, instage=1 (the defaults of main.py); got %r' % (inargs,))
+        if in_channel != 7 or inargs['outstage'] != 8 or inargs['instage'] != 1:
+            raise ValueError('the gfx950 engine is specialised for in_channel=7, outstage=8, instage=1 (what main.py:97,218 '
+                             'hard-code); got %r' % (inargs,))
+        if hidden != 8:
+            raise ValueError('hidden_channel_conv=%d is not supported: the gfx950 kernels are specialised for 8-wide rows '
+                             '(the reference default, main.py:520); a checkpoint trained at another width cannot be loaded' % hidden)
+        if not 1 <= block_layers <= 4:
+            raise ValueError('block_layers must be in 1..4 (main.py:521 default 1), got %d' % block_layers)
+        self.block_layers = block_layers
         self.scale_emb = nn.Embedding(self.scale_num, 8)
         self.scale_mlp = nn.ModuleList([PointwiseMLP([8 + in_channel, 16, 8]) for _ in range(self.scale_num)])
         self.upsampler = CNP(in_channels=8, channels=hidden, block_layers=block_layers, outstage=8, instage=1)
@@ -73,7 +82,7 @@ class LINR_PCGC_Model(nn.Module):
         """Re-home all parameters as views of one contiguous buffer in parameters() order (the kernels' layout)."""
         plist = list(self.parameters())
         total = sum(p.numel() for p in plist)
-        if plist and plist[0].is_cuda and total != _lib.lib().linr_param_count(self.scale_num):
+        if plist and plist[0].is_cuda and total != _lib.lib().linr_param_count(self.scale_num, self.block_layers):
             raise _lib.LinrError('parameter layout mismatch with liblinr_hip.so')
         flat = torch.empty(total, dtype=torch.float32, device=plist[0].device)
         off = 0
@@ -113,7 +122,7 @@ class LINR_PCGC_Model(nn.Module):
     # ---- frames ----------------------------------------------------------------------------------------------------
     def make_frame(self, scales, validate=True, with_arena=True):
         """Batched multi-scale frame for the fast path.  scales: list of per-scale input dicts (see engine.Frame)."""
-        return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena)
+        return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena, self.block_layers)
 
     def _scale_frame(self, d, need_occ=True):
         """Kernel map + arena for one scale's inputs.  Encoder-side inputs are cached by tensor identity; the cache
@@ -265,12 +274,26 @@ class FlatAdam:
         self.grad = torch.zeros_like(flat)
         self.t = 0                      # optimiser steps taken
         self.sched_steps = 0            # scheduler.step() calls (StepLR epoch counter)
+        # torch.optim.Adam keeps one step counter per parameter and skips parameters without a gradient: the context
+        # MLP of a scale that a frame lacks (custom_dataset.py:325) is not touched on that frame.  One counter per scale.
+        self.t_scale = np.zeros(model.scale_num, dtype=np.int64)
 
     def zero_grad(self):
         self.grad.zero_()
 
+    def reset(self):
+        """Back to the state of a freshly constructed optimiser, in place (no allocation, no host round trip)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.grad.zero_()
+        self.lr = self.initial_lr
+        self.t = 0
+        self.sched_steps = 0
+        self.t_scale[:] = 0
+
     def step(self):
         self.t += 1
+        self.t_scale += 1                # a dense gradient buffer: every parameter is updated
         ops.adam_step(self.model.flat_parameters(), self.grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay)
 
@@ -285,12 +308,22 @@ class FlatAdam:
         if self.lr < min_lr:
             self.lr = min_lr
 
+    def _scale_of_param(self):
+        """parameter index -> scale of its scale_mlp, or -1 (names: scale_mlp.<s>.<layer>.<weight|bias>)."""
+        out = []
+        for name, _ in self.model.named_parameters():
+            out.append(int(name.split('.')[1]) if name.startswith('scale_mlp.') else -1)
+        return out
+
     def state_dict(self):
         state, off = {}, 0
+        owner = self._scale_of_param()
         for i, p in enumerate(self.model._plist):
             n = p.numel()
-            state[i] = {'step': torch.tensor(float(self.t)), 'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
-                        'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+            t = self.t if owner[i] < 0 else int(self.t_scale[owner[i]])
+            if t > 0:                     # torch creates a parameter's state at its first update
+                state[i] = {'step': torch.tensor(float(t)), 'exp_avg': self.exp_avg[off:off + n].view(p.shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).clone()}
             off += n
         group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay,
                  'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False,
@@ -304,16 +337,26 @@ class FlatAdam:
         self.betas, self.eps, self.weight_decay = tuple(g['betas']), float(g['eps']), float(g['weight_decay'])
         off = 0
         steps = set()
+        owner = self._scale_of_param()
+        self.t_scale[:] = 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
         for i, p in enumerate(self.model._plist):
             n = p.numel()
             st = sd['state'].get(i)
             if st is not None:
                 self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
-                steps.add(int(float(st['step'])))
+                t = int(float(st['step']))
+                if owner[i] < 0:
+                    steps.add(t)
+                else:
+                    if self.t_scale[owner[i]] not in (0, t):
+                        raise ValueError('step counts differ inside scale_mlp.%d' % owner[i])
+                    self.t_scale[owner[i]] = t
             off += n
         if len(steps) > 1:
-            raise ValueError('per-parameter step counts differ; the fused Adam keeps one step counter')
+            raise ValueError('step counts of the shared parameters differ; the fused Adam keeps one counter for them')
         self.t = steps.pop() if steps else 0
 
 
@@ -323,7 +366,10 @@ def train_step(model, opt, frame, point_num):
     nothing synchronises with the host."""
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
     opt.t += 1
+    for i in range(frame.n_scales):                 # scales present in this frame advance their MLP's own counter
+        if frame.row_off[i + 1] > frame.row_off[i]:
+            opt.t_scale[frame.scale_idx[i]] += 1
     engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), opt.t,
-                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits)
+                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=opt.t_scale)
     opt.scheduler_step()
     return bits

@@ -156,7 +156,10 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
     """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3].
     with_offsets=False leaves 'offset_tensor' None: engine.Frame then reads the 7-neighbour occupancy off the kernel map
     it builds anyway (linr_kmap_offset_feat) and overfit.Gop stores those rows back into the dicts."""
-    pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
+    if torch.is_tensor(points):                    # device-resident input (synthetic.sequence_frame_device): no host round trip
+        pts = points[:, :3].to(device=device, dtype=torch.int64)
+    else:
+        pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
     cmin = pts.min(dim=0).values
     cur = qscTensor(pts - cmin)
     ori = cur.get_coord()

@@ -11,11 +11,11 @@ from .model_core import FlatAdam, LINR_PCGC_Model, train_step
 from .module_utils import prepare_frame
 
 
-def gen_model(scale_num, device='cuda', seed=None):
+def gen_model(scale_num, device='cuda', seed=None, block_layers=1):
     """Gen_Model of main.py:97,218."""
     if seed is not None:
         torch.manual_seed(seed)
-    m = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1,
+    m = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': block_layers,
                          'outstage': 8, 'instage': 1})
     return m.to(device)
 
@@ -23,7 +23,7 @@ def gen_model(scale_num, device='cuda', seed=None):
 class Gop:
     """A group of pictures resident on one GPU: per frame the batched multi-scale Frame + side data."""
 
-    def __init__(self, model, clouds, scale_num=None, min_point_num=64, device='cuda'):
+    def __init__(self, model, clouds, scale_num=None, min_point_num=64, device='cuda', block_layers=None):
         self.frames, self.point_nums, self.coord_mins, self.low_xyz, self.infos = [], [], [], [], []
         self.scale_num = scale_num
         for pts in clouds:
@@ -32,10 +32,14 @@ class Gop:
                 self.scale_num = fr['scale_num']             # frozen from frame 0 (main.py:77-78)
             self.infos.append(fr)
         self.model_scale_num = model.scale_num if model is not None else self.scale_num
+        if block_layers is None:
+            block_layers = model.block_layers if model is not None else 1
+        self.block_layers = int(block_layers)
         max_rows = 0
         from . import engine
         for fr in self.infos:
-            f = engine.Frame(fr['all_input_info'], self.model_scale_num, device, validate=True, with_arena=False)
+            f = engine.Frame(fr['all_input_info'], self.model_scale_num, device, validate=True, with_arena=False,
+                             block_layers=self.block_layers)
             for i, sinfo in enumerate(fr['all_input_info']):      # the reference's per-scale dicts carry 'offset_tensor'
                 sinfo['offset_tensor'] = f.offset_feat[f.scale_slice(i)]
                 sinfo['xyzqsc_t'].offset_tensor = sinfo['offset_tensor']
@@ -46,7 +50,7 @@ class Gop:
             max_rows = max(max_rows, f.rows)
         # one activation arena shared by all frames of the GOP (a step finishes before the next begins)
         from . import _lib
-        arena = torch.empty(_lib.lib().linr_net_arena_bytes(max_rows), dtype=torch.uint8, device=device)
+        arena = torch.empty(_lib.lib().linr_net_arena_bytes(max_rows, self.block_layers), dtype=torch.uint8, device=device)
         for f in self.frames:
             f.arena = arena
 

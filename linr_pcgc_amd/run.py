@@ -1,10 +1,13 @@
-"""Sequence driver on the fast path: the overfit -> encode -> decode flow of main.overfit_enc_dec (main.py:69-119) for a
-synthetic sequence, one process per GPU (GOP sharding of gop_parallel.py, no data-path collective).
+"""Sequence driver on the fast path: the overfit -> encode -> decode flow of main.overfit_enc_dec (main.py:69-119), one
+process per GPU (GOP sharding of gop_parallel.py, no data-path collective).
 
-    python -m linr_pcgc_amd.run --config loot10 --frames 64 --gop 32 --first-epoch 10 --others-epoch 10 --out /tmp/linr_out
+    python -m linr_pcgc_amd.run --config loot10 --frames 300 --gop 32 --first-epoch 10 --others-epoch 10 --out /tmp/linr_out
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m linr_pcgc_amd.run ...
+
+``run_sequence_job`` is the same flow as a function (bench.py --sequence and the tests call it).
 """
 import argparse
+import datetime
 import json
 import os
 import time
@@ -15,7 +18,7 @@ from . import codec, gop_parallel, overfit, ply, synthetic
 from .model_core import FlatAdam
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser('linr_pcgc_amd.run')
     ap.add_argument('--config', default='loot10')
     ap.add_argument('--input-glob', default=None, help="PLY / npy frames of a real sequence (sorted by name), e.g. '/data/loot/Ply/*.ply'; replaces --config")
@@ -28,10 +31,126 @@ def parse():
     ap.add_argument('--step-size', type=int, default=32)
     ap.add_argument('--min-lr', type=float, default=4e-4)
     ap.add_argument('--decay-rate', type=float, default=1e-4)
+    ap.add_argument('--block-layers', type=int, default=1)
     ap.add_argument('--seed', type=int, default=8807)
     ap.add_argument('--out', default='/tmp/linr_out')
+    ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
     ap.add_argument('--decode', action='store_true', help='decode every GOP again and check it is lossless')
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=None, decode_frames=None):
+    """Overfit + encode (+ decode check) of a whole sequence, sharded GOP-per-GPU.
+
+    stage_all=True: every GOP this rank will run under the static schedule is staged in HBM first and the timed
+    region starts behind a barrier with all inputs resident (bench.py's contract); otherwise GOPs are staged as they are
+    claimed (ranks >= 1 stage their first GOP while rank 0 runs GOP 0).  decode_frames: None = all frames of a GOP when
+    args.decode, or an int = the first n frames of each GOP.
+    Returns (summary dict on every rank, {gop index: result} of this rank)."""
+    groups = gop_parallel.split_gops(args.frames, args.gop)
+    device = 'cuda'
+
+    def load_frame(t):
+        if files is not None:
+            return ply.read_points(files[t])
+        return synthetic.sequence_frame_device(args.config, t, device)
+
+    def make_opt(model):
+        return FlatAdam(model, lr=args.learning_rate, weight_decay=args.decay_rate, step_size=args.step_size, gamma=args.gamma)
+
+    def stage(group):
+        t0 = time.time()
+        gop = overfit.Gop(None, [load_frame(t) for t in group], None, 64, device, block_layers=getattr(args, 'block_layers', 1))
+        torch.cuda.synchronize()
+        return gop, time.time() - t0
+
+    def run_gop(group, epochs, ckpt, staged):
+        gop, stage_s = staged if staged is not None else stage(group)
+        t0 = time.time()
+        model = overfit.gen_model(gop.scale_num, device, seed=args.seed, block_layers=getattr(args, 'block_layers', 1))
+        opt = make_opt(model)
+        if ckpt is not None:
+            overfit.warm_start(model, opt, ckpt)                 # main.py:241-248
+        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)), gop, 8)
+        res_dir = os.path.join(args.out, 'result_enc', gop_parallel.gop_name(group))
+        codec.write_gop(enc, res_dir)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        ok = None
+        if args.decode:
+            todo = list(range(len(group))) if decode_frames is None else list(range(min(decode_frames, len(group))))
+            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)),
+                                   codec.read_gop(res_dir), device, frames=todo, workers=4)
+            ok = all(torch.equal(d, torch.as_tensor(gop.infos[i]['ori']).cuda() +
+                                 torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32))
+                     for d, i in zip(dec, todo))
+        torch.cuda.synchronize()
+        t3 = time.time()
+        result = {'gop': gop_parallel.gop_name(group), 'frames': len(group), 'epochs': epochs, 'loss': losses,
+                  'bpp': enc['bpp'], 'points': enc['point_num'], 'lossless': ok, 'stage_s': stage_s, 'overfit_s': t1 - t0,
+                  'encode_s': t2 - t1, 'decode_s': t3 - t2, 'seconds': stage_s + (t3 - t0), 'rank': rank}
+        del gop
+        return model, opt, losses, result
+
+    def first_fn(group, staged=None):
+        model, opt, losses, result = run_gop(group, args.first_epoch, None, staged)
+        ck = overfit.checkpoint(model, opt, args.first_epoch - 1, losses[-1])
+        ck['result'] = result
+        return ck
+
+    def other_fn(group, ckpt, staged=None):
+        return run_gop(group, args.others_epoch, ckpt, staged)[3]
+
+    schedule = 'static' if stage_all else getattr(args, 'schedule', 'pull')
+    prepared = {}
+    t_stage0 = time.time()
+    if stage_all:
+        mine = ([0] if rank == 0 else []) + gop_parallel.assign_gops(groups, world)[rank]
+        for g in mine:
+            prepared[g] = stage(groups[g])
+    stage_all_s = time.time() - t_stage0
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.time()
+    results = gop_parallel.run_sequence(groups, os.path.join(args.out, 'output'), first_fn, other_fn, rank, world, dist,
+                                        prepare_fn=stage, schedule=schedule, prepared=prepared)
+    torch.cuda.synchronize()
+    my_wall = time.time() - t0
+    wall = gop_parallel.max_over_ranks(my_wall, dist, 'cuda')
+    # phase A = rank 0's GOP 0; phase B = the rest of the wall.  Phase-B efficiency = busy GPU-seconds of the GOPs >= 1
+    # over (ranks x phase-B wall): what SURVEY.md section 8e asks to be reported next to the whole-sequence wall.
+    timed = lambda r: r['overfit_s'] + r['encode_s'] + r['decode_s'] + (0.0 if stage_all else r['stage_s'])
+    phase_a = timed(results[0]) if 0 in results else 0.0
+    phase_a = gop_parallel.max_over_ranks(phase_a, dist, 'cuda')
+    busy_b = gop_parallel.sum_over_ranks(sum(timed(r) for g, r in results.items() if g != 0), dist, 'cuda')
+    bits = gop_parallel.sum_over_ranks(sum(r['bpp']['bpp_all'] * r['points'] for r in results.values()), dist, 'cuda')
+    points = gop_parallel.sum_over_ranks(sum(r['points'] for r in results.values()), dist, 'cuda')
+    lossless = gop_parallel.sum_over_ranks(sum(0 if (r['lossless'] in (True, None)) else 1 for r in results.values()), dist, 'cuda') == 0
+    phase_b = max(wall - phase_a, 1e-9)
+    summary = {'frames': args.frames, 'gops': len(groups), 'n_gpus': world, 'schedule': schedule, 'wall_s': round(wall, 4),
+               'sec_per_frame': round(wall / args.frames, 6), 'phase_a_s': round(phase_a, 4), 'phase_b_s': round(phase_b, 4),
+               'phase_b_efficiency': round(busy_b / (world * phase_b), 4) if len(groups) > 1 else None,
+               'ideal_speedup_bound': round(gop_parallel.ideal_speedup(groups, world), 3),
+               'bits_per_point': round(bits / max(points, 1.0), 5), 'lossless': bool(lossless) if args.decode else None,
+               'inputs_resident_before_t0': bool(stage_all), 'staging_s_this_rank': round(stage_all_s, 2)}
+    return summary, results
+
+
+def init_dist(local):
+    import torch.distributed as dist
+    backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL over xGMI; gloo only for 1-GPU rehearsals
+    # the only collectives are a start-up barrier and the final reductions of wall times: a rank that finishes early waits
+    # there for the slowest one, so the watchdog timeout has to cover a whole sequence
+    timeout = datetime.timedelta(hours=12)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=timeout)
+    else:
+        dist.init_process_group(backend, timeout=timeout)
+    return dist
 
 
 def main():
@@ -42,14 +161,7 @@ def main():
     if os.environ.get('LINR_BENCH_SINGLE_DEVICE'):          # rehearsal of the multi-rank flow on a 1-GPU box (with gloo)
         local = 0
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL over xGMI
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend)
+    dist = init_dist(local) if world > 1 else None
     files = None
     if args.input_glob:
         import glob
@@ -57,55 +169,12 @@ def main():
         if not files:
             raise ValueError('no file matches %s' % args.input_glob)
         args.frames = len(files)
-    groups = gop_parallel.split_gops(args.frames, args.gop)
-
-    def load_frame(t):
-        return ply.read_points(files[t]) if files is not None else synthetic.sequence_frame(args.config, t)
-
-    def make_opt(model):
-        return FlatAdam(model, lr=args.learning_rate, weight_decay=args.decay_rate, step_size=args.step_size, gamma=args.gamma)
-
-    def run_gop(group, epochs, ckpt):
-        t0 = time.time()
-        gop = overfit.Gop(None, [load_frame(t) for t in group], None, 64, 'cuda')
-        model = overfit.gen_model(gop.scale_num, 'cuda', seed=args.seed)
-        opt = make_opt(model)
-        if ckpt is not None:
-            overfit.warm_start(model, opt, ckpt)                 # main.py:241-248
-        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr)
-        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
-        res_dir = os.path.join(args.out, 'result_enc', gop_parallel.gop_name(group))
-        codec.write_gop(enc, res_dir)
-        ok = None
-        if args.decode:
-            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), codec.read_gop(res_dir), 'cuda', workers=4)
-            ok = all(torch.equal(d, torch.as_tensor(i['ori']).cuda() + torch.tensor(m, device='cuda', dtype=torch.int32))
-                     for d, i, m in zip(dec, gop.infos, gop.coord_mins))
-        torch.cuda.synchronize()
-        result = {'gop': gop_parallel.gop_name(group), 'frames': len(group), 'epochs': epochs, 'loss': losses,
-                  'bpp': enc['bpp'], 'lossless': ok, 'seconds': time.time() - t0, 'rank': rank}
-        return model, opt, losses, result
-
-    def first_fn(group):
-        model, opt, losses, result = run_gop(group, args.first_epoch, None)
-        ck = overfit.checkpoint(model, opt, args.first_epoch - 1, losses[-1])
-        ck['result'] = result
-        return ck
-
-    def other_fn(group, ckpt):
-        return run_gop(group, args.others_epoch, ckpt)[3]
-
-    t0 = time.time()
-    results = gop_parallel.run_sequence(groups, os.path.join(args.out, 'output'), first_fn, other_fn, rank, world, dist)
-    torch.cuda.synchronize()
-    wall = gop_parallel.max_over_ranks(time.time() - t0, dist, 'cuda')
+    summary, results = run_sequence_job(args, rank, world, dist, files=files)
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, 'results_rank%d.json' % rank), 'w') as f:
         json.dump({str(k): v for k, v in results.items()}, f, indent=1)
     if rank == 0:
-        print(json.dumps({'frames': args.frames, 'gops': len(groups), 'n_gpus': world, 'wall_s': round(wall, 3),
-                          'sec_per_frame': round(wall / args.frames, 4),
-                          'ideal_speedup_bound': round(gop_parallel.ideal_speedup(groups, world), 3)}))
+        print(json.dumps(summary))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,6 +35,49 @@ CONFIGS = {
 }
 
 
+def sphere_shell_device(bitdepth, radius, centre, thickness, device, slab=32):
+    """The same voxel list as sphere_shell, enumerated on the GPU (x slabs of the bounding box; integer distances compared
+    with the float64 thresholds, so the result is identical).  Returns an int32 [P,3] tensor on `device`, x-major sorted.
+    A 784 k-point frame takes ~0.7 s in sphere_shell's numpy loop and a few milliseconds here - what makes the 300-frame
+    sequence of BASELINE config[2] practical to stage."""
+    import torch
+    size = 1 << bitdepth
+    c = [int(v) for v in centre]
+    ext = int(math.ceil(radius + thickness)) + 1
+    lo = [max(v - ext, 0) for v in c]
+    hi = [min(v + ext + 1, size) for v in c]
+    r_in, r_out = max(radius - thickness, 0.0), radius + thickness
+    t_in, t_out = r_in * r_in, r_out * r_out
+    ys = torch.arange(lo[1], hi[1], device=device, dtype=torch.int64)
+    zs = torch.arange(lo[2], hi[2], device=device, dtype=torch.int64)
+    d2 = ((ys - c[1]) ** 2)[:, None] + ((zs - c[2]) ** 2)[None, :]
+    chunks = []
+    for x0 in range(lo[0], hi[0], slab):
+        xs = torch.arange(x0, min(x0 + slab, hi[0]), device=device, dtype=torch.int64)
+        d = (d2[None, :, :] + ((xs - c[0]) ** 2)[:, None, None]).to(torch.float64)
+        idx = ((d > t_in) & (d < t_out)).nonzero()                  # row-major = x, then y, then z: the x-major order
+        if idx.shape[0]:
+            chunks.append(torch.stack([xs[idx[:, 0]], ys[idx[:, 1]], zs[idx[:, 2]]], dim=1).to(torch.int32))
+    if not chunks:
+        return torch.zeros((0, 3), dtype=torch.int32, device=device)
+    return torch.cat(chunks, dim=0)
+
+
+def sequence_params(config, t):
+    cfg = CONFIGS[config] if isinstance(config, str) else config
+    size = 1 << cfg['bitdepth']
+    cx = size // 2 + int(math.floor(3 * math.sin(2 * math.pi * t / 30)))
+    cz = size // 2 + int(math.floor(2 * math.cos(2 * math.pi * t / 45)))
+    r = cfg['radius'] + int(math.floor(4 * math.sin(2 * math.pi * t / 20)))
+    return cfg['bitdepth'], r, (cx, size // 2, cz), cfg['thickness']
+
+
+def sequence_frame_device(config, t, device='cuda'):
+    """sequence_frame(config, t) enumerated on `device` (identical points, int32 tensor)."""
+    b, r, c, th = sequence_params(config, t)
+    return sphere_shell_device(b, r, c, th, device)
+
+
 def sequence_frame(config, t):
     """Frame t of the synthetic sequence: centre += (floor(3 sin(2 pi t/30)), 0, floor(2 cos(2 pi t/45))),
     radius += floor(4 sin(2 pi t/20)) - integer, seed-free motion."""

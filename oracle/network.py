@@ -10,7 +10,7 @@ Reference lines restated:
   scale context + bits        models/model_core.py:38-81
   CNP wiring                  models/upsample.py:137-217 (note :213 - always the ORIGINAL x_glob)
   make_block                  models/upsample.py:88-97
-  InceptionResNet             models/resnet.py:7-60 ; ResNetBlock :146-162 (block_layers == 1: no extra skip)
+  InceptionResNet             models/resnet.py:7-60 ; ResNetBlock :146-162 (extra skip when block_layers > 1)
   PointwiseMLP                models/module_utils.py:42-81
   merge_two_frames (=concat)  models/function_utils.py:58-69
 MinkowskiEngine semantics (third-party, not in tree): SURVEY.md Appendix B.  PARITY UNPINNED at bit level for this file;
@@ -52,10 +52,16 @@ def inception(x, nbr, sd, p):
 
 
 def make_block(x, nbr, sd, p):
-    """upsample.py:88-97: conv3 -> ReLU -> ResNetBlock(1 x Inception) -> conv3."""
+    """upsample.py:88-97: conv3 -> ReLU -> ResNetBlock -> conv3.  ResNetBlock (resnet.py:146-162) chains its Inception
+    layers and adds its input once more when there is more than one; the layer count is read off the state dict."""
     a = F.relu(conv3(x, nbr, sd[p + '.0.kernel'], sd[p + '.0.bias']))
-    i = inception(a, nbr, sd, p + '.2.layers.0')
-    return conv3(i, nbr, sd[p + '.3.kernel'], sd[p + '.3.bias'])
+    out, nl = a, 0
+    while (p + '.2.layers.%d.conv0_0.kernel' % nl) in sd:
+        out = inception(out, nbr, sd, p + '.2.layers.%d' % nl)
+        nl += 1
+    if nl > 1:
+        out = out + a
+    return conv3(out, nbr, sd[p + '.3.kernel'], sd[p + '.3.bias'])
 
 
 def scale_context(sd, offset_tensor, scale_idx):

@@ -58,9 +58,11 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_spconv_bwd_weight(p16, 8, p16, 8, p16, 16, 16, 8, 8, p16, p16, 0, p16, 16, None) == -2             # ws short
     # whole network: NULL frame / parameters, stage range
     assert lib.linr_net_forward(None, p16, p16, 4096, 0, 8, None, None, None) == -1
-    assert lib.linr_net_train_step(None, p16, p16, 4096, 1.0, None, None, 0.01, 1.0, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
-    assert lib.linr_param_count(0) < 0 or lib.linr_param_count(0) == 0
-    assert lib.linr_param_count(7) == 54712
+    assert lib.linr_net_train_step(None, p16, p16, 4096, 1.0, None, None, 0.01, 1, None, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
+    assert lib.linr_param_count(0, 1) < 0
+    assert lib.linr_param_count(7, 1) == 54712
+    assert lib.linr_net_arena_bytes(-1, 1) == 0 and lib.linr_net_arena_bytes(100, 9) == 0
+    assert lib.linr_net_arena_bytes(100, 2) > lib.linr_net_arena_bytes(100, 1) > 0
     # range coder: capacity / NULL checks
     assert lib.linr_ac_encode_binary(None, None, 4, p16, 64) == -1
     assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
@@ -70,8 +72,12 @@ def test_c_abi_argument_checks(lib):
 
 def test_param_count_matches_reference_checkpoint(lib, golden_dir):
     g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))
-    assert lib.linr_param_count(7) == len(g['flat']) == 54712
-    assert lib.linr_param_count(0) < 0 and lib.linr_param_count(17) < 0
+    assert lib.linr_param_count(7, 1) == len(g['flat']) == 54712
+    assert lib.linr_param_count(0, 1) < 0 and lib.linr_param_count(17, 1) < 0
+    # --block_layers (main.py:521): every extra Inception layer of block_in adds 27*8*4+4 + 2*(27*4*4+4) + 8*4+4 + 4*4+4 floats
+    per_layer = (27 * 8 * 4 + 4) + 2 * (27 * 4 * 4 + 4) + (8 * 4 + 4) + (4 * 4 + 4)
+    assert lib.linr_param_count(7, 2) == 54712 + per_layer and lib.linr_param_count(7, 3) == 54712 + 2 * per_layer
+    assert lib.linr_param_count(7, 0) < 0 and lib.linr_param_count(7, 5) < 0
 
 
 def test_state_dict_contract(golden_dir):
@@ -89,9 +95,34 @@ def test_state_dict_contract(golden_dir):
     m.load_state_dict(new)
     assert torch.equal(m.flat_parameters(), torch.from_numpy(g['flat']))          # parameters() order == flat order
     assert torch.equal(torch.cat([p.reshape(-1) for p in m.parameters()]), m.flat_parameters())
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match='hidden_channel_conv=16 is not supported'):
         LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 16, 'block_layers': 1, 'outstage': 8,
                          'instage': 1})
+    with pytest.raises(ValueError, match='block_layers'):
+        LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 5, 'outstage': 8,
+                         'instage': 1})
+
+
+def test_block_layers_state_dict_and_mismatch_is_rejected(lib, golden_dir):
+    """--block_layers 2 / 3 (main.py:521): the extra Inception layers appear under the reference's names
+    (upsampler.block_in.2.layers.<l>.*) right after layer 0, parameters() order == the kernels' flat order, and a
+    checkpoint of another depth is rejected by load_state_dict instead of being mis-loaded."""
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    mk = lambda bl: LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': bl,
+                                     'outstage': 8, 'instage': 1})
+    m1, m2, m3 = mk(1), mk(2), mk(3)
+    k1, k2 = list(m1.state_dict()), list(m2.state_dict())
+    extra = [k for k in k2 if k not in k1]
+    assert extra == ['upsampler.block_in.2.layers.1.%s.%s' % (c, t) for c in ('conv0_0', 'conv0_1', 'conv1_0', 'conv1_1', 'conv1_2')
+                     for t in ('kernel', 'bias')]
+    assert k2.index(extra[0]) == k2.index('upsampler.block_in.2.layers.0.conv1_2.bias') + 1
+    assert [k for k in k2 if k not in extra] == k1
+    assert m2.flat_parameters().numel() == lib.linr_param_count(7, 2) and m3.flat_parameters().numel() == lib.linr_param_count(7, 3)
+    assert torch.equal(torch.cat([p.reshape(-1) for p in m3.parameters()]), m3.flat_parameters())
+    with pytest.raises(RuntimeError, match='layers.1'):
+        m1.load_state_dict(m2.state_dict())                     # unexpected keys
+    with pytest.raises(RuntimeError, match='layers.1'):
+        m2.load_state_dict(m1.state_dict())                     # missing keys
 
 
 def test_init_statistics():
@@ -201,13 +232,18 @@ def test_flat_adam_state_dict_roundtrip():
     opt.exp_avg.normal_()
     opt.exp_avg_sq.uniform_()
     opt.t, opt.lr = 17, 0.00731
+    opt.t_scale[:] = [17, 17, 17, 17, 9, 0]                     # scale 4 was absent from 8 frames, scale 5 never seen
     sd = opt.state_dict()
+    names = [n for n, _ in m.named_parameters()]
+    assert all((i in sd['state']) == (not names[i].startswith('scale_mlp.5.')) for i in range(len(names)))
+    assert float(sd['state'][names.index('scale_mlp.4.0.weight')]['step']) == 9.0
     ref = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4)
     ref.load_state_dict(sd)                                     # torch accepts our format
     opt2 = FlatAdam(m)
     opt2.load_state_dict(ref.state_dict())
-    assert opt2.t == 17 and abs(opt2.lr - 0.00731) < 1e-12
-    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert opt2.t == 17 and abs(opt2.lr - 0.00731) < 1e-12 and opt2.t_scale.tolist() == [17, 17, 17, 17, 9, 0]
+    keep = torch.cat([torch.full((p.numel(),), 0.0 if n.startswith('scale_mlp.5.') else 1.0) for n, p in m.named_parameters()])
+    assert torch.equal(opt2.exp_avg, opt.exp_avg * keep) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq * keep)
     for i in range(1, 100):
         opt2.scheduler_step()
     assert abs(opt2.lr - 0.00731 * 0.992 ** 3) < 1e-12          # StepLR(32, 0.992) stepped per frame

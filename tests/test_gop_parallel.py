@@ -52,3 +52,61 @@ def test_two_rank_gloo_sequence():
         assert all(v['rank'] == 1 for v in r1['res'].values())
         assert r1['res'][2]['frames'] == [8, 9, 10, 11]
         assert os.path.exists(os.path.join(tmp, 'work', 'gop_0_3', 'model.pth'))
+
+
+def _pull_worker(rank, world, init_file, work_dir, out_dir):
+    """schedule='pull' + prepare_fn: ranks >= 1 stage their first GOP BEFORE the GOP-0 checkpoint exists (phase-A overlap),
+    every GOP >= 1 is taken exactly once from the claim-file queue, rank 0 joins the queue after GOP 0."""
+    import time
+    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
+    groups = gp.split_gops(5 * 4 + 2, 4)                     # 6 GOPs, the last one short
+    ck_path = os.path.join(work_dir, 'gop_0_3', 'model.pth')
+    staged_before_ckpt = []
+
+    def prepare_fn(group):
+        staged_before_ckpt.append((group[0], not os.path.exists(ck_path)))
+        return {'staged': group[0]}
+
+    def first_fn(group, prepared):
+        assert prepared == {'staged': 0}
+        time.sleep(0.5)                                      # rank 1 stages its first GOP meanwhile
+        return {'model': {'w': torch.ones(2)}, 'result': 'gop0'}
+
+    def other_fn(group, ckpt, prepared):
+        assert prepared == {'staged': group[0]} and float(ckpt['model']['w'][0]) == 1.0
+        time.sleep(0.05)
+        return {'rank': rank, 'first': group[0]}
+
+    res = gp.run_sequence(groups, work_dir, first_fn, other_fn, rank, world, dist, prepare_fn=prepare_fn, schedule='pull')
+    torch.save({'res': res, 'staged': staged_before_ckpt}, os.path.join(out_dir, 'p%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pull_schedule_and_phase_a_overlap():
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, 'init')
+        mp.spawn(_pull_worker, args=(2, init_file, os.path.join(tmp, 'work'), tmp), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(tmp, 'p0.pt'), weights_only=False)
+        r1 = torch.load(os.path.join(tmp, 'p1.pt'), weights_only=False)
+        done = sorted([g for g in r0['res'] if g != 0] + list(r1['res']))
+        assert done == [1, 2, 3, 4, 5] and 0 in r0['res']                    # every GOP exactly once
+        assert not (set(r0['res']) & set(r1['res']))
+        assert r1['staged'][0] == (4, True)                                 # rank 1 staged GOP 1 (frames 4..) before the checkpoint existed
+        assert len(r0['res']) >= 2 and len(r1['res']) >= 2                  # both ranks pulled from the queue in phase B
+        assert os.listdir(os.path.join(tmp, 'work', 'claims'))
+
+
+def test_rank0_failure_releases_waiting_ranks(tmp_path):
+    """A failing GOP 0 leaves an error marker; a waiting rank raises instead of polling for ever."""
+    groups = gp.split_gops(8, 4)
+    work = str(tmp_path / 'work')
+    import pytest
+
+    def boom(group):
+        raise ValueError('gop 0 failed')
+
+    with pytest.raises(ValueError):
+        gp.run_sequence(groups, work, boom, lambda g, c: None, rank=0, world=2)
+    with pytest.raises(RuntimeError):
+        gp.run_sequence(groups, work, boom, lambda g, c: None, rank=1, world=2)

@@ -1,7 +1,7 @@
 """GPU parity: every HIP kernel and the whole-network executor (through the C-ABI) against the CPU oracle.
 
 Tolerances (the reference states none): fp32 HIP vs fp32 oracle
-  logits  |d| <= 1e-4 + 1e-4 |x|     bits  rel <= 1e-5     gradients  |d| <= 1e-4 * max|g| + 1e-6
+  logits  |d| <= 1e-4 + 1e-4 |x|     bits  rel <= 1e-5     gradients  |d| <= 1e-4 * max|g of the SAME tensor| + 1e-9
 Integer / index / byte work (kernel map, streams, decoded geometry) is bit-exact.
 """
 import math
@@ -249,10 +249,10 @@ def test_adam_matches_torch(pkg):
 
 
 # ---- whole network --------------------------------------------------------------------------------------------------------
-def _model_and_oracle(pkg, scale_num, seed=8807):
+def _model_and_oracle(pkg, scale_num, seed=8807, block_layers=1):
     from linr_pcgc_amd.model_core import LINR_PCGC_Model
     torch.manual_seed(seed)
-    model = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1,
+    model = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': block_layers,
                              'outstage': 8, 'instage': 1})
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     return model.cuda(), sd
@@ -305,9 +305,29 @@ def test_net_forward_with_reference_trained_weights(pkg, shell, golden_dir):
     assert float(bits_m) > 4.0 * float(bits)
 
 
-def test_net_backward_matches_autograd(pkg, shell):
+def _grads_close_per_tensor(grads, sdo, rtol=1e-4, floor=1e-9):
+    """gradients rel <= 1e-4 - every tensor against ITS OWN largest gradient (a tensor whose gradients
+    are orders of magnitude below the model's largest one must still be right)."""
+    off, worst = 0, (0.0, '')
+    for name, v in sdo.items():
+        n = v.numel()
+        mine = grads[off:off + n].view(v.shape).detach().double().cpu()
+        ref = v.grad.detach().double()
+        gmax = float(ref.abs().max())
+        err = float((mine - ref).abs().max())
+        assert err <= rtol * gmax + floor, 'grad %s: max err %.3e vs tolerance %.3e (own max %.3e)' % (name, err, rtol * gmax + floor, gmax)
+        if gmax > 0 and err / gmax > worst[0]:
+            worst = (err / gmax, name)
+        off += n
+    return worst
+
+
+@pytest.mark.parametrize('block_layers', [1, 2, 3])
+def test_net_backward_matches_autograd(pkg, shell, block_layers):
+    """bits and all parameter gradients against autograd through the oracle, for --block_layers 1, 2, 3
+    (main.py:521; models/resnet.py:156-162 incl. the extra skip when > 1)."""
     from linr_pcgc_amd import engine
-    model, sd = _model_and_oracle(pkg, 5)
+    model, sd = _model_and_oracle(pkg, 5, block_layers=block_layers)
     frame = model.make_frame(shell['scales'])
     flat = model.flat_parameters()
     bits = torch.zeros(1, dtype=torch.float64, device='cuda')
@@ -316,18 +336,45 @@ def test_net_backward_matches_autograd(pkg, shell):
     gscale = 1.0 / shell['point_num']
     engine.net_backward(frame, flat, grads, gscale)
     sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
-    loss = onet.frame_bits(sdo, onet.to_torch_scales(shell['scales'])) * gscale
-    loss.backward()
-    off = 0
-    gmax = max(float(v.grad.abs().max()) for v in sdo.values())
-    for name, v in sdo.items():
-        n = v.numel()
-        mine = grads[off:off + n].view(v.shape)
-        _close(mine, v.grad, 1e-3, 1e-4 * gmax, 'grad ' + name)
-        off += n
+    bits_o = onet.frame_bits(sdo, onet.to_torch_scales(shell['scales']))
+    assert abs(float(bits) - float(bits_o)) <= 1e-5 * float(bits_o)
+    (bits_o * gscale).backward()
+    _grads_close_per_tensor(grads, sdo)
     grads2 = torch.zeros_like(flat)
     engine.net_backward(frame, flat, grads2, gscale)
     assert torch.equal(grads, grads2), 'backward must be bit-reproducible'
+
+
+@pytest.mark.parametrize('block_layers', [2, 3])
+def test_block_layers_train_and_lossless(pkg, shell, block_layers):
+    """--block_layers > 1 end to end: 4 fused train steps track torch.optim.Adam on the oracle, the staged decoder
+    reproduces the encoder's probabilities bit for bit and decodes the occupancy losslessly."""
+    from linr_pcgc_amd import engine
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, sd = _model_and_oracle(pkg, 5, block_layers=block_layers)
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tsc = onet.to_torch_scales(shell['scales'])
+    for it in range(4):
+        bits = train_step(model, opt, frame, shell['point_num'])
+        lo = onet.frame_bits(sdo, tsc)
+        (lo / shell['point_num']).backward()
+        opt_o.step()
+        opt_o.zero_grad()
+        assert abs(float(bits) - float(lo)) <= 3e-4 * float(lo), (it, float(bits), float(lo))
+    p1, _ = model.frame_probs(frame)
+    staged = torch.empty_like(p1)
+    for k in range(8):
+        engine.net_forward(frame, model.flat_parameters(), k, k + 1, staged, None)
+    assert torch.equal(p1, staged)
+    s0 = shell['scales'][0]
+    d = {'coord': torch.tensor(s0['coord'], device='cuda'), 'offset_tensor': torch.tensor(s0['offset_tensor'], device='cuda'),
+         'occ_lst': [torch.tensor(s0['occ'][:, i:i + 1], device='cuda') for i in range(8)], 'scale_idx': 0}
+    enc = model.encode(d)
+    dec = model.decode({'enc_bytes': enc['enc_bytes'], 'coord': d['coord'], 'offset_tensor': d['offset_tensor'], 'scale_idx': 0})
+    assert torch.equal(torch.cat(dec, dim=1).cpu(), torch.tensor(s0['occ']))
 
 
 def test_more_scales_than_one_grouped_launch(pkg):
@@ -793,3 +840,74 @@ def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
         ref = torch.as_tensor(info['ori']).cuda() + torch.tensor(mn, device='cuda', dtype=torch.int32)
         assert torch.equal(d, ref)
     assert 0 < enc['bpp']['point_bpp'] < 8 and enc['bpp']['model_bpp'] > 0      # tiny clouds: the 35 KB model dominates bpp_all
+
+
+def test_adam_skips_scales_a_frame_lacks(pkg, shell):
+    """torch.optim.Adam skips parameters whose .grad is None (zero_grad(set_to_none=True), torch 2's default) and keeps a
+    step counter per parameter: the context MLP of a scale that a frame does not contain (custom_dataset.py:325 stops
+    early on min_point_num) is left alone on that frame.  A 2-frame GOP whose second frame lacks the coarsest scale,
+    6 fused steps, against torch.optim.Adam on the oracle (grads of absent scales stay None there)."""
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, sd = _model_and_oracle(pkg, 5)
+    full = shell['scales']
+    frames = [model.make_frame(full), model.make_frame(full[:-1])]
+    tscs = [onet.to_torch_scales(full), onet.to_torch_scales(full[:-1])]
+    opt = FlatAdam(model)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    names = list(sdo)
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    for it in range(6):
+        j = it % 2
+        train_step(model, opt, frames[j], shell['point_num'])
+        (onet.frame_bits(sdo, tscs[j]) / shell['point_num']).backward()
+        if j == 1:
+            assert sdo['scale_mlp.4.0.weight'].grad is None           # the oracle's absent scale really has no gradient
+        opt_o.step()
+        opt_o.zero_grad()                                             # set_to_none=True
+    assert opt.t == 6 and opt.t_scale.tolist() == [6, 6, 6, 6, 3]
+    st = opt_o.state_dict()['state']
+    assert float(st[names.index('scale_mlp.4.0.weight')]['step']) == 3.0 and float(st[names.index('scale_mlp.0.0.weight')]['step']) == 6.0
+    flat_o = torch.cat([v.detach().reshape(-1) for v in sdo.values()])
+    _close(model.flat_parameters(), flat_o, 0, 3e-3, 'parameters after 6 Adam steps over frames with 5 / 4 scales')
+    # the absent scale's MLP is exactly where torch left it - closer than any update that also decayed it would be
+    off = 0
+    for n, v in sdo.items():
+        if n.startswith('scale_mlp.4.'):
+            mine = model.flat_parameters()[off:off + v.numel()].cpu()
+            _close(mine, v.detach().reshape(-1), 0, 5e-4, n)
+        off += v.numel()
+    # and our own optimiser state round-trips through torch's format with the per-parameter steps intact
+    opt2 = FlatAdam(model)
+    opt2.load_state_dict(opt.state_dict())
+    assert opt2.t_scale.tolist() == [6, 6, 6, 6, 3] and torch.equal(opt2.exp_avg, opt.exp_avg)
+
+
+def test_device_generator_equals_numpy_generator(pkg):
+    from linr_pcgc_amd import synthetic
+    for cfg, t in (('sphere8', 0), ('loot10', 17)):
+        a = synthetic.sequence_frame(cfg, t)
+        b = synthetic.sequence_frame_device(cfg, t, 'cuda')
+        assert b.dtype == torch.int32 and np.array_equal(a, b.cpu().numpy())
+
+
+def test_config2_sequence_300_frames_gop32(pkg, tmp_path):
+    """BASELINE config[2] on one GPU: the 300-frame loot10 stand-in in GOPs of 32 (10 GOPs, the last one 12 frames),
+    first_epoch = others_epoch = 1: GOP 0 from scratch, GOPs 1..9 warm-started from its checkpoint file (model + Adam
+    state), every GOP encoded to the reference's directory layout and EVERY frame decoded from the files and compared
+    bit for bit (main.py:83-104, encoder.py:57-156, decoder.py:51-146)."""
+    from linr_pcgc_amd import gop_parallel, run
+    out = str(tmp_path / 'seq')
+    args = run.parse(['--config', 'loot10', '--frames', '300', '--gop', '32', '--first-epoch', '1', '--others-epoch', '1',
+                      '--out', out, '--decode', '--schedule', 'pull'])
+    summary, results = run.run_sequence_job(args, 0, 1, None)
+    assert summary['gops'] == 10 and summary['frames'] == 300 and summary['lossless'] is True
+    assert sorted(results) == list(range(10))
+    assert [results[g]['frames'] for g in range(10)] == [32] * 9 + [12]
+    assert all(r['lossless'] for r in results.values())
+    assert abs(summary['ideal_speedup_bound'] - 1.0) < 1e-9                  # one GPU
+    assert abs(gop_parallel.ideal_speedup(gop_parallel.split_gops(300, 32), 8) - 300 / 76.0) < 1e-9
+    # warm start: after ONE epoch every later GOP is already far below GOP 0's from-scratch loss
+    assert all(results[g]['loss'][-1] < 0.8 * results[0]['loss'][-1] for g in range(1, 10))
+    assert 0.2 < summary['bits_per_point'] < 3.0
+    assert os.path.exists(os.path.join(out, 'output', 'gop_0_31', 'model.pth'))
+    assert os.path.exists(os.path.join(out, 'result_enc', 'gop_288_299', 'bins', 'frame0011_scale0.bin'))
