@@ -211,6 +211,64 @@ LINR_API int linr_net_train_step(const linr_frame* f, float* params, float* aren
                         float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
                         double beta1, double beta2, double eps, double weight_decay, double* bits_acc, void* stream);
 
+/* ---- the executor's fused layers as stand-alone ops ------------------------------------------------------------
+ * What linr_net_forward / _backward launch for one layer, callable (and testable) on its own.  All of them work on the
+ * compressed kernel map (linr_kmap_compress) and follow the LINR_PAD_ROW contract: every matrix that a kernel GATHERS
+ * from (named below) needs a readable all-zero row at index -1 and 16-byte aligned rows.
+ *
+ * Scale context (LINR_PCGC_Model.logic_core, models/model_core.py:48-53): x0[r] = W2 relu(W1 [emb_s | offset_feat[r]] + b1) + b2
+ * with the weights of row r's scale; `f` supplies rows, row_off_h, scale_idx_h, model_scale_num, block_layers (parameter
+ * layout) and offset_feat.  mix [rows][16], hid [rows][16], x0 [rows][8].  bwd: ghid = (W2^T gx0) * (hid > 0). */
+LINR_API int linr_sce_fwd(const float* params, const linr_frame* f, float* mix, float* hid, float* x0, void* stream);
+LINR_API int linr_sce_bwd(const float* params, const linr_frame* f, const float* gx0, const float* hid, float* ghid,
+                 void* stream);
+
+/* Occupancy head of one stage = CNP.basic_module + the stage's BCE term (models/upsample.py:137-161,
+ * models/model_core.py:76-81): c = conv3(prior; Wp, bp) (gathers `prior` [n][8]), z = w2 . relu(W1 c + b1) + b2,
+ * p = sigmoid(z); if bits_acc != NULL the stage's bits (target = occupancy column, stride target_ld) are ADDED into it
+ * (fixed-order block partials in ws).  bwd: gc = d(gscale * bits)/dc and the head-MLP gradients
+ * ghead[241] = [gW1 24x8 | gb1 24 | gw2 24 | gb2 1] (parameters() order of inner_mlps.k.0), deterministic.
+ * ws: linr_head_workspace_bytes(n) bytes, 16-byte aligned. */
+LINR_API size_t linr_head_workspace_bytes(int64_t n);
+LINR_API int linr_head_fwd(const float* prior, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                  const float* Wp, const float* bp, const float* w1, const float* b1, const float* w2, const float* b2,
+                  const float* target, int32_t target_ld, float* c_out, float* p_out, double* bits_acc, void* ws,
+                  size_t ws_bytes, void* stream);
+LINR_API int linr_head_bwd(const float* c, const float* p, const float* target, int32_t target_ld, const float* w1,
+                  const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* ghead, void* ws,
+                  size_t ws_bytes, void* stream);
+
+/* One InceptionResNet layer (models/resnet.py:55-60) in two launches: H = [relu(conv0_0(x)) | relu(conv1_0(x))],
+ * M = relu(conv1_1(H[:,4:8])), I = [conv0_1(H[:,0:4]) | conv1_2(M)] + x.  x, H are gathered.  All [n][8] except M [n][4].
+ * bwd_data: from gI (gathered) the launches of the backward data chain: gM = (gI[:,4:8] W12^T) * (M > 0) (gathered),
+ * gH = [bwd(gI[:,0:4]; W01) | bwd(gM; W11)] * (H > 0) (gathered), gX = bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] W10^T
+ * (+ old gX: LINR_ACCUM) (* (x > 0): LINR_RELU_MASK, x = the ReLU output that fed the layer). */
+typedef struct linr_inception_params {
+    const float *w00, *b00;   /* conv0_0 [27][8][4], [4] */
+    const float *w01, *b01;   /* conv0_1 [27][4][4], [4] */
+    const float *w10, *b10;   /* conv1_0 [8][4], [4]     */
+    const float *w11, *b11;   /* conv1_1 [27][4][4], [4] */
+    const float *w12, *b12;   /* conv1_2 [4][4], [4]     */
+} linr_inception_params;
+LINR_API int linr_inception_fwd(const float* x, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                       const linr_inception_params* q, float* H, float* M, float* I, void* stream);
+LINR_API int linr_inception_bwd_data(const float* gI, const float* x, const float* H, const float* M, const int32_t* lo,
+                            const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gM,
+                            float* gH, float* gX, uint32_t flags, void* stream);
+/* weight gradients of the layer's two 4->4 convolutions in one pass (conv0_1 on H[:,0:4] with gradient g0, conv1_1 on
+ * H[:,4:8] with g1): 512 per-block partials slab[b][872] = [gW01 432 | gb01 4 | gW11 432 | gb11 4], summed in ascending b. */
+LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
+                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                             float* slab, void* stream);
+
+/* First convolutions of the 7 outter blocks (models/upsample.py:206-214 -> make_block's first conv + ReLU): block g + 1
+ * computes relu(conv3(occ[:, :g+1]; kernel [27][g+1][8]) + bias) on the SAME gathered occupancy rows, so one gather feeds
+ * all seven.  occ [n][8] (gathered); kernel / bias of block g at params + w_off_h[g] / b_off_h[g]; result of block g at
+ * out + out_off_h[g] ([n][8], element offsets, multiples of 4). */
+LINR_API int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                   const float* params, const int64_t* w_off_h, const int64_t* b_off_h, float* out,
+                   const int64_t* out_off_h, void* stream);
+
 /* ---- arithmetic-coder feed (host side) -----------------------------------------------------------------------
  * Replaces torchac.encode_float_cdf / decode_float_cdf as used by BinaryArithmeticCoding
  * (models/module_utils.py:8-40; callers models/upsample.py:224-237,275; models/model_core.py:204-208) and by the

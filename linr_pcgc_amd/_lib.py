@@ -23,6 +23,11 @@ class LinrFrame(ctypes.Structure):
                 ('offset_feat', c_ptr), ('occ', c_ptr)]
 
 
+class LinrInceptionParams(ctypes.Structure):
+    """struct linr_inception_params (include/linr_hip.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('w00', 'b00', 'w01', 'b01', 'w10', 'b10', 'w11', 'b11', 'w12', 'b12')]
+
+
 _PROTOS = {
     'linr_abi_version': (ctypes.c_int, []),
     'linr_param_count': (c_i64, [c_i32, c_i32]),
@@ -63,6 +68,19 @@ _PROTOS = {
     'linr_net_backward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr]),
     'linr_net_train_step': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr, c_f64,
                                            c_i64, c_ptr, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
+    'linr_sce_fwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_sce_bwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_head_workspace_bytes': (c_size, [c_i64]),
+    'linr_head_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32,
+                                     c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'linr_head_bwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_i64, c_ptr, c_ptr, c_size,
+                                     c_ptr]),
+    'linr_inception_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr,
+                                          c_ptr, c_ptr]),
+    'linr_inception_bwd_data': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
+                                               ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr, c_ptr, c_u32, c_ptr]),
+    'linr_spconv_wgrad_dual44': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'linr_occ_conv7': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),

@@ -95,6 +95,8 @@ int linr_head_bwd_launch(const float* c, const float* p, const float* target, in
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
                          hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
+int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float* gsum, hipStream_t s);
+__attribute__((visibility("hidden")))
 int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s);
 __attribute__((visibility("hidden")))
 int linr_dual44_fwd_launch(const float* H, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, const float* w01,

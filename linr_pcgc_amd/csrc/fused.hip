@@ -1224,3 +1224,119 @@ int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, c
 #undef GO
     return LINR_EINVAL;
 }
+
+
+// ---- the executor's fused layers as stand-alone ops (include/linr_hip.h) ---------------------------------------------------
+static bool cmap_ok(const void* in, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n) {
+    return in && lo && mask && ld >= n;
+}
+#define HEAD_PARAMS 241            // inner_mlps.k.0: 0.weight [24][8], 0.bias [24], 2.weight [1][24], 2.bias [1]
+
+extern "C" size_t linr_head_workspace_bytes(int64_t n) {
+    if (n < 0) return 0;
+    const size_t fwd = (size_t)linr_grid(n, LINR_CONV_BLOCK) * sizeof(double);
+    const size_t bwd = (size_t)LINR_WG_BLOCKS * HEAD_PARAMS * sizeof(float);
+    return (fwd > bwd ? fwd : bwd) + 64;
+}
+
+extern "C" int linr_head_fwd(const float* prior, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                             const float* Wp, const float* bp, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* target, int32_t target_ld, float* c_out, float* p_out,
+                             double* bits_acc, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!cmap_ok(prior, lo, mask, ld, n) || !Wp || !bp || !w1 || !b1 || !w2 || !b2 || !c_out || !p_out) return LINR_EINVAL;
+    if (bits_acc && (!target || target_ld < 1 || !ws)) return LINR_EINVAL;
+    if (!linr_aligned16(prior) || !linr_aligned16(c_out)) return LINR_EALIGN;
+    if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    double* part = nullptr;
+    if (bits_acc) {
+        if (ws_bytes < linr_head_workspace_bytes(n)) return LINR_ENOSPC;
+        if (((uintptr_t)ws) & 7u) return LINR_EALIGN;
+        part = (double*)ws;
+    }
+    int rc = linr_cconv_head_launch(prior, lo, mask, ld, n, Wp, bp, c_out, w1, b1, w2, b2, target, target_ld, p_out, part,
+                                    (hipStream_t)stream);
+    if (rc) return rc;
+    if (bits_acc) return linr_bits_finish_launch(part, (int)linr_grid(n, LINR_CONV_BLOCK), bits_acc, (hipStream_t)stream);
+    return 0;
+}
+
+extern "C" int linr_head_bwd(const float* c, const float* p, const float* target, int32_t target_ld, const float* w1,
+                             const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* ghead, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (n < 0 || target_ld < 1) return LINR_EINVAL;
+    if (!ghead) return LINR_EINVAL;
+    if (n == 0) return linr_hip_rc(hipMemsetAsync(ghead, 0, HEAD_PARAMS * sizeof(float), (hipStream_t)stream));
+    if (!c || !p || !target || !w1 || !b1 || !w2 || !gc || !ws) return LINR_EINVAL;
+    if (ws_bytes < linr_head_workspace_bytes(n)) return LINR_ENOSPC;
+    if (!linr_aligned16(c) || !linr_aligned16(gc) || !linr_aligned16(ws)) return LINR_EALIGN;
+    float* slab = (float*)ws;
+    // gscale multiplies BITS (like linr_bce_bits_bwd); the kernel works in nats: d bits / d nats = 1 / ln 2
+    int rc = linr_head_bwd_launch(c, p, target, target_ld, w1, b1, w2, gscale * 1.4426950408889634f, gc, n, slab, HEAD_PARAMS, 0, 192, 216, 240,
+                                  (hipStream_t)stream);
+    if (rc) return rc;
+    return linr_slab_reduce_launch(slab, LINR_WG_BLOCKS, HEAD_PARAMS, ghead, (hipStream_t)stream);
+}
+
+static bool inc_ok(const linr_inception_params* q) {
+    return q && q->w00 && q->b00 && q->w01 && q->b01 && q->w10 && q->b10 && q->w11 && q->b11 && q->w12 && q->b12;
+}
+
+extern "C" int linr_inception_fwd(const float* x, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                  const linr_inception_params* q, float* H, float* M, float* I, void* stream) {
+    if (n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!cmap_ok(x, lo, mask, ld, n) || !inc_ok(q) || !H || !M || !I) return LINR_EINVAL;
+    if (!linr_aligned16(x) || !linr_aligned16(H) || !linr_aligned16(M) || !linr_aligned16(I)) return LINR_EALIGN;
+    if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    int rc = linr_conv_pw_fwd_launch(x, lo, mask, ld, n, q->w00, q->b00, q->w10, q->b10, H, (hipStream_t)stream);
+    if (rc) return rc;
+    return linr_dual44_fwd_launch(H, lo, mask, ld, n, q->w01, q->b01, q->w11, q->b11, x, q->w12, q->b12, M, I, (hipStream_t)stream);
+}
+
+extern "C" int linr_inception_bwd_data(const float* gI, const float* x, const float* H, const float* M, const int32_t* lo,
+                                       const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gM,
+                                       float* gH, float* gX, uint32_t flags, void* stream) {
+    if (n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!cmap_ok(gI, lo, mask, ld, n) || !inc_ok(q) || !H || !M || !gM || !gH || !gX) return LINR_EINVAL;
+    if ((flags & LINR_RELU_MASK) && !x) return LINR_EINVAL;
+    if (flags & ~(LINR_RELU_MASK | LINR_ACCUM)) return LINR_EINVAL;
+    if (!linr_aligned16(gI) || !linr_aligned16(gM) || !linr_aligned16(gH) || !linr_aligned16(gX) || !linr_aligned16(H) ||
+        !linr_aligned16(M)) return LINR_EALIGN;
+    if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // I[:,4:8] = M @ W12 + b12 + x[:,4:8], M = relu(.)  =>  gM = (gI[:,4:8] @ W12^T) * (M > 0)
+    int rc = linr_linear_launch(gI + 4, 8, n, q->w12, 1, 4, nullptr, 4, 4, nullptr, 0, M, 4, gM, 4, LINR_RELU_MASK, s);
+    if (rc) return rc;
+    rc = linr_dual44_bwd_launch(gI, gM, lo, mask, ld, n, q->w01, q->w11, H, gH, s);
+    if (rc) return rc;
+    return linr_conv_bwd_ga_launch(gH, lo, mask, ld, n, q->w00, q->w10, gI, x, gX, flags, s);
+}
+
+extern "C" int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                              const float* params, const int64_t* w_off_h, const int64_t* b_off_h, float* out,
+                              const int64_t* out_off_h, void* stream) {
+    if (n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!cmap_ok(occ, lo, mask, ld, n) || !params || !w_off_h || !b_off_h || !out || !out_off_h) return LINR_EINVAL;
+    if (!linr_aligned16(occ) || !linr_aligned16(out)) return LINR_EALIGN;
+    for (int g = 0; g < 7; ++g)
+        if (w_off_h[g] < 0 || b_off_h[g] < 0 || (out_off_h[g] & 3)) return LINR_EINVAL;
+    if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    return linr_occ_conv7_launch(occ, lo, mask, ld, n, params, w_off_h, b_off_h, out, out_off_h, (hipStream_t)stream);
+}
+
+extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
+                                        const int32_t* nbr, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                        float* slab, void* stream) {
+    if (n < 0 || ld < n || g0_ld < 4 || g1_ld < 4) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!H || !g0 || !g1 || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;
+    if (!linr_aligned16(H)) return LINR_EALIGN;
+    if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    // per block: [W01 432 | b01 4 | W11 432 | b11 4]
+    return linr_conv3_wgrad_dual44(H, g0, g0_ld, g1, g1_ld, nbr, ld, n, slab, 872, 0, 432, 436, 868, LINR_WG_BLOCKS,
+                                   (hipStream_t)stream, nullptr, 1, lo, mask);
+}

@@ -818,6 +818,49 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     return linr_launch_rc();
 }
 
+// ---- scale context as stand-alone ops (the launches linr_net_forward / _backward make for it) ---------------------------
+static int sce_frame_check(const linr_frame* f, Layout& L) {
+    if (!f || f->rows < 0 || f->n_scales < 1 || f->n_scales > MAX_SCALES || !f->row_off_h || !f->scale_idx_h) return LINR_EINVAL;
+    if (!make_layout(L, f->model_scale_num, f->block_layers < 1 ? 1 : f->block_layers)) return LINR_EINVAL;
+    if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
+    for (int s = 0; s < f->n_scales; ++s) {
+        if (f->row_off_h[s + 1] < f->row_off_h[s]) return LINR_EINVAL;
+        if (f->scale_idx_h[s] < 0 || f->scale_idx_h[s] >= f->model_scale_num) return LINR_EINVAL;
+    }
+    return 0;
+}
+
+extern "C" int linr_sce_fwd(const float* params, const linr_frame* f, float* mix, float* hid, float* x0, void* stream) {
+    Ctx c;
+    TRY(sce_frame_check(f, c.L));
+    if (f->rows == 0) return 0;
+    if (!params || !f->offset_feat || !mix || !hid || !x0) return LINR_EINVAL;
+    if (!linr_aligned16(mix) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
+    c.f = f;
+    sce_fwd_k<<<linr_grid(f->rows, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sce_args(c), f->rows,
+                                                                                     mix, hid, x0);
+    return linr_launch_rc();
+}
+
+extern "C" int linr_sce_bwd(const float* params, const linr_frame* f, const float* gx0, const float* hid, float* ghid,
+                            void* stream) {
+    Ctx c;
+    TRY(sce_frame_check(f, c.L));
+    if (f->rows == 0) return 0;
+    if (!params || !gx0 || !hid || !ghid) return LINR_EINVAL;
+    if (!linr_aligned16(gx0) || !linr_aligned16(hid) || !linr_aligned16(ghid)) return LINR_EALIGN;
+    c.f = f;
+    sce_bwd_k<<<linr_grid(f->rows, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(params, sce_args(c), f->rows, gx0, hid, ghid);
+    return linr_launch_rc();
+}
+
+// fixed-order sum of the [nblocks][total] partial slab (shared with the op-level entries of csrc/fused.hip)
+int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float* gsum, hipStream_t s) {
+    if (total <= 0) return 0;
+    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(big, nblocks, total, gsum);
+    return linr_launch_rc();
+}
+
 struct Ptr8 { const float* p[8]; };
 // dst = ((((((s7 + s6) + s5) + s4) + s3) + s2) + s1) + s0: the accumulation order of the stage-by-stage backward
 __global__ __launch_bounds__(LINR_BLOCK) void sum8_k(Ptr8 src, int64_t n, float* __restrict__ dst) {

@@ -1,7 +1,10 @@
 """GPU parity: every HIP kernel and the whole-network executor (through the C-ABI) against the CPU oracle.
 
 Tolerances (the reference states none): fp32 HIP vs fp32 oracle
-  logits  |d| <= 1e-4 + 1e-4 |x|     bits  rel <= 1e-5     gradients  |d| <= 1e-4 * max|g of the SAME tensor| + 1e-9
+  logits  |d| <= 1e-4 + 1e-4 |x|     bits  rel <= 1e-5
+  gradients, per tensor against ITS OWN largest entry: two fp32 evaluations of a ~20-layer network (HIP vs the fp32 oracle)
+  differ by up to ~3e-4 of it (block_layers 3), so  |d| <= 5e-4 * max|g_tensor| + 1e-9  there, and the HIP gradient must be as close to the
+  float64 oracle as the fp32 oracle itself is:  err_hip(f64) <= 2 * err_oracle32(f64) + 2e-5 * max|g_tensor|
 Integer / index / byte work (kernel map, streams, decoded geometry) is bit-exact.
 """
 import math
@@ -305,9 +308,10 @@ def test_net_forward_with_reference_trained_weights(pkg, shell, golden_dir):
     assert float(bits_m) > 4.0 * float(bits)
 
 
-def _grads_close_per_tensor(grads, sdo, rtol=1e-4, floor=1e-9):
-    """gradients rel <= 1e-4 - every tensor against ITS OWN largest gradient (a tensor whose gradients
-    are orders of magnitude below the model's largest one must still be right)."""
+def _grads_close_per_tensor(grads, sdo, rtol=5e-4, floor=1e-9, sd64=None):
+    """Every tensor against ITS OWN largest gradient (a tensor whose gradients are orders of magnitude below the model's
+    largest one must still be right).  sd64: the same leaves evaluated by the oracle in float64 - then the HIP gradient
+    must also be as accurate as the fp32 oracle is."""
     off, worst = 0, (0.0, '')
     for name, v in sdo.items():
         n = v.numel()
@@ -316,6 +320,10 @@ def _grads_close_per_tensor(grads, sdo, rtol=1e-4, floor=1e-9):
         gmax = float(ref.abs().max())
         err = float((mine - ref).abs().max())
         assert err <= rtol * gmax + floor, 'grad %s: max err %.3e vs tolerance %.3e (own max %.3e)' % (name, err, rtol * gmax + floor, gmax)
+        if sd64 is not None:
+            truth = sd64[name].grad
+            e_hip, e_o32 = float((mine - truth).abs().max()), float((ref - truth).abs().max())
+            assert e_hip <= 2.0 * e_o32 + 2e-5 * gmax + floor, 'grad %s vs float64: HIP %.3e, fp32 oracle %.3e (own max %.3e)' % (name, e_hip, e_o32, gmax)
         if gmax > 0 and err / gmax > worst[0]:
             worst = (err / gmax, name)
         off += n
@@ -339,7 +347,9 @@ def test_net_backward_matches_autograd(pkg, shell, block_layers):
     bits_o = onet.frame_bits(sdo, onet.to_torch_scales(shell['scales']))
     assert abs(float(bits) - float(bits_o)) <= 1e-5 * float(bits_o)
     (bits_o * gscale).backward()
-    _grads_close_per_tensor(grads, sdo)
+    sd64 = {k: v.double().clone().requires_grad_() for k, v in sd.items()}
+    (onet.frame_bits(sd64, onet.to_torch_scales(shell['scales'], torch.float64)) * gscale).backward()
+    _grads_close_per_tensor(grads, sdo, sd64=sd64)
     grads2 = torch.zeros_like(flat)
     engine.net_backward(frame, flat, grads2, gscale)
     assert torch.equal(grads, grads2), 'backward must be bit-reproducible'
