@@ -419,6 +419,40 @@ def main():
     decode_s = (time.time() - t0) / nd
     log('decode frames 0..%d: %.3f s/frame, lossless=%s' % (nd - 1, decode_s, lossless))
 
+    # bf16 / uint8-weight codec leg (BASELINE config[4]'s numerics on this workload): the SAME trained model coded with the
+    # bf16 executor (features bf16, weights as the uint8 codes of model.bin, de-quantised in-kernel).  Reported beside the fp32
+    # headline, never instead of it.
+    bf16_leg = None
+    try:
+        from linr_pcgc_amd.model_codec import Model_Estimate
+        barrier()
+        t0 = time.time()
+        enc_bf = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
+        barrier()
+        bf_codec_s = time.time() - t0
+        dec_bf = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc_bf, 'cuda', frames=list(range(nd)), workers=nd)
+        bf_lossless = all(bool(torch.equal(dec_bf[i], torch.as_tensor(gop.infos[i]['ori']).cuda() +
+                                           torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32))) for i in range(nd))
+        coded = Model_Estimate().compress_model(model, 8, True, overfit.gen_model(gop.scale_num, 'cuda'))['new_model']
+        fwd = {}
+        for prec in ('f32', 'bf16'):
+            fwd[prec] = _time_launches(lambda: coded.frame_probs(gop.frames[0], precision=prec), 20) * 1e3
+        rows0 = gop.frames[0].rows
+        # algorithmic bytes of one inference forward at 2-byte features: 48 conv3 x (2*(8+8) + 108) per row (SURVEY.md 8d form)
+        bf16_leg = {'dtype': 'bf16', 'weights': 'uint8 codes of quant_uniform2, de-quantised in-kernel',
+                    'codec_s_per_frame': round(bf_codec_s / len(gop), 5), 'bits_per_point': round(enc_bf['bpp']['bpp_all'], 5),
+                    'point_bpp': round(enc_bf['bpp']['point_bpp'], 6), 'point_bpp_fp32': round(enc['bpp']['point_bpp'], 6),
+                    'lossless_decode_frames0to3': bf_lossless,
+                    'forward_ms_per_frame': {k: round(v, 4) for k, v in fwd.items()},
+                    'forward_alg_gbs': {'bf16': round(rows0 * 48 * (2 * 16 + 108) / (fwd['bf16'] * 1e-3) / 1e9, 1),
+                                        'f32': round(rows0 * 48 * (4 * 16 + 108) / (fwd['f32'] * 1e-3) / 1e9, 1)}}
+        lossless = lossless and bf_lossless
+        log('bf16 leg: %s' % bf16_leg)
+        del enc_bf, dec_bf, coded
+    except Exception as e:
+        bf16_leg = {'error': repr(e)}
+        log('bf16 leg failed: %r' % (e,))
+
     overfit_s_per_frame = full_overfit_s / len(gop)
     value = (overfit_s_per_frame + codec_s_per_frame) / world
 
@@ -443,6 +477,7 @@ def main():
                'per_step_ms_hip_events': step_stats,
                'components_s_per_frame': {'overfit': round(overfit_s_per_frame, 5), 'codec_modelcomp_fwd_ac_write': round(codec_s_per_frame, 5),
                                           'decode_s_per_frame_4_in_flight': round(decode_s, 4)},
+               'bf16_codec': bf16_leg,
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}

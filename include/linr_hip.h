@@ -211,6 +211,23 @@ LINR_API int linr_net_train_step(const linr_frame* f, float* params, float* aren
                         float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
                         double beta1, double beta2, double eps, double weight_decay, double* bits_acc, void* stream);
 
+/* ---- bf16 / uint8-weight inference executor (BASELINE config[4]) ------------------------------------------------
+ * The codec codes the geometry with the DE-QUANTISED model (encoder.py:101-103, decoder.py:87): w = q/255*(max-min)+min
+ * for the uint8 codes q of quant_uniform2 (model_compression/model_size_est.py:72-91).  This entry takes the codes
+ * themselves as the model (`codes`: device uint8 [linr_param_count], parameters() order; min_param / max_param: the two
+ * floats of side_info.json) and de-quantises inside the kernels; features are bf16 (16-byte rows), every 3x3x3
+ * convolution runs on v_mfma_f32_4x4x4_16b_bf16 with fp32 accumulation, biases / pointwise layers / MLPs stay fp32.
+ * Inference only: same stage semantics as linr_net_forward (the encoder calls (0, 8), the decoder (k, k+1) after writing
+ * occupancy column k-1 into frame->occ; both run identical per-row arithmetic => bit-identical probabilities).
+ * probs: [8][rows] stage-major (required); bits_acc as in linr_net_forward.  Needs the compressed kernel map.
+ * arena: linr_net_bf16_arena_bytes(rows, block_layers) bytes, 64-byte aligned; stages of one frame must share it.
+ * Tolerance against the fp32 path on the same de-quantised weights (tests/test_gpu_bf16.py): logits |d| <= 5e-2,
+ * bits within 1 %. */
+LINR_API size_t linr_net_bf16_arena_bytes(int64_t rows, int32_t block_layers);
+LINR_API int linr_net_forward_bf16(const linr_frame* f, const uint8_t* codes, float min_param, float max_param, void* arena,
+                          size_t arena_bytes, int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc,
+                          void* stream);
+
 /* ---- the executor's fused layers as stand-alone ops ------------------------------------------------------------
  * What linr_net_forward / _backward launch for one layer, callable (and testable) on its own.  All of them work on the
  * compressed kernel map (linr_kmap_compress) and follow the LINR_PAD_ROW contract: every matrix that a kernel GATHERS

@@ -68,6 +68,9 @@ _PROTOS = {
     'linr_net_backward': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr]),
     'linr_net_train_step': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_f32, c_ptr, c_ptr, c_f64,
                                            c_i64, c_ptr, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
+    'linr_net_bf16_arena_bytes': (c_size, [c_i64, c_i32]),
+    'linr_net_forward_bf16': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_f32, c_f32, c_ptr, c_size, c_i32, c_i32, c_ptr,
+                                             c_ptr, c_ptr]),
     'linr_sce_fwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_sce_bwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_head_workspace_bytes': (c_size, [c_i64]),

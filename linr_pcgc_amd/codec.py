@@ -38,15 +38,19 @@ def dec_all_frame_low_xyz(low_byte):
     return [np.frombuffer(c, dtype=np.uint8).reshape(-1, 3) for c in chunks], mins
 
 
-def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None):
+def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32'):
     """encoder.encode_one_gop: quantise the model, then per frame ONE forward over all scales and 8 x scales
-    independent arithmetic-coded streams (thread pool)."""
+    independent arithmetic-coded streams (thread pool).  precision='bf16': the forward runs on the bf16 / uint8-weight
+    executor (BASELINE config[4]); the choice is recorded in side_info so that the decoder reproduces it."""
     if n_threads is None:
         n_threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else 8))
     comp = Model_Estimate().compress_model(model, bitdepth, True, model_ori)
     coded_model = comp['new_model']                      # the de-quantised model is what codes the geometry
+    coded_model.inference_precision = precision
     side_info = {'mu': comp['mu'], 'b': comp['b'], 'min_param': comp['min_param'], 'max_param': comp['max_param'],
                  'enc_mode': comp['enc_mode'], 'bitdepth': bitdepth}
+    if precision != 'f32':
+        side_info['precision'] = precision
     # Two-stage pipeline: the GPU forward + D2H of frame i+1 runs while a host thread range-codes frame i (the coder's C
     # call releases the GIL and fans the 8 x scales independent streams out over n_threads).
     from concurrent.futures import ThreadPoolExecutor
@@ -102,6 +106,7 @@ def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1):
     side = dict(enc['side_info'])
     side['final_bytes'] = enc['model_bin']
     model, _ = Model_Estimate().decompress_model(model_ori, side)
+    model.inference_precision = side.get('precision', 'f32')
     lows, mins = dec_all_frame_low_xyz(enc['low_enc_bytes'])
     todo = list(range(len(enc['frames'])) if frames is None else frames)
 

@@ -7,6 +7,7 @@
 // Arena: every activation / gradient matrix is [1 + rows][ld] with an all-zero row in FRONT (row index -1), so the
 // sparse convolutions read absent neighbours from it (LINR_PAD_ROW) with no branch.
 #include "common.h"
+#include "layout.h"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -14,76 +15,8 @@
 #include <atomic>
 
 #define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
-#define MAX_SCALES 16
 
 // ---- parameter layout (reference parameters() order) ------------------------------------------------------------
-#define MAX_BL 4              // block_layers of block_in (main.py:521 default 1; the outter blocks always have 1, upsample.py:72-76)
-struct IncP {                 // one InceptionResNet layer (models/resnet.py:7-60)
-    int64_t c00_w, c00_b;     // conv0_0  conv3 8->4
-    int64_t c01_w, c01_b;     // conv0_1  conv3 4->4
-    int64_t c10_w, c10_b;     // conv1_0  1x1 8->4   kernel [8][4]
-    int64_t c11_w, c11_b;     // conv1_1  conv3 4->4
-    int64_t c12_w, c12_b;     // conv1_2  1x1 4->4   kernel [4][4]
-};
-struct BlockP {
-    int cin;
-    int nl;                   // Inception layers of the ResNetBlock (.2.layers.0 .. nl-1)
-    int64_t a_w, a_b;         // .0   conv3 cin->8
-    IncP inc[MAX_BL];
-    int64_t b_w, b_b;         // .3   conv3 8->8
-};
-
-struct Layout {
-    int S;
-    int BL;                                        // block_layers of block_in
-    int64_t emb;                                   // [S][8]
-    int64_t m0_w[MAX_SCALES], m0_b[MAX_SCALES];    // Linear(15,16): weight [16][15]
-    int64_t m2_w[MAX_SCALES], m2_b[MAX_SCALES];    // Linear(16,8):  weight [8][16]
-    BlockP block_in;
-    int64_t h0_w[8], h0_b[8], h2_w[8], h2_b[8];    // inner_mlps.k.0: Linear(8,24), Linear(24,1)
-    int64_t pr_w[8], pr_b[8];                      // prune_blocks.k.0.conv: conv3 8->8
-    BlockP outter[7];
-    int64_t total;
-};
-
-static int64_t take(int64_t& cur, int64_t n) { int64_t o = cur; cur += n; return o; }
-
-static void layout_block(BlockP& b, int cin, int nl, int64_t& cur) {
-    b.cin = cin;
-    b.nl = nl;
-    b.a_w = take(cur, 27 * cin * 8);  b.a_b = take(cur, 8);
-    for (int l = 0; l < nl; ++l) {
-        IncP& q = b.inc[l];
-        q.c00_w = take(cur, 27 * 8 * 4);  q.c00_b = take(cur, 4);
-        q.c01_w = take(cur, 27 * 4 * 4);  q.c01_b = take(cur, 4);
-        q.c10_w = take(cur, 8 * 4);       q.c10_b = take(cur, 4);
-        q.c11_w = take(cur, 27 * 4 * 4);  q.c11_b = take(cur, 4);
-        q.c12_w = take(cur, 4 * 4);       q.c12_b = take(cur, 4);
-    }
-    b.b_w = take(cur, 27 * 8 * 8);    b.b_b = take(cur, 8);
-}
-
-static bool make_layout(Layout& L, int S, int BL = 1) {
-    if (S < 1 || S > MAX_SCALES || BL < 1 || BL > MAX_BL) return false;
-    L.S = S;
-    L.BL = BL;
-    int64_t cur = 0;
-    L.emb = take(cur, (int64_t)S * 8);
-    for (int s = 0; s < S; ++s) {
-        L.m0_w[s] = take(cur, 16 * 15); L.m0_b[s] = take(cur, 16);
-        L.m2_w[s] = take(cur, 8 * 16);  L.m2_b[s] = take(cur, 8);
-    }
-    layout_block(L.block_in, 8, BL, cur);
-    for (int k = 0; k < 8; ++k) {
-        L.h0_w[k] = take(cur, 24 * 8); L.h0_b[k] = take(cur, 24);
-        L.h2_w[k] = take(cur, 24);     L.h2_b[k] = take(cur, 1);
-    }
-    for (int k = 0; k < 8; ++k) { L.pr_w[k] = take(cur, 27 * 8 * 8); L.pr_b[k] = take(cur, 8); }
-    for (int k = 0; k < 7; ++k) layout_block(L.outter[k], k + 1, 1, cur);
-    L.total = cur;
-    return true;
-}
-
 extern "C" int linr_abi_version(void) { return LINR_ABI_VERSION; }
 
 extern "C" int64_t linr_param_count(int32_t scale_num, int32_t block_layers) {
@@ -451,14 +384,9 @@ extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches,
     return 0;
 }
 
-// Index source of the conv kernels (cconv_mfma_k and friends): LINR_CONV_TABLE=1 hands them the full nbr[27][ld] table
-// (mask == NULL selects the table decode in decode_offsets) instead of the compressed map.
-static bool conv_table() {
-    static const int v = getenv("LINR_CONV_TABLE") ? atoi(getenv("LINR_CONV_TABLE")) : 0;
-    return v != 0;
-}
-static const int32_t* clo(const Ctx& c) { return conv_table() ? c.f->nbr : c.f->nbr_lo; }
-static const uint32_t* cmk(const Ctx& c) { return conv_table() ? nullptr : c.f->nbr_mask; }
+// index source of the conv kernels: the compressed map (the full neighbour table was 4 % slower, profiles/README.md)
+static const int32_t* clo(const Ctx& c) { return c.f->nbr_lo; }
+static const uint32_t* cmk(const Ctx& c) { return c.f->nbr_mask; }
 
 // grouped launches need the matrix-core conv kernel (the VALU fallback of LINR_CONV_MFMA=0 is a single-layer kernel)
 static bool grouped_enabled() {
@@ -486,23 +414,16 @@ static bool wg_cmap() {
     return v != 0;
 }
 // ... except the 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row), where the decode is hidden
-// and the smaller index stream wins (LINR_WGRAD_CMAP4=0 gives them the table as well)
-static bool wg_cmap4() {
-    static const int v = getenv("LINR_WGRAD_CMAP4") ? atoi(getenv("LINR_WGRAD_CMAP4")) : 1;
-    return v != 0;
-}
+// and the smaller index stream wins: they always read the compressed map
+static bool wg_cmap4() { return true; }
 
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
-    static const int use_mfma = getenv("LINR_WGRAD_MFMA") ? atoi(getenv("LINR_WGRAD_MFMA")) : 1;
     TRY(stream_order(c.s, c.ws));
-    ProfScope ps(c.ws, 0, 1, use_mfma && cout == 8 && in_ld >= 8);
-    if (use_mfma)
-        return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
-                                     (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
-    return linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS,
-                                    LINR_PAD_ROW, c.ws);
+    ProfScope ps(c.ws, 0, 1, cout == 8 && in_ld >= 8);
+    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
+                                 (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask);
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,

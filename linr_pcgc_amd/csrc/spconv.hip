@@ -110,11 +110,7 @@ static int launch_gather(const float* in, int in_ld, const int32_t* nbr, int64_t
 #define LINR_GO(LWV, PADV)                                                                                          \
     spconv_gather_k<GIN, GOUT, BWD, LWV, PADV><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, nbr, nbr_ld, n, W, bias, res,  \
                                                                            res_ld, act, act_ld, out, out_ld, flags)
-    static const int wfixed = getenv("LINR_DEBUG_WFIXED") ? atoi(getenv("LINR_DEBUG_WFIXED")) : 0;
-    if (vec && pad && wfixed && GIN == 8 && GOUT == 8)
-        spconv_gather_k<GIN, GOUT, BWD, LW, true, true><<<grid, LINR_BLOCK, 0, s>>>(in, in_ld, nbr, nbr_ld, n, W, bias, res,
-                                                                                   res_ld, act, act_ld, out, out_ld, flags);
-    else if (vec && pad) LINR_GO(LW, true);
+    if (vec && pad) LINR_GO(LW, true);
     else if (vec) LINR_GO(LW, false);
     else if (pad) LINR_GO(0, true);
     else LINR_GO(0, false);

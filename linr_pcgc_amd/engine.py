@@ -71,6 +71,13 @@ class Frame:
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)
         self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
+    def bf16_arena(self):
+        """Arena of the bf16 / uint8-weight inference executor (allocated on first use, 64-byte aligned)."""
+        if getattr(self, '_arena_bf16', None) is None:
+            nbytes = _lib.lib().linr_net_bf16_arena_bytes(self.rows, self.block_layers)
+            self._arena_bf16 = torch.empty(nbytes + 64, dtype=torch.uint8, device=self.device)
+        return self._arena_bf16
+
     def cref(self):
         return ctypes.byref(self._c)
 
@@ -88,6 +95,15 @@ def net_forward(frame, flat_params, stage_begin=0, stage_end=8, probs=None, bits
     check(_lib.lib().linr_net_forward(frame.cref(), flat_params.data_ptr(), arena.data_ptr(), arena.numel(), stage_begin,
                                       stage_end, 0 if probs is None else probs.data_ptr(),
                                       0 if bits is None else bits.data_ptr(), _stream()), 'linr_net_forward')
+
+
+def net_forward_bf16(frame, codes, min_param, max_param, stage_begin, stage_end, probs, bits=None):
+    """linr_net_forward_bf16: inference from the uint8 weight codes with bf16 features.  probs: float32 [8, rows]."""
+    arena = frame.bf16_arena()
+    base = (arena.data_ptr() + 63) & ~63
+    check(_lib.lib().linr_net_forward_bf16(frame.cref(), codes.data_ptr(), float(min_param), float(max_param), base,
+                                           arena.numel() - (base - arena.data_ptr()), stage_begin, stage_end, probs.data_ptr(),
+                                           0 if bits is None else bits.data_ptr(), _stream()), 'linr_net_forward_bf16')
 
 
 def net_backward(frame, flat_params, flat_grads, gscale, arena=None):

@@ -92,11 +92,12 @@ def compress_params(params, bitdepth=8):
     return {'bpp_real': bit_real / n, 'bit_real': bit_real, 'side_info_bit': side_info_bit, 'bitdepth': bitdepth,
             'enc_mode': enc_mode, 'laplace_real_bpp': bit_laplace_real / n, 'zlib_bpp': bpp_zlib,
             'min_param': float(min_param), 'max_param': float(max_param), 'mu': float(mu), 'b': float(b),
-            'final_bytes': final_bytes, 'recon_ret': recon_ret}
+            'final_bytes': final_bytes, 'recon_ret': recon_ret, 'symbols': quant_ret.numpy().astype(np_type)}
 
 
-def decompress_params(enc_out, n):
-    """decompress_model (model_size_est.py:523-579): returns the de-quantised flat float32 vector (CPU)."""
+def decompress_params(enc_out, n, with_symbols=False):
+    """decompress_model (model_size_est.py:523-579): returns the de-quantised flat float32 vector (CPU)
+    (and, with_symbols, the integer codes it was rebuilt from)."""
     mode, data, bitdepth = enc_out['enc_mode'], enc_out['final_bytes'], enc_out['bitdepth']
     if mode == 0:
         q = np.frombuffer(data, dtype=np.uint8)
@@ -109,7 +110,8 @@ def decompress_params(enc_out, n):
     sym_max = float(np.ceil(2 ** bitdepth) - 1)
     min_p = torch.tensor(float(enc_out['min_param']), dtype=torch.float32)
     max_p = torch.tensor(float(enc_out['max_param']), dtype=torch.float32)
-    return recon / sym_max * (max_p - min_p) + min_p
+    out = recon / sym_max * (max_p - min_p) + min_p
+    return (out, np.asarray(q)) if with_symbols else out
 
 
 class Model_Estimate:
@@ -118,21 +120,28 @@ class Model_Estimate:
     quant_uniform2 = staticmethod(quant_uniform2)
 
     @staticmethod
-    def _fill(model, recon):
+    def _fill(model, recon, symbols=None, min_param=None, max_param=None, bitdepth=8):
+        """Writes the de-quantised parameters into `model`.  With 8-bit codes it also hands the model the codes themselves
+        (device uint8, parameters() order) + the two range floats: the bf16 inference path (linr_net_forward_bf16) runs
+        straight from them."""
         with torch.no_grad():
             model.flat_parameters().copy_(recon.to(model.flat_parameters().device))
+        if symbols is not None and bitdepth <= 8:
+            model.set_quantised(torch.as_tensor(np.ascontiguousarray(symbols).astype(np.uint8)), float(min_param), float(max_param))
         return model
 
     @torch.no_grad()
     def compress_model(self, model, bitdepth=8, derive_new_model=False, model_ori=None):
         out = compress_params(model.flat_parameters(), bitdepth)
-        out['new_model'] = self._fill(model_ori, out['recon_ret']) if (derive_new_model and model_ori is not None) else None
+        out['new_model'] = None
+        if derive_new_model and model_ori is not None:
+            out['new_model'] = self._fill(model_ori, out['recon_ret'], out['symbols'], out['min_param'], out['max_param'], bitdepth)
         return out
 
     @torch.no_grad()
     def decompress_model(self, new_model, enc_out):
-        recon = decompress_params(enc_out, new_model.flat_parameters().numel())
-        return self._fill(new_model, recon), recon
+        recon, q = decompress_params(enc_out, new_model.flat_parameters().numel(), with_symbols=True)
+        return self._fill(new_model, recon, q, enc_out['min_param'], enc_out['max_param'], enc_out['bitdepth']), recon
 
     @torch.no_grad()
     def compress_test(self, model, new_model, bitdepth=8):

@@ -75,6 +75,11 @@ class LINR_PCGC_Model(nn.Module):
         self._flat_grad = None
         self._plist = []
         self._frame_cache = {}
+        # inference numerics of frame_probs / codec / encode / decode: 'f32' (default) or 'bf16' = BASELINE config[4]'s bf16
+        # features + uint8 weight codes (needs set_quantised, which the model codec calls); training is always fp32
+        self.inference_precision = 'f32'
+        self._qcodes = None
+        self._qrange = None
         self._flatten()
 
     # ---- flat parameter buffer ------------------------------------------------------------------------------------
@@ -115,6 +120,23 @@ class LINR_PCGC_Model(nn.Module):
                 p.grad = self._flat_grad[off:off + n].view(p.shape)
             off += n
 
+    def set_quantised(self, codes, min_param, max_param):
+        """The model as its uint8 codes of quant_uniform2 (model_compression/model_size_est.py:72-91): what model.bin holds.
+        Called by Model_Estimate.compress_model / decompress_model next to the de-quantised fp32 fill."""
+        if codes.numel() != self._flat.numel():
+            raise ValueError('expected %d codes, got %d' % (self._flat.numel(), codes.numel()))
+        self._qcodes = codes.to(device=self._flat.device, dtype=torch.uint8).contiguous()
+        self._qrange = (float(min_param), float(max_param))
+
+    def _precision(self, precision):
+        precision = self.inference_precision if precision is None else precision
+        if precision not in ('f32', 'bf16'):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        if precision == 'bf16' and self._qcodes is None:
+            raise _lib.LinrError('the bf16 path runs from the uint8 weight codes: quantise the model first '
+                                 '(Model_Estimate.compress_model(..., derive_new_model=True) / decompress_model)')
+        return precision
+
     def flat_parameters(self):
         """The contiguous float32 buffer holding every parameter in parameters() order (what the model codec codes)."""
         return self._flat
@@ -153,12 +175,18 @@ class LINR_PCGC_Model(nn.Module):
         engine.net_forward(frame, self._flat, 0, 8, None, bits)
         return bits[0].to(torch.float32)
 
+    def _stage_forward(self, frame, k0, k1, probs, bits, precision):
+        if precision == 'bf16':
+            engine.net_forward_bf16(frame, self._qcodes, self._qrange[0], self._qrange[1], k0, k1, probs, bits)
+        else:
+            engine.net_forward(frame, self._flat, k0, k1, probs, bits)
+
     @torch.no_grad()
-    def frame_probs(self, frame):
+    def frame_probs(self, frame, precision=None):
         """One inference forward over a (possibly multi-scale) frame: probs float32 [8, rows], bits float64[1]."""
         probs = torch.empty((8, frame.rows), dtype=torch.float32, device=frame.device)
         bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
-        engine.net_forward(frame, self._flat, 0, 8, probs, bits)
+        self._stage_forward(frame, 0, 8, probs, bits, self._precision(precision))
         return probs, bits
 
     @torch.no_grad()
@@ -199,8 +227,9 @@ class LINR_PCGC_Model(nn.Module):
         """models/model_core.py:268-286 + CNP.decode (models/upsample.py:249-295): stage-serial, the SAME launches as
         the encoder's forward, so probabilities are bitwise identical.  Returns 8 x [N,1] float32 occupancy."""
         streams = unpack_bitstream(inagrs['enc_bytes'])
-        frame = self._scale_frame({'coord': inagrs['coord'], 'offset_tensor': inagrs.get('offset_tensor'),
-                                   'scale_idx': inagrs['scale_idx']}, need_occ=False)
+        s = {'coord': inagrs['coord'], 'offset_tensor': inagrs.get('offset_tensor'), 'scale_idx': inagrs['scale_idx']}
+        # decoder-side frames are never cached (fresh coordinates every call); the bf16 path brings its own small arena
+        frame = self.make_frame([s], with_arena=self._precision(None) == 'f32')
         return self.decode_frame(frame, [streams])
 
     def _host_buffers(self, rows):
@@ -215,7 +244,7 @@ class LINR_PCGC_Model(nn.Module):
         return buf
 
     @torch.no_grad()
-    def decode_frame(self, frame, streams_per_scale):
+    def decode_frame(self, frame, streams_per_scale, precision=None):
         """Staged decode of every scale of `frame` at once: stage k of all scales is one launch set.  Host side per
         stage: one D2H of the probabilities into pinned memory, linr_ac_decode_binary per scale straight on those
         buffers, one H2D of the decoded byte column (no torch CPU ops: they fan out over every host core)."""
@@ -225,8 +254,9 @@ class LINR_PCGC_Model(nn.Module):
         p_host, s_host = self._host_buffers(rows)
         p_np, s_np = p_host.numpy(), s_host.numpy()
         L = _lib.lib()
+        precision = self._precision(precision)
         for k in range(8):
-            engine.net_forward(frame, self._flat, k, k + 1, probs, None)
+            self._stage_forward(frame, k, k + 1, probs, None, precision)
             p_host[:rows].copy_(probs[k])                       # synchronous D2H
             for i in range(frame.n_scales):
                 sl = frame.scale_slice(i)

@@ -1,0 +1,172 @@
+"""GPU tests of the bf16 / uint8-weight inference path (BASELINE config[4]; csrc/net_bf16.hip, linr_net_forward_bf16).
+
+The reference has no reduced-precision path to compare with; what is checked:
+  * the in-kernel de-quantisation reproduces quant_uniform2's reconstruction (model_size_est.py:72-91) BIT FOR BIT;
+  * against the fp32 path on the same de-quantised weights, SURVEY.md section 8c's bf16 tolerances: logits |d| <= 5e-2,
+    bits within 1 %;
+  * against the bf16-emulating oracle (oracle/network_bf16.py: same roundings, different fp32 summation order):
+    logits |d| <= 2e-2, bits within 0.2 %;
+  * encoder (grouped, all stages) == decoder (stage by stage) probabilities bit for bit; encode -> decode lossless, also at
+    --block_layers 2 and on the config[4] geometry (11-bit sphere, 2.9 M points, 8 scales).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import network as onet          # noqa: E402
+from oracle import network_bf16 as obf      # noqa: E402
+from oracle import octree as ooct           # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def shell(golden_dir):
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    scales = []
+    for s in range(int(g['scale_num'])):
+        c = g['s%d_coord' % s]
+        scales.append({'coord': c, 'occ': g['s%d_occ' % s], 'offset_tensor': g['s%d_offset' % s], 'scale_idx': s,
+                       'nbr': ooct.neighbour_table(c)})
+    return {'scales': scales, 'point_num': int(len(g['ori']))}
+
+
+def _trained_quantised(shell, block_layers=1, steps=12):
+    """a model a few Adam steps away from its initialisation, pushed through the model codec: returns (coded model on the
+    GPU with codes attached, its de-quantised fp32 state dict on the CPU, frame)"""
+    from linr_pcgc_amd import overfit
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model = overfit.gen_model(5, 'cuda', seed=8807, block_layers=block_layers)
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    for _ in range(steps):
+        train_step(model, opt, frame, shell['point_num'])
+    comp = Model_Estimate().compress_model(model, 8, True, overfit.gen_model(5, 'cuda', block_layers=block_layers))
+    coded = comp['new_model']
+    sd = {k: v.detach().cpu().clone() for k, v in coded.state_dict().items()}
+    return coded, sd, frame, comp
+
+
+def _logits(p):
+    p = p.double()
+    return torch.log(p) - torch.log1p(-p)
+
+
+def test_dequantisation_is_bit_exact(shell):
+    """fp32 parameters the kernels rebuild from the uint8 codes == quant_uniform2's reconstruction (the values the fp32 path
+    and the reference's decoder use), bit for bit: the arena's first linr_param_count floats hold them."""
+    coded, sd, frame, comp = _trained_quantised(shell)
+    probs, bits = coded.frame_probs(frame, precision='bf16')
+    torch.cuda.synchronize()
+    arena = frame.bf16_arena()
+    base = (arena.data_ptr() + 63) & ~63
+    n = coded.flat_parameters().numel()
+    pf = arena[base - arena.data_ptr():base - arena.data_ptr() + 4 * n].view(torch.float32)
+    assert torch.equal(pf, coded.flat_parameters())
+    assert torch.equal(pf.cpu(), comp['recon_ret'])
+    assert coded._qcodes.dtype == torch.uint8 and int(coded._qcodes.max()) == 255 and int(coded._qcodes.min()) == 0
+
+
+@pytest.mark.parametrize('block_layers', [1, 2])
+def test_bf16_forward_against_fp32_path_and_bf16_oracle(shell, block_layers):
+    coded, sd, frame, _ = _trained_quantised(shell, block_layers)
+    p32, b32 = coded.frame_probs(frame, precision='f32')
+    pbf, bbf = coded.frame_probs(frame, precision='bf16')
+    pbf2, bbf2 = coded.frame_probs(frame, precision='bf16')
+    assert torch.equal(pbf, pbf2) and torch.equal(bbf, bbf2), 'deterministic'
+    z32, zbf = _logits(p32), _logits(pbf)
+    ok = (z32.abs() < 12) & (zbf.abs() < 12)                    # logits recovered from fp32 probabilities: skip the saturated ones
+    d = (z32 - zbf).abs()[ok]
+    assert float(d.max()) <= 5e-2, 'bf16 vs fp32 logits: max |d| %.4f' % float(d.max())
+    assert abs(float(bbf) - float(b32)) <= 0.01 * float(b32), (float(bbf), float(b32))
+    # the bf16-emulating oracle, scale by scale
+    tsc = onet.to_torch_scales(shell['scales'])
+    worst, bits_o = 0.0, 0.0
+    for i, s in enumerate(tsc):
+        ref = obf.forward_scale(sd, s)
+        bits_o += float(ref['bits'])
+        sl = frame.scale_slice(i)
+        for k in range(8):
+            zo = ref['logits'][k].view(-1).double()
+            zh = zbf[k, sl].cpu()
+            m = (zo.abs() < 12) & (zh.abs() < 12)
+            worst = max(worst, float((zo - zh).abs()[m].max()))
+    assert worst <= 2e-2, 'bf16 HIP vs bf16-emulating oracle logits: max |d| %.4f' % worst
+    assert abs(float(bbf) - bits_o) <= 2e-3 * bits_o, (float(bbf), bits_o)
+
+
+@pytest.mark.parametrize('block_layers', [1, 2])
+def test_bf16_staged_equals_one_shot_and_decodes_losslessly(shell, block_layers):
+    from linr_pcgc_amd import engine
+    coded, sd, frame, _ = _trained_quantised(shell, block_layers, steps=4)
+    one, _ = coded.frame_probs(frame, precision='bf16')
+    staged = torch.empty_like(one)
+    for k in range(8):
+        engine.net_forward_bf16(frame, coded._qcodes, coded._qrange[0], coded._qrange[1], k, k + 1, staged, None)
+    assert torch.equal(one, staged), 'the stage-serial decoder must reproduce the encoder bit for bit'
+    coded.inference_precision = 'bf16'
+    for s in shell['scales'][:2]:
+        d = {'coord': torch.tensor(s['coord'], device='cuda'), 'offset_tensor': torch.tensor(s['offset_tensor'], device='cuda'),
+             'occ_lst': [torch.tensor(s['occ'][:, i:i + 1], device='cuda') for i in range(8)], 'scale_idx': s['scale_idx']}
+        enc = coded.encode(d)
+        dec = coded.decode({'enc_bytes': enc['enc_bytes'], 'coord': d['coord'], 'offset_tensor': None, 'scale_idx': s['scale_idx']})
+        assert torch.equal(torch.cat(dec, dim=1).cpu(), torch.tensor(s['occ']))
+
+
+def test_bf16_needs_the_quantised_model():
+    from linr_pcgc_amd import _lib, overfit
+    model = overfit.gen_model(5, 'cuda', seed=1)
+    with pytest.raises(_lib.LinrError, match='uint8 weight codes'):
+        model._precision('bf16')
+
+
+def test_bf16_gop_codec_files_roundtrip(tmp_path):
+    """encode_gop(precision='bf16') -> reference directory layout -> decode from the files alone (the precision travels in
+    side_info.json) -> lossless; rate within 1 % of the fp32 codec of the same trained model."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sphere_shell(7, 40 + t) for t in range(3)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    overfit.overfit_gop(model, FlatAdam(model), gop, 6)
+    e32 = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    ebf = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
+    assert ebf['side_info']['precision'] == 'bf16' and 'precision' not in e32['side_info']
+    assert ebf['model_bin'] == e32['model_bin']
+    assert abs(ebf['bpp']['point_bpp'] - e32['bpp']['point_bpp']) <= 0.01 * e32['bpp']['point_bpp']
+    codec.write_gop(ebf, str(tmp_path / 'g'))
+    back = codec.read_gop(str(tmp_path / 'g'))
+    assert back['side_info']['precision'] == 'bf16'
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), back, 'cuda', workers=2)
+    for d, info, mn in zip(dec, gop.infos, gop.coord_mins):
+        assert torch.equal(d, torch.as_tensor(info['ori']).cuda() + torch.tensor(mn, device='cuda', dtype=torch.int32))
+    # decoding a bf16 stream with the fp32 executor must NOT be relied upon: the probabilities differ
+    p_bf, _ = codec.Model_Estimate().decompress_model(overfit.gen_model(gop.scale_num, 'cuda'), dict(back['side_info'], final_bytes=back['model_bin']))[0].frame_probs(gop.frames[0], precision='bf16')
+    p_32, _ = codec.Model_Estimate().decompress_model(overfit.gen_model(gop.scale_num, 'cuda'), dict(back['side_info'], final_bytes=back['model_bin']))[0].frame_probs(gop.frames[0], precision='f32')
+    assert not torch.equal(p_bf, p_32)
+
+
+def test_config4_owlii11_bf16_lossless():
+    """BASELINE config[4]: the Owlii stand-in (11-bit sphere r=480, ~2.9 M points, 8 scales), weights as uint8 codes, bf16
+    features: a briefly trained model, encode with the bf16 executor, decode with it from the streams alone: lossless;
+    rate within +1 % of the fp32 codec."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    pts = synthetic.sequence_frame_device('owlii11', 0, 'cuda')
+    gop = overfit.Gop(None, [pts], None, 64, 'cuda')
+    assert gop.point_nums[0] > 2800000 and gop.scale_num == 8 and gop.frames[0].rows > 1200000
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    opt = FlatAdam(model)
+    for _ in range(24):
+        train_step(model, opt, gop.frames[0], gop.point_nums[0])
+    e32 = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    ebf = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
+    assert ebf['bpp']['point_bpp'] <= 1.01 * e32['bpp']['point_bpp'], (ebf['bpp'], e32['bpp'])
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), ebf, 'cuda')
+    ref = torch.as_tensor(gop.infos[0]['ori']).cuda() + torch.tensor(gop.coord_mins[0], device='cuda', dtype=torch.int32)
+    assert torch.equal(dec[0], ref), 'bf16 decode must be bit-exact'

@@ -549,23 +549,39 @@ def test_staged_probs_bitwise_equal_one_shot(pkg, shell):
     assert torch.equal(one, staged)
 
 
-def test_grouped_launches_bitwise_equal_stage_by_stage(pkg, golden_dir, tmp_path):
-    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads / all scales of the scale context,
-    compressed-map weight gradients on a second stream) against the stage-by-stage, scale-by-scale single-stream one:
-    probabilities, bits and every gradient must be the same bits."""
+def _dump_under(env, golden_dir, out):
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(__file__), '_dump_net.py')
     golden = os.path.join(golden_dir, 'octree_shell128.npz')
-    res = {}
-    for tag, env in (('grouped', {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_SCE_FUSED': '1', 'LINR_WGRAD_CMAP': '0'}),
-                     ('staged', {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1'})):
-        out = str(tmp_path / (tag + '.npz'))
-        subprocess.run([sys.executable, script, golden, out], check=True, env=dict(os.environ, **env), timeout=600)
-        res[tag] = np.load(out)
+    clean = {k: v for k, v in os.environ.items() if not k.startswith('LINR_')}
+    subprocess.run([sys.executable, script, golden, out], check=True, env=dict(clean, **env), timeout=600)
+    return np.load(out)
+
+
+@pytest.fixture(scope='module')
+def default_dump(golden_dir, tmp_path_factory):
+    return _dump_under({}, golden_dir, str(tmp_path_factory.mktemp('dump') / 'default.npz'))
+
+
+# every executor switch the library reads from the environment (README.md): each one alone, and the two extreme
+# combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT
+SWITCHES = [{'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
+            {'LINR_CONV_MFMA': '2'}, {'LINR_WGRAD_CMAP': '1'}, {'LINR_WGRAD_STREAM': '1'},
+            {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0'},
+            {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_CONV_MFMA': '2', 'LINR_WGRAD_CMAP': '1'}]
+
+
+@pytest.mark.parametrize('env', SWITCHES, ids=lambda e: ','.join('%s=%s' % (k[5:], v) for k, v in e.items()))
+def test_executor_switch_is_bit_identical_to_default(pkg, golden_dir, tmp_path, default_dump, env):
+    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads / all scales of the scale context) against
+    every alternative path it can be switched to - stage by stage and scale by scale, VALU or LDS-staged convolutions,
+    compressed-map weight gradients, weight gradients on a second stream: same bits everywhere, which is what lets the
+    stage-serial decoder reproduce the encoder's probabilities."""
+    got = _dump_under(env, golden_dir, str(tmp_path / 'switched.npz'))
     for key in ('probs', 'bits', 'grads'):
-        assert np.array_equal(res['grouped'][key], res['staged'][key]), key
-    assert float(np.abs(res['grouped']['grads']).max()) > 0
+        assert np.array_equal(default_dump[key], got[key]), key
+    assert float(np.abs(got['grads']).max()) > 0
 
 
 def test_codec_stream_matches_oracle_coder(pkg, shell):
