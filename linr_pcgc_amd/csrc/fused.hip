@@ -930,28 +930,34 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         if ((lane & 31) < COUT && (DUAL || lane < 32)) sbias[wave][slot] = t;
         __syncthreads();
     }
-    if (wave == 0) {
-        // register i of accumulator (c, h)  <->  pair (kk, q), input channel 4q + c, output channel 4h + i
+    // register i of accumulator (c, h) on lane (kk, q)  <->  input channel 4q + c, output channel 4h + i of offset kk.  The
+    // folded sums sit in LDS (sacc[lane][slot]); ALL threads copy them out in DESTINATION order, so the block's slab row is
+    // written with coalesced dword stores (one lane-per-accumulator store per element would be 1,728 scattered 4-byte writes)
+    {
         float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
-        if (lane < (DUAL ? 8 : COUT)) {
-            float t = sbias[0][lane];
-            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][lane];
-            if (DUAL) dst[(lane < 4 ? d.b_off : dd.b_off1) + (lane & 3)] = t;
-            else dst[d.b_off + lane] = t;
+        const int tid = threadIdx.x;
+        if (tid < (DUAL ? 8 : COUT)) {
+            float t = sbias[0][tid];
+            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][tid];
+            if (DUAL) dst[(tid < 4 ? d.b_off : dd.b_off1) + (tid & 3)] = t;
+            else dst[d.b_off + tid] = t;
         }
-        const int64_t w_off = (DUAL && q) ? dd.w_off1 : d.w_off;
-        const int cinv = DUAL ? 4 : d.cin_valid;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ci = DUAL ? c : 4 * q + c;
-#pragma unroll
-            for (int h = 0; h < HB; ++h)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = mine[(c * HB + h) * 4 + i];
-                    const int co = 4 * h + i;
-                    if (live && ci < cinv) dst[w_off + (kk * cinv + ci) * COUT + co] = v;
-                }
+        if constexpr (DUAL) {
+            for (int e = tid; e < 2 * 432; e += WG_WAVES * 64) {
+                const int t = e / 432, r = e - 432 * t;
+                const int kq = r >> 4, slot = r & 15;                 // slot = ci * 4 + co (HB = 1)
+                dst[(t ? dd.w_off1 : d.w_off) + r] = sacc[(32 * t + kq) * (NA + 1) + slot];
+            }
+        } else {
+            const int cinv = d.cin_valid;
+            const int per_k = cinv * COUT, total = 27 * per_k;
+            for (int e = tid; e < total; e += WG_WAVES * 64) {
+                const int kq = e / per_k, r = e - kq * per_k;
+                const int ci = r / COUT, co = r - ci * COUT;
+                const int ln = (XQ == 2) ? 2 * kq + (ci >> 2) : kq;
+                const int slot = ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3);
+                dst[d.w_off + e] = sacc[ln * (NA + 1) + slot];
+            }
         }
     }
 }

@@ -292,13 +292,25 @@ static int g_ev_next = 0;
 static bool g_aux_ok = false;
 static std::mutex g_aux_mu;          // the pool is process-wide; executor calls may come from several host threads
 
-static bool aux_init() {
+// policy: LINR_WGRAD_STREAM=1 always, =0 never; unset = only for SMALL frames (rows < LINR_AUX_ROWS, default 150,000).  At
+// 336 k rows every grouped launch fills the chip and a second stream only adds contention (3.02 vs 2.83 ms/step); at 56 k
+// rows (BASELINE config[0]) a launch is a single partial wave of blocks bound by its own latency, and the ~14
+// weight-gradient launches overlap the backward data chain instead of queueing behind it.  Results are bit-identical
+// either way (tests/test_gpu_parity.py: switch test).
+static int aux_policy() {
+    static const int v = getenv("LINR_WGRAD_STREAM") ? atoi(getenv("LINR_WGRAD_STREAM")) : -1;
+    return v;
+}
+static int64_t aux_rows() {
+    static const int64_t v = getenv("LINR_AUX_ROWS") ? atoll(getenv("LINR_AUX_ROWS")) : 150000;
+    return v;
+}
+
+static bool aux_init(int64_t rows) {
+    const int pol = aux_policy();
+    if (pol == 0 || (pol < 0 && rows >= aux_rows())) return false;
     std::lock_guard<std::mutex> lk(g_aux_mu);
     if (g_aux_ok) return true;
-    // off by default: since the layers run as grouped launches every kernel fills the chip on its own and a second stream
-    // only adds contention (measured 3.02 ms/step with it, 2.83 without); LINR_WGRAD_STREAM=1 turns it on
-    const char* e = getenv("LINR_WGRAD_STREAM");
-    if (!e || atoi(e) == 0) return false;
     if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) return false;
     for (int i = 0; i < 64; ++i)
         if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return false;
@@ -926,7 +938,7 @@ static int backward_core(Ctx& c, float gscale) {
     Arena& a = c.A;
     const float* P = c.P;
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
-    c.ws = (c.f->nbr_lo && c.f->nbr_mask && aux_init()) ? g_aux : c.s;
+    c.ws = (c.f->nbr_lo && c.f->nbr_mask && aux_init(c.R)) ? g_aux : c.s;
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));

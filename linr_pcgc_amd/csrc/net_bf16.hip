@@ -28,9 +28,14 @@ typedef unsigned short bf16_t;
 __device__ __forceinline__ bf16_t f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }     // RNE (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-// torch: recon = q / sym_max * ten_range + min_n, each step one fp32 rounding (no fma contraction)
+// torch: recon = q / sym_max * ten_range + min_n, each step ONE fp32 rounding: hipcc contracts a * b + c into an fma by
+// default (-ffp-contract=fast-honor-pragmas), which changes the last bit where the sum cancels, so contraction is switched
+// off here; the division is IEEE (correctly rounded is hipcc's default for fp32 divide)
 __device__ __forceinline__ float dequant(const uint8_t* __restrict__ codes, int64_t i, float range, float minv) {
-    return __fadd_rn(__fmul_rn(__fdiv_rn((float)codes[i], 255.0f), range), minv);
+#pragma clang fp contract(off)
+    const float t = (float)codes[i] / 255.0f;
+    const float u = t * range;
+    return u + minv;
 }
 
 __global__ __launch_bounds__(LINR_BLOCK) void dequant_all_k(const uint8_t* __restrict__ codes, int64_t n, float range, float minv,

@@ -3,7 +3,7 @@
 # (box-to-box spread is ~5 %, so small effects only show when both arms run in one call; arms alternate A B A B)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 F=$1; A=$2; B=$3
-b(){ (cd $R && LINR_SKIP_ROOFLINE=1 python bench.py --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"); }
+b(){ (cd $R && LINR_SKIP_ROOFLINE=1 python bench.py --no-cpu-baseline --no-sequence 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"); }
 for arm in A B A B; do
   src=$A; [ $arm = B ] && src=$B
   cp $R/$src $R/linr_pcgc_amd/csrc/$F

@@ -5,7 +5,7 @@ TAG=${1:-step}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --no-cpu-baseline --steps 64 --warmup 32 --ramp-s 0 > /tmp/b_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $R/bench.py --no-cpu-baseline --no-sequence --steps 64 --warmup 32 --ramp-s 0 > /tmp/b_$TAG.log 2>&1
 tail -1 /tmp/b_$TAG.log | cut -c1-180
 mkdir -p $R/gpurun_out/prof_$TAG
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof_$TAG/kernel_stats.csv \;
