@@ -115,11 +115,21 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
  * [27][cin][cout] first, bias gradient [cout] last; their ascending sum over b is MinkowskiConvolution's kernel / bias
  * gradient (ME autograd of the call sites above).  `in`: [n][8] floats, 16-byte aligned, zero row at index -1.
  * lo / mask: the compressed map, or both NULL to take the indices from nbr[27][ld] (what the executor does by default:
- * 108 instead of 40 index bytes per row, but no decode instructions). */
+ * 108 instead of 40 index bytes per row, but no decode instructions).
+ * ranges: linr_wgrad_ranges_build's table or NULL.  With it (and in_ld = 8, a 16-byte aligned table with ld % 4 = 0) the
+ * gathered rows are staged through LDS: in the x-major order the neighbours of a chunk of 128 consecutive rows lie in three
+ * nearly contiguous row windows (one per x-slab), which the kernel copies with coalesced loads, double-buffered against the
+ * MFMAs of the previous chunk.  Same partial sums, bit for bit. */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                           const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin, int32_t cout,
-                           float* slab, void* stream);
+                           const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld, int64_t n,
+                           int32_t cin, int32_t cout, float* slab, void* stream);
+/* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
+ * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
+ * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */
+LINR_API size_t linr_wgrad_ranges_bytes(int64_t n);
+LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes,
+                            void* stream);
 
 /* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
  * linr_net_forward / _backward / _train_step (kind 0: spconv_wgrad_mfma_k<2,8>; kind 1:
@@ -186,6 +196,7 @@ typedef struct linr_frame {
     const uint32_t* nbr_mask;     /* [nbr_ld]     27-bit presence masks of the compressed map, or NULL           */
     const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
+    const int32_t* wg_ranges;     /* linr_wgrad_ranges_build over nbr (LDS windows of the weight-gradient kernels), or NULL */
 } linr_frame;
 
 LINR_API size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers);
@@ -275,8 +286,8 @@ LINR_API int linr_inception_bwd_data(const float* gI, const float* x, const floa
 /* weight gradients of the layer's two 4->4 convolutions in one pass (conv0_1 on H[:,0:4] with gradient g0, conv1_1 on
  * H[:,4:8] with g1): 512 per-block partials slab[b][872] = [gW01 432 | gb01 4 | gW11 432 | gb11 4], summed in ascending b. */
 LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
-                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
-                             float* slab, void* stream);
+                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld,
+                             int64_t n, float* slab, void* stream);
 
 /* First convolutions of the 7 outter blocks (models/upsample.py:206-214 -> make_block's first conv + ReLU): block g + 1
  * computes relu(conv3(occ[:, :g+1]; kernel [27][g+1][8]) + bias) on the SAME gathered occupancy rows, so one gather feeds
@@ -289,7 +300,11 @@ LINR_API int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_t*
 /* ---- arithmetic-coder feed (host side) -----------------------------------------------------------------------
  * Replaces torchac.encode_float_cdf / decode_float_cdf as used by BinaryArithmeticCoding
  * (models/module_utils.py:8-40; callers models/upsample.py:224-237,275; models/model_core.py:204-208) and by the
- * model stream (model_compression/model_size_est.py:470-482,545-563).  Bit-compatible with torchac 0.9.3 streams.
+ * model stream (model_compression/model_size_est.py:470-482,545-563).  Follows torchac 0.9.3's published
+ * coder (un-vendored, pinned in enviroment.yaml:32); the one known-answer vector the reference ships (the model stream of
+ * loot/gop_32_62) is met to the byte under a 90-bit header and sits one byte off under today's 82-bit header formula
+ * (tests/test_oracle_golden.py::test_model_stream_known_answer has the derivation) - real torchac is not installable here,
+ * so byte-compatibility beyond that vector is by construction, not by test.
  * All pointers here are HOST pointers.  Return: bytes written (>= 0) or a negative LINR_E* code. */
 LINR_API int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym_h, int64_t n, uint8_t* out_h, int64_t cap);
 LINR_API int     linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h);

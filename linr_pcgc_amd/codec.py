@@ -1,7 +1,7 @@
 """Per-GOP encode / decode: mirror of encoder.py:57-203, decoder.py:51-176 and test_utils.py:199-232,299-312.
 
 Stream layout is the reference's: per frame and scale ``pack_bitstream`` of the 8 per-stage
-torchac-compatible streams; ``low_enc_bytes`` = pack of per-frame uint8 coarsest coordinates + int32 minima;
+torchac-format streams (csrc/ac.cpp); ``low_enc_bytes`` = pack of per-frame uint8 coarsest coordinates + int32 minima;
 ``model.bin`` + side info from model_codec.  An encoded GOP is a dict of byte strings; ``write_gop`` / ``read_gop``
 map it to the reference's directory layout (bins/frameFFFF_scaleS.bin, bins/model.bin, bins/low_enc_bytes.bin,
 side_info.json).

@@ -495,8 +495,8 @@ extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, con
 extern "C" int64_t linr_spconv_wgrad_cmap_blocks(void) { return LINR_WG_BLOCKS; }
 
 extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                                      const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, int32_t cin,
-                                      int32_t cout, float* slab, void* stream) {
+                                      const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld, int64_t n,
+                                      int32_t cin, int32_t cout, float* slab, void* stream) {
     if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!in || !gout || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;     // lo / mask NULL: indices from nbr
@@ -506,7 +506,7 @@ extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const floa
     const int64_t elems = (int64_t)(27 * cin + 1) * cout;
     LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
     return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
-                                 lo, mask);
+                                 lo, mask, ranges);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
@@ -962,9 +962,299 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     }
 }
 
+// ---- the same weight-gradient kernel with the gathered rows staged through LDS ---------------------------------------------
+// spconv_wgrad_mfma_k is bound by the vector-memory address path, not by the matrix cores: per 8-row group a wave issues 8
+// divergent 16-byte gathers + 2 index loads (~176 TA cycles) against 64 MFMAs (512 cycles on ONE of the CU's four SIMDs that
+// share the TA).  In the x-major row order the neighbours that a CHUNK of consecutive rows needs lie in three nearly
+// contiguous row ranges, one per x-slab (dx = -1, 0, +1).  Coordinates are static, so those [first row, row count] windows
+// are computed ONCE per frame (linr_wgrad_ranges_build: chunks of LCH rows inside the fixed 512-block row partition) and the
+// kernel copies a chunk's three windows with fully coalesced 16-byte loads - each gathered row crosses the TA once per chunk
+// instead of up to 27 times - into one half of a double-buffered LDS image while the MFMAs of the previous chunk run from
+// the other half; every (offset, quad) lane reads its rows with ds_read_b128.  One block barrier per chunk.  A chunk whose
+// windows do not fit (scale boundaries, very dense slabs) gathers from global memory as before.
+// Rows, groups and waves are visited in the order of spconv_wgrad_mfma_k and the MFMAs are the same, so the partial sums
+// are bit-identical to it (tests: LINR_WGRAD_LDS=0 against the default).
+#define LCH 128                       // rows per chunk: 4 groups of 8 rows per wave
+#define LSLOTS 320                    // rows per x-slab window incl. the zero slot
+
+static inline int64_t wg_per(int64_t n) {          // rows per persistent block: the partition of spconv_wgrad_mfma_k
+    int64_t per = (n + LINR_WG_BLOCKS - 1) / LINR_WG_BLOCKS;
+    return (per + 7) & ~(int64_t)7;
+}
+static inline int wg_chunks(int64_t n) { return (int)((wg_per(n) + LCH - 1) / LCH); }
+
+// out[(b * cpb + j) * 8 + {0,1,2}] = first row of the window of x-slab 0..2 for chunk j of block b, + {4,5,6} = its row count
+// (0: no neighbour in that slab; > LSLOTS - 1: does not fit)
+__global__ __launch_bounds__(64) void wgrad_ranges_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t per, int cpb,
+                                                     int32_t* __restrict__ out) {
+    __shared__ int smn[27], smx[27];
+    const int b = blockIdx.x / cpb, j = blockIdx.x % cpb, k = threadIdx.x;
+    const int64_t bb1 = ((int64_t)(b + 1) * per < n) ? (int64_t)(b + 1) * per : n;
+    const int64_t r0 = (int64_t)b * per + (int64_t)j * LCH;
+    const int64_t r1 = (r0 + LCH < bb1) ? r0 + LCH : bb1;
+    if (k < 27) {
+        int mn = 0x7fffffff, mx = -1;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int v = nbr[(int64_t)k * ld + r];
+            if (v >= 0) { mn = min(mn, v); mx = max(mx, v); }
+        }
+        smn[k] = mn; smx[k] = mx;
+    }
+    __syncthreads();
+    if (k < 3) {
+        int mn = 0x7fffffff, mx = -1;
+        for (int t = k; t < 27; t += 3) { mn = min(mn, smn[t]); mx = max(mx, smx[t]); }
+        out[(int64_t)blockIdx.x * 8 + k] = mx < 0 ? 0 : mn;
+        out[(int64_t)blockIdx.x * 8 + 4 + k] = mx < 0 ? 0 : mx - mn + 1;
+    }
+    if (k == 3) { out[(int64_t)blockIdx.x * 8 + 3] = 0; out[(int64_t)blockIdx.x * 8 + 7] = 0; }
+}
+
+extern "C" size_t linr_wgrad_ranges_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return (size_t)LINR_WG_BLOCKS * wg_chunks(n) * 8 * sizeof(int32_t) + 64;
+}
+
+extern "C" int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes, void* stream) {
+    if (n < 0 || ld < n) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!nbr || !ranges) return LINR_EINVAL;
+    if (ranges_bytes < linr_wgrad_ranges_bytes(n)) return LINR_ENOSPC;
+    if (!linr_aligned16(ranges)) return LINR_EALIGN;
+    const int cpb = wg_chunks(n);
+    wgrad_ranges_k<<<LINR_WG_BLOCKS * cpb, 64, 0, (hipStream_t)stream>>>(nbr, ld, n, wg_per(n), cpb, ranges);
+    return linr_launch_rc();
+}
+
+template <int COUT, bool DUAL>
+__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_lds_k(WgradSrc S, const int32_t* __restrict__ nbr, int64_t nbr_ld,
+                                                                   int64_t n, const int32_t* __restrict__ ranges, LinrWgradDst d,
+                                                                   WgradDual dd, Grp gp = Grp()) {
+    static_assert(!DUAL || COUT == 4, "dual mode = two 4->4 convolutions");
+    static_assert(WG_WAVES == 4, "chunk layout assumes 4 waves");
+    {
+        const int gi = blockIdx.y;
+        S.in += gp.in[gi]; S.g0 += gp.res[gi];
+        if (S.g1) S.g1 += gp.act[gi];
+        d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
+        dd.w_off1 += gp.e0[gi]; dd.b_off1 += gp.e1[gi];
+        if (gp.e2[gi] > 0) d.cin_valid = (int)gp.e2[gi];
+    }
+    constexpr int HB = COUT / 4;
+    constexpr int NA = 4 * HB * 4;
+    constexpr int CBSZ = DUAL ? 3 : 4;
+    constexpr int GPW = LCH / 32;                 // groups per wave and chunk
+    constexpr int PPT = (LSLOTS * 2 + WG_WAVES * 64 - 1) / (WG_WAVES * 64);      // 16-byte pieces per thread and window
+    __shared__ float4 sX[2][3 * LSLOTS * 2];      // double-buffered windows: [chunk parity][slab][slot][2 x 16 B]
+    __shared__ float sacc[64 * (NA + 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = DUAL ? (lane >> 5) : (lane & 1);
+    const int kk = DUAL ? (lane & 31) : (lane >> 1);
+    const bool live = kk < 27;
+    const int k = live ? kk : 26;
+    const int sl = k % 3;                         // x-slab of this lane's offset: dx = k % 3 - 1
+    f32x4 acc[4][HB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < HB; ++h) acc[c][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 7) & ~(int64_t)7;
+    const int cpb = (int)((per + LCH - 1) / LCH);
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    const int nch = b1 > b0 ? (int)((b1 - b0 + LCH - 1) / LCH) : 0;
+    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
+    const char* pad = reinterpret_cast<const char*>(S.in - 8) + 16 * q;
+    const float* gsel = (DUAL && q) ? S.g1 : S.g0;
+    const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
+    const int gl = DUAL ? (lane & 31) : lane;
+    const int gu = (gl / COUT) & 7, gc = gl % COUT;
+    const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);
+    const int32_t* rg = ranges + (int64_t)blockIdx.x * cpb * 8;
+    float bsum = 0.0f;
+    if (threadIdx.x < 12)      // zero slots of both halves
+        sX[threadIdx.x / 6][((threadIdx.x % 6) >> 1) * LSLOTS * 2 + (threadIdx.x & 1)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    int32_t idx[GPW][8];                          // neighbour indices of the chunk being multiplied
+    int32_t idn[GPW][8];                          // ... of the next chunk (in flight during the MFMAs)
+    float4 v[3][PPT];                             // window pieces of the next chunk (in flight during the MFMAs)
+    int lo_c[3] = {0, 0, 0}, lo_n[3] = {0, 0, 0};
+    bool fits_c = false, fits_n = false;
+
+    auto load_idx = [&](int64_t c0, int32_t (&dst)[GPW][8]) {
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int64_t g0r = c0 + 8 * (wave + 4 * j);
+            if (g0r + 8 <= b1) {
+                const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
+                const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
+                dst[j][0] = a.x; dst[j][1] = a.y; dst[j][2] = a.z; dst[j][3] = a.w;
+                dst[j][4] = b.x; dst[j][5] = b.y; dst[j][6] = b.z; dst[j][7] = b.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dst[j][u] = (g0r + u < b1) ? nk[g0r + u] : -1;
+            }
+        }
+    };
+    // window descriptors of chunk ci (block-uniform scalar loads), then its pieces into v[][]
+    auto load_windows = [&](int ci, int (&lo)[3], bool& fits) {
+        const int4 l4 = *reinterpret_cast<const int4*>(rg + ci * 8);
+        const int4 s4 = *reinterpret_cast<const int4*>(rg + ci * 8 + 4);
+        lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z;
+        const int span[3] = {s4.x, s4.y, s4.z};
+        fits = span[0] <= LSLOTS - 1 && span[1] <= LSLOTS - 1 && span[2] <= LSLOTS - 1;
+        if (fits) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int pieces = span[s3] * 2;
+                const float4* srcg = reinterpret_cast<const float4*>(S.in) + (int64_t)lo[s3] * 2;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const int pidx = (int)threadIdx.x + j * WG_WAVES * 64;
+                    v[s3][j] = (pidx < pieces) ? srcg[pidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto store_windows = [&](int parity, int ci, bool fits) {
+        if (!fits) return;
+        const int4 s4 = *reinterpret_cast<const int4*>(rg + ci * 8 + 4);
+        const int span[3] = {s4.x, s4.y, s4.z};
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int pieces = span[s3] * 2;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int pidx = (int)threadIdx.x + j * WG_WAVES * 64;
+                if (pidx < pieces) sX[parity][s3 * LSLOTS * 2 + 2 + pidx] = v[s3][j];
+            }
+        }
+    };
+
+    if (nch > 0) {
+        load_windows(0, lo_n, fits_n);
+        load_idx(b0, idn);
+        store_windows(0, 0, fits_n);
+    }
+    __syncthreads();
+    for (int ci = 0; ci < nch; ++ci) {
+        const int64_t c0 = b0 + (int64_t)ci * LCH;
+        const int parity = ci & 1;
+        fits_c = fits_n;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) lo_c[s3] = lo_n[s3];
+#pragma unroll
+        for (int j = 0; j < GPW; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) idx[j][u] = idn[j][u];
+        // gradient tiles of THIS chunk first: vmcnt retires in order, so they must be older than the prefetches below
+        float gv[GPW];
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int64_t g0r = c0 + 8 * (wave + 4 * j);
+            gv[j] = (g0r + gu < b1) ? gsel[(g0r + gu) * gld + gc] : 0.0f;
+        }
+        if (ci + 1 < nch) {                       // block-uniform: next chunk's windows and indices fly during the MFMAs
+            load_windows(ci + 1, lo_n, fits_n);
+            load_idx(c0 + LCH, idn);
+        }
+        const char* xs = reinterpret_cast<const char*>(sX[parity]);
+        const uint32_t lbase = (uint32_t)(sl * LSLOTS * 32 + 16 * q) + 32u - (uint32_t)lo_c[sl] * 32u;      // + idx * 32 = the row's slot
+#pragma unroll
+        for (int j = 0; j < GPW; ++j) {
+            const int64_t g0r = c0 + 8 * (wave + 4 * j);
+            if (g0r >= b1) break;                 // wave-uniform
+            float4 x[8];
+            if (fits_c) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t o = idx[j][u] >= 0 ? lbase + (uint32_t)idx[j][u] * 32u : (uint32_t)(16 * q);
+                    x[u] = *reinterpret_cast<const float4*>(xs + o);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[j][u] + 1) * 32u);
+            }
+            bsum += gv[j];
+            static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                static_for<HB>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    constexpr int ab = u * HB + h;
+                    acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].x, acc[0][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].y, acc[1][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].z, acc[2][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].w, acc[3][h], CBSZ, ab, 0);
+                });
+            });
+        }
+        if (ci + 1 < nch) store_windows(parity ^ 1, ci + 1, fits_n);
+        __syncthreads();                          // next half filled; everybody is done reading this half
+    }
+    // fold waves in wave order (fixed => reproducible)
+    float* mine = sacc + lane * (NA + 1);
+    for (int w = 0; w < WG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = (c * HB + h) * 4 + i;
+                        mine[e] = (w == 0) ? acc[c][h][i] : mine[e] + acc[c][h][i];
+                    }
+        }
+        __syncthreads();
+    }
+    __shared__ float sbias[WG_WAVES][16];
+    {
+        float t = bsum;
+#pragma unroll
+        for (int m = COUT; m < 8 * COUT; m <<= 1) t += __shfl_xor(t, m, 64);
+        const int slot = DUAL ? ((lane >> 5) * 4 + (lane & 3)) : (lane % COUT);
+        if ((lane & 31) < COUT && (DUAL || lane < 32)) sbias[wave][slot] = t;
+        __syncthreads();
+    }
+    {
+        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+        const int tid = threadIdx.x;
+        if (tid < (DUAL ? 8 : COUT)) {
+            float t = sbias[0][tid];
+            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][tid];
+            if (DUAL) dst[(tid < 4 ? d.b_off : dd.b_off1) + (tid & 3)] = t;
+            else dst[d.b_off + tid] = t;
+        }
+        if constexpr (DUAL) {
+            for (int e = tid; e < 2 * 432; e += WG_WAVES * 64) {
+                const int t = e / 432, r = e - 432 * t;
+                dst[(t ? dd.w_off1 : d.w_off) + r] = sacc[(32 * t + (r >> 4)) * (NA + 1) + (r & 15)];
+            }
+        } else {
+            const int cinv = d.cin_valid;
+            const int per_k = cinv * COUT, total = 27 * per_k;
+            for (int e = tid; e < total; e += WG_WAVES * 64) {
+                const int kq = e / per_k, r = e - kq * per_k;
+                const int ci = r / COUT, co = r - ci * COUT;
+                dst[d.w_off + e] = sacc[(2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3)];
+            }
+        }
+    }
+}
+
+// The op-level entries use it whenever a window table is passed; the executor only under LINR_WGRAD_LDS=1.  Measured (same box, loot10): 2.82 ms/step against 2.56 with the direct-gather kernel - the
+// staging removes two thirds of the vector-memory instructions but the chunk barrier, the LDS bank conflicts of 27
+// unrelated rows per read and the extra address arithmetic cost more than that saves; kept as a tested alternative.
+bool linr_wgrad_lds_enabled() {
+    static const int v = getenv("LINR_WGRAD_LDS") ? atoi(getenv("LINR_WGRAD_LDS")) : 0;
+    return v != 0;
+}
+
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
-                          int ngroups, const int32_t* lo, const uint32_t* mask) {
+                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges) {
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;
@@ -980,6 +1270,13 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
         else spconv_wgrad_mfma_k<XQ, CO, false, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0);         \
         return linr_launch_rc();                                                                                             \
     } while (0)
+    // rows staged through LDS: 32-byte rows (in_ld 8), indices from the 16-byte aligned neighbour table
+    if (ranges && nblocks == LINR_WG_BLOCKS && in_ld == 8 && cin <= 8 && (cout == 8 || (cout == 4 && cin == 8)) && al &&
+        linr_aligned16(nbr) && linr_aligned16(in) && linr_aligned16(ranges)) {
+        if (cout == 8) spconv_wgrad_lds_k<8, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, g0);
+        else spconv_wgrad_lds_k<4, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, g0);
+        return linr_launch_rc();
+    }
     if (cin == 8 && cout == 8) GO(2, 8);
     if (cin == 8 && cout == 4) GO(2, 4);
     if (cin == 4 && cout == 4) GO(1, 4);
@@ -992,7 +1289,7 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups,
-                            const int32_t* lo, const uint32_t* mask) {
+                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges) {
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;
@@ -1001,6 +1298,10 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
     WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     WgradDual dd = {w_off1, b_off1};
+    if (ranges && nblocks == LINR_WG_BLOCKS && al && linr_aligned16(nbr) && linr_aligned16(H) && linr_aligned16(ranges)) {
+        spconv_wgrad_lds_k<4, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, grp);
+        return linr_launch_rc();
+    }
     if (idx == 2) spconv_wgrad_mfma_k<2, 4, true, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     else if (idx == 1) spconv_wgrad_mfma_k<2, 4, true, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     else spconv_wgrad_mfma_k<2, 4, true, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
@@ -1335,8 +1636,8 @@ extern "C" int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_
 }
 
 extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
-                                        const int32_t* nbr, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
-                                        float* slab, void* stream) {
+                                        const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
+                                        int64_t ld, int64_t n, float* slab, void* stream) {
     if (n < 0 || ld < n || g0_ld < 4 || g1_ld < 4) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!H || !g0 || !g1 || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;
@@ -1344,5 +1645,5 @@ extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     // per block: [W01 432 | b01 4 | W11 432 | b11 4]
     return linr_conv3_wgrad_dual44(H, g0, g0_ld, g1, g1_ld, nbr, ld, n, slab, 872, 0, 432, 436, 868, LINR_WG_BLOCKS,
-                                   (hipStream_t)stream, nullptr, 1, lo, mask);
+                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges);
 }

@@ -57,6 +57,11 @@ class Frame:
         self.nbr_mask = torch.zeros((self.nbr_ld,), dtype=torch.int32, device=device)      # padding columns: empty masks
         check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
                                             self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
+        # window table of the LDS-staged weight-gradient kernels (static coordinates: built once, like the kernel map)
+        nb = _lib.lib().linr_wgrad_ranges_bytes(R)
+        self.wg_ranges = torch.zeros(max(1, (nb + 3) // 4), dtype=torch.int32, device=device)
+        check(_lib.lib().linr_wgrad_ranges_build(self.nbr.data_ptr(), self.nbr_ld, R, self.wg_ranges.data_ptr(),
+                                                 self.wg_ranges.numel() * 4, _stream()), 'linr_wgrad_ranges_build')
         self.arena = None
         if with_arena:
             self.alloc_arena()
@@ -65,7 +70,7 @@ class Frame:
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
-                                 occ=self.occ.data_ptr())
+                                 occ=self.occ.data_ptr(), wg_ranges=self.wg_ranges.data_ptr())
 
     def alloc_arena(self):
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)

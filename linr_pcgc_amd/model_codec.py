@@ -3,7 +3,8 @@
 quant_uniform2 (model_size_est.py:72-91): global affine 8-bit quantisation of the flat parameter vector;
 compress_model (:390-521): Laplace(mu, b) arithmetic coding (mode 2) vs zlib (mode 1) vs raw (mode 0);
 decompress_model (:523-579).  The Laplace CDF keeps the reference's quirk (cumsum that does not start at 0 plus a
-trailing 0, :470-480) because it defines the byte stream.  Streams are torchac-compatible (csrc/ac.cpp).
+trailing 0, :470-480) because it defines the byte stream.  Streams follow torchac 0.9.3's published coder (csrc/ac.cpp;
+pinned by the reference's one known-answer vector, tests/test_oracle_golden.py::test_model_stream_known_answer).
 """
 import time
 import zlib

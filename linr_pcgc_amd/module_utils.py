@@ -1,7 +1,7 @@
 """Host-side mirror of models/module_utils.py: PointwiseMLP, BinaryArithmeticCoding, octree helpers.
 
 PointwiseMLP owns parameters only (its arithmetic runs in csrc/linear.hip through the engine).
-BinaryArithmeticCoding feeds the C++ range coder of csrc/ac.cpp (torchac-compatible streams).
+BinaryArithmeticCoding feeds the C++ range coder of csrc/ac.cpp (streams follow torchac 0.9.3's published coder).
 The octree helpers restate octree_level / QuickSearchCoord (models/module_utils.py:86-318) with 64-bit ravel keys and
 torch.searchsorted; they are device-agnostic torch code and run once per frame ("next" row N1 of SURVEY.md §8f).
 """

@@ -570,9 +570,10 @@ def default_dump(golden_dir, tmp_path_factory):
 
 # every executor switch the library reads from the environment (README.md): each one alone, and the two extreme
 # combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT
-SWITCHES = [{'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
+SWITCHES = [{'LINR_WGRAD_LDS': '1'}, {'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
             {'LINR_CONV_MFMA': '2'}, {'LINR_WGRAD_CMAP': '1'}, {'LINR_WGRAD_STREAM': '1'},
-            {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0'},
+            {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',
+             'LINR_WGRAD_LDS': '1'},
             {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_CONV_MFMA': '2', 'LINR_WGRAD_CMAP': '1'}]
 
 
@@ -661,6 +662,13 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     gw_t, gb_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, None, None, n, cin, cout)      # indices from the nbr table
     assert torch.equal(gw_t, gw) and torch.equal(gb_t, gb)
     slab1 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
+    # rows staged through LDS (window table; needs a 16-byte friendly leading dimension): bit-identical partials
+    ld4 = (n + 63) // 64 * 64
+    nbr4 = torch.full((27, ld4), -1, dtype=torch.int32, device=dev)
+    nbr4[:, :n] = nbr
+    slab_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False)
+    slab_l = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, ranges=ops.wgrad_ranges(nbr4, n))
+    assert torch.equal(slab_t, slab_l), 'LDS-staged weight gradients must equal the direct gathers bit for bit'
     slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
 
