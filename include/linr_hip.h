@@ -127,6 +127,10 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
 /* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
  * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
  * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */
+/* 8-row tiled copy of the kernel map for the weight-gradient kernels: tile8[g][k][u] = nbr[k][8 g + u] (-1 beyond n), so the
+ * 27 x 8 indices of a row group are 864 contiguous bytes.  tile8: linr_kmap_tile8_bytes(n) bytes, 16-byte aligned. */
+LINR_API size_t linr_kmap_tile8_bytes(int64_t n);
+LINR_API int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream);
 LINR_API size_t linr_wgrad_ranges_bytes(int64_t n);
 LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes,
                             void* stream);
@@ -197,6 +201,7 @@ typedef struct linr_frame {
     const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
     const int32_t* wg_ranges;     /* linr_wgrad_ranges_build over nbr (LDS windows of the weight-gradient kernels), or NULL */
+    const int32_t* nbr8;          /* linr_kmap_tile8 over nbr (8-row tiled copy of the kernel map), or NULL               */
 } linr_frame;
 
 LINR_API size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers);

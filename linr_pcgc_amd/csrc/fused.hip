@@ -35,23 +35,32 @@ extern "C" int linr_kmap_compress(const int32_t* nbr, int64_t nbr_ld, int64_t n,
     return linr_launch_rc();
 }
 
-// byte offsets (from the pad row) of the 27 neighbours of `row`; absent -> 0 (the pad row itself)
+// byte offsets (from the pad row) of the 27 neighbours of `row`; absent -> 0 (the pad row itself).  Rows are 4 << sh bytes
+// wide: the scaling is a shift by a wave-uniform amount (v_mul_lo_u32 is a quarter-rate instruction and there would be 27 of
+// them per lane), and the nine column bases are read through uniform base pointers + ONE 32-bit row offset (global_load
+// saddr form) instead of nine 64-bit address computations.
 template <bool BWD>
 __device__ __forceinline__ void decode_offsets(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                int64_t ld, int64_t row, uint32_t rowbytes, uint32_t (&off)[27]) {
+    const uint32_t sh = __builtin_amdgcn_readfirstlane(rowbytes >= 32u ? 5u : (rowbytes >= 16u ? 4u : (rowbytes >= 4u ? 2u : 0u)));
+    const uint32_t r32 = (uint32_t)row;
     if (mask == nullptr) {            // `lo` is the full table nbr[27][ld]: no decode arithmetic, 27 coalesced index loads
 #pragma unroll
-        for (int k = 0; k < 27; ++k) off[BWD ? 26 - k : k] = (uint32_t)(lo[(int64_t)k * ld + row] + 1) * rowbytes;
+        for (int k = 0; k < 27; ++k) {
+            const int32_t* lk = lo + (int64_t)k * ld;
+            off[BWD ? 26 - k : k] = (uint32_t)(lk[r32] + 1) << sh;
+        }
         return;
     }
-    const uint32_t m = mask[row];
+    const uint32_t m = mask[r32];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const uint32_t base = (uint32_t)lo[(int64_t)q * ld + row] + 1u;     // +1: row index -> offset from the pad row
+        const int32_t* lq = lo + (int64_t)q * ld;
+        const uint32_t base = (uint32_t)lq[r32] + 1u;     // +1: row index -> offset from the pad row
         const uint32_t b0 = (m >> (3 * q)) & 1u, b1 = (m >> (3 * q + 1)) & 1u, b2 = (m >> (3 * q + 2)) & 1u;
-        const uint32_t o0 = b0 ? base * rowbytes : 0u;
-        const uint32_t o1 = b1 ? (base + b0) * rowbytes : 0u;
-        const uint32_t o2 = b2 ? (base + b0 + b1) * rowbytes : 0u;
+        const uint32_t o0 = b0 ? base << sh : 0u;
+        const uint32_t o1 = b1 ? (base + b0) << sh : 0u;
+        const uint32_t o2 = b2 ? (base + b0 + b1) << sh : 0u;
         // forward uses offset k, backward-data the mirrored offset 26-k  (k = q + 9*dz)
         if (!BWD) { off[q] = o0; off[q + 9] = o1; off[q + 18] = o2; }
         else      { off[26 - q] = o0; off[26 - (q + 9)] = o1; off[26 - (q + 18)] = o2; }
@@ -506,7 +515,7 @@ extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const floa
     const int64_t elems = (int64_t)(27 * cin + 1) * cout;
     LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
     return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
-                                 lo, mask, ranges);
+                                 lo, mask, ranges, nullptr);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
@@ -576,9 +585,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __rest
     uint32_t off[27];
     decode_offsets<BWD>(lo, mask, ld, row, 1u, off);                  // row index + 1 (0 = pad row); scaled per matrix below
     const char* pad0 = reinterpret_cast<const char*>(in - in_ld);
-    const uint32_t rb0 = (uint32_t)in_ld * 4u;
+    // row pitches are 16 or 32 bytes: scale by wave-uniform shifts (v_mul_lo_u32 is quarter rate)
+    const uint32_t rb0 = __builtin_amdgcn_readfirstlane(in_ld == 8 ? 5u : 4u);
     const char* pad1 = BWD ? reinterpret_cast<const char*>(d.in2 - d.in2_ld) : pad0 + 16;     // fwd: second half of the same row
-    const uint32_t rb1 = BWD ? (uint32_t)d.in2_ld * 4u : rb0;
+    const uint32_t rb1 = BWD ? __builtin_amdgcn_readfirstlane(d.in2_ld == 8 ? 5u : 4u) : rb0;
     f32x4 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { acc0[j] = BWD ? 0.0f : d.b01[j]; acc1[j] = BWD ? 0.0f : d.b11[j]; }
@@ -586,16 +596,16 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __rest
     float x0[PF + 1][4], x1[PF + 1][4];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        RowLoadF<4>::run(pad0 + off[u] * rb0, x0[u]);
-        RowLoadF<4>::run(pad1 + off[u] * rb1, x1[u]);
+        RowLoadF<4>::run(pad0 + (off[u] << rb0), x0[u]);
+        RowLoadF<4>::run(pad1 + (off[u] << rb1), x1[u]);
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<27>([&](auto kc) {
         constexpr int k = decltype(kc)::value;            // weight tap (decode_offsets already mirrored `off` for BWD)
         constexpr int g = k / 8, ab = (k % 8) * 2;
         if constexpr (k + PF < 27) {
-            RowLoadF<4>::run(pad0 + off[k + PF] * rb0, x0[(k + PF) % (PF + 1)]);
-            RowLoadF<4>::run(pad1 + off[k + PF] * rb1, x1[(k + PF) % (PF + 1)]);
+            RowLoadF<4>::run(pad0 + (off[k + PF] << rb0), x0[(k + PF) % (PF + 1)]);
+            RowLoadF<4>::run(pad1 + (off[k + PF] << rb1), x1[(k + PF) % (PF + 1)]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -802,7 +812,9 @@ struct WgradSrc {
 };
 struct WgradDual { int64_t w_off1, b_off1; };
 
-// IDX: where a lane's neighbour indices come from - 0: nbr[27][ld], scalar loads; 1: nbr, 16-byte loads;
+// IDX: where a lane's neighbour indices come from - 3: the 8-row tiled table nbr8[row / 8][27][8] (linr_kmap_tile8: the 27 x 8
+// indices of a row group are 864 contiguous bytes, so the two index loads of a group touch 7 cache lines instead of 27);
+// 0: nbr[27][ld], scalar loads; 1: nbr, 16-byte loads;
 // 2: the compressed map (nbr = its 9 column bases lo[9][ld], plus the 27-bit masks): 40 instead of 108 index bytes per row
 // and 9 + 1 instead of 27 distinct cache lines per load instruction.
 template <int XQ, int COUT, bool DUAL, int IDX>
@@ -837,13 +849,12 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     per = (per + 7) & ~(int64_t)7;
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const int32_t* nk = nbr + (int64_t)(IDX == 2 ? k % 9 : k) * nbr_ld;
+    const int32_t* nk = IDX == 3 ? nbr + 8 * k : nbr + (int64_t)(IDX == 2 ? k % 9 : k) * nbr_ld;
     // compressed map: tap k = q9 + 9 j is present iff bit (3 q9 + j) of the row's mask is set and then sits at
     // lo[q9][r] + (number of present taps below it in the same column)
     const int cshift = 3 * (k % 9), cj = k / 9;
     const uint32_t cpm = 1u << cj, cam = cpm - 1u;
     const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
-    const uint32_t rowbytes = (uint32_t)S.in_ld * 4u;
     // this lane's element of the 8-row gradient tile: row gu, channel gc of matrix gsel
     const float* gsel = (DUAL && q) ? S.g1 : S.g0;
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
@@ -851,9 +862,55 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
     const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);      // live components per quad (>= 4: all)
     float bsum = 0.0f;
+    if constexpr (IDX == 3) {
+        // Tiled index table: software-pipelined by one group.  The indices and the gradient element of group t+1 are requested
+        // right after the gathers of group t (vmcnt retires in order, so they must be YOUNGER than the gathers the MFMAs wait
+        // for) and land while the 64 MFMAs of group t run; the loop top then finds them ready instead of paying a full
+        // memory latency before it can even issue its gathers.  The table has spare all -1 groups behind the last row group,
+        // so the prefetch needs no bounds check; rows beyond n gather the zero row.  Same groups, same order => same bits.
+        int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
+        float gvn = 0.0f;
+        if (b0 + 8 * wave < b1) {          // wave-uniform; blocks behind the last row (b0 >= n) must not touch the table at all
+            const int64_t g0r = b0 + 8 * wave;
+            ia = *reinterpret_cast<const int4*>(nk + g0r * 27);
+            ib = *reinterpret_cast<const int4*>(nk + g0r * 27 + 4);
+            gvn = (g0r + gu < n) ? gsel[(g0r + gu) * gld + gc] : 0.0f;
+        }
+        for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
+            const int32_t idx[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+            const float gv = gvn;
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << 5));
+            {
+                const int64_t g1r = g0r + 8 * WG_WAVES;
+                ia = *reinterpret_cast<const int4*>(nk + g1r * 27);
+                ib = *reinterpret_cast<const int4*>(nk + g1r * 27 + 4);
+                gvn = (g1r + gu < n) ? gsel[(g1r + gu) * gld + gc] : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bsum += gv;
+            static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                static_for<HB>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    constexpr int ab = u * HB + h;
+                    acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
+                    if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
+                });
+            });
+        }
+    } else
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
-        if (IDX >= 1 && g0r + 8 <= n) {
+        if constexpr (IDX == 3) {          // (pipelined above)
+            const int4 a = *reinterpret_cast<const int4*>(nk + g0r * 27);
+            const int4 b = *reinterpret_cast<const int4*>(nk + g0r * 27 + 4);
+            idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
+            idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+        } else if (IDX >= 1 && g0r + 8 <= n) {
             const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
             const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
             idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
@@ -885,7 +942,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[u] + 1) * rowbytes);
+            x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << 5));          // 32-byte rows (in_ld = 8)
         }
         bsum += gv;                      // bias gradient: column sums of the gradient rows (lanes beyond the 27 offsets
                                          // gather offset 26's rows again; their products are never written)
@@ -1008,6 +1065,33 @@ __global__ __launch_bounds__(64) void wgrad_ranges_k(const int32_t* __restrict__
         out[(int64_t)blockIdx.x * 8 + 4 + k] = mx < 0 ? 0 : mx - mn + 1;
     }
     if (k == 3) { out[(int64_t)blockIdx.x * 8 + 3] = 0; out[(int64_t)blockIdx.x * 8 + 7] = 0; }
+}
+
+// nbr8[g][k][u] = nbr[k][8 g + u] (-1 beyond n): the index tile of one 8-row group, contiguous
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_tile8_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t groups,
+                                                           int32_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (e >= groups * 216) return;
+    const int64_t g = e / 216;
+    const int r = (int)(e - g * 216), k = r >> 3, u = r & 7;
+    const int64_t row = 8 * g + u;
+    out[e] = row < n ? nbr[(int64_t)k * ld + row] : -1;
+}
+
+extern "C" size_t linr_kmap_tile8_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return (size_t)((n + 7) / 8 + 2 * WG_WAVES) * 216 * sizeof(int32_t);
+}
+
+extern "C" int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream) {
+    if (n < 0 || ld < n) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!nbr || !tile8) return LINR_EINVAL;
+    if (tile8_bytes < linr_kmap_tile8_bytes(n)) return LINR_ENOSPC;
+    if (!linr_aligned16(tile8)) return LINR_EALIGN;
+    const int64_t groups = (n + 7) / 8 + 2 * WG_WAVES;      // spare all -1 groups: the pipelined kernel prefetches one stride ahead
+    kmap_tile8_k<<<linr_grid(groups * 216, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, ld, n, groups, tile8);
+    return linr_launch_rc();
 }
 
 extern "C" size_t linr_wgrad_ranges_bytes(int64_t n) {
@@ -1254,7 +1338,8 @@ bool linr_wgrad_lds_enabled() {
 
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
-                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges) {
+                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8) {
+    if (in_ld != 8) return LINR_EINVAL;               // the kernels address gathered rows as idx << 5
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;
@@ -1265,7 +1350,8 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
     d.cin_valid = cin;
 #define GO(XQ, CO)                                                                                                           \
     do {                                                                                                                     \
-        if (idx == 2) spconv_wgrad_mfma_k<XQ, CO, false, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
+        if (tile8 && idx != 2) spconv_wgrad_mfma_k<XQ, CO, false, 3><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8, mask, nbr_ld, n, d, dd, g0); \
+        else if (idx == 2) spconv_wgrad_mfma_k<XQ, CO, false, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
         else if (idx == 1) spconv_wgrad_mfma_k<XQ, CO, false, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
         else spconv_wgrad_mfma_k<XQ, CO, false, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0);         \
         return linr_launch_rc();                                                                                             \
@@ -1289,7 +1375,7 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups,
-                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges) {
+                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8) {
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;
@@ -1302,7 +1388,8 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
         spconv_wgrad_lds_k<4, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, grp);
         return linr_launch_rc();
     }
-    if (idx == 2) spconv_wgrad_mfma_k<2, 4, true, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
+    if (tile8 && idx != 2) spconv_wgrad_mfma_k<2, 4, true, 3><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8, mask, nbr_ld, n, d, dd, grp);
+    else if (idx == 2) spconv_wgrad_mfma_k<2, 4, true, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     else if (idx == 1) spconv_wgrad_mfma_k<2, 4, true, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     else spconv_wgrad_mfma_k<2, 4, true, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
     return linr_launch_rc();
@@ -1645,5 +1732,5 @@ extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     // per block: [W01 432 | b01 4 | W11 432 | b11 4]
     return linr_conv3_wgrad_dual44(H, g0, g0_ld, g1, g1_ld, nbr, ld, n, slab, 872, 0, 432, 436, 868, LINR_WG_BLOCKS,
-                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges);
+                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges, nullptr);
 }
