@@ -292,11 +292,13 @@ static int g_ev_next = 0;
 static bool g_aux_ok = false;
 static std::mutex g_aux_mu;          // the pool is process-wide; executor calls may come from several host threads
 
-// policy: LINR_WGRAD_STREAM=1 always, =0 never; unset = only for SMALL frames (rows < LINR_AUX_ROWS, default 150,000).  At
-// 336 k rows every grouped launch fills the chip and a second stream only adds contention (3.02 vs 2.83 ms/step); at 56 k
-// rows (BASELINE config[0]) a launch is a single partial wave of blocks bound by its own latency, and the ~14
-// weight-gradient launches overlap the backward data chain instead of queueing behind it.  Results are bit-identical
-// either way (tests/test_gpu_parity.py: switch test).
+// Second-stream policy (LINR_WGRAD_STREAM: 1 = every weight-gradient launch, 0 = none, unset = auto).  Auto: the GROUPED
+// launches (7 outter blocks / 8 heads per launch) fill the chip on their own and a second stream only adds contention
+// (3.02 vs 2.83 ms/step with everything on it), so they stay on the caller's stream unless the frame is small
+// (rows < LINR_AUX_ROWS, default 150,000); the SINGLE launches of block_in (1,319 blocks = 1.3 blocks per CU at 336 k rows:
+// bound by their own latency and tail) do overlap: its five weight-gradient launches run beside its backward data chain,
+// and in the forward pass the occupancy-only part of the outter blocks runs beside [scale context -> block_in].
+// Results are bit-identical either way (tests/test_gpu_parity.py: switch test).
 static int aux_policy() {
     static const int v = getenv("LINR_WGRAD_STREAM") ? atoi(getenv("LINR_WGRAD_STREAM")) : -1;
     return v;
@@ -306,16 +308,21 @@ static int64_t aux_rows() {
     return v;
 }
 
-static bool aux_init(int64_t rows) {
-    const int pol = aux_policy();
-    if (pol == 0 || (pol < 0 && rows >= aux_rows())) return false;
+// the auxiliary stream (created on first use), or nullptr when switched off / unavailable
+static hipStream_t aux_stream() {
+    if (aux_policy() == 0) return nullptr;
     std::lock_guard<std::mutex> lk(g_aux_mu);
-    if (g_aux_ok) return true;
-    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) return false;
+    if (g_aux_ok) return g_aux;
+    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (int i = 0; i < 64; ++i)
-        if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     g_aux_ok = true;
-    return true;
+    return g_aux;
+}
+// should the grouped weight-gradient launches go to the auxiliary stream too?
+static bool aux_all(int64_t rows) {
+    const int pol = aux_policy();
+    return pol > 0 || (pol < 0 && rows < aux_rows());
 }
 
 // everything issued on `from` so far happens-before whatever is issued on `to` next
@@ -616,7 +623,9 @@ static void goffs(int64_t* dst, const float* const* ptrs, int n) {
 // Teacher-forced forward of all 8 stages with the 7 outter blocks and the 8 heads as grouped launches (their inputs -
 // the ground-truth occupancy and x_glob - are all known up front).  Same kernels and per-row arithmetic as the staged
 // path below, so the decoder reproduces these probabilities bit for bit.
-static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
+// part 1: the occupancy-only layers of the outter blocks (first conv, conv0_0 | conv1_0, both 4->4 convs: they do not need
+// x_glob); part 2: everything that does (tail conv + x_glob, the 8 heads).  3 = both.
+static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
@@ -632,6 +641,7 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
         p_c01w[g] = P + bp.inc[0].c01_w; p_c01b[g] = P + bp.inc[0].c01_b; p_c11w[g] = P + bp.inc[0].c11_w; p_c11b[g] = P + bp.inc[0].c11_b;
         p_c12w[g] = P + bp.inc[0].c12_w; p_c12b[g] = P + bp.inc[0].c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
     }
+    if (part & 1) {
     {   // first conv of every outter block: A[b] = relu(conv3(occ[:, :b]; a) + a_b), one shared gather (csrc/fused.hip)
         static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
         if (shared) {
@@ -662,6 +672,8 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc) {
         TRY(linr_dual44_fwd_launch(pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c01b[0], p_c11w[0], p_c11b[0], pA[0], p_c12w[0],
                                    p_c12b[0], a.M[1], a.I[1], c.s, &gp, 7));
     }
+    }
+    if (!(part & 2)) return linr_launch_rc();
     {   // O[b] = conv3(I; b) + x_glob
         Grp gp = Grp();
         goffs(gp.in, pI, 7); goffs(gp.w, p_bw, 7); goffs(gp.b, p_bb, 7); goffs(gp.out, pO, 7);
@@ -700,11 +712,22 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     const float* P = c.P;
     // ground-truth / decoded occupancy into the padded arena copy (the decoder updates one column per call)
     TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+    const bool batched = grouped_enabled();
+    const bool all_grouped = batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask;
+    hipStream_t aux = all_grouped ? aux_stream() : nullptr;
     if (stage_begin == 0) {
         PadList pl;
         pl.n = a.npad;
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
         zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
+        if (aux) {      // the occupancy-only layers of the 7 outter blocks run beside [scale context -> block_in] (single launches)
+            hipStream_t main_s = c.s;
+            TRY(stream_order(main_s, aux));
+            c.s = aux;
+            const int rc = forward_batched(c, nullptr, nullptr, 1);
+            c.s = main_s;
+            TRY(rc);
+        }
         // scale context: one small MLP per scale (model_core.py:48-53)
         static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
         if (sce_fused) {
@@ -723,8 +746,13 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         }
         TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
     }
-    const bool batched = grouped_enabled();
-    if (batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask) return forward_batched(c, probs, bits_acc);
+    if (all_grouped) {
+        if (aux) {
+            TRY(stream_order(aux, c.s));
+            return forward_batched(c, probs, bits_acc, 2);
+        }
+        return forward_batched(c, probs, bits_acc);
+    }
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
@@ -945,7 +973,9 @@ static int backward_core(Ctx& c, float gscale) {
     Arena& a = c.A;
     const float* P = c.P;
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
-    c.ws = (c.f->nbr_lo && c.f->nbr_mask && aux_init(c.R)) ? g_aux : c.s;
+    const bool cm_ = c.f->nbr_lo && c.f->nbr_mask;
+    hipStream_t aux = cm_ ? aux_stream() : nullptr;
+    c.ws = (aux && aux_all(c.R)) ? aux : c.s;
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      LINR_WG_BLOCKS, c.s)));
@@ -972,6 +1002,7 @@ static int backward_core(Ctx& c, float gscale) {
         axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO[k], c.R * 8, a.gXG, k == 7 ? 0 : 1);
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
+    if (aux) c.ws = aux;             // block_in and the scale context: single launches, overlapped with the data chain
     TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
     // scale context: all non-empty scales as one launch per layer when they fit one grouped launch
     int ns = 0, sl[MAX_SCALES];
