@@ -119,11 +119,13 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
  * ranges: linr_wgrad_ranges_build's table or NULL.  With it (and in_ld = 8, a 16-byte aligned table with ld % 4 = 0) the
  * gathered rows are staged through LDS: in the x-major order the neighbours of a chunk of 128 consecutive rows lie in three
  * nearly contiguous row windows (one per x-slab), which the kernel copies with coalesced loads, double-buffered against the
- * MFMAs of the previous chunk.  Same partial sums, bit for bit. */
+ * MFMAs of the previous chunk.  Same partial sums, bit for bit.
+ * tile8: linr_kmap_tile8's table or NULL.  With it (and lo / mask / ranges NULL) the indices come from the 8-row tiled copy of
+ * the kernel map with a one-group software pipeline - the executor's default.  Same partial sums, bit for bit. */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                           const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld, int64_t n,
-                           int32_t cin, int32_t cout, float* slab, void* stream);
+                           const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
+                           int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream);
 /* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
  * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
  * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */

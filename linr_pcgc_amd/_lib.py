@@ -35,7 +35,7 @@ _PROTOS = {
     'linr_kmap_build': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_spconv_wgrad_cmap_blocks': (ctypes.c_int64, []),
-    'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'linr_kmap_tile8_bytes': (c_size, [c_i64]),
     'linr_kmap_tile8': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_wgrad_ranges_bytes': (c_size, [c_i64]),

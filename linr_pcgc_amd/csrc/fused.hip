@@ -504,8 +504,8 @@ extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, con
 extern "C" int64_t linr_spconv_wgrad_cmap_blocks(void) { return LINR_WG_BLOCKS; }
 
 extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                                      const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld, int64_t n,
-                                      int32_t cin, int32_t cout, float* slab, void* stream) {
+                                      const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
+                                      int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream) {
     if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!in || !gout || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;     // lo / mask NULL: indices from nbr
@@ -514,8 +514,9 @@ extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const floa
     if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;
     const int64_t elems = (int64_t)(27 * cin + 1) * cout;
     LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
+    if (tile8 && !linr_aligned16(tile8)) return LINR_EALIGN;
     return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
-                                 lo, mask, ranges, nullptr);
+                                 lo, mask, ranges, tile8);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
@@ -855,6 +856,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int cshift = 3 * (k % 9), cj = k / 9;
     const uint32_t cpm = 1u << cj, cam = cpm - 1u;
     const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
+    const uint32_t rsh = __builtin_amdgcn_readfirstlane(S.in_ld == 8 ? 5u : 4u);      // 32- or 16-byte rows: a uniform shift, not a multiply
     // this lane's element of the 8-row gradient tile: row gu, channel gc of matrix gsel
     const float* gsel = (DUAL && q) ? S.g1 : S.g0;
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
             const float gv = gvn;
             float4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << 5));
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << rsh));
             {
                 const int64_t g1r = g0r + 8 * WG_WAVES;
                 ia = *reinterpret_cast<const int4*>(nk + g1r * 27);
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         float4 x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << 5));          // 32-byte rows (in_ld = 8)
+            x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << rsh));
         }
         bsum += gv;                      // bias gradient: column sums of the gradient rows (lanes beyond the 27 offsets
                                          // gather offset 26's rows again; their products are never written)
@@ -1339,7 +1341,7 @@ bool linr_wgrad_lds_enabled() {
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
                           int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8) {
-    if (in_ld != 8) return LINR_EINVAL;               // the kernels address gathered rows as idx << 5
+    if (in_ld != 8 && in_ld != 4) return LINR_EINVAL;  // the kernels address gathered rows by a shift: 32- or 16-byte rows
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;

@@ -296,8 +296,9 @@ static std::mutex g_aux_mu;          // the pool is process-wide; executor calls
 // launches (7 outter blocks / 8 heads per launch) fill the chip on their own and a second stream only adds contention
 // (3.02 vs 2.83 ms/step with everything on it), so they stay on the caller's stream unless the frame is small
 // (rows < LINR_AUX_ROWS, default 150,000); the SINGLE launches of block_in (1,319 blocks = 1.3 blocks per CU at 336 k rows:
-// bound by their own latency and tail) do overlap: its five weight-gradient launches run beside its backward data chain,
-// and in the forward pass the occupancy-only part of the outter blocks runs beside [scale context -> block_in].
+// bound by their own latency and tail) do overlap: its five weight-gradient launches run beside its backward data chain
+// (the same trick in the forward pass - the occupancy-only layers of the outter blocks beside [scale context -> block_in] -
+// gained 0.3 % and distorted the live timing of the roofline kernels, so it was not kept).
 // Results are bit-identical either way (tests/test_gpu_parity.py: switch test).
 static int aux_policy() {
     static const int v = getenv("LINR_WGRAD_STREAM") ? atoi(getenv("LINR_WGRAD_STREAM")) : -1;
@@ -714,20 +715,11 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
     const bool batched = grouped_enabled();
     const bool all_grouped = batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask;
-    hipStream_t aux = all_grouped ? aux_stream() : nullptr;
     if (stage_begin == 0) {
         PadList pl;
         pl.n = a.npad;
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
         zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
-        if (aux) {      // the occupancy-only layers of the 7 outter blocks run beside [scale context -> block_in] (single launches)
-            hipStream_t main_s = c.s;
-            TRY(stream_order(main_s, aux));
-            c.s = aux;
-            const int rc = forward_batched(c, nullptr, nullptr, 1);
-            c.s = main_s;
-            TRY(rc);
-        }
         // scale context: one small MLP per scale (model_core.py:48-53)
         static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
         if (sce_fused) {
@@ -746,13 +738,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         }
         TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
     }
-    if (all_grouped) {
-        if (aux) {
-            TRY(stream_order(aux, c.s));
-            return forward_batched(c, probs, bits_acc, 2);
-        }
-        return forward_batched(c, probs, bits_acc);
-    }
+    if (all_grouped) return forward_batched(c, probs, bits_acc);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {

@@ -429,7 +429,7 @@ extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const floa
         const int elems = (27 * cin + 1) * cout;
         LinrWgradDst d = {(float*)ws, elems, 0, 27 * cin * cout, cin};
         // rows with a zero pad row in front (LINR_PAD_ROW) take the executor's matrix-core kernel (csrc/fused.hip)
-        int rc = (flags & LINR_PAD_ROW) ? linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, s)
+        int rc = ((flags & LINR_PAD_ROW) && (in_ld == 4 || in_ld == 8)) ? linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, s)
                                         : linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, flags, s);
         if (rc) return rc;
         slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, elems, 27 * cin * cout, gW, gb, flags);

@@ -669,6 +669,8 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     slab_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False)
     slab_l = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, ranges=ops.wgrad_ranges(nbr4, n))
     assert torch.equal(slab_t, slab_l), 'LDS-staged weight gradients must equal the direct gathers bit for bit'
+    slab_8 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, tile8=ops.kmap_tile8(nbr4, n))
+    assert torch.equal(slab_t, slab_8), 'tiled-index pipelined weight gradients must equal the table kernel bit for bit'
     slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
 
