@@ -433,17 +433,21 @@ static bool wg_cmap() {
     static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 0;
     return v != 0;
 }
-// ... except the 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row), where the decode is hidden
-// and the smaller index stream wins: they always read the compressed map
-static bool wg_cmap4() { return true; }
-// window table of the LDS-staged weight-gradient kernels: only under LINR_WGRAD_LDS=1 (csrc/fused.hip has the measurement)
-static const int32_t* wg_rg(const Ctx& c) { return linr_wgrad_lds_enabled() ? c.f->wg_ranges : nullptr; }
 // 8-row tiled index table (linr_kmap_tile8) for the direct-gather weight-gradient kernels; LINR_WGRAD_TILE8=0 reads nbr[27][ld]
 static const int32_t* wg_t8(const Ctx& c) {
+    if (wg_cmap()) return nullptr;            // LINR_WGRAD_CMAP=1: every weight-gradient kernel decodes the compressed map
     static const int v = getenv("LINR_WGRAD_TILE8") ? atoi(getenv("LINR_WGRAD_TILE8")) : 1;
     return v ? c.f->nbr8 : nullptr;
 }
 
+// The 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row) preferred the compressed map over the
+// plain table in round 1; with the 8-row tiled table + one-group pipeline (linr_kmap_tile8) they are 3.8 % of the whole
+// step faster still (2.537 -> 2.441 ms/step, same box), so the compressed map is only their fallback for frames without a
+// tiled table (and what LINR_WGRAD_CMAP=1 selects for all weight-gradient kernels).
+static bool wg_cmap4_impl(bool have_tile8) { return !have_tile8 || wg_cmap(); }
+#define wg_cmap4() wg_cmap4_impl(wg_t8(c) != nullptr)
+// window table of the LDS-staged weight-gradient kernels: only under LINR_WGRAD_LDS=1 (csrc/fused.hip has the measurement)
+static const int32_t* wg_rg(const Ctx& c) { return linr_wgrad_lds_enabled() ? c.f->wg_ranges : nullptr; }
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
