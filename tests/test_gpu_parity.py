@@ -951,3 +951,17 @@ def test_config2_sequence_300_frames_gop32(pkg, tmp_path):
     assert 0.2 < summary['bits_per_point'] < 3.0
     assert os.path.exists(os.path.join(out, 'output', 'gop_0_31', 'model.pth'))
     assert os.path.exists(os.path.join(out, 'result_enc', 'gop_288_299', 'bins', 'frame0011_scale0.bin'))
+
+
+def test_config3_andrew10_two_gop_sequence(pkg, tmp_path):
+    """BASELINE config[3] in miniature on one GPU: the MVUB andrew10 stand-in (10-bit 2-voxel-thick shell, 1.3 M points,
+    K_eff 16-18: the densest kernel map of the configs), 64 frames in GOPs of 32, one epoch each: GOP 1 warm-starts from
+    GOP 0's checkpoint, both are encoded to files, 3 frames per GOP decoded from the files and compared bit for bit."""
+    from linr_pcgc_amd import run
+    out = str(tmp_path / 'seq3')
+    args = run.parse(['--config', 'andrew10', '--frames', '64', '--gop', '32', '--first-epoch', '1', '--others-epoch', '1',
+                      '--out', out, '--decode'])
+    summary, results = run.run_sequence_job(args, 0, 1, None, decode_frames=3)
+    assert summary['gops'] == 2 and summary['lossless'] is True and sorted(results) == [0, 1]
+    assert results[0]['points'] > 32 * 1250000 and all(r['lossless'] for r in results.values())
+    assert results[1]['loss'][-1] < 0.8 * results[0]['loss'][-1]          # warm start
