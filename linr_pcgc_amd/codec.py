@@ -51,9 +51,13 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
                  'enc_mode': comp['enc_mode'], 'bitdepth': bitdepth}
     if precision != 'f32':
         side_info['precision'] = precision
-    # Two-stage pipeline: the GPU forward + D2H of frame i+1 runs while a host thread range-codes frame i (the coder's C
-    # call releases the GIL and fans the 8 x scales independent streams out over n_threads).
+    # Pipeline: the GPU forward + D2H of frame i+1 runs while host workers range-code earlier frames (the coder's C call
+    # releases the GIL).  A frame has 8 x scales independent streams, but the 8 streams of its finest scale carry 73 % of the
+    # symbols, so one frame keeps only ~8 threads busy: TWO frames are coded concurrently, each on half of the threads
+    # (measured: 2.1 ms per frame with one worker x 16 threads, the forward + copies take 1.3 ms).
     from concurrent.futures import ThreadPoolExecutor
+    workers = 2 if n_threads >= 4 else 1
+    per_job = max(1, n_threads // workers)
 
     def code(p_host, occ_host, row_off, n_scales):
         ps, ss = [], []
@@ -62,17 +66,48 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
             for k in range(8):
                 ps.append(p_host[k, a:b])
                 ss.append(occ_host[k, a:b])
-        streams = encode_streams(ps, ss, n_threads)
+        streams = encode_streams(ps, ss, per_job)
         return [pack_bitstream(streams[8 * i:8 * i + 8]) for i in range(n_scales)]
 
-    jobs, bits_dev = [], []
-    with ThreadPoolExecutor(max_workers=1) as coder:
-        for f in gop.frames:
+    # Device side: forward of frame i+1 on the caller's stream while a copy stream moves the probabilities (fp32) and the
+    # occupancy symbols (cast to 1 byte on the GPU) of frame i into a ring of pinned buffers; the host thread only waits for
+    # a copy that is already one frame old before it hands the buffers to a coder worker.
+    RING = 4
+    max_rows = max(f.rows for f in gop.frames)
+    dev = gop.frames[0].device
+    p_pin = [torch.empty(8 * max_rows, dtype=torch.float32, pin_memory=True) for _ in range(RING)]
+    o_pin = [torch.empty(8 * max_rows, dtype=torch.uint8, pin_memory=True) for _ in range(RING)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    jobs, bits_dev, pending = [], [], []
+
+    def hand_over(entry, coder):
+        slot, rows, f, keep, ev_c = entry
+        ev_c.synchronize()
+        p_host = p_pin[slot][:8 * rows].view(8, rows).numpy()
+        occ_host = o_pin[slot][:8 * rows].view(8, rows).numpy()
+        jobs.append(coder.submit(code, p_host, occ_host, f.row_off, f.n_scales))
+
+    with ThreadPoolExecutor(max_workers=workers) as coder:
+        for i, f in enumerate(gop.frames):
+            slot = i % RING
+            if i >= RING:
+                jobs[i - RING].result()                     # the worker that read this slot's buffers has finished
             probs, bits = coded_model.frame_probs(f)
             bits_dev.append(bits)
-            p_host = probs.cpu().numpy()                                        # synchronises this frame only
-            occ_host = f.occ.t().to(torch.uint8).contiguous().cpu().numpy()      # cast on the GPU: 1 byte per symbol over PCIe
-            jobs.append(coder.submit(code, p_host, occ_host, f.row_off, f.n_scales))
+            occ_t = f.occ.t().to(torch.uint8).contiguous()
+            ev_f = torch.cuda.Event()
+            ev_f.record()
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev_f)
+                p_pin[slot][:8 * f.rows].view(8, f.rows).copy_(probs, non_blocking=True)
+                o_pin[slot][:8 * f.rows].view(8, f.rows).copy_(occ_t, non_blocking=True)
+                ev_c = torch.cuda.Event()
+                ev_c.record(copy_stream)
+            pending.append((slot, f.rows, f, (probs, occ_t), ev_c))         # keeps the device tensors alive until copied
+            if len(pending) > 1:
+                hand_over(pending.pop(0), coder)
+        while pending:
+            hand_over(pending.pop(0), coder)
         frames_bytes = [j.result() for j in jobs]
     bits_est = float(torch.stack(bits_dev).sum())
     low = enc_all_frame_low_xyz(gop)

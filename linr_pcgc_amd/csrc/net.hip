@@ -404,7 +404,8 @@ extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches,
     return 0;
 }
 
-// index source of the conv kernels: the compressed map (the full neighbour table was 4 % slower, profiles/README.md)
+// index source of the conv kernels: the compressed map (the full neighbour table is 5 % slower also after the shift
+// addressing of round 2: 2.565 vs 2.438 ms/step, profiles/r02_ab_conv_table.txt)
 static const int32_t* clo(const Ctx& c) { return c.f->nbr_lo; }
 static const uint32_t* cmk(const Ctx& c) { return c.f->nbr_mask; }
 

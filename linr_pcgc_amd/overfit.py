@@ -57,6 +57,14 @@ class Gop:
     def __len__(self):
         return len(self.frames)
 
+    def subset(self, n):
+        """A view of the first n frames (shares every buffer): warm-up runs, spot checks."""
+        import copy
+        g = copy.copy(self)
+        g.frames, g.point_nums, g.coord_mins = self.frames[:n], self.point_nums[:n], self.coord_mins[:n]
+        g.low_xyz, g.infos = self.low_xyz[:n], self.infos[:n]
+        return g
+
 
 def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None):
     """main.py:297-437: frames in fixed order, one optimiser + StepLR step per frame, lr clamp after each epoch.
