@@ -122,7 +122,7 @@ def kernel_roofline(model, gop, live, iters=10):
                 'single_launch_us': round(single_s * 1e6, 2)}
 
     d_wg = _time_launches(lambda: ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab,
-                                                        reduce=False, tile8=f.nbr8), iters)
+                                                        reduce=False, tile8t=f.nbr8t), iters)
     d_cv = _time_launches(lambda: ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out), iters)
     roof = entry('spconv_wgrad_mfma_k<2,8>', 'spconv_wgrad_mfma_8x8_bytes_per_launch', live['wgrad'], d_wg)
     roof['conv'] = entry('cconv_mfma_k<8,8,fwd,LOADW=8>', 'cconv_mfma_8x8_fwd_bytes_per_launch', live['conv'], d_cv)

@@ -121,11 +121,15 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
  * nearly contiguous row windows (one per x-slab), which the kernel copies with coalesced loads, double-buffered against the
  * MFMAs of the previous chunk.  Same partial sums, bit for bit.
  * tile8: linr_kmap_tile8's table or NULL.  With it (and lo / mask / ranges NULL) the indices come from the 8-row tiled copy of
- * the kernel map with a one-group software pipeline - the executor's default.  Same partial sums, bit for bit. */
+ * the kernel map with a one-group software pipeline.  Same partial sums, bit for bit.
+ * tile8t: linr_kmap_tile8t's table or NULL.  With it (in_ld = 8) the gathers are laid out like the convolutions' - lane = (tap of
+ * 4, row of 8, quad): four 256-byte runs per instruction - into a wave-private LDS image that every (tap, quad) lane reads
+ * back transposed (conflict-free pitch); the executor's default.  Same partial sums, bit for bit.  Takes precedence. */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
-                           int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream);
+                           const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab,
+                           void* stream);
 /* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
  * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
  * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */
@@ -133,6 +137,10 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
  * 27 x 8 indices of a row group are 864 contiguous bytes.  tile8: linr_kmap_tile8_bytes(n) bytes, 16-byte aligned. */
 LINR_API size_t linr_kmap_tile8_bytes(int64_t n);
 LINR_API int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream);
+/* The tiled copy in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[4 j + t][8 g + u] (-1 for tap 27, j = 7,
+ * beyond n).  tile8t: linr_kmap_tile8t_bytes(n) bytes, 16-byte aligned. */
+LINR_API size_t linr_kmap_tile8t_bytes(int64_t n);
+LINR_API int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8t, size_t tile8t_bytes, void* stream);
 LINR_API size_t linr_wgrad_ranges_bytes(int64_t n);
 LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes,
                             void* stream);
@@ -204,6 +212,7 @@ typedef struct linr_frame {
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
     const int32_t* wg_ranges;     /* linr_wgrad_ranges_build over nbr (LDS windows of the weight-gradient kernels), or NULL */
     const int32_t* nbr8;          /* linr_kmap_tile8 over nbr (8-row tiled copy of the kernel map), or NULL               */
+    const int32_t* nbr8t;         /* linr_kmap_tile8t over nbr (the tiled copy in gather-lane order), or NULL             */
 } linr_frame;
 
 LINR_API size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers);
@@ -293,8 +302,8 @@ LINR_API int linr_inception_bwd_data(const float* gI, const float* x, const floa
 /* weight gradients of the layer's two 4->4 convolutions in one pass (conv0_1 on H[:,0:4] with gradient g0, conv1_1 on
  * H[:,4:8] with g1): 512 per-block partials slab[b][872] = [gW01 432 | gb01 4 | gW11 432 | gb11 4], summed in ascending b. */
 LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
-                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, int64_t ld,
-                             int64_t n, float* slab, void* stream);
+                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
+                             const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream);
 
 /* First convolutions of the 7 outter blocks (models/upsample.py:206-214 -> make_block's first conv + ReLU): block g + 1
  * computes relu(conv3(occ[:, :g+1]; kernel [27][g+1][8]) + bias) on the SAME gathered occupancy rows, so one gather feeds

@@ -505,7 +505,8 @@ extern "C" int64_t linr_spconv_wgrad_cmap_blocks(void) { return LINR_WG_BLOCKS; 
 
 extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
                                       const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
-                                      int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream) {
+                                      const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab,
+                                      void* stream) {
     if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!in || !gout || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;     // lo / mask NULL: indices from nbr
@@ -516,7 +517,7 @@ extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const floa
     LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
     if (tile8 && !linr_aligned16(tile8)) return LINR_EALIGN;
     return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
-                                 lo, mask, ranges, tile8);
+                                 lo, mask, ranges, tile8, tile8t);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
@@ -1333,6 +1334,203 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_lds_k(WgradSrc S, 
 // The op-level entries use it whenever a window table is passed; the executor only under LINR_WGRAD_LDS=1.  Measured (same box, loot10): 2.82 ms/step against 2.56 with the direct-gather kernel - the
 // staging removes two thirds of the vector-memory instructions but the chunk barrier, the LDS bank conflicts of 27
 // unrelated rows per read and the extra address arithmetic cost more than that saves; kept as a tested alternative.
+// ---- weight gradients with COALESCED gathers and an LDS transpose --------------------------------------------------------------
+// All weight-gradient kernels above take ~20 us per row pass whatever their MFMA count (8->8: 64 MFMAs per group, 8->4 and the
+// dual 4->4: 32): they are bound by the L1 return path.  With lane = (tap, channel quad) a gather instruction delivers 54
+// 16-byte pieces from ~20 different cache lines - about 55 % of the rate the convolutions reach with lane = row on the same
+// bytes.  Here the gather of an 8-row group is laid out the convolutions' way - lane = (tap t of 4, row u of 8, quad q): one
+// instruction fetches 4 taps x 8 CONSECUTIVE rows, i.e. four 256-byte runs - into a wave-private tap-major LDS image
+// [tap][row][quad] with a tap pitch of 8 x 32 + 32 bytes, and every (tap, quad) lane reads its eight rows back with
+// ds_read_b128: the pitch makes the 16-byte slot index (2 tap + quad + 2 row) mod 16 = (lane + 2 row) mod 16, conflict-free for
+// the hardware's 16-lane groups; the writes are 128 contiguous bytes per 8 lanes.  No block barrier (LDS operations of one wave
+// execute in order).  Indices come from a second tiled table (linr_kmap_tile8t: [group][tap of 4][row][tap group j] so that a
+// lane's seven indices are 32 contiguous bytes).  Pipeline: while the MFMAs of group t run, the gathers of group t+1 and the
+// indices of group t+2 are in flight.  Same groups, same order, same MFMAs => same partial sums, bit for bit.
+#define TW_PITCH 288                  // bytes per tap in the LDS image: 8 rows x 32 B + 32 B
+#define TW_TAPS 28                    // 27 taps + one dump slot for the unused lane group of the 7th gather
+template <int COUT, bool DUAL>
+__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, const int32_t* __restrict__ tile8t, int64_t n,
+                                                                 LinrWgradDst d, WgradDual dd, Grp gp = Grp()) {
+    static_assert(!DUAL || COUT == 4, "dual mode = two 4->4 convolutions");
+    {
+        const int gi = blockIdx.y;
+        S.in += gp.in[gi]; S.g0 += gp.res[gi];
+        if (S.g1) S.g1 += gp.act[gi];
+        d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
+        dd.w_off1 += gp.e0[gi]; dd.b_off1 += gp.e1[gi];
+        if (gp.e2[gi] > 0) d.cin_valid = (int)gp.e2[gi];
+    }
+    constexpr int HB = COUT / 4;
+    constexpr int NA = 4 * HB * 4;
+    constexpr int CBSZ = DUAL ? 3 : 4;
+    // one LDS buffer: the four wave-private images during the row loop, the fold scratch afterwards (32 KB per block: four
+    // blocks per CU)
+    constexpr int IMG_F4 = TW_TAPS * TW_PITCH / 16;
+    static_assert(WG_WAVES * IMG_F4 * 4 >= 64 * (NA + 1), "fold scratch must fit the images");
+    __shared__ float4 smem[WG_WAVES * IMG_F4];
+    float* sacc = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // MFMA-side role of the lane: (tap kk, quad q) as in spconv_wgrad_mfma_k
+    const int q = DUAL ? (lane >> 5) : (lane & 1);
+    const int kk = DUAL ? (lane & 31) : (lane >> 1);
+    const int k = kk < 27 ? kk : 26;
+    // gather-side role: (tap t of the instruction's 4, row u, quad gq)
+    const int gq = lane & 1, gu8 = (lane >> 1) & 7, gt = lane >> 4;
+    f32x4 acc[4][HB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < HB; ++h) acc[c][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    const char* pad = reinterpret_cast<const char*>(S.in - 8) + 16 * gq;
+    const float* gsel = (DUAL && q) ? S.g1 : S.g0;
+    const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
+    const int gl = DUAL ? (lane & 31) : lane;
+    const int gu = (gl / COUT) & 7, gc = gl % COUT;
+    const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);
+    // the lane's 8 indices (7 used) of a group: tile8t[group][gt][gu8][0..7]
+    const int32_t* tk = tile8t + (gt * 8 + gu8) * 8;
+    char* img = reinterpret_cast<char*>(smem + wave * IMG_F4);
+    // write position of gather j: tap 4 j + gt (tap 27 = the dump slot); read position of MFMA row u: tap k
+    const uint32_t wr0 = (uint32_t)(gt * TW_PITCH + gu8 * 32 + gq * 16);
+    const uint32_t rd0 = (uint32_t)(k * TW_PITCH + q * 16);
+    float bsum = 0.0f;
+    const int64_t g00 = b0 + 8 * wave;
+    int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
+    float gvn = 0.0f, gvc = 0.0f;
+    float4 xg[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) xg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g00 < b1) {                        // wave-uniform; blocks behind the last row must not touch the tables at all
+        const int4 a0 = *reinterpret_cast<const int4*>(tk + g00 * 32);
+        const int4 c0 = *reinterpret_cast<const int4*>(tk + g00 * 32 + 4);
+        gvc = (g00 + gu < n) ? gsel[(g00 + gu) * gld + gc] : 0.0f;
+        const int32_t i0[8] = {a0.x, a0.y, a0.z, a0.w, c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(i0[j] + 1) << 5));
+        const int64_t g1r = g00 + 8 * WG_WAVES;           // spare all -1 groups behind the last row group: no bounds check
+        ia = *reinterpret_cast<const int4*>(tk + g1r * 32);
+        ib = *reinterpret_cast<const int4*>(tk + g1r * 32 + 4);
+        gvn = (g1r + gu < n) ? gsel[(g1r + gu) * gld + gc] : 0.0f;
+    }
+    for (int64_t g0r = g00; g0r < b1; g0r += 8 * WG_WAVES) {
+        // (a) the gathered pieces of this group (requested one iteration ago) -> LDS image, tap-major
+#pragma unroll
+        for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wr0 + (uint32_t)(4 * j * TW_PITCH)) = xg[j];
+        const float gv = gvc;
+        // (b) next group's gathers (its indices arrived during the last MFMAs) and the indices of the group after it
+        {
+            const int32_t idn[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idn[j] + 1) << 5));
+            gvc = gvn;
+            const int64_t g2r = g0r + 16 * WG_WAVES;
+            ia = *reinterpret_cast<const int4*>(tk + g2r * 32);
+            ib = *reinterpret_cast<const int4*>(tk + g2r * 32 + 4);
+            gvn = (g2r + gu < n) ? gsel[(g2r + gu) * gld + gc] : 0.0f;
+        }
+        // (c) transposed read: this lane's (tap, quad) for the 8 rows of the group
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(img + rd0 + (uint32_t)(u * 32));
+        bsum += gv;
+        static_for<8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            static_for<HB>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                constexpr int ab = u * HB + h;
+                acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
+                if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
+            });
+        });
+    }
+    __syncthreads();
+    // fold waves in wave order (fixed => reproducible)
+    float* mine = sacc + lane * (NA + 1);
+    for (int w = 0; w < WG_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int h = 0; h < HB; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = (c * HB + h) * 4 + i;
+                        mine[e] = (w == 0) ? acc[c][h][i] : mine[e] + acc[c][h][i];
+                    }
+        }
+        __syncthreads();
+    }
+    __shared__ float sbias[WG_WAVES][16];
+    {
+        float t = bsum;
+#pragma unroll
+        for (int m = COUT; m < 8 * COUT; m <<= 1) t += __shfl_xor(t, m, 64);
+        const int slot = DUAL ? ((lane >> 5) * 4 + (lane & 3)) : (lane % COUT);
+        if ((lane & 31) < COUT && (DUAL || lane < 32)) sbias[wave][slot] = t;
+        __syncthreads();
+    }
+    {
+        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
+        const int tid = threadIdx.x;
+        if (tid < (DUAL ? 8 : COUT)) {
+            float t = sbias[0][tid];
+            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][tid];
+            if (DUAL) dst[(tid < 4 ? d.b_off : dd.b_off1) + (tid & 3)] = t;
+            else dst[d.b_off + tid] = t;
+        }
+        if constexpr (DUAL) {
+            for (int e = tid; e < 2 * 432; e += WG_WAVES * 64) {
+                const int t = e / 432, r = e - 432 * t;
+                dst[(t ? dd.w_off1 : d.w_off) + r] = sacc[(32 * t + (r >> 4)) * (NA + 1) + (r & 15)];
+            }
+        } else {
+            const int cinv = d.cin_valid;
+            const int per_k = cinv * COUT, total = 27 * per_k;
+            for (int e = tid; e < total; e += WG_WAVES * 64) {
+                const int kq = e / per_k, r = e - kq * per_k;
+                const int ci = r / COUT, co = r - ci * COUT;
+                dst[d.w_off + e] = sacc[(2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3)];
+            }
+        }
+    }
+}
+
+// tile8t[g][t][u][j] = nbr[4 j + t][8 g + u] (-1 for tap 27, for j = 7 and beyond n): a lane (t, u) of the transposing kernel reads
+// its seven indices of group g as two 16-byte loads
+__global__ __launch_bounds__(LINR_BLOCK) void kmap_tile8t_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t groups,
+                                                            int32_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (e >= groups * 256) return;
+    const int64_t g = e >> 8;
+    const int r = (int)(e & 255), t = r >> 6, u = (r >> 3) & 7, j = r & 7;
+    const int k = 4 * j + t;
+    const int64_t row = 8 * g + u;
+    out[e] = (j < 7 && k < 27 && row < n) ? nbr[(int64_t)k * ld + row] : -1;
+}
+
+extern "C" size_t linr_kmap_tile8t_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return (size_t)((n + 7) / 8 + 3 * WG_WAVES) * 256 * sizeof(int32_t);
+}
+
+extern "C" int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8t, size_t tile8t_bytes, void* stream) {
+    if (n < 0 || ld < n) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!nbr || !tile8t) return LINR_EINVAL;
+    if (tile8t_bytes < linr_kmap_tile8t_bytes(n)) return LINR_ENOSPC;
+    if (!linr_aligned16(tile8t)) return LINR_EALIGN;
+    const int64_t groups = (n + 7) / 8 + 3 * WG_WAVES;      // spare all -1 groups: the kernel prefetches two strides ahead
+    kmap_tile8t_k<<<linr_grid(groups * 256, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, ld, n, groups, tile8t);
+    return linr_launch_rc();
+}
+
 bool linr_wgrad_lds_enabled() {
     static const int v = getenv("LINR_WGRAD_LDS") ? atoi(getenv("LINR_WGRAD_LDS")) : 0;
     return v != 0;
@@ -1340,7 +1538,8 @@ bool linr_wgrad_lds_enabled() {
 
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
-                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8) {
+                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
+                          const int32_t* tile8t) {
     if (in_ld != 8 && in_ld != 4) return LINR_EINVAL;  // the kernels address gathered rows by a shift: 32- or 16-byte rows
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
@@ -1359,6 +1558,12 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
         return linr_launch_rc();                                                                                             \
     } while (0)
     // rows staged through LDS: 32-byte rows (in_ld 8), indices from the 16-byte aligned neighbour table
+    // coalesced gathers + LDS transpose: 32-byte rows, the transposed tiled table
+    if (tile8t && in_ld == 8 && cin <= 8 && (cout == 8 || (cout == 4 && cin == 8)) && linr_aligned16(in) && linr_aligned16(tile8t)) {
+        if (cout == 8) spconv_wgrad_t_k<8, false><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8t, n, d, dd, g0);
+        else spconv_wgrad_t_k<4, false><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8t, n, d, dd, g0);
+        return linr_launch_rc();
+    }
     if (ranges && nblocks == LINR_WG_BLOCKS && in_ld == 8 && cin <= 8 && (cout == 8 || (cout == 4 && cin == 8)) && al &&
         linr_aligned16(nbr) && linr_aligned16(in) && linr_aligned16(ranges)) {
         if (cout == 8) spconv_wgrad_lds_k<8, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, g0);
@@ -1377,7 +1582,8 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups,
-                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8) {
+                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
+                            const int32_t* tile8t) {
     const bool al = (nbr_ld % 4 == 0);
     const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
     const int32_t* tab = idx == 2 ? lo : nbr;
@@ -1386,6 +1592,14 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
     WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     WgradDual dd = {w_off1, b_off1};
+    if (tile8t && linr_aligned16(H) && linr_aligned16(tile8t)) {
+        const Grp grp_t = gp ? *gp : Grp();
+        WgradSrc St = {H, 8, g0, g0_ld, g1, g1_ld};
+        LinrWgradDst dt = {big, block_stride, w_off0, b_off0, 4};
+        WgradDual ddt = {w_off1, b_off1};
+        spconv_wgrad_t_k<4, true><<<dim3(nblocks, ngroups), WG_WAVES * 64, 0, s>>>(St, tile8t, n, dt, ddt, grp_t);
+        return linr_launch_rc();
+    }
     if (ranges && nblocks == LINR_WG_BLOCKS && al && linr_aligned16(nbr) && linr_aligned16(H) && linr_aligned16(ranges)) {
         spconv_wgrad_lds_k<4, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, grp);
         return linr_launch_rc();
@@ -1726,7 +1940,7 @@ extern "C" int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_
 
 extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
                                         const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
-                                        int64_t ld, int64_t n, float* slab, void* stream) {
+                                        const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream) {
     if (n < 0 || ld < n || g0_ld < 4 || g1_ld < 4) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!H || !g0 || !g1 || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;
@@ -1734,5 +1948,5 @@ extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     // per block: [W01 432 | b01 4 | W11 432 | b11 4]
     return linr_conv3_wgrad_dual44(H, g0, g0_ld, g1, g1_ld, nbr, ld, n, slab, 872, 0, 432, 436, 868, LINR_WG_BLOCKS,
-                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges, nullptr);
+                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges, nullptr, tile8t);
 }

@@ -67,6 +67,10 @@ class Frame:
         self.nbr8 = torch.empty(max(4, (nb8 + 3) // 4), dtype=torch.int32, device=device)
         check(_lib.lib().linr_kmap_tile8(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr8.data_ptr(), self.nbr8.numel() * 4, _stream()),
               'linr_kmap_tile8')
+        nb8t = _lib.lib().linr_kmap_tile8t_bytes(R)
+        self.nbr8t = torch.empty(max(4, (nb8t + 3) // 4), dtype=torch.int32, device=device)
+        check(_lib.lib().linr_kmap_tile8t(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr8t.data_ptr(), self.nbr8t.numel() * 4,
+                                          _stream()), 'linr_kmap_tile8t')
         self.arena = None
         if with_arena:
             self.alloc_arena()
@@ -75,7 +79,7 @@ class Frame:
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
-                                 occ=self.occ.data_ptr(), wg_ranges=self.wg_ranges.data_ptr(), nbr8=self.nbr8.data_ptr())
+                                 occ=self.occ.data_ptr(), wg_ranges=self.wg_ranges.data_ptr(), nbr8=self.nbr8.data_ptr(), nbr8t=self.nbr8t.data_ptr())
 
     def alloc_arena(self):
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)

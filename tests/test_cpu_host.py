@@ -54,7 +54,7 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_spconv_fwd(p16, 4, p16, 16, 16, p16, p16, 8, 8, None, 0, p16, 8, 0, None) == -1      # in_ld < cin
     assert lib.linr_spconv_cmap(0, p16, 5, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -1   # ld 5
     assert lib.linr_spconv_cmap(0, p16 + 4, 8, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -3
-    assert lib.linr_spconv_wgrad_cmap(p16, 8, p16, 8, p16, p16, p16, None, None, 16, 16, 8, 5, p16, None) == -1              # cout 5
+    assert lib.linr_spconv_wgrad_cmap(p16, 8, p16, 8, p16, p16, p16, None, None, None, 16, 16, 8, 5, p16, None) == -1              # cout 5
     assert lib.linr_wgrad_ranges_build(p16, 4, 8, p16, 1 << 20, None) == -1 and lib.linr_wgrad_ranges_build(p16, 8, 8, p16, 16, None) == -2
     assert lib.linr_spconv_bwd_weight(p16, 8, p16, 8, p16, 16, 16, 8, 8, p16, p16, 0, p16, 16, None) == -2             # ws short
     # whole network: NULL frame / parameters, stage range

@@ -570,7 +570,7 @@ def default_dump(golden_dir, tmp_path_factory):
 
 # every executor switch the library reads from the environment (README.md): each one alone, and the two extreme
 # combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT
-SWITCHES = [{'LINR_WGRAD_LDS': '1'}, {'LINR_WGRAD_TILE8': '0'}, {'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
+SWITCHES = [{'LINR_WGRAD_LDS': '1'}, {'LINR_WGRAD_T': '0'}, {'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
             {'LINR_CONV_MFMA': '2'}, {'LINR_WGRAD_CMAP': '1'}, {'LINR_WGRAD_STREAM': '1'},
             {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',
              'LINR_WGRAD_LDS': '1'},
@@ -671,6 +671,8 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     assert torch.equal(slab_t, slab_l), 'LDS-staged weight gradients must equal the direct gathers bit for bit'
     slab_8 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, tile8=ops.kmap_tile8(nbr4, n))
     assert torch.equal(slab_t, slab_8), 'tiled-index pipelined weight gradients must equal the table kernel bit for bit'
+    slab_tt = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, tile8t=ops.kmap_tile8t(nbr4, n))
+    assert torch.equal(slab_t, slab_tt), 'coalesced-gather + LDS-transpose weight gradients must equal the table kernel bit for bit'
     slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
 

@@ -1,5 +1,5 @@
-"""Launches the two kernels bench.py's roofline reports (executor configuration, frame 0 of loot10) a few times so that
-rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE can attribute HBM traffic to them."""
+"""Launches the 8->8 weight-gradient kernel in its four index / gather variants (plain table, 8-row tiled table + pipeline,
+coalesced gathers + LDS transpose, LDS-staged windows) on frame 0 of loot10 for tools/wgrad_pmc.sh."""
 import os
 import sys
 
@@ -15,12 +15,11 @@ f = engine.Frame(fr['all_input_info'], fr['scale_num'], dev, with_arena=False)
 R = f.rows
 x = torch.zeros((R + 1, 8), device=dev); x[1:].normal_()
 g = torch.randn((R, 8), device=dev)
-out = torch.empty((R, 8), device=dev)
-w = torch.randn(27, 8, 8, device=dev) * 0.1
-b = torch.zeros(8, device=dev)
 slab = torch.empty((512, 27 * 64 + 8), device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False)
+    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8=f.nbr8)
     ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8t=f.nbr8t)
-    ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out)
+    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, ranges=f.wg_ranges)
 torch.cuda.synchronize()
 print('rows', R)
