@@ -146,7 +146,7 @@ LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, 
                             void* stream);
 
 /* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
- * linr_net_forward / _backward / _train_step (kind 0: spconv_wgrad_mfma_k<2,8>; kind 1:
+ * linr_net_forward / _backward / _train_step (kind 0: the 8->8 weight-gradient kernel, spconv_wgrad_t_k<8> by default; kind 1:
  * cconv_mfma_k<8,8,forward, plain epilogue>) is bracketed by a HIP event pair on the stream it is launched on.
  * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,
