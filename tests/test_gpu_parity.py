@@ -806,6 +806,17 @@ def test_tiny_and_ragged_frames(pkg, n):
     grads = torch.zeros_like(model.flat_parameters())
     engine.net_backward(frame, model.flat_parameters(), grads, 1.0)
     assert bool(torch.isfinite(grads).all())
+    # the weight-gradient kernels at row counts below one 8-row group / with most of their 512 blocks empty: against autograd
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    onet.forward_scale(sdo, onet.to_torch_scales([sc])[0])['bits'].backward()
+    off = 0
+    for name, v in sdo.items():
+        m = v.numel()
+        mine = grads[off:off + m].view(v.shape).cpu().double()
+        ref = torch.zeros_like(v).double() if v.grad is None else v.grad.double()      # scale MLPs of absent scales: no gradient
+        gmax = float(ref.abs().max())
+        assert float((mine - ref).abs().max()) <= 2e-4 * gmax + 1e-6, name
+        off += m
 
 
 def test_overfit_is_run_to_run_deterministic(pkg):
