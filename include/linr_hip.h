@@ -124,7 +124,8 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
  * the kernel map with a one-group software pipeline.  Same partial sums, bit for bit.
  * tile8t: linr_kmap_tile8t's table or NULL.  With it (in_ld = 8) the gathers are laid out like the convolutions' - lane = (tap of
  * 4, row of 8, quad): four 256-byte runs per instruction - into a wave-private LDS image that every (tap, quad) lane reads
- * back transposed (conflict-free pitch); the executor's default.  Same partial sums, bit for bit.  Takes precedence. */
+ * back transposed (conflict-free pitch); the executor's default for the 4-output kernels.  Same partial sums, bit for bit.
+ * Takes precedence over the other tables. */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
@@ -146,7 +147,7 @@ LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, 
                             void* stream);
 
 /* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
- * linr_net_forward / _backward / _train_step (kind 0: the 8->8 weight-gradient kernel, spconv_wgrad_t_k<8> by default; kind 1:
+ * linr_net_forward / _backward / _train_step (kind 0: the 8->8 weight-gradient kernel, spconv_wgrad_mfma_k<2,8,false,3> by default; kind 1:
  * cconv_mfma_k<8,8,forward, plain epilogue>) is bracketed by a HIP event pair on the stream it is launched on.
  * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,

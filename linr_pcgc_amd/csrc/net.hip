@@ -441,12 +441,14 @@ static const int32_t* wg_t8(const Ctx& c) {
     return v ? c.f->nbr8 : nullptr;
 }
 
-// transposed tiled table for the coalesced-gather + LDS-transpose weight-gradient kernels (csrc/fused.hip: spconv_wgrad_t_k);
-// LINR_WGRAD_T=0 falls back to the direct (tap, quad) gathers
-static const int32_t* wg_t8t(const Ctx& c) {
+// transposed tiled table for the coalesced-gather + LDS-transpose weight-gradient kernels (csrc/fused.hip: spconv_wgrad_t_k).
+// LINR_WGRAD_T: 1 (default) = the 4-output kernels (conv 8->4, dual 4->4: 80.9 / 78.8 us per launch against 91.7 / 80.3
+// with direct gathers), 2 = the 8-output kernels too (105.0 against 102.7 us: their 64 MFMAs per group leave less room for
+// the LDS instructions), 0 = none
+static const int32_t* wg_t8t(const Ctx& c, int cout) {
     if (wg_cmap()) return nullptr;
     static const int v = getenv("LINR_WGRAD_T") ? atoi(getenv("LINR_WGRAD_T")) : 1;
-    return v ? c.f->nbr8t : nullptr;
+    return (v >= 2 || (v == 1 && cout == 4)) ? c.f->nbr8t : nullptr;
 }
 // The 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row) preferred the compressed map over the
 // plain table in round 1; with the 8-row tiled table + one-group pipeline (linr_kmap_tile8) they are 3.8 % of the whole
@@ -462,7 +464,7 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
     TRY(stream_order(c.s, c.ws));
     ProfScope ps(c.ws, 0, 1, cout == 8 && in_ld >= 8);
     return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
-                                 (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c));
+                                 (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, cout));
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
@@ -552,7 +554,7 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
             TRY(stream_order(c.s, c.ws));
             TRY(linr_conv3_wgrad_dual44(t.H, t.gI, 8, t.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, q.c01_w, q.c01_b,
                                         q.c11_w, q.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
-                                        c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+                                        c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
             TRY(linr_dual44_bwd_launch(t.gI, t.gM, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c01_w, P + q.c11_w, t.H, t.gH, c.s));
         } else {
             // I[:,0:4] = conv3(H0; c01) + X[:,0:4]
@@ -875,7 +877,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
             ProfScope ps(c.ws, 0, 8);
-            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
         }
         {   // ... and gO[k] = bwd(gC[k])
             Grp gp = Grp();
@@ -909,7 +911,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
@@ -930,7 +932,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
         goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
         goffs(gq.act, pH, 7);
@@ -941,7 +943,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
         goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
@@ -960,7 +962,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c)));
+        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     return 0;
 }
