@@ -57,11 +57,14 @@ class Frame:
         self.nbr_mask = torch.zeros((self.nbr_ld,), dtype=torch.int32, device=device)      # padding columns: empty masks
         check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
                                             self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
-        # window table of the LDS-staged weight-gradient kernels (static coordinates: built once, like the kernel map)
-        nb = _lib.lib().linr_wgrad_ranges_bytes(R)
-        self.wg_ranges = torch.zeros(max(1, (nb + 3) // 4), dtype=torch.int32, device=device)
-        check(_lib.lib().linr_wgrad_ranges_build(self.nbr.data_ptr(), self.nbr_ld, R, self.wg_ranges.data_ptr(),
-                                                 self.wg_ranges.numel() * 4, _stream()), 'linr_wgrad_ranges_build')
+        # window table of the LDS-staged weight-gradient kernels: only that alternative (LINR_WGRAD_LDS=1) reads it
+        import os
+        self.wg_ranges = None
+        if os.environ.get('LINR_WGRAD_LDS', '0') not in ('', '0'):
+            nb = _lib.lib().linr_wgrad_ranges_bytes(R)
+            self.wg_ranges = torch.zeros(max(1, (nb + 3) // 4), dtype=torch.int32, device=device)
+            check(_lib.lib().linr_wgrad_ranges_build(self.nbr.data_ptr(), self.nbr_ld, R, self.wg_ranges.data_ptr(),
+                                                     self.wg_ranges.numel() * 4, _stream()), 'linr_wgrad_ranges_build')
         # 8-row tiled copy of the kernel map: the index loads of the weight-gradient kernels become coalesced
         nb8 = _lib.lib().linr_kmap_tile8_bytes(R)
         self.nbr8 = torch.empty(max(4, (nb8 + 3) // 4), dtype=torch.int32, device=device)
@@ -79,7 +82,7 @@ class Frame:
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
-                                 occ=self.occ.data_ptr(), wg_ranges=self.wg_ranges.data_ptr(), nbr8=self.nbr8.data_ptr(), nbr8t=self.nbr8t.data_ptr())
+                                 occ=self.occ.data_ptr(), wg_ranges=0 if self.wg_ranges is None else self.wg_ranges.data_ptr(), nbr8=self.nbr8.data_ptr(), nbr8t=self.nbr8t.data_ptr())
 
     def alloc_arena(self):
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)

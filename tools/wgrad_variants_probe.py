@@ -20,6 +20,6 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False)
     ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8=f.nbr8)
     ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8t=f.nbr8t)
-    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, ranges=f.wg_ranges)
+    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, ranges=ops.wgrad_ranges(f.nbr, R))
 torch.cuda.synchronize()
 print('rows', R)
