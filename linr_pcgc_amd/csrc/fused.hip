@@ -1793,11 +1793,11 @@ __global__ __launch_bounds__(LINR_BLOCK, 4) void head_bwd_k(HeadBwdArgs A, int64
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
-                         hipStream_t s, const Grp* gp, int ngroups) {
+                         hipStream_t s, const Grp* gp, int ngroups, int nblocks) {
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
     HeadBwdArgs A = {c, p, target, target_ld, w1, b1, w2, gscale, gc, big, block_stride, off_w1, off_b1, off_w2, off_b2};
-    head_bwd_k<<<dim3(LINR_WG_BLOCKS, ngroups), LINR_BLOCK, 0, s>>>(A, n, g0);
+    head_bwd_k<<<dim3(nblocks, ngroups), LINR_BLOCK, 0, s>>>(A, n, g0);
     return linr_launch_rc();
 }
 

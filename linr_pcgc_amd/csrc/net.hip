@@ -282,7 +282,18 @@ struct Ctx {
     hipStream_t ws;          // weight-gradient kernels (== s, or the auxiliary stream when overlapping)
     int64_t R;
     int64_t nbr_ld;
+    int nb;                  // persistent blocks of the weight-gradient kernels = partial rows of the slab for this frame
 };
+
+// Persistent blocks per weight-gradient launch: 2 per CU (512) fill the chip at BASELINE sizes, but every block ends with a
+// fold over its waves and writes one slab row per parameter, and the final reduction reads nb x n_params floats - fixed
+// costs that dominate small frames (56 k rows: 110 rows per block).  Multiples of 32 (wgrad_reduce_k's association).
+static int wg_blocks_for(int64_t rows) {
+    static const int forced = getenv("LINR_WG_BLOCKS") ? atoi(getenv("LINR_WG_BLOCKS")) : 0;
+    if (forced >= 32 && forced <= LINR_WG_BLOCKS && forced % 32 == 0) return forced;
+    // measured (ms/step): 56 k rows: 512 -> 0.685, 256 -> 0.627, 128 -> 0.637, 64 -> 0.71; 337 k rows: 512 -> 2.398, 384 -> 2.410, 256 -> 2.440
+    return rows >= 200000 ? LINR_WG_BLOCKS : 256;
+}
 
 // Weight-gradient kernels only feed the final reduction, so they CAN run on a second stream next to the backward data
 // chain (optional, see aux_init).  The stream and a small event pool are created once per process.
@@ -463,7 +474,7 @@ static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, in
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
     TRY(stream_order(c.s, c.ws));
     ProfScope ps(c.ws, 0, 1, cout == 8 && in_ld >= 8);
-    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, LINR_WG_BLOCKS, c.ws, nullptr, 1,
+    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, c.nb, c.ws, nullptr, 1,
                                  (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, cout));
 }
 
@@ -478,7 +489,7 @@ static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, i
                         int64_t w_off, int ws_ci, int ws_co, int64_t b_off) {
     LinrLinDst d = {c.A.BIG, c.L.total, w_off, ws_ci, ws_co, b_off};
     TRY(stream_order(c.s, c.ws));
-    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, LINR_WG_BLOCKS, c.ws);
+    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, c.nb, c.ws);
 }
 
 // Per-layer matrices of block slot b (0 = block_in, 1..7 = outter blocks): layer 0 uses the slot's own H/M/I, the extra
@@ -553,7 +564,7 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
         if (cm) {
             TRY(stream_order(c.s, c.ws));
             TRY(linr_conv3_wgrad_dual44(t.H, t.gI, 8, t.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, q.c01_w, q.c01_b,
-                                        q.c11_w, q.c11_b, LINR_WG_BLOCKS, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
+                                        q.c11_w, q.c11_b, c.nb, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
                                         c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
             TRY(linr_dual44_bwd_launch(t.gI, t.gM, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c01_w, P + q.c11_w, t.H, t.gH, c.s));
         } else {
@@ -605,6 +616,7 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     c.P = (const float*)params;
     c.R = f->rows;
     c.nbr_ld = f->nbr_ld;
+    c.nb = wg_blocks_for(f->rows);
     make_arena(c.A, f->rows, (float*)arena, c.L.total, c.L.BL);
     return 0;
 }
@@ -869,7 +881,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             for (int k = 0; k < 8; ++k) gp.e1[k] = k;
             goffs_i(gp.e3, o_w1, 8); goffs_i(gp.e4, o_b1, 8); goffs_i(gp.e5, o_w2, 8); goffs_i(gp.e6, o_b2, 8);
             TRY(linr_head_bwd_launch(a.C[0], a.P[0], a.OCC, 8, h_w1[0], h_b1[0], h_w2[0], gz_scale, a.gC[0], c.R, a.BIG, L.total,
-                                     o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8));
+                                     o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8, c.nb));
         }
         {   // C = conv3(prior_k; prune_k): weight gradients ...
             Grp gp = Grp();
@@ -877,7 +889,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             TRY(stream_order(c.s, c.ws));
             ProfScope ps(c.ws, 0, 8);
-            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
         }
         {   // ... and gO[k] = bwd(gC[k])
             Grp gp = Grp();
@@ -911,7 +923,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
@@ -924,7 +936,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pM, 7); goffs(gp.res, p_gI, 7); goffs_i(gp.w, o_c12w, 7); goffs_i(gp.b, o_c12b, 7);
         LinrLinDst d = {a.BIG, L.total, o_c12w[0], 4, 1, o_c12b[0]};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7));
+        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.ws, &gp, 7));
     }
     {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
@@ -932,7 +944,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+                                    o_c11w[0], o_c11b[0], c.nb, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
         goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
         goffs(gq.act, pH, 7);
@@ -943,11 +955,11 @@ static int backward_batched(Ctx& c, float gz_scale) {
         goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
         goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
-        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, LINR_WG_BLOCKS, c.ws, &gq, 7));
+        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, 7));
     }
     {   // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
         Grp gp = Grp();
@@ -962,7 +974,7 @@ static int backward_batched(Ctx& c, float gz_scale) {
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
         ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, LINR_WG_BLOCKS, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     return 0;
 }
@@ -978,7 +990,7 @@ static int backward_core(Ctx& c, float gscale) {
     c.ws = (aux && aux_all(c.R)) ? aux : c.s;
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
-                                     LINR_WG_BLOCKS, c.s)));
+                                     c.nb, c.s)));
     const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
     if (grouped) TRY(backward_batched(c, gz_scale));
@@ -986,7 +998,7 @@ static int backward_core(Ctx& c, float gscale) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
             // recompute the hidden layer, gC and the four head-parameter gradients in one launch (csrc/fused.hip)
             TRY(linr_head_bwd_launch(a.C[k], a.P[k], a.OCC + k, 8, P + c.L.h0_w[k], P + c.L.h0_b[k], P + c.L.h2_w[k], gz_scale,
-                                     a.gC[k], c.R, a.BIG, c.L.total, c.L.h0_w[k], c.L.h0_b[k], c.L.h2_w[k], c.L.h2_b[k], c.s));
+                                     a.gC[k], c.R, a.BIG, c.L.total, c.L.h0_w[k], c.L.h0_b[k], c.L.h2_w[k], c.L.h2_b[k], c.s, nullptr, 1, c.nb));
         } else {
             TRY(linr_bce_bits_bwd(a.P[k], a.OCC + k, 8, c.R, gz_scale, a.gZ, c.s));
             // z = HH @ h2 + b ; HH = relu(C @ h0 + b)
@@ -1027,8 +1039,8 @@ static int backward_core(Ctx& c, float gscale) {
         LinrLinDst d2 = {a.BIG, c.L.total, c.L.m2_w[si0], 1, 16, c.L.m2_b[si0]};
         LinrLinDst d0 = {a.BIG, c.L.total, c.L.m0_w[si0], 1, 15, c.L.m0_b[si0]};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, LINR_WG_BLOCKS, c.ws, &g2, ns));
-        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, LINR_WG_BLOCKS, c.ws, &g0, ns));
+        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, c.nb, c.ws, &g2, ns));
+        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, c.nb, c.ws, &g0, ns));
     } else
     for (int s = 0; s < f->n_scales; ++s) {
         const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
@@ -1041,7 +1053,7 @@ static int backward_core(Ctx& c, float gscale) {
     }
     // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
     TRY(stream_order(c.ws, c.s));
-    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, LINR_WG_BLOCKS, c.L.total, a.GSUM);
+    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM);
     if (ns > 0) {
         EmbArgs ea;
         for (int j = 0; j < ns; ++j) {
