@@ -6,7 +6,8 @@ import torch  # noqa: F401  - MUST precede loading liblinr_hip.so: both link lib
 #                             end up with ONE HIP runtime, the one PyTorch bundles (streams and memory come from it).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liblinr_hip.so')
+# LINR_HIP_LIB: another build of the same library (kernel experiments, tools/wgrad_floor_lab.sh); the ABI check below still applies
+LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so')
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 ABI_VERSION = 2

@@ -52,15 +52,27 @@ __device__ __forceinline__ void decode_offsets(const int32_t* __restrict__ lo, c
         }
         return;
     }
-    const uint32_t m = mask[r32];
+    // Byte offsets in 32 bits (9 * ld * 4 < 2^32; maps with ld >= 2^26 take the plain 64-bit path) make every one of the ten
+    // loads a saddr-form global_load (the uniform table base in SGPRs + one VGPR offset, one v_add per column) - left to
+    // itself hipcc folds the column stride into the lane's 64-bit address and spends two quarter-rate v_mad_u64_u32 per
+    // column on it.  Per column:
+    // L = (lo + 1) << sh; a tap's offset is L advanced by one row per present tap below it and zeroed when absent:
+    //   m_j = -bit_j (v_bfe_i32), o_j = t_j & m_j, t_{j+1} = t_j - m_j * R (one v_mad_i32_i24)   => 9 VALU ops per column
+    const uint32_t rb = r32 << 2;
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(mask) + rb);
+    const int negR = -(int)(1u << sh);
+    const char* lob = reinterpret_cast<const char*>(lo);
+    const uint32_t ld4 = (uint32_t)ld << 2;
+    const bool small = ld < ((int64_t)1 << 26);            // wave-uniform
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const int32_t* lq = lo + (int64_t)q * ld;
-        const uint32_t base = (uint32_t)lq[r32] + 1u;     // +1: row index -> offset from the pad row
-        const uint32_t b0 = (m >> (3 * q)) & 1u, b1 = (m >> (3 * q + 1)) & 1u, b2 = (m >> (3 * q + 2)) & 1u;
-        const uint32_t o0 = b0 ? base << sh : 0u;
-        const uint32_t o1 = b1 ? (base + b0) << sh : 0u;
-        const uint32_t o2 = b2 ? (base + b0 + b1) << sh : 0u;
+        const int32_t lv = small ? *reinterpret_cast<const int32_t*>(lob + (rb + (uint32_t)q * ld4)) : (lo + (int64_t)q * ld)[r32];
+        const uint32_t L = ((uint32_t)lv + 1u) << sh;             // +1: row index -> offset from the pad row
+        const int m0 = __builtin_amdgcn_sbfe(m, 3 * q, 1), m1 = __builtin_amdgcn_sbfe(m, 3 * q + 1, 1),
+                  m2 = __builtin_amdgcn_sbfe(m, 3 * q + 2, 1);
+        const uint32_t t1 = L + (uint32_t)__mul24(m0, negR);
+        const uint32_t t2 = t1 + (uint32_t)__mul24(m1, negR);
+        const uint32_t o0 = L & (uint32_t)m0, o1 = t1 & (uint32_t)m1, o2 = t2 & (uint32_t)m2;
         // forward uses offset k, backward-data the mirrored offset 26-k  (k = q + 9*dz)
         if (!BWD) { off[q] = o0; off[q + 9] = o1; off[q + 18] = o2; }
         else      { off[26 - q] = o0; off[26 - (q + 9)] = o1; off[26 - (q + 18)] = o2; }
@@ -872,6 +884,8 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
         // memory latency before it can even issue its gathers.  The table has spare all -1 groups behind the last row group,
         // so the prefetch needs no bounds check; rows beyond n gather the zero row.  Same groups, same order => same bits.
         int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
+        const char* ubase = reinterpret_cast<const char*>(S.in - S.in_ld);          // the zero pad row
+        const uint32_t uoff = (1u << rsh) + 16u * q;
         float gvn = 0.0f;
         if (b0 + 8 * wave < b1) {          // wave-uniform; blocks behind the last row (b0 >= n) must not touch the table at all
             const int64_t g0r = b0 + 8 * wave;
@@ -884,7 +898,13 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
             const float gv = gvn;
             float4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idx[u] + 1) << rsh));
+            for (int u = 0; u < 8; ++u) {
+                // saddr form (uniform base + 32-bit lane offset: two 32-bit VALU ops per gather instead of a 64-bit add), and
+                // the gathers are issued in the order the MFMAs consume them (left alone, hipcc issued rows 2..7, 0, 1 and the
+                // first MFMA then waited for the seventh gather): -5 % per launch
+                x[u] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)idx[u] << rsh) + uoff));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             {
                 const int64_t g1r = g0r + 8 * WG_WAVES;
                 ia = *reinterpret_cast<const int4*>(nk + g1r * 27);
