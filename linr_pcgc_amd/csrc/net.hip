@@ -427,6 +427,13 @@ static bool grouped_enabled() {
     return batched != 0 && conv_mfma != 0;
 }
 
+// block_in joins the grouped launches of the outter blocks when it has their shape (one Inception layer) - LINR_JOIN_BLOCK_IN=0
+// keeps its layers as single launches (the round-1/2 schedule; same kernels, same bits)
+static bool join_block_in(const Ctx& c) {
+    static const int v = getenv("LINR_JOIN_BLOCK_IN") ? atoi(getenv("LINR_JOIN_BLOCK_IN")) : 1;
+    return v != 0 && grouped_enabled() && c.f->nbr_lo && c.f->nbr_mask && c.L.block_in.nl == 1;
+}
+
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
     if (c.f->nbr_lo && c.f->nbr_mask) {
@@ -652,18 +659,24 @@ static void goffs(int64_t* dst, const float* const* ptrs, int n) {
 // path below, so the decoder reproduces these probabilities bit for bit.
 // part 1: the occupancy-only layers of the outter blocks (first conv, conv0_0 | conv1_0, both 4->4 convs: they do not need
 // x_glob); part 2: everything that does (tail conv + x_glob, the 8 heads).  3 = both.
-static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3) {
+static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3, bool join = false) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
     const int32_t* lo = clo(c);
     const uint32_t* mk = cmk(c);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
-    const float *pA[7], *pH[7], *pM[7], *pI[7], *pO[7], *p_ab[7], *p_c00w[7], *p_c00b[7], *p_c10w[7], *p_c10b[7], *p_c01w[7],
-        *p_c01b[7], *p_c11w[7], *p_c11b[7], *p_c12w[7], *p_c12b[7], *p_bw[7], *p_bb[7];
-    for (int g = 0; g < 7; ++g) {
-        const BlockP& bp = L.outter[g];
-        pA[g] = a.A[g + 1]; pH[g] = a.H[g + 1]; pM[g] = a.M[g + 1]; pI[g] = a.I[g + 1]; pO[g] = a.O[g + 1];
+    // join: block_in (arena slot 0; its first conv has already run) rides as group 0 of the Inception-layer launches - the
+    // eight blocks have the same structure behind their first conv (models/upsample.py:88-97) and do not depend on each
+    // other until prior_k = x_glob + outter_k.  g0 = first slot in the grouped launches, ng = their group count; the
+    // occupancy conv and the tail conv (which needs x_glob as residual) always cover slots 1..7 = arrays + o7.
+    const int g0 = join ? 0 : 1, ng = 8 - g0, o7 = 1 - g0;
+    const float *pA[8], *pH[8], *pM[8], *pI[8], *pO[8], *p_ab[8], *p_c00w[8], *p_c00b[8], *p_c10w[8], *p_c10b[8], *p_c01w[8],
+        *p_c01b[8], *p_c11w[8], *p_c11b[8], *p_c12w[8], *p_c12b[8], *p_bw[8], *p_bb[8];
+    for (int g = 0; g < ng; ++g) {
+        const int b = g0 + g;
+        const BlockP& bp = b == 0 ? L.block_in : L.outter[b - 1];
+        pA[g] = a.A[b]; pH[g] = a.H[b]; pM[g] = a.M[b]; pI[g] = a.I[b]; pO[g] = a.O[b];
         p_ab[g] = P + bp.a_b; p_c00w[g] = P + bp.inc[0].c00_w; p_c00b[g] = P + bp.inc[0].c00_b; p_c10w[g] = P + bp.inc[0].c10_w; p_c10b[g] = P + bp.inc[0].c10_b;
         p_c01w[g] = P + bp.inc[0].c01_w; p_c01b[g] = P + bp.inc[0].c01_b; p_c11w[g] = P + bp.inc[0].c11_w; p_c11b[g] = P + bp.inc[0].c11_b;
         p_c12w[g] = P + bp.inc[0].c12_w; p_c12b[g] = P + bp.inc[0].c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
@@ -673,7 +686,7 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3)
         static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
         if (shared) {
             int64_t w_off[7], b_off[7], o_off[7];
-            for (int g = 0; g < 7; ++g) { w_off[g] = L.outter[g].a_w; b_off[g] = L.outter[g].a_b; o_off[g] = pA[g] - pA[0]; }
+            for (int g = 0; g < 7; ++g) { w_off[g] = L.outter[g].a_w; b_off[g] = L.outter[g].a_b; o_off[g] = a.A[g + 1] - a.A[1]; }
             TRY(linr_occ_conv7_launch(a.OCC, lo, mk, c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, c.s));
         } else {
             PadSrc ps;
@@ -681,31 +694,33 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3)
             pad_weights_k<<<linr_grid(7 * 1728, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, ps, a.WPAD);
             Grp gp = Grp();
             for (int g = 0; g < 7; ++g) gp.w[g] = (int64_t)g * 1728;
-            goffs(gp.b, p_ab, 7); goffs(gp.out, pA, 7);
-            TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[0], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
+            goffs(gp.b, p_ab + o7, 7); goffs(gp.out, pA + o7, 7);
+            TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[o7], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
                                   LINR_RELU, c.s, &gp, 7));
         }
     }
     {   // H = [relu(conv0_0(A)) | relu(conv1_0(A))]
         Grp gp = Grp();
-        goffs(gp.in, pA, 7); goffs(gp.w, p_c00w, 7); goffs(gp.b, p_c00b, 7); goffs(gp.out, pH, 7);
-        goffs(gp.e0, p_c10w, 7); goffs(gp.e1, p_c10b, 7);
-        TRY(linr_conv_pw_fwd_launch(pA[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c00b[0], p_c10w[0], p_c10b[0], a.H[1], c.s, &gp, 7));
+        goffs(gp.in, pA, ng); goffs(gp.w, p_c00w, ng); goffs(gp.b, p_c00b, ng); goffs(gp.out, pH, ng);
+        goffs(gp.e0, p_c10w, ng); goffs(gp.e1, p_c10b, ng);
+        TRY(linr_conv_pw_fwd_launch(pA[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c00b[0], p_c10w[0], p_c10b[0], a.H[g0], c.s, &gp, ng));
     }
     {   // both 4->4 convs + conv1_2 + residual -> M, I
         Grp gp = Grp();
-        goffs(gp.in, pH, 7); goffs(gp.w, p_c01w, 7); goffs(gp.b, p_c01b, 7); goffs(gp.e1, p_c11w, 7); goffs(gp.e2, p_c11b, 7);
-        goffs(gp.res, pA, 7); goffs(gp.e3, p_c12w, 7); goffs(gp.e4, p_c12b, 7); goffs(gp.e5, pM, 7); goffs(gp.out, pI, 7);
+        goffs(gp.in, pH, ng); goffs(gp.w, p_c01w, ng); goffs(gp.b, p_c01b, ng); goffs(gp.e1, p_c11w, ng); goffs(gp.e2, p_c11b, ng);
+        goffs(gp.res, pA, ng); goffs(gp.e3, p_c12w, ng); goffs(gp.e4, p_c12b, ng); goffs(gp.e5, pM, ng); goffs(gp.out, pI, ng);
         TRY(linr_dual44_fwd_launch(pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c01b[0], p_c11w[0], p_c11b[0], pA[0], p_c12w[0],
-                                   p_c12b[0], a.M[1], a.I[1], c.s, &gp, 7));
+                                   p_c12b[0], a.M[g0], a.I[g0], c.s, &gp, ng));
     }
     }
     if (!(part & 2)) return linr_launch_rc();
+    if (join)   // x_glob = O[0] = conv3(I[0]; b) of block_in: the one tail conv the others wait for
+        TRY(conv3(c, false, a.I[0], 8, P + L.block_in.b_w, P + L.block_in.b_b, 8, 8, nullptr, 0, nullptr, 0, a.O[0], 8, 0));
     {   // O[b] = conv3(I; b) + x_glob
         Grp gp = Grp();
-        goffs(gp.in, pI, 7); goffs(gp.w, p_bw, 7); goffs(gp.b, p_bb, 7); goffs(gp.out, pO, 7);
+        goffs(gp.in, pI + o7, 7); goffs(gp.w, p_bw + o7, 7); goffs(gp.b, p_bb + o7, 7); goffs(gp.out, pO + o7, 7);
         ProfScope ps(c.s, 1, 7);
-        TRY(linr_cconv_launch(false, pI[0], 8, lo, mk, c.nbr_ld, c.R, p_bw[0], p_bb[0], 8, 8, a.O[0], 8, nullptr, 0, a.O[1], 8, 0,
+        TRY(linr_cconv_launch(false, pI[o7], 8, lo, mk, c.nbr_ld, c.R, p_bw[o7], p_bb[o7], 8, 8, a.O[0], 8, nullptr, 0, a.O[1], 8, 0,
                               c.s, &gp, 7));
     }
     {   // the 8 occupancy heads
@@ -762,9 +777,15 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
             TRY(linear(c, a.HID + r0 * 16, 16, n, P + c.L.m2_w[si], 1, 16, P + c.L.m2_b[si], 16, 8, nullptr, 0, nullptr, 0,
                        a.X0 + r0 * 8, 8, 0));
         }
-        TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
+        if (all_grouped && join_block_in(c)) {
+            // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
+            const BlockP& bi = c.L.block_in;
+            TRY(conv3(c, false, a.X0, 8, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0, nullptr, 0, a.A[0], 8, LINR_RELU));
+        } else {
+            TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
+        }
     }
-    if (all_grouped) return forward_batched(c, probs, bits_acc);
+    if (all_grouped) return forward_batched(c, probs, bits_acc, 3, join_block_in(c));
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
@@ -859,7 +880,7 @@ static void goffs_i(int64_t* dst, const int64_t* v, int n) {
 // Backward of the 8 heads and the 7 outter blocks as grouped launches (one launch per layer, gridDim.y = group); every
 // kernel, its per-row arithmetic and the slab rows it writes are those of the stage-by-stage path, so gradients are
 // bitwise the same.
-static int backward_batched(Ctx& c, float gz_scale) {
+static int backward_batched(Ctx& c, float gz_scale, bool join) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
@@ -901,80 +922,84 @@ static int backward_batched(Ctx& c, float gz_scale) {
         for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
         sum8_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(src, c.R * 8, a.gXG);
     }
-    // outter blocks 1..7 (group g = block g + 1); gO[b] is the gradient of the block output
-    const float *pA[7], *pH[7], *pM[7], *pI[7], *p_gO[7], *p_gI[7], *p_gM[7], *p_gH[7], *p_gA[7], *p_bw[7], *p_c12w[7], *p_c01w[7],
-        *p_c11w[7], *p_c00w[7], *p_c10w[7];
-    int64_t o_bw[7], o_bb[7], o_c12w[7], o_c12b[7], o_c01w[7], o_c01b[7], o_c11w[7], o_c11b[7], o_c00w[7], o_c00b[7], o_c10w[7],
-        o_c10b[7], o_aw[7], o_ab[7];
-    for (int g = 0; g < 7; ++g) {
-        const BlockP& bp = L.outter[g];
-        const int b = g + 1;
-        pA[g] = a.A[b]; pH[g] = a.H[b]; pM[g] = a.M[b]; pI[g] = a.I[b]; p_gO[g] = a.gO[b]; p_gI[g] = a.gI[b]; p_gM[g] = a.gM[b];
-        p_gH[g] = a.gH[b]; p_gA[g] = a.gA[b];
+    // outter blocks 1..7 (slot b = block b; gO[b] is the gradient of the block output) and, with `join`, block_in as slot 0
+    // (output gradient gXG = the sum above): one group per slot, g0 = first slot, ng = group count
+    const int g0 = join ? 0 : 1, ng = 8 - g0, o7 = 1 - g0;
+    const float *pA[8], *pH[8], *pM[8], *pI[8], *p_gO[8], *p_gI[8], *p_gM[8], *p_gH[8], *p_gA[8], *p_bw[8], *p_c12w[8], *p_c01w[8],
+        *p_c11w[8], *p_c00w[8], *p_c10w[8], *p_in[8];
+    int64_t o_bw[8], o_bb[8], o_c12w[8], o_c12b[8], o_c01w[8], o_c01b[8], o_c11w[8], o_c11b[8], o_c00w[8], o_c00b[8], o_c10w[8],
+        o_c10b[8], o_aw[8], o_ab[8];
+    for (int g = 0; g < ng; ++g) {
+        const int b = g0 + g;
+        const BlockP& bp = b == 0 ? L.block_in : L.outter[b - 1];
+        pA[g] = a.A[b]; pH[g] = a.H[b]; pM[g] = a.M[b]; pI[g] = a.I[b]; p_gO[g] = b == 0 ? a.gXG : a.gO[b]; p_gI[g] = a.gI[b];
+        p_gM[g] = a.gM[b]; p_gH[g] = a.gH[b]; p_gA[g] = a.gA[b]; p_in[g] = b == 0 ? a.X0 : a.OCC;
         p_bw[g] = P + bp.b_w; p_c12w[g] = P + bp.inc[0].c12_w; p_c01w[g] = P + bp.inc[0].c01_w; p_c11w[g] = P + bp.inc[0].c11_w;
         p_c00w[g] = P + bp.inc[0].c00_w; p_c10w[g] = P + bp.inc[0].c10_w;
         o_bw[g] = bp.b_w; o_bb[g] = bp.b_b; o_c12w[g] = bp.inc[0].c12_w; o_c12b[g] = bp.inc[0].c12_b; o_c01w[g] = bp.inc[0].c01_w; o_c01b[g] = bp.inc[0].c01_b;
         o_c11w[g] = bp.inc[0].c11_w; o_c11b[g] = bp.inc[0].c11_b; o_c00w[g] = bp.inc[0].c00_w; o_c00b[g] = bp.inc[0].c00_b; o_c10w[g] = bp.inc[0].c10_w;
         o_c10b[g] = bp.inc[0].c10_b; o_aw[g] = bp.a_w; o_ab[g] = bp.a_b;
     }
+    (void)o7;
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
-        goffs(gp.in, pI, 7); goffs(gp.res, p_gO, 7); goffs_i(gp.w, o_bw, 7); goffs_i(gp.b, o_bb, 7);
+        goffs(gp.in, pI, ng); goffs(gp.res, p_gO, ng); goffs_i(gp.w, o_bw, ng); goffs_i(gp.b, o_bb, ng);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        ProfScope ps(c.ws, 0, ng);
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, ng, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
-        goffs(gp.in, p_gO, 7); goffs(gp.w, p_bw, 7); goffs(gp.out, p_gI, 7); goffs(gp.e0, p_c12w, 7); goffs(gp.e1, pM, 7);
-        goffs(gp.e2, p_gM, 7);
-        TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[1], a.gM[1], c.s, &gp, 7));
+        goffs(gp.in, p_gO, ng); goffs(gp.w, p_bw, ng); goffs(gp.out, p_gI, ng); goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng);
+        goffs(gp.e2, p_gM, ng);
+        TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[g0], a.gM[g0], c.s, &gp, ng));
     }
     {   // conv1_2 weight gradient: M^T gI[:,4:8]
         Grp gp = Grp();
-        goffs(gp.in, pM, 7); goffs(gp.res, p_gI, 7); goffs_i(gp.w, o_c12w, 7); goffs_i(gp.b, o_c12b, 7);
+        goffs(gp.in, pM, ng); goffs(gp.res, p_gI, ng); goffs_i(gp.w, o_c12w, ng); goffs_i(gp.b, o_c12b, ng);
         LinrLinDst d = {a.BIG, L.total, o_c12w[0], 4, 1, o_c12b[0]};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.ws, &gp, 7));
+        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.ws, &gp, ng));
     }
     {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
-        goffs(gp.in, pH, 7); goffs(gp.res, p_gI, 7); goffs(gp.act, p_gM, 7); goffs_i(gp.w, o_c01w, 7); goffs_i(gp.b, o_c01b, 7);
-        goffs_i(gp.e0, o_c11w, 7); goffs_i(gp.e1, o_c11b, 7);
+        goffs(gp.in, pH, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, p_gM, ng); goffs_i(gp.w, o_c01w, ng); goffs_i(gp.b, o_c01b, ng);
+        goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], c.nb, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+                                    o_c11w[0], o_c11b[0], c.nb, c.ws, &gp, ng, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
-        goffs(gq.in, p_gI, 7); goffs(gq.out, p_gH, 7); goffs(gq.e0, p_gM, 7); goffs(gq.w, p_c01w, 7); goffs(gq.e1, p_c11w, 7);
-        goffs(gq.act, pH, 7);
-        TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[1], c.s, &gq, 7));
+        goffs(gq.in, p_gI, ng); goffs(gq.out, p_gH, ng); goffs(gq.e0, p_gM, ng); goffs(gq.w, p_c01w, ng); goffs(gq.e1, p_c11w, ng);
+        goffs(gq.act, pH, ng);
+        TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[g0], c.s, &gq, ng));
     }
     {   // conv0_0 (8->4) and conv1_0 (1x1 8->4) weight gradients
         Grp gp = Grp();
-        goffs(gp.in, pA, 7); goffs(gp.res, p_gH, 7); goffs_i(gp.w, o_c00w, 7); goffs_i(gp.b, o_c00b, 7);
+        goffs(gp.in, pA, ng); goffs(gp.res, p_gH, ng); goffs_i(gp.w, o_c00w, ng); goffs_i(gp.b, o_c00b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.ws, &gp, 7, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.ws, &gp, ng, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
         Grp gq = Grp();
-        goffs(gq.in, pA, 7); goffs(gq.res, p_gH, 7); goffs_i(gq.w, o_c10w, 7); goffs_i(gq.b, o_c10b, 7);
+        goffs(gq.in, pA, ng); goffs(gq.res, p_gH, ng); goffs_i(gq.w, o_c10w, ng); goffs_i(gq.b, o_c10b, ng);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
-        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, 7));
+        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, ng));
     }
     {   // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
         Grp gp = Grp();
-        goffs(gp.in, p_gH, 7); goffs(gp.w, p_c00w, 7); goffs(gp.res, p_gI, 7); goffs(gp.act, pA, 7); goffs(gp.out, p_gA, 7);
-        goffs(gp.e0, p_c10w, 7); goffs(gp.e1, p_gH, 7);
-        TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[1], LINR_RELU_MASK, c.s, &gp, 7));
+        goffs(gp.in, p_gH, ng); goffs(gp.w, p_c00w, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, pA, ng); goffs(gp.out, p_gA, ng);
+        goffs(gp.e0, p_c10w, ng); goffs(gp.e1, p_gH, ng);
+        TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[g0], LINR_RELU_MASK, c.s, &gp, ng));
     }
-    {   // A = relu(conv3(occ[:, :b]; a)): weight gradient on the first b channels of the occupancy rows
+    {   // A = relu(conv3(in; a)): weight gradient on the first b channels of the occupancy rows (outter block b) or on all 8
+        // channels of the scale context x0 (block_in)
         Grp gp = Grp();
-        goffs(gp.res, p_gA, 7); goffs_i(gp.w, o_aw, 7); goffs_i(gp.b, o_ab, 7);
-        for (int g = 0; g < 7; ++g) gp.e2[g] = g + 1;
+        goffs(gp.in, p_in, ng); goffs(gp.res, p_gA, ng); goffs_i(gp.w, o_aw, ng); goffs_i(gp.b, o_ab, ng);
+        for (int g = 0; g < ng; ++g) gp.e2[g] = (g0 + g == 0) ? 8 : g0 + g;
         LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
         TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, 7);
-        TRY(linr_conv3_wgrad_mfma(a.OCC, 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, 7, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        ProfScope ps(c.ws, 0, ng);
+        TRY(linr_conv3_wgrad_mfma(p_in[0], 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, ng, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     return 0;
 }
@@ -993,7 +1018,8 @@ static int backward_core(Ctx& c, float gscale) {
                                      c.nb, c.s)));
     const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
-    if (grouped) TRY(backward_batched(c, gz_scale));
+    const bool join = grouped && join_block_in(c);
+    if (grouped) TRY(backward_batched(c, gz_scale, join));
     for (int k = grouped ? -1 : 7; k >= 0; --k) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
             // recompute the hidden layer, gC and the four head-parameter gradients in one launch (csrc/fused.hip)
@@ -1014,8 +1040,13 @@ static int backward_core(Ctx& c, float gscale) {
         axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO[k], c.R * 8, a.gXG, k == 7 ? 0 : 1);
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
-    if (aux) c.ws = aux;             // block_in and the scale context: single launches, overlapped with the data chain
-    TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
+    if (aux) c.ws = aux;             // block_in (unless joined) and the scale context: single launches, overlapped with the data chain
+    if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
+        const BlockP& bi = c.L.block_in;
+        TRY(conv3(c, true, a.gA[0], 8, P + bi.a_w, nullptr, bi.cin, 8, nullptr, 0, nullptr, 0, a.gX0, 8, 0));
+    } else {
+        TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
+    }
     // scale context: all non-empty scales as one launch per layer when they fit one grouped launch
     int ns = 0, sl[MAX_SCALES];
     for (int s = 0; s < f->n_scales; ++s)
