@@ -303,13 +303,16 @@ static int g_ev_next = 0;
 static bool g_aux_ok = false;
 static std::mutex g_aux_mu;          // the pool is process-wide; executor calls may come from several host threads
 
-// Second-stream policy (LINR_WGRAD_STREAM: 1 = every weight-gradient launch, 0 = none, unset = auto).  Auto: the GROUPED
-// launches (7 outter blocks / 8 heads per launch) fill the chip on their own and a second stream only adds contention
-// (3.02 vs 2.83 ms/step with everything on it), so they stay on the caller's stream unless the frame is small
-// (rows < LINR_AUX_ROWS, default 150,000); the SINGLE launches of block_in (1,319 blocks = 1.3 blocks per CU at 336 k rows:
-// bound by their own latency and tail) do overlap: its five weight-gradient launches run beside its backward data chain
-// (the same trick in the forward pass - the occupancy-only layers of the outter blocks beside [scale context -> block_in] -
-// gained 0.3 % and distorted the live timing of the roofline kernels, so it was not kept).
+// Second-stream policy (LINR_WGRAD_STREAM: 1 = every weight-gradient launch, 0 = none, unset = auto).  Since block_in rides in
+// the grouped launches (join_block_in) the step has no single weight-gradient launches left, and auto = ONE stream:
+//   * small frames (sphere8, 54 k rows): 0.545 ms/step on one stream vs 0.554 with the weight gradients on a second one;
+//   * large frames (loot10, 337 k rows): 2.311 on one stream vs 2.321 with LINR_WGRAD_STREAM=1 LINR_FWD_OVERLAP=1 (the grouped
+//     weight-gradient launches beside the backward-data chain, the shared occupancy conv beside [scale context -> block_in's
+//     first conv]); a schedule that still hands the scale context's weight gradients to the second stream measured 2.353
+//     against 2.329 for everything on it - the event hand-offs cost more than the overlap of chip-filling grouped launches
+//     brings (profiles/r02_ab_overlap_policy.txt).  One stream also keeps every kernel timeable on its own.
+// The schedule with block_in's single launches (LINR_JOIN_BLOCK_IN=0, block_layers > 1) keeps the round-1 rule: its single
+// launches on the second stream, the grouped ones too for frames below LINR_AUX_ROWS (150,000) rows.
 // Results are bit-identical either way (tests/test_gpu_parity.py: switch test).
 static int aux_policy() {
     static const int v = getenv("LINR_WGRAD_STREAM") ? atoi(getenv("LINR_WGRAD_STREAM")) : -1;
@@ -331,10 +334,10 @@ static hipStream_t aux_stream() {
     g_aux_ok = true;
     return g_aux;
 }
-// should the grouped weight-gradient launches go to the auxiliary stream too?
-static bool aux_all(int64_t rows) {
+// do the grouped weight-gradient launches go to the auxiliary stream?
+static bool aux_all(int64_t rows, bool join) {
     const int pol = aux_policy();
-    return pol > 0 || (pol < 0 && rows < aux_rows());
+    return pol > 0 || (pol < 0 && !join && rows < aux_rows());
 }
 
 // everything issued on `from` so far happens-before whatever is issued on `to` next
@@ -432,6 +435,11 @@ static bool grouped_enabled() {
 static bool join_block_in(const Ctx& c) {
     static const int v = getenv("LINR_JOIN_BLOCK_IN") ? atoi(getenv("LINR_JOIN_BLOCK_IN")) : 1;
     return v != 0 && grouped_enabled() && c.f->nbr_lo && c.f->nbr_mask && c.L.block_in.nl == 1;
+}
+
+static bool fwd_overlap() {          // opt-in, see the second-stream policy above
+    static const int v = getenv("LINR_FWD_OVERLAP") ? atoi(getenv("LINR_FWD_OVERLAP")) : 0;
+    return v != 0;
 }
 
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
@@ -659,7 +667,7 @@ static void goffs(int64_t* dst, const float* const* ptrs, int n) {
 // path below, so the decoder reproduces these probabilities bit for bit.
 // part 1: the occupancy-only layers of the outter blocks (first conv, conv0_0 | conv1_0, both 4->4 convs: they do not need
 // x_glob); part 2: everything that does (tail conv + x_glob, the 8 heads).  3 = both.
-static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3, bool join = false) {
+static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3, bool join = false, hipStream_t occ_on = nullptr) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
@@ -682,6 +690,9 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3,
         p_c12w[g] = P + bp.inc[0].c12_w; p_c12b[g] = P + bp.inc[0].c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
     }
     if (part & 1) {
+    if (occ_on) {    // the shared occupancy conv was launched on `occ_on` beside the scale context + block_in's first conv
+        TRY(stream_order(occ_on, c.s));
+    } else
     {   // first conv of every outter block: A[b] = relu(conv3(occ[:, :b]; a) + a_b), one shared gather (csrc/fused.hip)
         static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
         if (shared) {
@@ -756,11 +767,25 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
     const bool batched = grouped_enabled();
     const bool all_grouped = batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask;
+    hipStream_t occ_on = nullptr;
     if (stage_begin == 0) {
         PadList pl;
         pl.n = a.npad;
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
         zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
+        if (all_grouped && join_block_in(c) && fwd_overlap()) {
+            // The first convs of the outter blocks read the occupancy only: they run on the second stream while this one does
+            // the scale context and block_in's first conv (both single launches that leave most of the chip idle).
+            hipStream_t aux = aux_stream();
+            static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
+            if (aux && shared) {
+                int64_t w_off[7], b_off[7], o_off[7];
+                for (int g = 0; g < 7; ++g) { w_off[g] = c.L.outter[g].a_w; b_off[g] = c.L.outter[g].a_b; o_off[g] = a.A[g + 1] - a.A[1]; }
+                TRY(stream_order(c.s, aux));
+                TRY(linr_occ_conv7_launch(a.OCC, clo(c), cmk(c), c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, aux));
+                occ_on = aux;
+            }
+        }
         // scale context: one small MLP per scale (model_core.py:48-53)
         static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
         if (sce_fused) {
@@ -780,12 +805,16 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         if (all_grouped && join_block_in(c)) {
             // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
             const BlockP& bi = c.L.block_in;
-            TRY(conv3(c, false, a.X0, 8, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0, nullptr, 0, a.A[0], 8, LINR_RELU));
+            if (occ_on)     // (not through conv3(): a launch that shares the chip must not enter the live roofline timing)
+                TRY(linr_cconv_launch(false, a.X0, 8, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0,
+                                      nullptr, 0, a.A[0], 8, LINR_RELU, c.s));
+            else
+                TRY(conv3(c, false, a.X0, 8, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0, nullptr, 0, a.A[0], 8, LINR_RELU));
         } else {
             TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
         }
     }
-    if (all_grouped) return forward_batched(c, probs, bits_acc, 3, join_block_in(c));
+    if (all_grouped) return forward_batched(c, probs, bits_acc, 3, join_block_in(c), occ_on);
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
@@ -1012,13 +1041,13 @@ static int backward_core(Ctx& c, float gscale) {
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
     const bool cm_ = c.f->nbr_lo && c.f->nbr_mask;
     hipStream_t aux = cm_ ? aux_stream() : nullptr;
-    c.ws = (aux && aux_all(c.R)) ? aux : c.s;
     // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
     TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
                                      c.nb, c.s)));
     const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
     const bool join = grouped && join_block_in(c);
+    c.ws = (aux && aux_all(c.R, join)) ? aux : c.s;
     if (grouped) TRY(backward_batched(c, gz_scale, join));
     for (int k = grouped ? -1 : 7; k >= 0; --k) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
@@ -1040,7 +1069,7 @@ static int backward_core(Ctx& c, float gscale) {
         axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO[k], c.R * 8, a.gXG, k == 7 ? 0 : 1);
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
-    if (aux) c.ws = aux;             // block_in (unless joined) and the scale context: single launches, overlapped with the data chain
+    if (aux && (aux_all(c.R, join) || !join)) c.ws = aux;     // block_in (unless joined) and the scale context: single launches, overlapped with the data chain
     if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
         const BlockP& bi = c.L.block_in;
         TRY(conv3(c, true, a.gA[0], 8, P + bi.a_w, nullptr, bi.cin, 8, nullptr, 0, nullptr, 0, a.gX0, 8, 0));
