@@ -251,13 +251,20 @@ __global__ void sce_emb_grad_k(const float* __restrict__ gb1, const float* __res
 // its quarter of the slab rows in ascending order, quarters added in order) => bit-reproducible.  One thread per
 // parameter alone would be 214 blocks of latency-bound streaming on 256 CUs.
 #define RED_SPLIT 4       // threads per parameter: each sums nblocks / RED_SPLIT slab rows
+// Parameters nobody wrote partials for - the scale embedding (its gradient is derived from the reduced sums afterwards) and
+// the context MLPs of scales the frame does not contain - lie in [0, prefix): `zr` lists those ranges and the reduction
+// writes 0 for them WITHOUT reading the slab, which therefore needs no clearing pass (a 2-D memset of nb rows per step).
+struct ZeroRanges { int n; int64_t prefix; int64_t b[MAX_SCALES + 1], e[MAX_SCALES + 1]; };
 __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
-                                                             float* __restrict__ gsum) {
+                                                             float* __restrict__ gsum, ZeroRanges zr) {
     __shared__ float part[RED_SPLIT][LINR_BLOCK / RED_SPLIT];
     const int lp = threadIdx.x % (LINR_BLOCK / RED_SPLIT), q = threadIdx.x / (LINR_BLOCK / RED_SPLIT);
     const int64_t p = (int64_t)blockIdx.x * (LINR_BLOCK / RED_SPLIT) + lp;
     float s = 0.0f;
-    if (p < total) {
+    bool skip = false;
+    if (p < zr.prefix)
+        for (int i = 0; i < zr.n; ++i) skip = skip || (p >= zr.b[i] && p < zr.e[i]);
+    if (p < total && !skip) {
         float a[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = 0.0f;
@@ -887,7 +894,9 @@ extern "C" int linr_sce_bwd(const float* params, const linr_frame* f, const floa
 // fixed-order sum of the [nblocks][total] partial slab (shared with the op-level entries of csrc/fused.hip)
 int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float* gsum, hipStream_t s) {
     if (total <= 0) return 0;
-    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(big, nblocks, total, gsum);
+    ZeroRanges zr;
+    zr.n = 0; zr.prefix = 0;
+    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(big, nblocks, total, gsum, zr);
     return linr_launch_rc();
 }
 
@@ -1041,9 +1050,6 @@ static int backward_core(Ctx& c, float gscale) {
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
     const bool cm_ = c.f->nbr_lo && c.f->nbr_mask;
     hipStream_t aux = cm_ ? aux_stream() : nullptr;
-    // scale-context columns (embedding + per-scale MLPs) of scales this frame does not contain get no partials: zero them
-    TRY(linr_hip_rc(hipMemset2DAsync(a.BIG, (size_t)c.L.total * sizeof(float), 0, (size_t)c.L.block_in.a_w * sizeof(float),
-                                     c.nb, c.s)));
     const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
     const bool join = grouped && join_block_in(c);
@@ -1113,7 +1119,20 @@ static int backward_core(Ctx& c, float gscale) {
     }
     // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
     TRY(stream_order(c.ws, c.s));
-    wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM);
+    {   // the scale embedding and the context MLPs of absent scales get no partials: the reduction writes their zeros itself
+        ZeroRanges zr;
+        zr.n = 0; zr.prefix = c.L.block_in.a_w;
+        zr.b[zr.n] = c.L.emb; zr.e[zr.n] = c.L.emb + (int64_t)c.L.S * 8; ++zr.n;
+        bool present[MAX_SCALES] = {};
+        for (int j = 0; j < ns; ++j) present[f->scale_idx_h[sl[j]]] = true;
+        for (int si = 0; si < c.L.S; ++si)
+            if (!present[si]) {
+                zr.b[zr.n] = c.L.m0_w[si];
+                zr.e[zr.n] = si + 1 < c.L.S ? c.L.m0_w[si + 1] : c.L.block_in.a_w;
+                ++zr.n;
+            }
+        wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM, zr);
+    }
     if (ns > 0) {
         EmbArgs ea;
         for (int j = 0; j < ns; ++j) {
