@@ -390,11 +390,12 @@ class FlatAdam:
         self.t = steps.pop() if steps else 0
 
 
-def train_step(model, opt, frame, point_num):
+def train_step(model, opt, frame, point_num, out=None):
     """One iteration of main.py:305-321 on a batched frame: bits -> loss = bits/point_num -> backward -> Adam ->
     StepLR, as ONE C-ABI call (linr_net_train_step).  Returns the device-resident bits accumulator (float64[1]);
-    nothing synchronises with the host."""
-    bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+    nothing synchronises with the host.  `out`: a zeroed float64[1] device tensor to add the bits into (e.g. one slot of a
+    per-GOP vector that is cleared once per epoch) - saves the per-step allocation + fill."""
+    bits = torch.zeros(1, dtype=torch.float64, device=frame.device) if out is None else out
     opt.t += 1
     for i in range(frame.n_scales):                 # scales present in this frame advance their MLP's own counter
         if frame.row_off[i + 1] > frame.row_off[i]:

@@ -70,13 +70,15 @@ def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None):
     """main.py:297-437: frames in fixed order, one optimiser + StepLR step per frame, lr clamp after each epoch.
     Returns the per-epoch mean loss (bits per point), like the reference logs."""
     losses = []
+    dev = gop.frames[0].device
+    bits = torch.zeros(len(gop), dtype=torch.float64, device=dev)         # one slot per frame: no per-step torch kernels
+    pns = torch.tensor([float(pn) for pn in gop.point_nums], dtype=torch.float64, device=dev)
     for epoch in range(epochs):
-        acc = torch.zeros(1, dtype=torch.float64, device=gop.frames[0].device)
-        for f, pn in zip(gop.frames, gop.point_nums):
-            bits = train_step(model, opt, f, pn)
-            acc += bits / pn
+        bits.zero_()
+        for j, (f, pn) in enumerate(zip(gop.frames, gop.point_nums)):
+            train_step(model, opt, f, pn, out=bits[j:j + 1])
         opt.clamp_lr(min_lr)
-        loss_mean = float(acc) / len(gop)                    # the only host sync of the epoch
+        loss_mean = float((bits / pns).sum()) / len(gop)     # the only host sync of the epoch
         losses.append(loss_mean)
         if on_epoch is not None:
             on_epoch(epoch, loss_mean)
