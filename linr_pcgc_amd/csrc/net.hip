@@ -292,14 +292,19 @@ struct Ctx {
     int nb;                  // persistent blocks of the weight-gradient kernels = partial rows of the slab for this frame
 };
 
-// Persistent blocks per weight-gradient launch: 2 per CU (512) fill the chip at BASELINE sizes, but every block ends with a
-// fold over its waves and writes one slab row per parameter, and the final reduction reads nb x n_params floats - fixed
-// costs that dominate small frames (56 k rows: 110 rows per block).  Multiples of 32 (wgrad_reduce_k's association).
+// Persistent blocks per weight-gradient launch (multiples of 32: wgrad_reduce_k's association).  Every block ends with a fold
+// over its waves and writes one slab row per parameter, and the final reduction reads nb x n_params floats: fixed costs that
+// grow with nb, while the grouped launches (8 groups since block_in joined them) bring nb x 8 blocks anyway.  Measured,
+// ms/step with the joined schedule: 337 k rows (loot10): 512 -> 2.291, 384 -> 2.277, 256 -> 2.271, 192 -> 2.305, 160 -> 2.293,
+// 128 -> 2.285; 373 k rows (andrew10): 512 -> 2.626, 256 -> 2.614, 160 -> 2.656; 54 k rows (sphere8): 384 -> 0.566, 256 -> 0.533,
+// 192 -> 0.532, 128 -> 0.506, 96 -> 0.509, 64 -> 0.531 (profiles/r02_ab_wg_blocks.txt).  The block count decides how the partial
+// sums associate, i.e. the rounding of the gradients; nothing else depends on it (tests: test_block_count_changes_only_the_rounding).
+// The LDS-staged kernel (LINR_WGRAD_LDS=1) has its window table built for the 512-block partition.
 static int wg_blocks_for(int64_t rows) {
     static const int forced = getenv("LINR_WG_BLOCKS") ? atoi(getenv("LINR_WG_BLOCKS")) : 0;
     if (forced >= 32 && forced <= LINR_WG_BLOCKS && forced % 32 == 0) return forced;
-    // measured (ms/step): 56 k rows: 512 -> 0.685, 256 -> 0.627, 128 -> 0.637, 64 -> 0.71; 337 k rows: 512 -> 2.398, 384 -> 2.410, 256 -> 2.440
-    return rows >= 200000 ? LINR_WG_BLOCKS : 256;
+    if (linr_wgrad_lds_enabled()) return LINR_WG_BLOCKS;
+    return rows >= 100000 ? 256 : 128;
 }
 
 // Weight-gradient kernels only feed the final reduction, so they CAN run on a second stream next to the backward data

@@ -564,29 +564,54 @@ def _dump_under(env, golden_dir, out):
 
 
 @pytest.fixture(scope='module')
-def default_dump(golden_dir, tmp_path_factory):
-    return _dump_under({}, golden_dir, str(tmp_path_factory.mktemp('dump') / 'default.npz'))
+def base_dumps(golden_dir, tmp_path_factory):
+    """Reference dumps per base environment ({} = the default executor), computed once."""
+    cache = {}
+
+    def get(base):
+        key = tuple(sorted(base.items()))
+        if key not in cache:
+            cache[key] = _dump_under(base, golden_dir, str(tmp_path_factory.mktemp('dump') / ('base%d.npz' % len(cache))))
+        return cache[key]
+    return get
 
 
 # every executor switch the library reads from the environment (README.md): each one alone, and the two extreme
-# combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT
-SWITCHES = [{'LINR_JOIN_BLOCK_IN': '0'}, {'LINR_WGRAD_STREAM': '1', 'LINR_FWD_OVERLAP': '1'}, {'LINR_JOIN_BLOCK_IN': '0', 'LINR_WGRAD_STREAM': '0'}, {'LINR_WGRAD_LDS': '1'}, {'LINR_WGRAD_T': '0'}, {'LINR_WGRAD_T': '2'}, {'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {'LINR_BATCHED': '0'}, {'LINR_SCE_FUSED': '0'}, {'LINR_OCC_SHARED': '0'}, {'LINR_CONV_MFMA': '0'},
-            {'LINR_CONV_MFMA': '2'}, {'LINR_WGRAD_CMAP': '1'}, {'LINR_WGRAD_STREAM': '1'},
-            {'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',
-             'LINR_WGRAD_LDS': '1'},
-            {'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_CONV_MFMA': '2', 'LINR_WGRAD_CMAP': '1'}]
+# combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT.  The LDS-staged
+# weight-gradient kernel works on the 512-block row partition only, so it is compared with the default executor at 512
+# persistent blocks (the partition decides the association of the per-block partial sums).
+B512 = {'LINR_WG_BLOCKS': '512'}
+SWITCHES = [({'LINR_JOIN_BLOCK_IN': '0'}, {}), ({'LINR_WGRAD_STREAM': '1', 'LINR_FWD_OVERLAP': '1'}, {}),
+            ({'LINR_JOIN_BLOCK_IN': '0', 'LINR_WGRAD_STREAM': '0'}, {}), ({'LINR_WGRAD_LDS': '1'}, B512), ({'LINR_WGRAD_T': '0'}, {}),
+            ({'LINR_WGRAD_T': '2'}, {}), ({'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {}), ({'LINR_BATCHED': '0'}, {}),
+            ({'LINR_SCE_FUSED': '0'}, {}), ({'LINR_OCC_SHARED': '0'}, {}), ({'LINR_CONV_MFMA': '0'}, {}), ({'LINR_CONV_MFMA': '2'}, {}),
+            ({'LINR_WGRAD_CMAP': '1'}, {}), ({'LINR_WGRAD_STREAM': '1'}, {}),
+            ({'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',
+              'LINR_WGRAD_LDS': '1'}, B512),
+            ({'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_CONV_MFMA': '2', 'LINR_WGRAD_CMAP': '1'}, {})]
 
 
-@pytest.mark.parametrize('env', SWITCHES, ids=lambda e: ','.join('%s=%s' % (k[5:], v) for k, v in e.items()))
-def test_executor_switch_is_bit_identical_to_default(pkg, golden_dir, tmp_path, default_dump, env):
-    """The grouped executor (one launch per layer for the 7 outter blocks / 8 heads / all scales of the scale context) against
-    every alternative path it can be switched to - stage by stage and scale by scale, VALU or LDS-staged convolutions,
-    compressed-map weight gradients, weight gradients on a second stream: same bits everywhere, which is what lets the
-    stage-serial decoder reproduce the encoder's probabilities."""
-    got = _dump_under(env, golden_dir, str(tmp_path / 'switched.npz'))
+@pytest.mark.parametrize('env,base', SWITCHES, ids=lambda e: ','.join('%s=%s' % (k[5:], v) for k, v in e.items()) or 'default')
+def test_executor_switch_is_bit_identical_to_default(pkg, golden_dir, tmp_path, base_dumps, env, base):
+    """The grouped executor (one launch per layer for block_in + the 7 outter blocks / 8 heads / all scales of the scale
+    context) against every alternative path it can be switched to - stage by stage and scale by scale, block_in as single
+    launches, VALU or LDS-staged convolutions, compressed-map weight gradients, weight gradients on a second stream: same
+    bits everywhere, which is what lets the stage-serial decoder reproduce the encoder's probabilities."""
+    ref = base_dumps(base)
+    got = _dump_under(dict(base, **env), golden_dir, str(tmp_path / 'switched.npz'))
     for key in ('probs', 'bits', 'grads'):
-        assert np.array_equal(default_dump[key], got[key]), key
+        assert np.array_equal(ref[key], got[key]), key
     assert float(np.abs(got['grads']).max()) > 0
+
+
+def test_block_count_changes_only_the_rounding(pkg, golden_dir, tmp_path, base_dumps):
+    """The number of persistent weight-gradient blocks decides how the per-block partial sums associate: probabilities and
+    bits must not move at all, gradients only by rounding."""
+    ref = base_dumps({})
+    got = base_dumps(B512)
+    assert np.array_equal(ref['probs'], got['probs']) and np.array_equal(ref['bits'], got['bits'])
+    scale = float(np.abs(ref['grads']).max())
+    assert float(np.abs(ref['grads'] - got['grads']).max()) <= 2e-5 * scale
 
 
 def test_codec_stream_matches_oracle_coder(pkg, shell):
