@@ -197,12 +197,15 @@ LINR_API int linr_adam_step(float* params, const float* grads, float* exp_avg, f
  * shared by all scales, only the scale-context MLP differs (models/model_core.py:31-35).
  * Replaces LINR_PCGC_Model.logic_core/forward (models/model_core.py:38-81) + CNP.forward
  * (models/upsample.py:163-217) and the autograd backward that main.py:315-316 runs. */
+#define LINR_FRAME_OCC_PADDED 1
 typedef struct linr_frame {
     int64_t rows;                 /* total rows over all scales, < 2^27 - 1 (32-bit byte offsets of the gathers)  */
     int32_t n_scales;             /* scales present in this frame (<= model scale_num)                      */
     int32_t model_scale_num;      /* LINR_PCGC_Model scale_num (fixes the parameter layout)                 */
     int32_t block_layers;         /* Inception layers of block_in (main.py:521); 0 is read as 1              */
-    int32_t reserved_;
+    int32_t flags;                /* 0, or LINR_FRAME_OCC_PADDED: `occ` is row 0 of a [rows + 1][8] buffer whose row -1 is all
+                                   * zero - the executor then gathers the occupancy in place instead of keeping a padded
+                                   * copy in its arena (one device copy per call less) */
     const int64_t* row_off_h;     /* HOST [n_scales+1] first row of each scale                              */
     const int32_t* scale_idx_h;   /* HOST [n_scales]  which scale embedding / scale MLP each scale uses     */
     const int32_t* nbr;           /* [27][nbr_ld] kernel map with global row ids                            */

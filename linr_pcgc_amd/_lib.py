@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so')
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
+LINR_FRAME_OCC_PADDED = 1
 ABI_VERSION = 2
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
@@ -19,7 +20,7 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 class LinrFrame(ctypes.Structure):
     """struct linr_frame (include/linr_hip.h)."""
     _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('block_layers', c_i32),
-                ('reserved_', c_i32), ('row_off_h', c_ptr),
+                ('flags', c_i32), ('row_off_h', c_ptr),
                 ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('nbr_lo', c_ptr), ('nbr_mask', c_ptr),
                 ('offset_feat', c_ptr), ('occ', c_ptr), ('wg_ranges', c_ptr), ('nbr8', c_ptr), ('nbr8t', c_ptr)]
 

@@ -141,9 +141,17 @@ __device__ __forceinline__ int sce_scale_of(const SceArgs& a, int64_t r) {
     return s;
 }
 
+// The blocks behind the last row block clear the arena's pad rows (PadList; one pad per 32 threads) - the job of zero_pads_k,
+// without its launch: the first kernel that reads a pad row comes after this one on the stream.
 __global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
                                                         int64_t n, float* __restrict__ mix, float* __restrict__ hid,
-                                                        float* __restrict__ x0) {
+                                                        float* __restrict__ x0, float* __restrict__ pad_base, PadList pl) {
+    const int64_t row_blocks = (n + LINR_BLOCK - 1) / LINR_BLOCK;
+    if ((int64_t)blockIdx.x >= row_blocks) {
+        const int b = (int)((int64_t)blockIdx.x - row_blocks) * (LINR_BLOCK / 32) + (int)(threadIdx.x >> 5), t = threadIdx.x & 31;
+        if (b < pl.n && t < pl.w[b]) pad_base[pl.off[b] + t] = 0.0f;
+        return;
+    }
     const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (r >= n) return;
     const int s = sce_scale_of(a, r);
@@ -645,6 +653,10 @@ static int check_frame(const linr_frame* f, const void* params, const void* aren
     c.nbr_ld = f->nbr_ld;
     c.nb = wg_blocks_for(f->rows);
     make_arena(c.A, f->rows, (float*)arena, c.L.total, c.L.BL);
+    if (f->flags & LINR_FRAME_OCC_PADDED) {        // the caller's occupancy buffer has the zero row in front: use it in place
+        if (!f->occ || !linr_aligned16(f->occ)) return LINR_EINVAL;
+        c.A.OCC = const_cast<float*>(f->occ);
+    }
     return 0;
 }
 
@@ -775,8 +787,10 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
     if (c.R == 0) return 0;
     Arena& a = c.A;
     const float* P = c.P;
-    // ground-truth / decoded occupancy into the padded arena copy (the decoder updates one column per call)
-    TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+    // ground-truth / decoded occupancy (the decoder updates one column per call): gathered in place when the caller's buffer
+    // has the zero row in front (check_frame points a.OCC at it), else copied into the padded arena matrix
+    if (!(f->flags & LINR_FRAME_OCC_PADDED))
+        TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
     const bool batched = grouped_enabled();
     const bool all_grouped = batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask;
     hipStream_t occ_on = nullptr;
@@ -784,7 +798,8 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         PadList pl;
         pl.n = a.npad;
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
-        zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);
+        static const int sce_fused_ = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
+        if (!sce_fused_) zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);          // (the fused scale context clears them itself)
         if (all_grouped && join_block_in(c) && fwd_overlap()) {
             // The first convs of the outter blocks read the occupancy only: they run on the second stream while this one does
             // the scale context and block_in's first conv (both single launches that leave most of the chip idle).
@@ -801,7 +816,8 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         // scale context: one small MLP per scale (model_core.py:48-53)
         static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
         if (sce_fused) {
-            sce_fwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, f->offset_feat, sce_args(c), c.R, a.MIX, a.HID, a.X0);
+            sce_fwd_k<<<linr_grid(c.R, LINR_BLOCK) + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
+                P, f->offset_feat, sce_args(c), c.R, a.MIX, a.HID, a.X0, a.base, pl);
         } else
         for (int s = 0; s < f->n_scales; ++s) {
             const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
@@ -880,7 +896,7 @@ extern "C" int linr_sce_fwd(const float* params, const linr_frame* f, float* mix
     if (!linr_aligned16(mix) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
     c.f = f;
     sce_fwd_k<<<linr_grid(f->rows, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sce_args(c), f->rows,
-                                                                                     mix, hid, x0);
+                                                                                     mix, hid, x0, nullptr, PadList{{}, {}, 0});
     return linr_launch_rc();
 }
 

@@ -37,7 +37,9 @@ class Frame:
         self.nbr_ld = (R + 63) // 64 * 64          # padded leading dimension: 16-byte aligned index rows
         self.nbr = torch.full((27, self.nbr_ld), -1, dtype=torch.int32, device=device)     # padding columns: no neighbour
         self.offset_feat = torch.empty((R, 7), dtype=torch.float32, device=device)
-        self.occ = torch.zeros((R, 8), dtype=torch.float32, device=device)
+        # occupancy with a zero row in front: the executor gathers it in place (LINR_FRAME_OCC_PADDED)
+        self._occ_buf = torch.zeros((R + 1, 8), dtype=torch.float32, device=device)
+        self.occ = self._occ_buf[1:]
         for i, s in enumerate(scales):
             r0, r1 = int(self.row_off[i]), int(self.row_off[i + 1])
             coord = torch.as_tensor(s['coord']).to(device=device, dtype=torch.int32).contiguous()
@@ -78,7 +80,7 @@ class Frame:
         if with_arena:
             self.alloc_arena()
         self._c = _lib.LinrFrame(rows=R, n_scales=self.n_scales, model_scale_num=self.model_scale_num,
-                                 block_layers=self.block_layers, reserved_=0,
+                                 block_layers=self.block_layers, flags=_lib.LINR_FRAME_OCC_PADDED,
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),

@@ -256,7 +256,7 @@ def test_scale_context_forward_backward(env, golden_dir):
     sidx = np.asarray([si for _, si in use], dtype=np.int32)
     R = int(row_off[-1])
     off_feat = torch.cat(offs).to(dev).contiguous()
-    fr = env['lib'].LinrFrame(rows=R, n_scales=3, model_scale_num=5, block_layers=2, reserved_=0, row_off_h=row_off.ctypes.data,
+    fr = env['lib'].LinrFrame(rows=R, n_scales=3, model_scale_num=5, block_layers=2, flags=0, row_off_h=row_off.ctypes.data,
                               scale_idx_h=sidx.ctypes.data, nbr=0, nbr_ld=R, nbr_lo=0, nbr_mask=0, offset_feat=off_feat.data_ptr(), occ=0, wg_ranges=0, nbr8=0, nbr8t=0)
     mix, hid, x0 = (torch.empty((R, c), device=dev) for c in (16, 16, 8))
     env['lib'].check(L.linr_sce_fwd(model.flat_parameters().data_ptr(), ctypes.byref(fr), mix.data_ptr(), hid.data_ptr(), x0.data_ptr(),
