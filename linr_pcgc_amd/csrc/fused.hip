@@ -1406,7 +1406,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     per = (per + 7) & ~(int64_t)7;
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const char* pad = reinterpret_cast<const char*>(S.in - 8) + 16 * gq;
+    // gathers in saddr form: uniform base (the zero pad row) + a 32-bit lane offset ((index + 1) * 32 + 16 quad)
+    const char* ubase = reinterpret_cast<const char*>(S.in - 8);
+    const uint32_t uoff = 32u + 16u * gq;
     const float* gsel = (DUAL && q) ? S.g1 : S.g0;
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
     const int gl = DUAL ? (lane & 31) : lane;
@@ -1431,7 +1433,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
         gvc = (g00 + gu < n) ? gsel[(g00 + gu) * gld + gc] : 0.0f;
         const int32_t i0[8] = {a0.x, a0.y, a0.z, a0.w, c0.x, c0.y, c0.z, c0.w};
 #pragma unroll
-        for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(i0[j] + 1) << 5));
+        for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)i0[j] << 5) + uoff));
         const int64_t g1r = g00 + 8 * WG_WAVES;           // spare all -1 groups behind the last row group: no bounds check
         ia = *reinterpret_cast<const int4*>(tk + g1r * 32);
         ib = *reinterpret_cast<const int4*>(tk + g1r * 32 + 4);
@@ -1441,12 +1443,13 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
         // (a) the gathered pieces of this group (requested one iteration ago) -> LDS image, tap-major
 #pragma unroll
         for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wr0 + (uint32_t)(4 * j * TW_PITCH)) = xg[j];
+        __builtin_amdgcn_sched_barrier(0);      // writes first: hoisting the next gathers above them costs 14 register-pair copies
         const float gv = gvc;
         // (b) next group's gathers (its indices arrived during the last MFMAs) and the indices of the group after it
         {
             const int32_t idn[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
 #pragma unroll
-            for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(pad + ((uint32_t)(idn[j] + 1) << 5));
+            for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)idn[j] << 5) + uoff));
             gvc = gvn;
             const int64_t g2r = g0r + 16 * WG_WAVES;
             ia = *reinterpret_cast<const int4*>(tk + g2r * 32);
