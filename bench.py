@@ -74,8 +74,8 @@ def _time_launches(go, iters):
 
 def kernel_roofline(model, gop, live, iters=10):
     """Dominant kernel = the top line of the rocprofv3 kernel statistics of this command (profiles/): the 8->8
-    backward-weight kernel spconv_wgrad_mfma_k<2,8> (round 2: its tiled-index, software-pipelined form IDX = 3;
-    24 row passes per step in 5 launches, ~21 % of the step).  The
+    backward-weight kernel (round 2: spconv_wgrad_t_k<8>, coalesced gathers + wave-private LDS transpose; 24 row passes per
+    step in 3 grouped launches, ~20 % of the step).  The
     second line, the 8->8 convolution cconv_mfma_k<8,8,fwd> (the template behind forward, backward-data and the fused
     head / Inception variants, ~40 % together), is reported next to it as `conv`.
     `avg_launch_us` is measured LIVE over the timed region: the library brackets every launch of the two kernels inside
@@ -123,9 +123,9 @@ def kernel_roofline(model, gop, live, iters=10):
                 'single_launch_us': round(single_s * 1e6, 2)}
 
     d_wg = _time_launches(lambda: ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab,
-                                                        reduce=False, tile8=f.nbr8), iters)
+                                                        reduce=False, tile8t=f.nbr8t), iters)
     d_cv = _time_launches(lambda: ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out), iters)
-    roof = entry('spconv_wgrad_mfma_k<2,8,false,3> (8->8 weight gradient, tiled index table)', 'spconv_wgrad_mfma_8x8_bytes_per_launch', live['wgrad'], d_wg)
+    roof = entry('spconv_wgrad_t_k<8,false> (8->8 weight gradient: coalesced gathers + LDS transpose)', 'spconv_wgrad_mfma_8x8_bytes_per_launch', live['wgrad'], d_wg)
     roof['conv'] = entry('cconv_mfma_k<8,8,fwd,LOADW=8>', 'cconv_mfma_8x8_fwd_bytes_per_launch', live['conv'], d_cv)
     return roof
 

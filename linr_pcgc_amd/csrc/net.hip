@@ -488,12 +488,13 @@ static const int32_t* wg_t8(const Ctx& c) {
 }
 
 // transposed tiled table for the coalesced-gather + LDS-transpose weight-gradient kernels (csrc/fused.hip: spconv_wgrad_t_k).
-// LINR_WGRAD_T: 1 (default) = the 4-output kernels (conv 8->4, dual 4->4: 80.9 / 78.8 us per launch against 91.7 / 80.3
-// with direct gathers), 2 = the 8-output kernels too (105.0 against 102.7 us: their 64 MFMAs per group leave less room for
-// the LDS instructions), 0 = none
+// LINR_WGRAD_T: 2 (default) = every weight-gradient kernel, 1 = the 4-output kernels only (conv 8->4, dual 4->4), 0 = none.
+// First measurement (r2, 5-to-7-group schedule): 80.9 / 78.8 us per launch against 91.7 / 80.3 with direct gathers for the
+// 4-output kernels, but 105.0 against 102.7 for the 8->8 one.  After the LDS writes were pinned in front of the next gathers (no
+// register-pair copies) and the gathers went to saddr form, the 8->8 kernel wins too: 2.241 vs 2.253 ms/step (same box).
 static const int32_t* wg_t8t(const Ctx& c, int cout) {
-    if (wg_cmap()) return nullptr;
-    static const int v = getenv("LINR_WGRAD_T") ? atoi(getenv("LINR_WGRAD_T")) : 1;
+    if (wg_cmap() || linr_wgrad_lds_enabled()) return nullptr;      // (the launchers prefer this table over the other index sources)
+    static const int v = getenv("LINR_WGRAD_T") ? atoi(getenv("LINR_WGRAD_T")) : 2;
     return (v >= 2 || (v == 1 && cout == 4)) ? c.f->nbr8t : nullptr;
 }
 // The 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row) preferred the compressed map over the

@@ -583,7 +583,7 @@ def base_dumps(golden_dir, tmp_path_factory):
 B512 = {'LINR_WG_BLOCKS': '512'}
 SWITCHES = [({'LINR_JOIN_BLOCK_IN': '0'}, {}), ({'LINR_WGRAD_STREAM': '1', 'LINR_FWD_OVERLAP': '1'}, {}),
             ({'LINR_JOIN_BLOCK_IN': '0', 'LINR_WGRAD_STREAM': '0'}, {}), ({'LINR_WGRAD_LDS': '1'}, B512), ({'LINR_WGRAD_T': '0'}, {}),
-            ({'LINR_WGRAD_T': '2'}, {}), ({'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {}), ({'LINR_BATCHED': '0'}, {}),
+            ({'LINR_WGRAD_T': '1'}, {}), ({'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {}), ({'LINR_BATCHED': '0'}, {}),
             ({'LINR_SCE_FUSED': '0'}, {}), ({'LINR_OCC_SHARED': '0'}, {}), ({'LINR_CONV_MFMA': '0'}, {}), ({'LINR_CONV_MFMA': '2'}, {}),
             ({'LINR_WGRAD_CMAP': '1'}, {}), ({'LINR_WGRAD_STREAM': '1'}, {}),
             ({'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',

@@ -20,7 +20,7 @@ w = torch.randn(27, 8, 8, device=dev) * 0.1
 b = torch.zeros(8, device=dev)
 slab = torch.empty((512, 27 * 64 + 8), device=dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8=f.nbr8)
+    ops.spconv_wgrad_cmap(x[1:], g, f.nbr, None, None, R, 8, 8, slab=slab, reduce=False, tile8t=f.nbr8t)
     ops.spconv_cmap(x[1:], f.nbr_lo, f.nbr_mask, R, w, b, out=out)
 torch.cuda.synchronize()
 print('rows', R)
