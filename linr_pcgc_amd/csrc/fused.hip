@@ -1386,8 +1386,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     // one LDS buffer: the four wave-private images during the row loop, the fold scratch afterwards (32 KB per block: four
     // blocks per CU)
     constexpr int IMG_F4 = TW_TAPS * TW_PITCH / 16;
-    static_assert(WG_WAVES * IMG_F4 * 4 >= 64 * (NA + 1), "fold scratch must fit the images");
-    __shared__ float4 smem[WG_WAVES * IMG_F4];
+    constexpr int FOLD_F4 = 16 * (NA + 1);                 // one wave's accumulators: 64 lanes x (NA + 1) floats
+    constexpr int SMEM_F4 = WG_WAVES * (IMG_F4 > FOLD_F4 ? IMG_F4 : FOLD_F4);
+    __shared__ float4 smem[SMEM_F4];
     float* sacc = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1474,21 +1475,17 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
         });
     }
     __syncthreads();
-    // fold waves in wave order (fixed => reproducible)
-    float* mine = sacc + lane * (NA + 1);
-    for (int w = 0; w < WG_WAVES; ++w) {
-        if (wave == w) {
+    // Every wave parks its accumulators in its own LDS slice; the copy-out below adds the four slices in wave order
+    // (((w0 + w1) + w2) + w3: the association of the former wave-by-wave fold, so the bits do not change) - one barrier instead
+    // of four and no read-modify-write passes.
+    {
+        float* mine = sacc + (wave * 64 + lane) * (NA + 1);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int h = 0; h < HB; ++h)
+            for (int h = 0; h < HB; ++h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = (c * HB + h) * 4 + i;
-                        mine[e] = (w == 0) ? acc[c][h][i] : mine[e] + acc[c][h][i];
-                    }
-        }
-        __syncthreads();
+                for (int i = 0; i < 4; ++i) mine[(c * HB + h) * 4 + i] = acc[c][h][i];
     }
     __shared__ float sbias[WG_WAVES][16];
     {
@@ -1500,6 +1497,13 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
         __syncthreads();
     }
     {
+        auto fold4 = [&](int e) {
+            constexpr int W = 64 * (NA + 1);
+            float t = sacc[e];
+#pragma unroll
+            for (int w = 1; w < WG_WAVES; ++w) t += sacc[w * W + e];
+            return t;
+        };
         float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
         const int tid = threadIdx.x;
         if (tid < (DUAL ? 8 : COUT)) {
@@ -1511,7 +1515,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
         if constexpr (DUAL) {
             for (int e = tid; e < 2 * 432; e += WG_WAVES * 64) {
                 const int t = e / 432, r = e - 432 * t;
-                dst[(t ? dd.w_off1 : d.w_off) + r] = sacc[(32 * t + (r >> 4)) * (NA + 1) + (r & 15)];
+                dst[(t ? dd.w_off1 : d.w_off) + r] = fold4((32 * t + (r >> 4)) * (NA + 1) + (r & 15));
             }
         } else {
             const int cinv = d.cin_valid;
@@ -1519,7 +1523,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
             for (int e = tid; e < total; e += WG_WAVES * 64) {
                 const int kq = e / per_k, r = e - kq * per_k;
                 const int ci = r / COUT, co = r - ci * COUT;
-                dst[d.w_off + e] = sacc[(2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3)];
+                dst[d.w_off + e] = fold4((2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3));
             }
         }
     }

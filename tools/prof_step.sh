@@ -9,4 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python
 tail -1 /tmp/b_$TAG.log | cut -c1-180
 mkdir -p $R/gpurun_out/prof_$TAG
 find /tmp/prof_$TAG -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof_$TAG/kernel_stats.csv \;
+find /tmp/prof_$TAG -name "*kernel_trace.csv" -exec cp {} $R/gpurun_out/prof_$TAG/kernel_trace.csv \;
 python3 $R/tools/step_table.py $R/gpurun_out/prof_$TAG/kernel_stats.csv 96
