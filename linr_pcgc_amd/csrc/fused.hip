@@ -1519,11 +1519,19 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
             }
         } else {
             const int cinv = d.cin_valid;
-            const int per_k = cinv * COUT, total = 27 * per_k;
-            for (int e = tid; e < total; e += WG_WAVES * 64) {
-                const int kq = e / per_k, r = e - kq * per_k;
-                const int ci = r / COUT, co = r - ci * COUT;
-                dst[d.w_off + e] = fold4((2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3));
+            if (cinv == 8) {          // all but the first convs of the outter blocks: constant divisors (a runtime division costs ~20 VALU ops)
+                for (int e = tid; e < 27 * 8 * COUT; e += WG_WAVES * 64) {
+                    const int kq = e / (8 * COUT), r = e % (8 * COUT);
+                    const int ci = r / COUT, co = r % COUT;
+                    dst[d.w_off + e] = fold4((2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3));
+                }
+            } else {
+                const int per_k = cinv * COUT, total = 27 * per_k;
+                for (int e = tid; e < total; e += WG_WAVES * 64) {
+                    const int kq = e / per_k, r = e - kq * per_k;
+                    const int ci = r / COUT, co = r - ci * COUT;
+                    dst[d.w_off + e] = fold4((2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3));
+                }
             }
         }
     }
