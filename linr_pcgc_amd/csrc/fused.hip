@@ -1414,7 +1414,6 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
     const int gl = DUAL ? (lane & 31) : lane;
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
-    const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);
     // the lane's 8 indices (7 used) of a group: tile8t[group][gt][gu8][0..7]
     const int32_t* tk = tile8t + (gt * 8 + gu8) * 8;
     char* img = reinterpret_cast<char*>(smem + wave * IMG_F4);
@@ -1467,10 +1466,13 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
             static_for<HB>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 constexpr int ab = u * HB + h;
+                // all four components unconditionally: the cin_valid skip of spconv_wgrad_mfma_k (scalar branches between the
+                // MFMAs) costs this kernel more than the dead MFMAs of the three narrow first convs do (2.213 vs 2.227 ms/step);
+                // accumulators of input channels >= cin_valid are never written out
                 acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
-                if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
-                if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
-                if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
+                acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
+                acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
+                acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
             });
         });
     }
