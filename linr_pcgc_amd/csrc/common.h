@@ -9,6 +9,14 @@
 
 static inline int linr_hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 static inline int linr_launch_rc() { return linr_hip_rc(hipGetLastError()); }
+// Order in which every 3x3x3 forward / backward-data convolution kernel visits its 27 taps: step kk handles tap
+// LINR_TAP(kk) = column (kk / 3) + 9 * dz-index (kk % 3), i.e. the three dz taps of a (dx,dy) column back to back.  In the x-major row
+// order those three neighbours are consecutive rows, so the second and third gather of a column hit the cache lines the
+// first one brought in (pure gathers: 19.2 -> 17.7 us per pass, tools/gather_probe.hip; step -1.8 %).  The order is part
+// of the arithmetic (fp32 accumulation order of every output): ALL kernels of that family use it - MFMA, VALU, gather-table
+// reference, dual 4->4, shared occupancy conv - which keeps them bit-identical to each other and the decoder to the encoder.
+#define LINR_TAP(kk) (((kk) / 3) + 9 * ((kk) % 3))
+
 static inline bool linr_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline unsigned linr_grid(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 

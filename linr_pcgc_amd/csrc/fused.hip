@@ -89,7 +89,7 @@ template <int W> struct RowLoadF {
     }
 };
 
-// Plain conv3 forward / backward-data on the compressed map.  Same arithmetic order as spconv_gather_k (k ascending,
+// Plain conv3 forward / backward-data on the compressed map.  Same arithmetic order as spconv_gather_k (taps in LINR_TAP order,
 // gathered channel ascending) => bit-identical results.  `in` must have the zero pad row at index -1.
 //   BWD == false: acc[o] += x[i] * W[(k*GIN + i)*GOUT + o]
 //   BWD == true : acc[o] += x[i] * W[(k*GOUT + o)*GIN + i]   (gathered rows come from the mirrored offset)
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_k(const float* __restrict__ 
 #pragma unroll
     for (int o = 0; o < GOUT; ++o) acc[o] = (bias != nullptr) ? bias[o] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
+    for (int kk = 0; kk < 27; ++kk) {
+        const int k = LINR_TAP(kk);
         float x[LOADW];
         RowLoadF<LOADW>::run(pad + off[k], x);
         const float* __restrict__ wk = W + k * GIN * GOUT;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_k(const float* __restrict__ 
 // of their N dimension at Cout = 8).  The lane keeps the thread-per-row layout of the VALU kernel: B = the lane's
 // gathered feature x[ci], D = the lane's 4 accumulators, A = the weight row held by lanes 0..GOUT-1 (read from an LDS
 // copy of the whole [27][Cin][Cout] kernel).  K = 1 makes every instruction a single-rounding fmaf(x, w, acc), issued
-// in the same order as the VALU kernel (k ascending, ci ascending) => bit-identical results, at the MFMA rate
+// in the same order as the VALU kernel (taps in LINR_TAP order, ci ascending) => bit-identical results, at the MFMA rate
 // (measured 91-119 TFLOP/s for this stream vs 52-71 TFLOP/s for v_pk_fma_f32; tools/mfma_probe.hip, valu_probe.hip).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -288,18 +289,19 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
     // ds_read (a generic pointer would become flat loads, which force vmcnt(0)/lgkmcnt(0) waits and kill the pipeline)
     auto taps = [&](auto ld) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ld(off[u], x[u]);
+        for (int u = 0; u < PF; ++u) ld(off[LINR_TAP(u)], x[u]);
         __builtin_amdgcn_sched_barrier(0);
         static_for<27>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
+            constexpr int kk = decltype(kc)::value;          // step; k = the tap it handles (common.h: LINR_TAP)
+            constexpr int k = LINR_TAP(kk);
             constexpr int g = k / KPV, ab = (k % KPV) * HB;
-            if constexpr (k + PF < 27) ld(off[k + PF], x[(k + PF) % (PF + 1)]);
+            if constexpr (kk + PF < 27) ld(off[LINR_TAP(kk + PF)], x[(kk + PF) % (PF + 1)]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GIN; ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[0], 4, ab, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[0], 4, ab, 0);
                 if constexpr (GOUT == 8)
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[k % (PF + 1)][i], acc[1], 4, ab + 1, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[1], 4, ab + 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -610,22 +612,23 @@ __global__ __launch_bounds__(LINR_BLOCK) void cconv_dual44_k(const float* __rest
     float x0[PF + 1][4], x1[PF + 1][4];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        RowLoadF<4>::run(pad0 + (off[u] << rb0), x0[u]);
-        RowLoadF<4>::run(pad1 + (off[u] << rb1), x1[u]);
+        RowLoadF<4>::run(pad0 + (off[LINR_TAP(u)] << rb0), x0[u]);
+        RowLoadF<4>::run(pad1 + (off[LINR_TAP(u)] << rb1), x1[u]);
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<27>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;            // weight tap (decode_offsets already mirrored `off` for BWD)
+        constexpr int kk = decltype(kc)::value;           // step; k = weight tap (decode_offsets already mirrored `off` for BWD)
+        constexpr int k = LINR_TAP(kk);
         constexpr int g = k / 8, ab = (k % 8) * 2;
-        if constexpr (k + PF < 27) {
-            RowLoadF<4>::run(pad0 + (off[k + PF] << rb0), x0[(k + PF) % (PF + 1)]);
-            RowLoadF<4>::run(pad1 + (off[k + PF] << rb1), x1[(k + PF) % (PF + 1)]);
+        if constexpr (kk + PF < 27) {
+            RowLoadF<4>::run(pad0 + (off[LINR_TAP(kk + PF)] << rb0), x0[(kk + PF) % (PF + 1)]);
+            RowLoadF<4>::run(pad1 + (off[LINR_TAP(kk + PF)] << rb1), x1[(kk + PF) % (PF + 1)]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x0[k % (PF + 1)][i], acc0, 4, ab, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x1[k % (PF + 1)][i], acc1, 4, ab + 1, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x0[kk % (PF + 1)][i], acc0, 4, ab, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x1[kk % (PF + 1)][i], acc1, 4, ab + 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -718,7 +721,7 @@ int linr_conv_bwd_ga_launch(const float* gH, const int32_t* lo, const uint32_t* 
 // channel) pairs x 2 output quads = 56 MFMA blocks instead of 7 x 16 with zero-extended kernels, and 1/7 of the gathers.
 // The weights sit in LDS as the A-operand image wl[k][v][lane]: block (lane >> 2) of register v is combo 16 v + block,
 // combo c <-> pair p = c / 2 (block g = tri^-1(p), channel ci = p - g (g + 1) / 2), quad h = c % 2.  Per output the chain is
-// bias, then k ascending, ci ascending fmaf - the chain of cconv_mfma_k on that block alone, so the decoder's
+// bias, then taps in LINR_TAP order, ci ascending fmaf - the chain of cconv_mfma_k on that block alone, so the decoder's
 // block-by-block forward gives the same bits.
 struct Occ7Args { int64_t w[7], b[7], out[7]; };       // parameter offsets (kernel, bias) and output element offsets per block
 
@@ -757,16 +760,16 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __re
     float x[PF + 1][8];
     float wr[2][4];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) RowLoadF<8>::run(pad + off[u], x[u]);
+    for (int u = 0; u < PF; ++u) RowLoadF<8>::run(pad + off[LINR_TAP(u)], x[u]);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) wr[0][v] = wl[v * 64 + lane];
+    for (int v = 0; v < 4; ++v) wr[0][v] = wl[(LINR_TAP(0) * 4 + v) * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
     static_for<27>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k + PF < 27) RowLoadF<8>::run(pad + off[k + PF], x[(k + PF) % (PF + 1)]);
-        if constexpr (k + 1 < 27) {
+        constexpr int kk = decltype(kc)::value;            // step; tap LINR_TAP(kk)
+        if constexpr (kk + PF < 27) RowLoadF<8>::run(pad + off[LINR_TAP(kk + PF)], x[(kk + PF) % (PF + 1)]);
+        if constexpr (kk + 1 < 27) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) wr[(k + 1) & 1][v] = wl[((k + 1) * 4 + v) * 64 + lane];
+            for (int v = 0; v < 4; ++v) wr[(kk + 1) & 1][v] = wl[(LINR_TAP(kk + 1) * 4 + v) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
         // input channel outermost: consecutive MFMAs write different accumulators (no back-to-back dependent issue), and
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __re
                 static_for<2>([&](auto hc) {
                     constexpr int h = decltype(hc)::value;
                     constexpr int c = 2 * (g * (g + 1) / 2 + ci) + h;
-                    acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[k & 1][c / 16], x[k % (PF + 1)][ci], acc[g][h], 4, c % 16, 0);
+                    acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[kk & 1][c / 16], x[kk % (PF + 1)][ci], acc[g][h], 4, c % 16, 0);
                 });
             });
         });

@@ -161,13 +161,14 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
     constexpr int PF = 4;
     uint4 x[PF + 1];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const uint4*>(pad + off[u]);
+    for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(u)]);
     __builtin_amdgcn_sched_barrier(0);
     sfor<27>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k + PF < 27) x[(k + PF) % (PF + 1)] = *reinterpret_cast<const uint4*>(pad + off[k + PF]);
+        constexpr int kk = decltype(kc)::value;              // step; k = the tap it handles (common.h: LINR_TAP, the fp32 family's order)
+        constexpr int k = LINR_TAP(kk);
+        if constexpr (kk + PF < 27) x[(kk + PF) % (PF + 1)] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(kk + PF)]);
         __builtin_amdgcn_sched_barrier(0);
-        const uint4 r = x[k % (PF + 1)];
+        const uint4 r = x[kk % (PF + 1)];
         const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(r.x, r.y));
         const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(r.z, r.w));
         if constexpr (MODE == 0 || MODE == 1) {

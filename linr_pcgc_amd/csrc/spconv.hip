@@ -45,7 +45,8 @@ __global__ __launch_bounds__(LINR_BLOCK) void spconv_gather_k(
 #pragma unroll
     for (int k = 0; k < 27; ++k) idx[k] = nbr[(int64_t)(BWD ? 26 - k : k) * nbr_ld + row];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
+    for (int kk = 0; kk < 27; ++kk) {
+        const int k = LINR_TAP(kk);               // tap order of the conv family (common.h)
         const int32_t j = idx[k];
         if (PAD || j >= 0) {
             constexpr int XW = LOADW ? LOADW : GIN;
