@@ -10,9 +10,13 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-template <int ORD>
+template <int ORD, int XCD = 0>
 __global__ __launch_bounds__(256) void gather_a(const float* __restrict__ x, const int* __restrict__ nbr, long ld, long n, float* out) {
-    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    // XCD 1: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2): give every XCD one contiguous range of tiles
+    const long nb = gridDim.x, per = (nb + 7) / 8;
+    const long blk = XCD ? (long)(blockIdx.x % 8) * per + blockIdx.x / 8 : (long)blockIdx.x;
+    if (blk >= nb) return;
+    const long row = blk * 256 + threadIdx.x;
     const long r = row < n ? row : n - 1;
     const char* base = (const char*)x;
     float4 acc = make_float4(0, 0, 0, 0);
@@ -89,7 +93,7 @@ int main() {
     CK(hipMemset(x, 0, (n + 1) * 32));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int blocks = (int)((n + 255) / 256), iters = 50;
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) {
@@ -97,11 +101,12 @@ int main() {
                 else if (v == 1) gather_b<0><<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 2) gather_c<<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 3) gather_a<1><<<blocks, 256>>>(x, nbr, ld, n, out);
-                else gather_b<1><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else if (v == 4) gather_b<1><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else gather_a<1, 1><<<(blocks + 7) / 8 * 8, 256>>>(x, nbr, ld, n, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const char* nm[5] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major"};
+            const char* nm[6] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges"};
             if (rep) printf("%-40s %.2f us per pass (%ld rows, 27 taps x 32 B)\n", nm[v], ms * 1e3 / iters, n);
         }
     }
