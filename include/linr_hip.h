@@ -101,7 +101,7 @@ LINR_API int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const float*
 /* The same convolution on the COMPRESSED kernel map (linr_kmap_compress) and the matrix cores
  * (v_mfma_f32_4x4x1_16b_f32 with broadcast weights: 64 rows x 4 output channels x 1 input channel per instruction, no
  * padding; K = 1 keeps every product a single-rounding fmaf in the order of the conv family (the three dz taps of a (dx,dy)
- * column back to back: tap = kk / 3 + 9 * (kk % 3) at step kk; channel ascending), so results are
+ * column back to back, column by column inside an x-slab - LINR_TAP in csrc/common.h; channel ascending), so results are
  * bit-identical to linr_spconv_fwd / _bwd_data).  This is what the network executor launches.  Requirements: `in`
  * 16-byte aligned with in_ld in {4, 8} and a zero row at index -1 (LINR_PAD_ROW contract), cout (fwd) / cin (bwd) in {4, 8}.
  * bwd != 0 selects backward-data with `in` = output gradient, `out` = input gradient. */

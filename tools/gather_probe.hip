@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void gather_a(const float* __restrict__ x, con
     float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
     for (int kk = 0; kk < 27; ++kk) {
-        const int k = ORD ? (kk / 3) + 9 * (kk % 3) : kk;          // ORD 1: the three dz taps of a (dx,dy) column back to back
+        // ORD 1: the three dz taps of a (dx,dy) column back to back; ORD 2: additionally the three dy columns of an x-slab back to back
+        const int k = ORD == 2 ? (kk / 9) + 3 * ((kk / 3) % 3) + 9 * (kk % 3) : ORD ? (kk / 3) + 9 * (kk % 3) : kk;
         const unsigned off = (unsigned)(nbr[k * ld + r] + 1) << 5;
         const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 16);
         acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
@@ -93,7 +94,7 @@ int main() {
     CK(hipMemset(x, 0, (n + 1) * 32));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int blocks = (int)((n + 255) / 256), iters = 50;
-    for (int v = 0; v < 6; ++v) {
+    for (int v = 0; v < 7; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) {
@@ -102,11 +103,12 @@ int main() {
                 else if (v == 2) gather_c<<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 3) gather_a<1><<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 4) gather_b<1><<<blocks, 256>>>(x, nbr, ld, n, out);
-                else gather_a<1, 1><<<(blocks + 7) / 8 * 8, 256>>>(x, nbr, ld, n, out);
+                else if (v == 5) gather_a<1, 1><<<(blocks + 7) / 8 * 8, 256>>>(x, nbr, ld, n, out);
+                else gather_a<2><<<blocks, 256>>>(x, nbr, ld, n, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const char* nm[6] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges"};
+            const char* nm[7] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges", "A3 lane=row, taps x-slab-major (dx, dy, dz)"};
             if (rep) printf("%-40s %.2f us per pass (%ld rows, 27 taps x 32 B)\n", nm[v], ms * 1e3 / iters, n);
         }
     }
