@@ -139,8 +139,9 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
  * 27 x 8 indices of a row group are 864 contiguous bytes.  tile8: linr_kmap_tile8_bytes(n) bytes, 16-byte aligned. */
 LINR_API size_t linr_kmap_tile8_bytes(int64_t n);
 LINR_API int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream);
-/* The tiled copy in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[4 j + t][8 g + u] (-1 for tap 27, j = 7,
- * beyond n).  tile8t: linr_kmap_tile8t_bytes(n) bytes, 16-byte aligned. */
+/* The tiled copy in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[tap(4 j + t)][8 g + u] (-1 for position 27,
+ * j = 7, beyond n), tap(p) = p / 9 + 3 * ((p / 3) % 3) + 9 * (p % 3): the conv family's slab-major tap sequence, so that the four
+ * taps of one gather instruction are neighbours in memory.  tile8t: linr_kmap_tile8t_bytes(n) bytes, 16-byte aligned. */
 LINR_API size_t linr_kmap_tile8t_bytes(int64_t n);
 LINR_API int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8t, size_t tile8t_bytes, void* stream);
 LINR_API size_t linr_wgrad_ranges_bytes(int64_t n);

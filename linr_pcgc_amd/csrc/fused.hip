@@ -1420,8 +1420,14 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     // the lane's 8 indices (7 used) of a group: tile8t[group][gt][gu8][0..7]
     const int32_t* tk = tile8t + (gt * 8 + gu8) * 8;
     char* img = reinterpret_cast<char*>(smem + wave * IMG_F4);
-    // write position of gather j: tap 4 j + gt (tap 27 = the dump slot); read position of MFMA row u: tap k
-    const uint32_t wr0 = (uint32_t)(gt * TW_PITCH + gu8 * 32 + gq * 16);
+    // write position of gather j: the tap at position 4 j + gt of the slab-major sequence (position 27 = the dump slot); read
+    // position of MFMA row u: tap k
+    uint32_t wofs[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int p = 4 * j + gt;
+        wofs[j] = (uint32_t)((p < 27 ? LINR_TAP(p) : 27) * TW_PITCH + gu8 * 32 + gq * 16);
+    }
     const uint32_t rd0 = (uint32_t)(k * TW_PITCH + q * 16);
     float bsum = 0.0f;
     const int64_t g00 = b0 + 8 * wave;
@@ -1445,7 +1451,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     for (int64_t g0r = g00; g0r < b1; g0r += 8 * WG_WAVES) {
         // (a) the gathered pieces of this group (requested one iteration ago) -> LDS image, tap-major
 #pragma unroll
-        for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wr0 + (uint32_t)(4 * j * TW_PITCH)) = xg[j];
+        for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wofs[j]) = xg[j];
         __builtin_amdgcn_sched_barrier(0);      // writes first: hoisting the next gathers above them costs 14 register-pair copies
         const float gv = gvc;
         // (b) next group's gathers (its indices arrived during the last MFMAs) and the indices of the group after it
@@ -1542,17 +1548,18 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_t_k(WgradSrc S, co
     }
 }
 
-// tile8t[g][t][u][j] = nbr[4 j + t][8 g + u] (-1 for tap 27, for j = 7 and beyond n): a lane (t, u) of the transposing kernel reads
-// its seven indices of group g as two 16-byte loads
+// tile8t[g][t][u][j] = nbr[LINR_TAP(4 j + t)][8 g + u] (-1 for position 27, for j = 7 and beyond n): a lane (t, u) of the transposing
+// kernel reads its seven indices of group g as two 16-byte loads.  Gather instruction j fetches the taps at positions 4 j .. 4 j + 3
+// of the convolutions' slab-major tap sequence (common.h: LINR_TAP), i.e. neighbours that sit in the same few cache lines
 __global__ __launch_bounds__(LINR_BLOCK) void kmap_tile8t_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t groups,
                                                             int32_t* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (e >= groups * 256) return;
     const int64_t g = e >> 8;
     const int r = (int)(e & 255), t = r >> 6, u = (r >> 3) & 7, j = r & 7;
-    const int k = 4 * j + t;
+    const int p = 4 * j + t;                 // position in the gather sequence; its tap: the convolutions' slab-major order
     const int64_t row = 8 * g + u;
-    out[e] = (j < 7 && k < 27 && row < n) ? nbr[(int64_t)k * ld + row] : -1;
+    out[e] = (j < 7 && p < 27 && row < n) ? nbr[(int64_t)LINR_TAP(p) * ld + row] : -1;
 }
 
 extern "C" size_t linr_kmap_tile8t_bytes(int64_t n) {
