@@ -18,6 +18,12 @@ from .model_codec import Model_Estimate
 from .model_core import encode_streams
 from .module_utils import octree_level_obj, qscTensor, unique_sorted  # noqa: F401
 
+# The probabilities the range coder sees must be reproduced BIT FOR BIT by the decoder, so the fp32 evaluation order of the
+# network is part of the stream format.  ARITH_VERSION names it: 1 = taps in ascending index order (rounds 1 and 2 up to the
+# "joined schedule" builds), 2 = slab-major tap order (csrc/common.h: LINR_TAP).  A stream carries the version it was coded
+# with in side_info.json; decoding one of another version raises instead of silently producing wrong geometry.
+ARITH_VERSION = 2
+
 
 def enc_all_frame_low_xyz(gop):
     """test_utils.py:199-232: uint8 coarsest-scale coordinates per frame + int32 coordinate minima."""
@@ -51,6 +57,7 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
                  'enc_mode': comp['enc_mode'], 'bitdepth': bitdepth}
     if precision != 'f32':
         side_info['precision'] = precision
+    side_info['arith_version'] = ARITH_VERSION
     # Pipeline: the GPU forward + D2H of frame i+1 runs while host workers range-code earlier frames (the coder's C call
     # releases the GIL).  A frame has 8 x scales independent streams, but the 8 streams of its finest scale carry 73 % of the
     # symbols, so one frame keeps only ~8 threads busy: TWO frames are coded concurrently, each on half of the threads
@@ -139,6 +146,12 @@ def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1):
     be parallelised, but the range decoding of one frame overlaps the stage forwards and copies of the others; the
     C calls release the GIL)."""
     side = dict(enc['side_info'])
+    coded_with = int(side.pop('arith_version', 1))
+    if coded_with != ARITH_VERSION:
+        from ._lib import LinrError
+        raise LinrError('this stream was coded with network arithmetic version %d; this build decodes version %d (the fp32 '
+                        'accumulation order of the convolutions is part of the stream format: decode with the build that '
+                        'encoded it)' % (coded_with, ARITH_VERSION))
     side['final_bytes'] = enc['model_bin']
     model, _ = Model_Estimate().decompress_model(model_ori, side)
     model.inference_precision = side.get('precision', 'f32')

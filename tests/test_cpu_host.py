@@ -275,3 +275,15 @@ def test_ply_reader(tmp_path, binary):
     with pytest.raises(ValueError):
         open(str(tmp_path / 'd.ply'), 'wb').write(b'plx\n')
         ply.read_points(str(tmp_path / 'd.ply'))
+
+
+def test_decoder_refuses_streams_of_another_arithmetic_version():
+    """The decoder must reproduce the encoder's probabilities bit for bit, so the fp32 evaluation order of the network is part of
+    the stream format (codec.ARITH_VERSION, written to side_info.json): a stream of another version is refused before anything
+    touches the GPU; streams without the tag are version 1."""
+    from linr_pcgc_amd import codec
+    from linr_pcgc_amd._lib import LinrError
+    assert codec.ARITH_VERSION >= 2
+    for side in ({'arith_version': codec.ARITH_VERSION - 1}, {}):
+        with pytest.raises(LinrError, match='arithmetic version'):
+            codec.decode_gop(None, {'side_info': side, 'model_bin': b'', 'low_enc_bytes': b'', 'frames': []})
