@@ -261,6 +261,21 @@ LINR_API int linr_net_forward_bf16(const linr_frame* f, const uint8_t* codes, fl
                           size_t arena_bytes, int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc,
                           void* stream);
 
+/* Staged DECODE of one frame object (decoder.decode_one_frame, decoder.py:153-176 + CNP.decode, models/upsample.py:249-295) as
+ * ONE call: for stage k = 0..7 { linr_net_forward[_bf16](k, k+1); probabilities of the stage -> pinned host buffer; the range
+ * decoder on every scale's stream k (linr_ac_decode_binary, host); decoded symbols -> column k of f->occ } - the loop the
+ * reference runs in Python with 16 .cpu() round trips per scale.  The call returns after the last stage (it synchronises
+ * the stream once per stage by construction) and does not hold the Python GIL, so a host thread per frame scales.
+ * streams_h / stream_len_h: HOST arrays [f->n_scales][8] of the per-stage streams (pack_bitstream payloads) and their byte
+ * lengths; f->occ must be writable device memory (the frame's occupancy, zeroed by the caller; LINR_FRAME_OCC_PADDED honoured);
+ * probs [8][rows] device scratch (holds all 8 stages' probabilities afterwards); p_pinned [rows] floats and s_pinned [rows]
+ * bytes of page-locked host memory; s_dev [rows] bytes of device scratch.  codes == NULL: fp32 executor with `params`;
+ * otherwise the bf16 / uint8-weight executor with codes, min_param, max_param (then `arena` is a linr_net_bf16_arena_bytes one). */
+LINR_API int linr_net_decode_stages(const linr_frame* f, const float* params, const uint8_t* codes, float min_param,
+                           float max_param, void* arena, size_t arena_bytes, const uint8_t* const* streams_h,
+                           const int64_t* stream_len_h, float* probs, float* p_pinned, uint8_t* s_pinned, uint8_t* s_dev,
+                           void* stream);
+
 /* ---- the executor's fused layers as stand-alone ops ------------------------------------------------------------
  * What linr_net_forward / _backward launch for one layer, callable (and testable) on its own.  All of them work on the
  * compressed kernel map (linr_kmap_compress) and follow the LINR_PAD_ROW contract: every matrix that a kernel GATHERS

@@ -94,6 +94,8 @@ _PROTOS = {
     'linr_occ_conv7': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'linr_net_decode_stages': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
+                                              c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_cdf16': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_ac_encode_binary_batch': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32]),

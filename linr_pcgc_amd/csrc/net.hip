@@ -1178,6 +1178,40 @@ extern "C" int linr_net_backward(const linr_frame* f, const float* params, float
     return linr_launch_rc();
 }
 
+// decoded byte column -> float column k of the occupancy matrix [rows][8]
+__global__ __launch_bounds__(LINR_BLOCK) void occ_col_from_u8_k(const uint8_t* __restrict__ sym, int64_t n, float* __restrict__ occ_col) {
+    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (r < n) occ_col[r * 8] = (float)sym[r];
+}
+
+extern "C" int linr_net_decode_stages(const linr_frame* f, const float* params, const uint8_t* codes, float min_param,
+                                      float max_param, void* arena, size_t arena_bytes, const uint8_t* const* streams_h,
+                                      const int64_t* stream_len_h, float* probs, float* p_pinned, uint8_t* s_pinned,
+                                      uint8_t* s_dev, void* stream) {
+    if (!f || !arena || !streams_h || !stream_len_h || !probs || !p_pinned || !s_pinned || !s_dev || !f->occ) return LINR_EINVAL;
+    if (!codes && !params) return LINR_EINVAL;
+    const int64_t R = f->rows;
+    if (R == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float* occ = const_cast<float*>(f->occ);
+    for (int k = 0; k < 8; ++k) {
+        if (codes) TRY(linr_net_forward_bf16(f, codes, min_param, max_param, arena, arena_bytes, k, k + 1, probs, nullptr, stream));
+        else TRY(linr_net_forward(f, params, (float*)arena, arena_bytes, k, k + 1, probs, nullptr, stream));
+        TRY(linr_hip_rc(hipMemcpyAsync(p_pinned, probs + (int64_t)k * R, (size_t)R * sizeof(float), hipMemcpyDeviceToHost, s)));
+        TRY(linr_hip_rc(hipStreamSynchronize(s)));
+        for (int i = 0; i < f->n_scales; ++i) {
+            const int64_t r0 = f->row_off_h[i], n = f->row_off_h[i + 1] - r0;
+            if (n <= 0) continue;
+            const int rc = linr_ac_decode_binary(p_pinned + r0, n, streams_h[i * 8 + k], stream_len_h[i * 8 + k], s_pinned + r0);
+            if (rc) return rc;
+        }
+        TRY(linr_hip_rc(hipMemcpyAsync(s_dev, s_pinned, (size_t)R, hipMemcpyHostToDevice, s)));
+        occ_col_from_u8_k<<<linr_grid(R, LINR_BLOCK), LINR_BLOCK, 0, s>>>(s_dev, R, occ + k);
+        TRY(linr_launch_rc());
+    }
+    return linr_hip_rc(hipStreamSynchronize(s));       // s_pinned / p_pinned may be reused by the caller right away
+}
+
 extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
                                    float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
                                    double beta1, double beta2, double eps, double weight_decay, double* bits_acc,

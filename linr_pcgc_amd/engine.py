@@ -125,6 +125,27 @@ def net_forward_bf16(frame, codes, min_param, max_param, stage_begin, stage_end,
                                            0 if bits is None else bits.data_ptr(), _stream()), 'linr_net_forward_bf16')
 
 
+def net_decode_stages(frame, flat_params, streams_per_scale, probs, p_pinned, s_pinned, s_dev, qcodes=None, qrange=None):
+    """linr_net_decode_stages: the 8 decode stages of a frame object (stage forward, D2H, range decoder, H2D, occupancy column)
+    in one C call that does not hold the GIL.  streams_per_scale: [n_scales][8] byte strings; qcodes / qrange select the bf16 /
+    uint8-weight executor.  frame.occ must be zeroed by the caller and holds the decoded occupancy afterwards."""
+    n = frame.n_scales
+    bufs = [np.frombuffer(streams_per_scale[i][k], dtype=np.uint8) for i in range(n) for k in range(8)]
+    ptrs = (ctypes.c_void_p * (8 * n))(*[b.ctypes.data if b.size else None for b in bufs])
+    lens = (ctypes.c_int64 * (8 * n))(*[int(b.size) for b in bufs])
+    if qcodes is None:
+        arena, codes, lo, hi = frame.arena, None, 0.0, 0.0
+        base, nbytes = arena.data_ptr(), arena.numel()
+    else:
+        arena = frame.bf16_arena()
+        base = (arena.data_ptr() + 63) & ~63
+        nbytes = arena.numel() - (base - arena.data_ptr())
+        codes, lo, hi = qcodes.data_ptr(), float(qrange[0]), float(qrange[1])
+    check(_lib.lib().linr_net_decode_stages(frame.cref(), None if flat_params is None else flat_params.data_ptr(), codes, lo, hi,
+                                            base, nbytes, ptrs, lens, probs.data_ptr(), p_pinned.data_ptr(), s_pinned.data_ptr(),
+                                            s_dev.data_ptr(), _stream()), 'linr_net_decode_stages')
+
+
 def net_backward(frame, flat_params, flat_grads, gscale, arena=None):
     """flat_grads += gscale * d bits / d params (needs a preceding full net_forward on the same arena)."""
     arena = frame.arena if arena is None else arena

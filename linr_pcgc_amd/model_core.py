@@ -251,22 +251,14 @@ class LINR_PCGC_Model(nn.Module):
         frame.occ.zero_()
         rows = frame.rows
         probs = torch.empty((8, rows), dtype=torch.float32, device=frame.device)
+        s_dev = torch.empty(max(rows, 1), dtype=torch.uint8, device=frame.device)
         p_host, s_host = self._host_buffers(rows)
-        p_np, s_np = p_host.numpy(), s_host.numpy()
-        L = _lib.lib()
         precision = self._precision(precision)
-        for k in range(8):
-            self._stage_forward(frame, k, k + 1, probs, None, precision)
-            p_host[:rows].copy_(probs[k])                       # synchronous D2H
-            for i in range(frame.n_scales):
-                sl = frame.scale_slice(i)
-                n = sl.stop - sl.start
-                if n == 0:
-                    continue
-                buf = np.frombuffer(streams_per_scale[i][k], dtype=np.uint8)
-                _lib.check(L.linr_ac_decode_binary(p_np[sl.start:].ctypes.data, n, buf.ctypes.data if buf.size else None,
-                                                   buf.size, s_np[sl.start:].ctypes.data), 'linr_ac_decode_binary')
-            frame.occ[:, k] = s_host[:rows].to(frame.device, non_blocking=False).to(torch.float32)
+        # the whole stage loop is one C call (csrc/net.hip: linr_net_decode_stages): no Python between the stages, no GIL held
+        if precision == 'bf16':
+            engine.net_decode_stages(frame, None, streams_per_scale, probs, p_host, s_host, s_dev, self._qcodes, self._qrange)
+        else:
+            engine.net_decode_stages(frame, self._flat, streams_per_scale, probs, p_host, s_host, s_dev)
         return [frame.occ[:, k:k + 1].clone() for k in range(8)]
 
 
