@@ -132,6 +132,15 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
                            const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab,
                            void* stream);
+/* Backward of a convolution 8 -> 8 from ONE gather of the output gradient (csrc/fused_bwd.hip; what the executor launches for
+ * the prune convolutions, the blocks' tail convolutions and block_in's first convolution, i.e. the autograd nodes of
+ * upsample.py:20-23,88-97):  gin = backward-data of linr_spconv_cmap (bit-identical to it) and per-block partials of the
+ * kernel / bias gradient, slab[b][27 * 64 + 8], b < nblocks (every row is written; their ascending sum over b is
+ * MinkowskiConvolution's kernel / bias gradient).  gW[k] = sum_i in[i]^T gout[nbr(i, 26 - k)] - the rows backward-data gathers
+ * anyway - is accumulated from a wave-private LDS image of the gathered rows.  gout: [n][8], 16-byte aligned, zero row at
+ * index -1; in: [n][8] (the convolution's input); gin: [n][8], 16-byte aligned. */
+LINR_API int linr_spconv_bwd_fused(const float* gout, const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                          int64_t n, const float* W, float* gin, float* slab, int32_t nblocks, void* stream);
 /* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
  * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
  * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */

@@ -139,6 +139,12 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr,
                           int ngroups = 1, const int32_t* lo = nullptr, const uint32_t* mask = nullptr,
                           const int32_t* ranges = nullptr, const int32_t* tile8 = nullptr, const int32_t* tile8t = nullptr);
+struct PwArgs;
+// backward-data + weight gradient of a conv 8->8 from one gather (csrc/fused_bwd.hip); pw != nullptr: gM epilogue
+__attribute__((visibility("hidden")))
+int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                 const float* W, float* out, const PwArgs* pw, LinrWgradDst d, int nb, hipStream_t s,
+                                 const Grp* gp = nullptr, int ngroups = 1);
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,

@@ -7,6 +7,7 @@
 // Arena: every activation / gradient matrix is [1 + rows][ld] with an all-zero row in FRONT (row index -1), so the
 // sparse convolutions read absent neighbours from it (LINR_PAD_ROW) with no branch.
 #include "common.h"
+#include "conv_common.h"
 #include "layout.h"
 #include <math.h>
 #include <stdlib.h>
@@ -455,6 +456,13 @@ static bool grouped_enabled() {
 static bool join_block_in(const Ctx& c) {
     static const int v = getenv("LINR_JOIN_BLOCK_IN") ? atoi(getenv("LINR_JOIN_BLOCK_IN")) : 1;
     return v != 0 && grouped_enabled() && c.f->nbr_lo && c.f->nbr_mask && c.L.block_in.nl == 1;
+}
+
+// backward-data and weight gradient of the 8->8 convolutions from ONE gather (csrc/fused_bwd.hip); LINR_FUSED_BWD=0 restores the
+// two-kernel schedule (same input gradients bit for bit, weight gradients in another summation order)
+static bool fused_bwd(const Ctx& c) {
+    static const int v = getenv("LINR_FUSED_BWD") ? atoi(getenv("LINR_FUSED_BWD")) : 1;
+    return v != 0 && c.f->nbr_lo && c.f->nbr_mask;
 }
 
 static bool fwd_overlap() {          // opt-in, see the second-stream policy above
@@ -964,6 +972,14 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             TRY(linr_head_bwd_launch(a.C[0], a.P[0], a.OCC, 8, h_w1[0], h_b1[0], h_w2[0], gz_scale, a.gC[0], c.R, a.BIG, L.total,
                                      o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8, c.nb));
         }
+        if (fused_bwd(c)) {   // C = conv3(prior_k; prune_k): gO[k] = bwd(gC[k]) and the weight gradients from one gather of gC
+            Grp gp = Grp();
+            goffs(gp.in, h_gC, 8); goffs(gp.res, hO, 8); goffs(gp.w, h_prw, 8); goffs(gp.out, h_gO, 8);
+            goffs_i(gp.e3, o_prw, 8); goffs_i(gp.e4, o_prb, 8);
+            LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
+            ProfScope ps(c.s, 0, 8);
+            TRY(linr_conv88_bwd_wgrad_launch(a.gC[0], a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], a.gO[0], nullptr, d, c.nb, c.s, &gp, 8));
+        } else {
         {   // C = conv3(prior_k; prune_k): weight gradients ...
             Grp gp = Grp();
             goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
@@ -977,6 +993,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             goffs(gp.in, h_gC, 8); goffs(gp.w, h_prw, 8); goffs(gp.out, h_gO, 8);
             TRY(linr_cconv_launch(true, a.gC[0], 8, lo, mk, c.nbr_ld, c.R, h_prw[0], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO[0],
                                   8, 0, c.s, &gp, 8));
+        }
         }
         Ptr8 src;
         for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
@@ -1001,6 +1018,15 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         o_c10b[g] = bp.inc[0].c10_b; o_aw[g] = bp.a_w; o_ab[g] = bp.a_b;
     }
     (void)o7;
+    if (fused_bwd(c)) {   // O = conv3(I; b): gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0) and the weight gradient, one gather of gO
+        Grp gp = Grp();
+        goffs(gp.in, p_gO, ng); goffs(gp.res, pI, ng); goffs(gp.w, p_bw, ng); goffs(gp.out, p_gI, ng);
+        goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng); goffs(gp.e2, p_gM, ng); goffs_i(gp.e3, o_bw, ng); goffs_i(gp.e4, o_bb, ng);
+        LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
+        PwArgs pw = {p_c12w[0], nullptr, pM[0], a.gM[g0]};
+        ProfScope ps(c.s, 0, ng);
+        TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng));
+    } else {
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
         goffs(gp.in, pI, ng); goffs(gp.res, p_gO, ng); goffs_i(gp.w, o_bw, ng); goffs_i(gp.b, o_bb, ng);
@@ -1014,6 +1040,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         goffs(gp.in, p_gO, ng); goffs(gp.w, p_bw, ng); goffs(gp.out, p_gI, ng); goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng);
         goffs(gp.e2, p_gM, ng);
         TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[g0], a.gM[g0], c.s, &gp, ng));
+    }
     }
     {   // conv1_2 weight gradient: M^T gI[:,4:8]
         Grp gp = Grp();
@@ -1053,13 +1080,16 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
     }
     {   // A = relu(conv3(in; a)): weight gradient on the first b channels of the occupancy rows (outter block b) or on all 8
         // channels of the scale context x0 (block_in)
+        // (with the fused backward block_in's first conv - slot 0 - gets its weight gradient from the launch that also produces
+        // its input gradient, backward_core; the grouped launch then covers the outter blocks only)
+        const int s0 = (join && fused_bwd(c)) ? 1 : 0, nq = ng - s0;
         Grp gp = Grp();
-        goffs(gp.in, p_in, ng); goffs(gp.res, p_gA, ng); goffs_i(gp.w, o_aw, ng); goffs_i(gp.b, o_ab, ng);
-        for (int g = 0; g < ng; ++g) gp.e2[g] = (g0 + g == 0) ? 8 : g0 + g;
-        LinrWgradDst d = {a.BIG, L.total, o_aw[0], o_ab[0], 1};
+        goffs(gp.in, p_in + s0, nq); goffs(gp.res, p_gA + s0, nq); goffs_i(gp.w, o_aw + s0, nq); goffs_i(gp.b, o_ab + s0, nq);
+        for (int g = 0; g < nq; ++g) gp.e2[g] = (g0 + s0 + g == 0) ? 8 : g0 + s0 + g;
+        LinrWgradDst d = {a.BIG, L.total, o_aw[s0], o_ab[s0], 1};
         TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, ng);
-        TRY(linr_conv3_wgrad_mfma(p_in[0], 8, p_gA[0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, ng, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        ProfScope ps(c.ws, 0, nq, !fused_bwd(c));
+        TRY(linr_conv3_wgrad_mfma(p_in[s0], 8, p_gA[s0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, nq, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
     }
     return 0;
 }
@@ -1098,7 +1128,11 @@ static int backward_core(Ctx& c, float gscale) {
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
     if (aux && (aux_all(c.R, join) || !join)) c.ws = aux;     // block_in (unless joined) and the scale context: single launches, overlapped with the data chain
-    if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
+    if (join && fused_bwd(c)) {      // first conv of block_in: input gradient and weight gradient from one gather of gA[0]
+        const BlockP& bi = c.L.block_in;
+        LinrWgradDst d = {a.BIG, c.L.total, bi.a_w, bi.a_b, 8};
+        TRY(linr_conv88_bwd_wgrad_launch(a.gA[0], a.X0, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, a.gX0, nullptr, d, c.nb, c.s));
+    } else if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
         const BlockP& bi = c.L.block_in;
         TRY(conv3(c, true, a.gA[0], 8, P + bi.a_w, nullptr, bi.cin, 8, nullptr, 0, nullptr, 0, a.gX0, 8, 0));
     } else {

@@ -231,6 +231,21 @@ def spconv_wgrad_cmap(x, gout, nbr, lo, mask, n, cin, cout, slab=None, reduce=Tr
     return tot[:27 * cin * cout].view(27, cin, cout), tot[27 * cin * cout:]
 
 
+def spconv_bwd_fused(gout, x, lo, mask, n, kernel, nblocks=256, reduce=True):
+    """linr_spconv_bwd_fused: backward-data and weight gradient of a conv 8->8 from one gather of the output gradient.
+    gout: view buf[1:] of a [n+1, 8] buffer whose row 0 is zero; x [n, 8] the convolution's input.
+    Returns (gin [n, 8], gW [27, 8, 8], gb [8]), or (gin, slab [nblocks, 1736]) with reduce=False."""
+    gin = torch.empty((n, 8), dtype=torch.float32, device=gout.device)
+    slab = torch.full((nblocks, 1736), float('nan'), dtype=torch.float32, device=gout.device)
+    check(_lib.lib().linr_spconv_bwd_fused(gout.data_ptr(), x.data_ptr(), lo.data_ptr(), mask.data_ptr(), lo.stride(0), n,
+                                           kernel.data_ptr(), gin.data_ptr(), slab.data_ptr(), nblocks, _stream()),
+          'linr_spconv_bwd_fused')
+    if not reduce:
+        return gin, slab
+    tot = slab.double().sum(dim=0).float()
+    return gin, tot[:1728].view(27, 8, 8), tot[1728:]
+
+
 def octree_occupancy(child, parent):
     """occ float32 [N,8] of the parents (sorted unique floor(child/2)) of a sorted unique child list (int32 [M,3])."""
     _dev(child, torch.int32, 'child')

@@ -280,3 +280,34 @@ def test_scale_context_forward_backward(env, golden_dir):
     bad = np.asarray([0, 1, 5], dtype=np.int32)
     fr.scale_idx_h = bad.ctypes.data
     assert L.linr_sce_fwd(model.flat_parameters().data_ptr(), ctypes.byref(fr), mix.data_ptr(), hid.data_ptr(), x0.data_ptr(), _stream()) == -1
+
+
+@pytest.mark.parametrize('nblocks', [256, 4])
+def test_conv88_backward_fused_one_gather(env, nblocks):
+    """linr_spconv_bwd_fused (backward-data + weight gradient of a conv 8->8 from ONE gather of the output gradient): the input
+    gradient is bit-identical to linr_spconv_cmap's backward-data, kernel / bias gradients match autograd of the oracle
+    convolution (MinkowskiConvolution backward, a18) and every slab row is written."""
+    from linr_pcgc_amd import ops
+    dev, n = env['dev'], env['n']
+    gen = torch.Generator().manual_seed(77 + nblocks)
+    x_h = torch.randn(n, 8, generator=gen)
+    go_h = torch.randn(n, 8, generator=gen)
+    w_h = torch.randn(27, 8, 8, generator=gen) * 0.2
+    xo = x_h.clone().requires_grad_()
+    wo = w_h.clone().requires_grad_()
+    bo = torch.zeros(1, 8, requires_grad=True)
+    onet.conv3(xo, env['nbr_t'], wo, bo).backward(go_h)
+    _, go = _padded(go_h, dev)
+    x = x_h.to(dev).contiguous()
+    w = w_h.to(dev).contiguous()
+    ref_gin = ops.spconv_cmap(go, env['lo'], env['mask'], n, w, None, bwd=True)
+    gin, slab = ops.spconv_bwd_fused(go, x, env['lo'], env['mask'], n, w, nblocks=nblocks, reduce=False)
+    assert torch.equal(gin, ref_gin)
+    assert bool(torch.isfinite(slab).all()), 'slab rows left unwritten'
+    tot = slab.double().sum(dim=0)
+    _rel_own_max(tot[:1728].view(27, 8, 8), wo.grad, 'fused kernel gradient')
+    _rel_own_max(tot[1728:], bo.grad.reshape(-1), 'fused bias gradient')
+    _close(gin, xo.grad, 1e-4, 1e-4, 'fused input gradient')
+    # run-to-run reproducible (fixed fold order)
+    gin2, slab2 = ops.spconv_bwd_fused(go, x, env['lo'], env['mask'], n, w, nblocks=nblocks, reduce=False)
+    assert torch.equal(slab, slab2) and torch.equal(gin, gin2)
