@@ -335,6 +335,17 @@ LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g
                              const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
                              const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream);
 
+/* The backward of an Inception layer's two convolution pairs in the same form (models/resnet.py:55-60; gM comes from the
+ * caller: the tail convolution's epilogue or a pointwise op):
+ *   gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)  with dW01, db01, dW11, db11  (one gather of [gI[:, 0:4] | gM]), then
+ *   gX = (bwd(gH[:, 0:4]; W00) + gI (+ old gX: LINR_ACCUM) + gH[:, 4:8] @ W10^T) (* (x > 0): LINR_RELU_MASK)  with dW00, db00.
+ * gH and gX are bit-identical to linr_inception_bwd_data's.  slab: [nblocks][1744] per-block partials
+ * [W00 864 | b00 4 | W01 432 | b01 4 | W11 432 | b11 4 | pad 4], every row written; sum over the rows = the gradients.
+ * The pointwise kernels' gradients (conv1_0, conv1_2) are linr_linear_bwd_weight's job.  gI, gH, gX, x, H: [n][8], gM: [n][4], all
+ * 16-byte aligned; gI, gM and gH need the zero row at index -1. */
+LINR_API int linr_inception_bwd_fused(const float* gI, const float* gM, const float* x, const float* H, const int32_t* lo,
+                             const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gH, float* gX,
+                             uint32_t flags, float* slab, int32_t nblocks, void* stream);
 /* First convolutions of the 7 outter blocks (models/upsample.py:206-214 -> make_block's first conv + ReLU): block g + 1
  * computes relu(conv3(occ[:, :g+1]; kernel [27][g+1][8]) + bias) on the SAME gathered occupancy rows, so one gather feeds
  * all seven.  occ [n][8] (gathered); kernel / bias of block g at params + w_off_h[g] / b_off_h[g]; result of block g at

@@ -379,7 +379,7 @@ static int stream_order(hipStream_t from, hipStream_t to) {
 struct ProfRec { hipEvent_t e0, e1; int passes; };
 static std::atomic<bool> g_prof_on{false};
 static std::mutex g_prof_mu;                    // guards the two vectors below
-static std::vector<ProfRec> g_prof[2];          // used records
+static std::vector<ProfRec> g_prof[4];          // used records
 static std::vector<ProfRec> g_prof_free;        // pre-created event pairs (creating events in the hot path costs ~20 us each)
 
 struct ProfScope {
@@ -408,11 +408,11 @@ extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kep
     if (mode == 0) return 0;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (mode == 1)
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 4; ++k) {
             for (auto& r : g_prof[k]) g_prof_free.push_back(r);
             g_prof[k].clear();
         }
-    while (g_prof_free.size() + g_prof[0].size() + g_prof[1].size() < 2 * LINR_PROF_MAX) {
+    while (g_prof_free.size() + g_prof[0].size() + g_prof[1].size() + g_prof[2].size() + g_prof[3].size() < 2 * LINR_PROF_MAX) {
         ProfRec r;
         r.passes = 0;
         if (hipEventCreate(&r.e0) != hipSuccess) break;
@@ -424,7 +424,7 @@ extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kep
 }
 
 extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes) {
-    if (kind < 0 || kind > 1 || !total_ms || !launches || !passes) return LINR_EINVAL;
+    if (kind < 0 || kind > 3 || !total_ms || !launches || !passes) return LINR_EINVAL;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double t = 0.0;
     int64_t np = 0;
@@ -1049,7 +1049,14 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         TRY(stream_order(c.s, c.ws));
         TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.ws, &gp, ng));
     }
-    {   // both 4->4 convs: weight gradients, then gH
+    if (fused_bwd(c)) {   // both 4->4 convs: gH and the two kernel / bias gradients from one gather of [gI[:,0:4] | gM]
+        Grp gp = Grp();
+        goffs(gp.in, p_gI, ng); goffs(gp.e5, p_gM, ng); goffs(gp.res, pH, ng); goffs(gp.w, p_c01w, ng); goffs(gp.e6, p_c11w, ng);
+        goffs(gp.out, p_gH, ng); goffs_i(gp.e3, o_c01w, ng); goffs_i(gp.e4, o_c01b, ng); goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
+        ProfScope ps(c.s, 2, ng);
+        TRY(linr_dual44_bwd_wgrad_launch(p_gI[0], p_gM[0], pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], a.gH[g0], a.BIG, L.total,
+                                         o_c01w[0], o_c01b[0], o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng));
+    } else {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
         goffs(gp.in, pH, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, p_gM, ng); goffs_i(gp.w, o_c01w, ng); goffs_i(gp.b, o_c01b, ng);
         goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
@@ -1061,22 +1068,35 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         goffs(gq.act, pH, ng);
         TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[g0], c.s, &gq, ng));
     }
-    {   // conv0_0 (8->4) and conv1_0 (1x1 8->4) weight gradients
+    {   // conv1_0 (1x1 8->4) weight gradient
+        Grp gq = Grp();
+        goffs(gq.in, pA, ng); goffs(gq.res, p_gH, ng); goffs_i(gq.w, o_c10w, ng); goffs_i(gq.b, o_c10b, ng);
+        LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
+        TRY(stream_order(c.s, c.ws));
+        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, ng));
+    }
+    if (fused_bwd(c)) {   // conv0_0 (8->4): gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0) and its weight gradient, one gather
+        Grp gp = Grp();
+        goffs(gp.in, p_gH, ng); goffs(gp.res, pA, ng); goffs(gp.w, p_c00w, ng); goffs(gp.act, p_gI, ng); goffs(gp.out, p_gA, ng);
+        goffs(gp.e0, p_c10w, ng); goffs_i(gp.e3, o_c00w, ng); goffs_i(gp.e4, o_c00b, ng);
+        LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
+        ProfScope ps(c.s, 3, ng);
+        TRY(linr_conv84_bwd_wgrad_launch(p_gH[0], pA[0], p_gI[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], a.gA[g0], LINR_RELU_MASK, d,
+                                         c.nb, c.s, &gp, ng));
+    } else {
+    {   // conv0_0 (8->4) weight gradient
         Grp gp = Grp();
         goffs(gp.in, pA, ng); goffs(gp.res, p_gH, ng); goffs_i(gp.w, o_c00w, ng); goffs_i(gp.b, o_c00b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         TRY(stream_order(c.s, c.ws));
         TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.ws, &gp, ng, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
-        Grp gq = Grp();
-        goffs(gq.in, pA, ng); goffs(gq.res, p_gH, ng); goffs_i(gq.w, o_c10w, ng); goffs_i(gq.b, o_c10b, ng);
-        LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
-        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, ng));
     }
     {   // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
         Grp gp = Grp();
         goffs(gp.in, p_gH, ng); goffs(gp.w, p_c00w, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, pA, ng); goffs(gp.out, p_gA, ng);
         goffs(gp.e0, p_c10w, ng); goffs(gp.e1, p_gH, ng);
         TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[g0], LINR_RELU_MASK, c.s, &gp, ng));
+    }
     }
     {   // A = relu(conv3(in; a)): weight gradient on the first b channels of the occupancy rows (outter block b) or on all 8
         // channels of the scale context x0 (block_in)

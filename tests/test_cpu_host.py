@@ -68,7 +68,7 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_ac_encode_binary(None, None, 4, p16, 64) == -1
     assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
     tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
-    assert lib.linr_prof_read(2, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
+    assert lib.linr_prof_read(4, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
 
 
 def test_param_count_matches_reference_checkpoint(lib, golden_dir):

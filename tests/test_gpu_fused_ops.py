@@ -311,3 +311,51 @@ def test_conv88_backward_fused_one_gather(env, nblocks):
     # run-to-run reproducible (fixed fold order)
     gin2, slab2 = ops.spconv_bwd_fused(go, x, env['lo'], env['mask'], n, w, nblocks=nblocks, reduce=False)
     assert torch.equal(slab, slab2) and torch.equal(gin, gin2)
+
+
+@pytest.mark.parametrize('nblocks,flags', [(256, 0), (3, 6)])
+def test_inception_backward_fused_pairs(env, nblocks, flags):
+    """linr_inception_bwd_fused (both conv pairs of an Inception layer's backward, each from ONE gather): gH and gX are
+    bit-identical to linr_inception_bwd_data's, the kernel / bias gradients of conv0_0, conv0_1 and conv1_1 match autograd through
+    oracle.network.inception (models/resnet.py:55-60); flags 6 = LINR_ACCUM | LINR_RELU_MASK (block_in's layer 0)."""
+    L, dev, n = env['L'], env['dev'], env['n']
+    gen = torch.Generator().manual_seed(23 + nblocks)
+    x_h = torch.relu(torch.randn(n, 8, generator=gen))
+    w_h, w_d = _inc_params(gen, dev)
+    q = _inc_struct(env, w_d)
+    _, x = _padded(x_h, dev)
+    _, H = _empty_padded(n, 8, dev)
+    _, M = _empty_padded(n, 4, dev)
+    _, I = _empty_padded(n, 8, dev)
+    env['lib'].check(L.linr_inception_fwd(x.data_ptr(), env['lo'].data_ptr(), env['mask'].data_ptr(), env['ld'], n,
+                                          ctypes.byref(q), H.data_ptr(), M.data_ptr(), I.data_ptr(), _stream()), 'linr_inception_fwd')
+    xo = x_h.clone().requires_grad_()
+    wo = {k: v.clone().requires_grad_() for k, v in w_h.items()}
+    ref = _oracle_inception(xo, env['nbr_t'], wo)
+    gI_h = torch.randn(n, 8, generator=gen)
+    ref.backward(gI_h)
+    _, gI = _padded(gI_h, dev)
+    _, gM = _empty_padded(n, 4, dev)
+    _, gH = _empty_padded(n, 8, dev)
+    _, gX = _empty_padded(n, 8, dev)
+    old = torch.randn(n, 8, generator=gen).to(dev)
+    gX[:] = old
+    args = (gI.data_ptr(), x.data_ptr(), H.data_ptr(), M.data_ptr(), env['lo'].data_ptr(), env['mask'].data_ptr(), env['ld'], n,
+            ctypes.byref(q), gM.data_ptr(), gH.data_ptr(), gX.data_ptr())
+    env['lib'].check(L.linr_inception_bwd_data(*args, flags, _stream()), 'linr_inception_bwd_data')     # also leaves gM
+    _, gH2 = _empty_padded(n, 8, dev)
+    _, gX2 = _empty_padded(n, 8, dev)
+    gX2[:] = old
+    slab = torch.full((nblocks, 1744), float('nan'), device=dev)
+    env['lib'].check(L.linr_inception_bwd_fused(gI.data_ptr(), gM.data_ptr(), x.data_ptr(), H.data_ptr(), env['lo'].data_ptr(),
+                                                env['mask'].data_ptr(), env['ld'], n, ctypes.byref(q), gH2.data_ptr(), gX2.data_ptr(),
+                                                flags, slab.data_ptr(), nblocks, _stream()), 'linr_inception_bwd_fused')
+    assert torch.equal(gH, gH2) and torch.equal(gX, gX2)
+    assert bool(torch.isfinite(slab[:, :1740]).all()), 'slab rows left unwritten'
+    tot = slab.double().sum(0).cpu()
+    _rel_own_max(tot[:864].view(27, 8, 4), wo['w00'].grad, 'gW00')
+    _rel_own_max(tot[864:868], wo['b00'].grad, 'gb00')
+    _rel_own_max(tot[868:1300].view(27, 4, 4), wo['w01'].grad, 'gW01')
+    _rel_own_max(tot[1300:1304], wo['b01'].grad, 'gb01')
+    _rel_own_max(tot[1304:1736].view(27, 4, 4), wo['w11'].grad, 'gW11')
+    _rel_own_max(tot[1736:1740], wo['b11'].grad, 'gb11')
