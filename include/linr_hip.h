@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 2
+#define LINR_ABI_VERSION 3
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -110,28 +110,25 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
                      const float* res, int32_t res_ld, const float* act, int32_t act_ld, float* out, int32_t out_ld,
                      uint32_t flags, void* stream);
 
-/* Backward-weight of the same convolution as the executor runs it (spconv_wgrad_mfma_k on the compressed map: lane =
- * (offset, channel quad), gathered quad x broadcast gradient tile on v_mfma_f32_4x4x1, row order fixed => reproducible).
+/* Backward-weight of the same convolution as a stand-alone kernel (the executor uses it for the first convolutions of the outter
+ * blocks, whose inputs need no gradient, and for the schedules without the fused backward below): lane = (offset, channel quad),
+ * gathered quad x broadcast gradient tile on v_mfma_f32_4x4x1, row order fixed => reproducible.
  * Writes linr_spconv_wgrad_cmap_blocks() (= 512) per-block partials: slab[b][(27 cin + 1) cout], kernel gradient
  * [27][cin][cout] first, bias gradient [cout] last; their ascending sum over b is MinkowskiConvolution's kernel / bias
  * gradient (ME autograd of the call sites above).  `in`: [n][8] floats, 16-byte aligned, zero row at index -1.
- * lo / mask: the compressed map, or both NULL to take the indices from nbr[27][ld] (what the executor does by default:
- * 108 instead of 40 index bytes per row, but no decode instructions).
- * ranges: linr_wgrad_ranges_build's table or NULL.  With it (and in_ld = 8, a 16-byte aligned table with ld % 4 = 0) the
- * gathered rows are staged through LDS: in the x-major order the neighbours of a chunk of 128 consecutive rows lie in three
- * nearly contiguous row windows (one per x-slab), which the kernel copies with coalesced loads, double-buffered against the
- * MFMAs of the previous chunk.  Same partial sums, bit for bit.
- * tile8: linr_kmap_tile8's table or NULL.  With it (and lo / mask / ranges NULL) the indices come from the 8-row tiled copy of
- * the kernel map with a one-group software pipeline.  Same partial sums, bit for bit.
- * tile8t: linr_kmap_tile8t's table or NULL.  With it (in_ld = 8) the gathers are laid out like the convolutions' - lane = (tap of
- * 4, row of 8, quad): four 256-byte runs per instruction - into a wave-private LDS image that every (tap, quad) lane reads
- * back transposed (conflict-free pitch); the executor's default for the 4-output kernels.  Same partial sums, bit for bit.
- * Takes precedence over the other tables. */
+ * tile8t: linr_kmap_tile8t's table or NULL.  With it the gathers are laid out like the convolutions' - lane = (tap of 4, row of
+ * 8, quad): four 256-byte runs per instruction - into a wave-private LDS image that every (tap, quad) lane reads back
+ * transposed (spconv_wgrad_t_k, the executor's choice); without it the indices come from nbr[27][ld] and every lane gathers its
+ * own (tap, quad) (spconv_wgrad_mfma_k).  Same partial sums, bit for bit. */
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                           const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
-                           const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab,
-                           void* stream);
+                           const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream);
+/* The tiled copy of the kernel map in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[tap(4 j + t)][8 g + u]
+ * (-1 for position 27, j = 7, beyond n), tap(p) = p / 9 + 3 * ((p / 3) % 3) + 9 * (p % 3): the conv family's slab-major tap
+ * sequence, so that the four taps of one gather instruction are neighbours in memory.  tile8t: linr_kmap_tile8t_bytes(n) bytes,
+ * 16-byte aligned. */
+LINR_API size_t linr_kmap_tile8t_bytes(int64_t n);
+LINR_API int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8t, size_t tile8t_bytes, void* stream);
 /* Backward of a convolution 8 -> 8 from ONE gather of the output gradient (csrc/fused_bwd.hip; what the executor launches for
  * the prune convolutions, the blocks' tail convolutions and block_in's first convolution, i.e. the autograd nodes of
  * upsample.py:20-23,88-97):  gin = backward-data of linr_spconv_cmap (bit-identical to it) and per-block partials of the
@@ -141,29 +138,19 @@ LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float*
  * index -1; in: [n][8] (the convolution's input); gin: [n][8], 16-byte aligned. */
 LINR_API int linr_spconv_bwd_fused(const float* gout, const float* in, const int32_t* lo, const uint32_t* mask, int64_t ld,
                           int64_t n, const float* W, float* gin, float* slab, int32_t nblocks, void* stream);
-/* Per-frame window table of the LDS-staged weight-gradient kernels (coordinates are static over all epochs, so it is built
- * once next to the kernel map): for every chunk of 128 rows inside the fixed 512-block row partition, the first row and the
- * row count of the neighbour window of each x-slab.  ranges: linr_wgrad_ranges_bytes(n) bytes, 16-byte aligned. */
-/* 8-row tiled copy of the kernel map for the weight-gradient kernels: tile8[g][k][u] = nbr[k][8 g + u] (-1 beyond n), so the
- * 27 x 8 indices of a row group are 864 contiguous bytes.  tile8: linr_kmap_tile8_bytes(n) bytes, 16-byte aligned. */
-LINR_API size_t linr_kmap_tile8_bytes(int64_t n);
-LINR_API int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream);
-/* The tiled copy in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[tap(4 j + t)][8 g + u] (-1 for position 27,
- * j = 7, beyond n), tap(p) = p / 9 + 3 * ((p / 3) % 3) + 9 * (p % 3): the conv family's slab-major tap sequence, so that the four
- * taps of one gather instruction are neighbours in memory.  tile8t: linr_kmap_tile8t_bytes(n) bytes, 16-byte aligned. */
-LINR_API size_t linr_kmap_tile8t_bytes(int64_t n);
-LINR_API int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8t, size_t tile8t_bytes, void* stream);
-LINR_API size_t linr_wgrad_ranges_bytes(int64_t n);
-LINR_API int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes,
-                            void* stream);
-
-/* Measurement aid for bench.py's roofline: while enabled, every launch of the two roofline kernels inside
- * linr_net_forward / _backward / _train_step (kind 0: the 8->8 weight-gradient kernel, spconv_wgrad_mfma_k<2,8,false,3> by default; kind 1:
- * cconv_mfma_k<8,8,forward, plain epilogue>) is bracketed by a HIP event pair on the stream it is launched on.
- * linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
+/* Measurement aid for bench.py's roofline: while enabled, the launches of a training step inside linr_net_forward /
+ * _backward / _train_step are bracketed by HIP event pairs on the stream they are launched on, by kernel class:
+ *   0 fused backward 8->8 (conv_bwd_wgrad_k<0>)   1 conv 8->8 forward, plain epilogue   2 fused backward of the two 4->4 convs
+ *   3 fused backward of conv0_0 8->4              4 prune conv + head forward           5 conv0_0 | conv1_0 forward
+ *   6 both 4->4 convs forward                     7 shared occupancy conv               8 head backward
+ *   9 stand-alone conv weight gradients          10 pointwise weight gradients         11 scale context (forward, backward)
+ *  12 sums, reduction, Adam                      13 stand-alone backward-data convolutions (schedules without the fused backward)
+ * linr_prof_mask selects the classes that are recorded (default: 0 and 1; an event pair costs a few microseconds of stream
+ * time).  linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,
- * 0 = stop (records are kept).  An event pair costs a few microseconds of stream time, so bench.py samples every 8th
- * step.  Mutex-guarded; 2048 launches in total. */
+ * 0 = stop (records are kept).  Mutex-guarded; 4096 launches in total. */
+#define LINR_PROF_KINDS 14
+LINR_API int linr_prof_mask(uint32_t mask);
 LINR_API int linr_prof_enable(int32_t mode);
 LINR_API int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes);
 
@@ -225,8 +212,6 @@ typedef struct linr_frame {
     const uint32_t* nbr_mask;     /* [nbr_ld]     27-bit presence masks of the compressed map, or NULL           */
     const float*   offset_feat;   /* [rows][7]  7-neighbour occupancy (qscTensor.set_offset_tensor)         */
     const float*   occ;           /* [rows][8]  child occupancy ground truth (occ_lst concatenated)         */
-    const int32_t* wg_ranges;     /* linr_wgrad_ranges_build over nbr (LDS windows of the weight-gradient kernels), or NULL */
-    const int32_t* nbr8;          /* linr_kmap_tile8 over nbr (8-row tiled copy of the kernel map), or NULL               */
     const int32_t* nbr8t;         /* linr_kmap_tile8t over nbr (the tiled copy in gather-lane order), or NULL             */
 } linr_frame;
 
@@ -332,8 +317,7 @@ LINR_API int linr_inception_bwd_data(const float* gI, const float* x, const floa
 /* weight gradients of the layer's two 4->4 convolutions in one pass (conv0_1 on H[:,0:4] with gradient g0, conv1_1 on
  * H[:,4:8] with g1): 512 per-block partials slab[b][872] = [gW01 432 | gb01 4 | gW11 432 | gb11 4], summed in ascending b. */
 LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
-                             const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
-                             const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream);
+                             const int32_t* nbr, const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream);
 
 /* The backward of an Inception layer's two convolution pairs in the same form (models/resnet.py:55-60; gM comes from the
  * caller: the tail convolution's epilogue or a pointwise op):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -22,7 +22,7 @@ class LinrFrame(ctypes.Structure):
     _fields_ = [('rows', c_i64), ('n_scales', c_i32), ('model_scale_num', c_i32), ('block_layers', c_i32),
                 ('flags', c_i32), ('row_off_h', c_ptr),
                 ('scale_idx_h', c_ptr), ('nbr', c_ptr), ('nbr_ld', c_i64), ('nbr_lo', c_ptr), ('nbr_mask', c_ptr),
-                ('offset_feat', c_ptr), ('occ', c_ptr), ('wg_ranges', c_ptr), ('nbr8', c_ptr), ('nbr8t', c_ptr)]
+                ('offset_feat', c_ptr), ('occ', c_ptr), ('nbr8t', c_ptr)]
 
 
 class LinrInceptionParams(ctypes.Structure):
@@ -37,16 +37,13 @@ _PROTOS = {
     'linr_kmap_build': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_kmap_validate': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_spconv_wgrad_cmap_blocks': (ctypes.c_int64, []),
-    'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    'linr_spconv_wgrad_cmap': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     'linr_spconv_bwd_fused': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
     'linr_inception_bwd_fused': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
                                                 ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr, c_u32, c_ptr, c_i32, c_ptr]),
     'linr_kmap_tile8t_bytes': (c_size, [c_i64]),
     'linr_kmap_tile8t': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
-    'linr_kmap_tile8_bytes': (c_size, [c_i64]),
-    'linr_kmap_tile8': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
-    'linr_wgrad_ranges_bytes': (c_size, [c_i64]),
-    'linr_wgrad_ranges_build': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
+    'linr_prof_mask': (ctypes.c_int, [c_u32]),
     'linr_prof_enable': (ctypes.c_int, [c_i32]),
     'linr_prof_read': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr]),
     'linr_octree_occupancy': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
@@ -93,7 +90,7 @@ _PROTOS = {
                                           c_ptr, c_ptr]),
     'linr_inception_bwd_data': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
                                                ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr, c_ptr, c_u32, c_ptr]),
-    'linr_spconv_wgrad_dual44': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'linr_spconv_wgrad_dual44': (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'linr_occ_conv7': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_ac_encode_binary': (c_i64, [c_ptr, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),

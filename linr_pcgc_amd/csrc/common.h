@@ -106,8 +106,6 @@ int linr_head_bwd_launch(const float* c, const float* p, const float* target, in
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
                          hipStream_t s, const Grp* gp = nullptr, int ngroups = 1, int nblocks = LINR_WG_BLOCKS);
 __attribute__((visibility("hidden")))
-bool linr_wgrad_lds_enabled();
-__attribute__((visibility("hidden")))
 int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float* gsum, hipStream_t s);
 __attribute__((visibility("hidden")))
 int linr_bits_finish_launch(const double* partial, int count, double* bits_acc, hipStream_t s);
@@ -137,8 +135,7 @@ int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* m
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr,
-                          int ngroups = 1, const int32_t* lo = nullptr, const uint32_t* mask = nullptr,
-                          const int32_t* ranges = nullptr, const int32_t* tile8 = nullptr, const int32_t* tile8t = nullptr);
+                          int ngroups = 1, const int32_t* tile8t = nullptr);
 struct PwArgs;
 // backward-data + weight gradient of a conv 8->8 from one gather (csrc/fused_bwd.hip); pw != nullptr: gM epilogue
 __attribute__((visibility("hidden")))
@@ -159,5 +156,4 @@ __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp = nullptr,
-                            int ngroups = 1, const int32_t* lo = nullptr, const uint32_t* mask = nullptr,
-                            const int32_t* ranges = nullptr, const int32_t* tile8 = nullptr, const int32_t* tile8t = nullptr);
+                            int ngroups = 1, const int32_t* tile8t = nullptr);

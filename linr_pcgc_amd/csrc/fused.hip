@@ -126,29 +126,10 @@ struct HeadArgs {
     double* partial;      // [gridDim.x] block partial sums of nats, or nullptr
 };
 
-// STAGE: neighbour rows come from an LDS copy instead of per-lane global gathers.  In the x-major row order the
-// neighbours a block's 256 consecutive rows need lie in THREE nearly contiguous row ranges, one per x-slab (dx = -1, 0, +1;
-// each covers the dy, dz = -1..1 columns of that slab).  The block finds the three [min, max] ranges (LDS atomics), copies
-// them with fully coalesced 16-byte loads (~26 wave-loads instead of 216 divergent ones - the texture addresser's
-// lane-request rate is what bounds the direct-gather kernel), and the 27 taps read rows from LDS.  A block whose ranges do
-// not fit (scale boundaries, sphere poles) falls back to direct gathers.  Arithmetic order is unchanged => identical bits.
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
-#define STAGE_SLOTS 384                  // rows per slab window incl. the zero slot
-#define STAGE_SLAB_BYTES (STAGE_SLOTS * 32)
-
 #ifndef LINR_CONV_BLOCK
 #define LINR_CONV_BLOCK 256
 #endif
-template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0, bool STAGE = false>
+template <int GIN, int GOUT, bool BWD, int LOADW, int EPI = 0>
 __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __restrict__ in, int in_ld,
                                                            const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                            int64_t ld, int64_t n, const float* __restrict__ W,
@@ -199,7 +180,7 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
     const char* pad = reinterpret_cast<const char*>(in - in_ld);
     const uint32_t rowbytes = (uint32_t)in_ld * 4u;
     uint32_t off[27];
-    decode_offsets<BWD>(lo, mask, ld, row, STAGE ? 1u : rowbytes, off);       // STAGE: row index + 1 (0 = absent)
+    decode_offsets<BWD>(lo, mask, ld, row, rowbytes, off);
     f32x4 acc[GOUT / 4];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
@@ -207,106 +188,26 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void cconv_mfma_k(const float* __r
         for (int j = 0; j < 4; ++j) acc[h][j] = (bias != nullptr) ? bias[4 * h + j] : 0.0f;
     constexpr int PF = 4;
     float x[PF + 1][LOADW];
-    // the offset loop; SRC = 0: rows from global memory (per-lane gathers), SRC = 1: rows from the LDS windows.
     // Left to itself hipcc waits (vmcnt(0)) right after every 16-byte gather - 54 serial round trips per wave.  The loop
     // is therefore pipelined by hand: the load of offset k+PF is issued before the MFMAs of offset k and sched_barrier
     // keeps it there, so the compiler's own counted waits leave PF rows in flight.
-    // `ld(off, x)` fetches one row: the LDS variant indexes the __shared__ array itself so that the compiler emits
-    // ds_read (a generic pointer would become flat loads, which force vmcnt(0)/lgkmcnt(0) waits and kill the pipeline)
-    auto taps = [&](auto ld) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ld(off[LINR_TAP(u)], x[u]);
+    for (int u = 0; u < PF; ++u) RowLoadF<LOADW>::run(pad + off[LINR_TAP(u)], x[u]);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<27>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;          // step; k = the tap it handles (common.h: LINR_TAP)
+        constexpr int k = LINR_TAP(kk);
+        constexpr int g = k / KPV, ab = (k % KPV) * HB;
+        if constexpr (kk + PF < 27) RowLoadF<LOADW>::run(pad + off[LINR_TAP(kk + PF)], x[(kk + PF) % (PF + 1)]);
         __builtin_amdgcn_sched_barrier(0);
-        static_for<27>([&](auto kc) {
-            constexpr int kk = decltype(kc)::value;          // step; k = the tap it handles (common.h: LINR_TAP)
-            constexpr int k = LINR_TAP(kk);
-            constexpr int g = k / KPV, ab = (k % KPV) * HB;
-            if constexpr (kk + PF < 27) ld(off[LINR_TAP(kk + PF)], x[(kk + PF) % (PF + 1)]);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < GIN; ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[0], 4, ab, 0);
-                if constexpr (GOUT == 8)
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[1], 4, ab + 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    auto ld_global = [&](uint32_t o, float (&xr)[LOADW]) { RowLoadF<LOADW>::run(pad + o, xr); };
-    if constexpr (!STAGE) {
-        taps(ld_global);
-    } else {
-        __shared__ float4 sX[3 * STAGE_SLOTS * 2];
-        auto ld_lds = [&](uint32_t o, float (&xr)[LOADW]) {
-#pragma unroll
-            for (int v = 0; v < LOADW / 4; ++v) {
-                const float4 t = sX[(o >> 4) + v];
-                xr[4 * v] = t.x; xr[4 * v + 1] = t.y; xr[4 * v + 2] = t.z; xr[4 * v + 3] = t.w;
-            }
-        };
-        __shared__ int smm[6];
-        char* xs = reinterpret_cast<char*>(sX);
-        if (threadIdx.x < 3) { smm[threadIdx.x] = 0x7fffffff; smm[3 + threadIdx.x] = -1; }
-        if (threadIdx.x < 6) sX[(threadIdx.x >> 1) * STAGE_SLOTS * 2 + (threadIdx.x & 1)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        __syncthreads();
-        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
-        static_for<27>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int sl = (BWD ? 26 - k : k) % 3;        // x-slab of the table offset this tap reads
-            if (off[k] != 0u) { const int j = (int)off[k] - 1; mn[sl] = min(mn[sl], j); mx[sl] = max(mx[sl], j); }
-        });
-        // wave-level reduction first: 256 same-address LDS atomics per slab serialise (measured: ~10 us per launch and slab)
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            const int wmn = wave_min_i32(mn[sl]), wmx = wave_max_i32(mx[sl]);
-            if ((threadIdx.x & 63) == 0 && wmx >= 0) { atomicMin(&smm[sl], wmn); atomicMax(&smm[3 + sl], wmx); }
+        for (int i = 0; i < GIN; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[0], 4, ab, 0);
+            if constexpr (GOUT == 8)
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i], acc[1], 4, ab + 1, 0);
         }
-        __syncthreads();
-        int lo_s[3], span[3];
-        bool fits = true;
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            lo_s[sl] = smm[sl];
-            span[sl] = smm[3 + sl] < 0 ? 0 : smm[3 + sl] - smm[sl] + 1;
-            fits = fits && span[sl] <= STAGE_SLOTS - 1;
-        }
-        if (fits) {                                            // block-uniform
-            // all (<= 9) 16-byte pieces of this thread are requested before the first one is written to LDS
-            constexpr int PPT = (STAGE_SLOTS * 2 + LINR_CONV_BLOCK - 1) / LINR_CONV_BLOCK;     // pieces per thread and slab
-            float4 v[3][PPT];
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                const int pieces = (int)(((uint32_t)span[sl] * rowbytes) >> 4);
-                const char* srcg = reinterpret_cast<const char*>(in) + (int64_t)lo_s[sl] * rowbytes;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const int pidx = (int)threadIdx.x + j * LINR_CONV_BLOCK;
-                    v[sl][j] = (pidx < pieces) ? *reinterpret_cast<const float4*>(srcg + 16 * pidx) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                const int pieces = (int)(((uint32_t)span[sl] * rowbytes) >> 4);
-                char* dst = xs + sl * STAGE_SLAB_BYTES + rowbytes;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const int pidx = (int)threadIdx.x + j * LINR_CONV_BLOCK;
-                    if (pidx < pieces) *reinterpret_cast<float4*>(dst + 16 * pidx) = v[sl][j];
-                }
-            }
-            static_for<27>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                constexpr int sl = (BWD ? 26 - k : k) % 3;
-                off[k] = (uint32_t)(sl * STAGE_SLAB_BYTES) + (off[k] ? ((off[k] - 1u) - (uint32_t)lo_s[sl] + 1u) * rowbytes : 0u);
-            });
-            __syncthreads();
-            taps(ld_lds);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 27; ++k) off[k] *= rowbytes;
-            taps(ld_global);
-        }
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    });
     float a[GOUT];
 #pragma unroll
     for (int h = 0; h < GOUT / 4; ++h)
@@ -444,20 +345,18 @@ extern "C" int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, con
 extern "C" int64_t linr_spconv_wgrad_cmap_blocks(void) { return LINR_WG_BLOCKS; }
 
 extern "C" int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
-                                      const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
                                       const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab,
                                       void* stream) {
     if (n < 0 || ld < n || in_ld != 8 || gout_ld < cout) return LINR_EINVAL;
     if (n == 0) return 0;
-    if (!in || !gout || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;     // lo / mask NULL: indices from nbr
-    if (!linr_aligned16(in)) return LINR_EALIGN;          // lo / mask / ld not 16-byte friendly: the kernel reads the nbr table
+    if (!in || !gout || !nbr || !slab) return LINR_EINVAL;
+    if (!linr_aligned16(in)) return LINR_EALIGN;
     if (!((cin == 8 && (cout == 8 || cout == 4)) || (cin < 8 && cin >= 1 && cout == 8))) return LINR_EINVAL;
     if ((uint64_t)(n + 1) * (uint64_t)in_ld * 4u >= 0xFFFFFFFFull) return LINR_EINVAL;
     const int64_t elems = (int64_t)(27 * cin + 1) * cout;
     LinrWgradDst d = {slab, elems, 0, (int64_t)27 * cin * cout, cin};
-    if (tile8 && !linr_aligned16(tile8)) return LINR_EALIGN;
-    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1,
-                                 lo, mask, ranges, tile8, tile8t);
+    if (tile8t && !linr_aligned16(tile8t)) return LINR_EALIGN;
+    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, ld, n, cin, cout, d, LINR_WG_BLOCKS, (hipStream_t)stream, nullptr, 1, tile8t);
 }
 
 // prune conv 8->8 + head of stage k in one launch; partial: [linr_grid(n,256)] doubles or nullptr
@@ -755,14 +654,11 @@ struct WgradSrc {
 };
 struct WgradDual { int64_t w_off1, b_off1; };
 
-// IDX: where a lane's neighbour indices come from - 3: the 8-row tiled table nbr8[row / 8][27][8] (linr_kmap_tile8: the 27 x 8
-// indices of a row group are 864 contiguous bytes, so the two index loads of a group touch 7 cache lines instead of 27);
-// 0: nbr[27][ld], scalar loads; 1: nbr, 16-byte loads;
-// 2: the compressed map (nbr = its 9 column bases lo[9][ld], plus the 27-bit masks): 40 instead of 108 index bytes per row
-// and 9 + 1 instead of 27 distinct cache lines per load instruction.
+// IDX: how a lane reads its neighbour indices from nbr[27][ld] - 0: scalar loads, 1: 16-byte loads (table 16-byte aligned, ld % 4 == 0).
+// This is the direct-gather form: the fallback for frames without the transposed tiled table and the bitwise reference of
+// spconv_wgrad_t_k below.
 template <int XQ, int COUT, bool DUAL, int IDX>
-__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S, const int32_t* __restrict__ nbr,
-                                                                    const uint32_t* __restrict__ cmask, int64_t nbr_ld,
+__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S, const int32_t* __restrict__ nbr, int64_t nbr_ld,
                                                                     int64_t n, LinrWgradDst d, WgradDual dd, Grp gp = Grp()) {
     static_assert(!DUAL || (XQ == 2 && COUT == 4), "dual mode = two 4->4 convolutions");
     {   // group offsets: in, res = g0, act = g1, w/b = slab offsets of conv 0, e0/e1 = of conv 1, e2 = cin_valid override
@@ -792,11 +688,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     per = (per + 7) & ~(int64_t)7;
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const int32_t* nk = IDX == 3 ? nbr + 8 * k : nbr + (int64_t)(IDX == 2 ? k % 9 : k) * nbr_ld;
-    // compressed map: tap k = q9 + 9 j is present iff bit (3 q9 + j) of the row's mask is set and then sits at
-    // lo[q9][r] + (number of present taps below it in the same column)
-    const int cshift = 3 * (k % 9), cj = k / 9;
-    const uint32_t cpm = 1u << cj, cam = cpm - 1u;
+    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
     const char* pad = reinterpret_cast<const char*>(S.in - S.in_ld) + 16 * q;
     const uint32_t rsh = __builtin_amdgcn_readfirstlane(S.in_ld == 8 ? 5u : 4u);      // 32- or 16-byte rows: a uniform shift, not a multiply
     // this lane's element of the 8-row gradient tile: row gu, channel gc of matrix gsel
@@ -806,86 +698,13 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     const int gu = (gl / COUT) & 7, gc = gl % COUT;
     const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);      // live components per quad (>= 4: all)
     float bsum = 0.0f;
-    if constexpr (IDX == 3) {
-        // Tiled index table: software-pipelined by one group.  The indices and the gradient element of group t+1 are requested
-        // right after the gathers of group t (vmcnt retires in order, so they must be YOUNGER than the gathers the MFMAs wait
-        // for) and land while the 64 MFMAs of group t run; the loop top then finds them ready instead of paying a full
-        // memory latency before it can even issue its gathers.  The table has spare all -1 groups behind the last row group,
-        // so the prefetch needs no bounds check; rows beyond n gather the zero row.  Same groups, same order => same bits.
-        int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
-        const char* ubase = reinterpret_cast<const char*>(S.in - S.in_ld);          // the zero pad row
-        const uint32_t uoff = (1u << rsh) + 16u * q;
-        float gvn = 0.0f;
-        if (b0 + 8 * wave < b1) {          // wave-uniform; blocks behind the last row (b0 >= n) must not touch the table at all
-            const int64_t g0r = b0 + 8 * wave;
-            ia = *reinterpret_cast<const int4*>(nk + g0r * 27);
-            ib = *reinterpret_cast<const int4*>(nk + g0r * 27 + 4);
-            gvn = (g0r + gu < n) ? gsel[(g0r + gu) * gld + gc] : 0.0f;
-        }
-        for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
-            const int32_t idx[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-            const float gv = gvn;
-            float4 x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                // saddr form (uniform base + 32-bit lane offset: two 32-bit VALU ops per gather instead of a 64-bit add), and
-                // the gathers are issued in the order the MFMAs consume them (left alone, hipcc issued rows 2..7, 0, 1 and the
-                // first MFMA then waited for the seventh gather): -5 % per launch
-                x[u] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)idx[u] << rsh) + uoff));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            {
-                const int64_t g1r = g0r + 8 * WG_WAVES;
-                ia = *reinterpret_cast<const int4*>(nk + g1r * 27);
-                ib = *reinterpret_cast<const int4*>(nk + g1r * 27 + 4);
-                gvn = (g1r + gu < n) ? gsel[(g1r + gu) * gld + gc] : 0.0f;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            bsum += gv;
-            static_for<8>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                static_for<HB>([&](auto hc) {
-                    constexpr int h = decltype(hc)::value;
-                    constexpr int ab = u * HB + h;
-                    acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].x, acc[0][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].y, acc[1][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].z, acc[2][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv, x[u].w, acc[3][h], CBSZ, ab, 0);
-                });
-            });
-        }
-    } else
     for (int64_t g0r = b0 + 8 * wave; g0r < b1; g0r += 8 * WG_WAVES) {
         int32_t idx[8];
-        if constexpr (IDX == 3) {          // (pipelined above)
-            const int4 a = *reinterpret_cast<const int4*>(nk + g0r * 27);
-            const int4 b = *reinterpret_cast<const int4*>(nk + g0r * 27 + 4);
-            idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
-            idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
-        } else if (IDX >= 1 && g0r + 8 <= n) {
+        if (IDX >= 1 && g0r + 8 <= n) {
             const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
             const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
             idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w;
             idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
-            if constexpr (IDX == 2) {
-                const uint4 ma = *reinterpret_cast<const uint4*>(cmask + g0r);
-                const uint4 mb = *reinterpret_cast<const uint4*>(cmask + g0r + 4);
-                const uint32_t m[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t bits = m[u] >> cshift;
-                    idx[u] = (bits & cpm) ? idx[u] + __popc(bits & cam) : -1;
-                }
-            }
-        } else if constexpr (IDX == 2) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                idx[u] = -1;
-                if (g0r + u < n) {
-                    const uint32_t bits = cmask[g0r + u] >> cshift;
-                    if (bits & cpm) idx[u] = nk[g0r + u] + __popc(bits & cam);
-                }
-            }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) idx[u] = (g0r + u < n) ? nk[g0r + u] : -1;
@@ -971,318 +790,6 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_mfma_k(WgradSrc S,
     }
 }
 
-// ---- the same weight-gradient kernel with the gathered rows staged through LDS ---------------------------------------------
-// spconv_wgrad_mfma_k is bound by the vector-memory address path, not by the matrix cores: per 8-row group a wave issues 8
-// divergent 16-byte gathers + 2 index loads (~176 TA cycles) against 64 MFMAs (512 cycles on ONE of the CU's four SIMDs that
-// share the TA).  In the x-major row order the neighbours that a CHUNK of consecutive rows needs lie in three nearly
-// contiguous row ranges, one per x-slab (dx = -1, 0, +1).  Coordinates are static, so those [first row, row count] windows
-// are computed ONCE per frame (linr_wgrad_ranges_build: chunks of LCH rows inside the fixed 512-block row partition) and the
-// kernel copies a chunk's three windows with fully coalesced 16-byte loads - each gathered row crosses the TA once per chunk
-// instead of up to 27 times - into one half of a double-buffered LDS image while the MFMAs of the previous chunk run from
-// the other half; every (offset, quad) lane reads its rows with ds_read_b128.  One block barrier per chunk.  A chunk whose
-// windows do not fit (scale boundaries, very dense slabs) gathers from global memory as before.
-// Rows, groups and waves are visited in the order of spconv_wgrad_mfma_k and the MFMAs are the same, so the partial sums
-// are bit-identical to it (tests: LINR_WGRAD_LDS=0 against the default).
-#define LCH 128                       // rows per chunk: 4 groups of 8 rows per wave
-#define LSLOTS 320                    // rows per x-slab window incl. the zero slot
-
-static inline int64_t wg_per(int64_t n) {          // rows per persistent block: the partition of spconv_wgrad_mfma_k
-    int64_t per = (n + LINR_WG_BLOCKS - 1) / LINR_WG_BLOCKS;
-    return (per + 7) & ~(int64_t)7;
-}
-static inline int wg_chunks(int64_t n) { return (int)((wg_per(n) + LCH - 1) / LCH); }
-
-// out[(b * cpb + j) * 8 + {0,1,2}] = first row of the window of x-slab 0..2 for chunk j of block b, + {4,5,6} = its row count
-// (0: no neighbour in that slab; > LSLOTS - 1: does not fit)
-__global__ __launch_bounds__(64) void wgrad_ranges_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t per, int cpb,
-                                                     int32_t* __restrict__ out) {
-    __shared__ int smn[27], smx[27];
-    const int b = blockIdx.x / cpb, j = blockIdx.x % cpb, k = threadIdx.x;
-    const int64_t bb1 = ((int64_t)(b + 1) * per < n) ? (int64_t)(b + 1) * per : n;
-    const int64_t r0 = (int64_t)b * per + (int64_t)j * LCH;
-    const int64_t r1 = (r0 + LCH < bb1) ? r0 + LCH : bb1;
-    if (k < 27) {
-        int mn = 0x7fffffff, mx = -1;
-        for (int64_t r = r0; r < r1; ++r) {
-            const int v = nbr[(int64_t)k * ld + r];
-            if (v >= 0) { mn = min(mn, v); mx = max(mx, v); }
-        }
-        smn[k] = mn; smx[k] = mx;
-    }
-    __syncthreads();
-    if (k < 3) {
-        int mn = 0x7fffffff, mx = -1;
-        for (int t = k; t < 27; t += 3) { mn = min(mn, smn[t]); mx = max(mx, smx[t]); }
-        out[(int64_t)blockIdx.x * 8 + k] = mx < 0 ? 0 : mn;
-        out[(int64_t)blockIdx.x * 8 + 4 + k] = mx < 0 ? 0 : mx - mn + 1;
-    }
-    if (k == 3) { out[(int64_t)blockIdx.x * 8 + 3] = 0; out[(int64_t)blockIdx.x * 8 + 7] = 0; }
-}
-
-// nbr8[g][k][u] = nbr[k][8 g + u] (-1 beyond n): the index tile of one 8-row group, contiguous
-__global__ __launch_bounds__(LINR_BLOCK) void kmap_tile8_k(const int32_t* __restrict__ nbr, int64_t ld, int64_t n, int64_t groups,
-                                                           int32_t* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (e >= groups * 216) return;
-    const int64_t g = e / 216;
-    const int r = (int)(e - g * 216), k = r >> 3, u = r & 7;
-    const int64_t row = 8 * g + u;
-    out[e] = row < n ? nbr[(int64_t)k * ld + row] : -1;
-}
-
-extern "C" size_t linr_kmap_tile8_bytes(int64_t n) {
-    if (n < 0) return 0;
-    return (size_t)((n + 7) / 8 + 2 * WG_WAVES) * 216 * sizeof(int32_t);
-}
-
-extern "C" int linr_kmap_tile8(const int32_t* nbr, int64_t ld, int64_t n, int32_t* tile8, size_t tile8_bytes, void* stream) {
-    if (n < 0 || ld < n) return LINR_EINVAL;
-    if (n == 0) return 0;
-    if (!nbr || !tile8) return LINR_EINVAL;
-    if (tile8_bytes < linr_kmap_tile8_bytes(n)) return LINR_ENOSPC;
-    if (!linr_aligned16(tile8)) return LINR_EALIGN;
-    const int64_t groups = (n + 7) / 8 + 2 * WG_WAVES;      // spare all -1 groups: the pipelined kernel prefetches one stride ahead
-    kmap_tile8_k<<<linr_grid(groups * 216, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(nbr, ld, n, groups, tile8);
-    return linr_launch_rc();
-}
-
-extern "C" size_t linr_wgrad_ranges_bytes(int64_t n) {
-    if (n < 0) return 0;
-    return (size_t)LINR_WG_BLOCKS * wg_chunks(n) * 8 * sizeof(int32_t) + 64;
-}
-
-extern "C" int linr_wgrad_ranges_build(const int32_t* nbr, int64_t ld, int64_t n, int32_t* ranges, size_t ranges_bytes, void* stream) {
-    if (n < 0 || ld < n) return LINR_EINVAL;
-    if (n == 0) return 0;
-    if (!nbr || !ranges) return LINR_EINVAL;
-    if (ranges_bytes < linr_wgrad_ranges_bytes(n)) return LINR_ENOSPC;
-    if (!linr_aligned16(ranges)) return LINR_EALIGN;
-    const int cpb = wg_chunks(n);
-    wgrad_ranges_k<<<LINR_WG_BLOCKS * cpb, 64, 0, (hipStream_t)stream>>>(nbr, ld, n, wg_per(n), cpb, ranges);
-    return linr_launch_rc();
-}
-
-template <int COUT, bool DUAL>
-__global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_lds_k(WgradSrc S, const int32_t* __restrict__ nbr, int64_t nbr_ld,
-                                                                   int64_t n, const int32_t* __restrict__ ranges, LinrWgradDst d,
-                                                                   WgradDual dd, Grp gp = Grp()) {
-    static_assert(!DUAL || COUT == 4, "dual mode = two 4->4 convolutions");
-    static_assert(WG_WAVES == 4, "chunk layout assumes 4 waves");
-    {
-        const int gi = blockIdx.y;
-        S.in += gp.in[gi]; S.g0 += gp.res[gi];
-        if (S.g1) S.g1 += gp.act[gi];
-        d.w_off += gp.w[gi]; d.b_off += gp.b[gi];
-        dd.w_off1 += gp.e0[gi]; dd.b_off1 += gp.e1[gi];
-        if (gp.e2[gi] > 0) d.cin_valid = (int)gp.e2[gi];
-    }
-    constexpr int HB = COUT / 4;
-    constexpr int NA = 4 * HB * 4;
-    constexpr int CBSZ = DUAL ? 3 : 4;
-    constexpr int GPW = LCH / 32;                 // groups per wave and chunk
-    constexpr int PPT = (LSLOTS * 2 + WG_WAVES * 64 - 1) / (WG_WAVES * 64);      // 16-byte pieces per thread and window
-    __shared__ float4 sX[2][3 * LSLOTS * 2];      // double-buffered windows: [chunk parity][slab][slot][2 x 16 B]
-    __shared__ float sacc[64 * (NA + 1)];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q = DUAL ? (lane >> 5) : (lane & 1);
-    const int kk = DUAL ? (lane & 31) : (lane >> 1);
-    const bool live = kk < 27;
-    const int k = live ? kk : 26;
-    const int sl = k % 3;                         // x-slab of this lane's offset: dx = k % 3 - 1
-    f32x4 acc[4][HB];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int h = 0; h < HB; ++h) acc[c][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    int64_t per = (n + gridDim.x - 1) / gridDim.x;
-    per = (per + 7) & ~(int64_t)7;
-    const int cpb = (int)((per + LCH - 1) / LCH);
-    const int64_t b0 = (int64_t)blockIdx.x * per;
-    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    const int nch = b1 > b0 ? (int)((b1 - b0 + LCH - 1) / LCH) : 0;
-    const int32_t* nk = nbr + (int64_t)k * nbr_ld;
-    const char* pad = reinterpret_cast<const char*>(S.in - 8) + 16 * q;
-    const float* gsel = (DUAL && q) ? S.g1 : S.g0;
-    const int gld = (DUAL && q) ? S.g1_ld : S.g0_ld;
-    const int gl = DUAL ? (lane & 31) : lane;
-    const int gu = (gl / COUT) & 7, gc = gl % COUT;
-    const int ncomp = __builtin_amdgcn_readfirstlane(d.cin_valid);
-    const int32_t* rg = ranges + (int64_t)blockIdx.x * cpb * 8;
-    float bsum = 0.0f;
-    if (threadIdx.x < 12)      // zero slots of both halves
-        sX[threadIdx.x / 6][((threadIdx.x % 6) >> 1) * LSLOTS * 2 + (threadIdx.x & 1)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-
-    int32_t idx[GPW][8];                          // neighbour indices of the chunk being multiplied
-    int32_t idn[GPW][8];                          // ... of the next chunk (in flight during the MFMAs)
-    float4 v[3][PPT];                             // window pieces of the next chunk (in flight during the MFMAs)
-    int lo_c[3] = {0, 0, 0}, lo_n[3] = {0, 0, 0};
-    bool fits_c = false, fits_n = false;
-
-    auto load_idx = [&](int64_t c0, int32_t (&dst)[GPW][8]) {
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int64_t g0r = c0 + 8 * (wave + 4 * j);
-            if (g0r + 8 <= b1) {
-                const int4 a = *reinterpret_cast<const int4*>(nk + g0r);
-                const int4 b = *reinterpret_cast<const int4*>(nk + g0r + 4);
-                dst[j][0] = a.x; dst[j][1] = a.y; dst[j][2] = a.z; dst[j][3] = a.w;
-                dst[j][4] = b.x; dst[j][5] = b.y; dst[j][6] = b.z; dst[j][7] = b.w;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dst[j][u] = (g0r + u < b1) ? nk[g0r + u] : -1;
-            }
-        }
-    };
-    // window descriptors of chunk ci (block-uniform scalar loads), then its pieces into v[][]
-    auto load_windows = [&](int ci, int (&lo)[3], bool& fits) {
-        const int4 l4 = *reinterpret_cast<const int4*>(rg + ci * 8);
-        const int4 s4 = *reinterpret_cast<const int4*>(rg + ci * 8 + 4);
-        lo[0] = l4.x; lo[1] = l4.y; lo[2] = l4.z;
-        const int span[3] = {s4.x, s4.y, s4.z};
-        fits = span[0] <= LSLOTS - 1 && span[1] <= LSLOTS - 1 && span[2] <= LSLOTS - 1;
-        if (fits) {
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const int pieces = span[s3] * 2;
-                const float4* srcg = reinterpret_cast<const float4*>(S.in) + (int64_t)lo[s3] * 2;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) {
-                    const int pidx = (int)threadIdx.x + j * WG_WAVES * 64;
-                    v[s3][j] = (pidx < pieces) ? srcg[pidx] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-    };
-    auto store_windows = [&](int parity, int ci, bool fits) {
-        if (!fits) return;
-        const int4 s4 = *reinterpret_cast<const int4*>(rg + ci * 8 + 4);
-        const int span[3] = {s4.x, s4.y, s4.z};
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-            const int pieces = span[s3] * 2;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const int pidx = (int)threadIdx.x + j * WG_WAVES * 64;
-                if (pidx < pieces) sX[parity][s3 * LSLOTS * 2 + 2 + pidx] = v[s3][j];
-            }
-        }
-    };
-
-    if (nch > 0) {
-        load_windows(0, lo_n, fits_n);
-        load_idx(b0, idn);
-        store_windows(0, 0, fits_n);
-    }
-    __syncthreads();
-    for (int ci = 0; ci < nch; ++ci) {
-        const int64_t c0 = b0 + (int64_t)ci * LCH;
-        const int parity = ci & 1;
-        fits_c = fits_n;
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) lo_c[s3] = lo_n[s3];
-#pragma unroll
-        for (int j = 0; j < GPW; ++j)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) idx[j][u] = idn[j][u];
-        // gradient tiles of THIS chunk first: vmcnt retires in order, so they must be older than the prefetches below
-        float gv[GPW];
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int64_t g0r = c0 + 8 * (wave + 4 * j);
-            gv[j] = (g0r + gu < b1) ? gsel[(g0r + gu) * gld + gc] : 0.0f;
-        }
-        if (ci + 1 < nch) {                       // block-uniform: next chunk's windows and indices fly during the MFMAs
-            load_windows(ci + 1, lo_n, fits_n);
-            load_idx(c0 + LCH, idn);
-        }
-        const char* xs = reinterpret_cast<const char*>(sX[parity]);
-        const uint32_t lbase = (uint32_t)(sl * LSLOTS * 32 + 16 * q) + 32u - (uint32_t)lo_c[sl] * 32u;      // + idx * 32 = the row's slot
-#pragma unroll
-        for (int j = 0; j < GPW; ++j) {
-            const int64_t g0r = c0 + 8 * (wave + 4 * j);
-            if (g0r >= b1) break;                 // wave-uniform
-            float4 x[8];
-            if (fits_c) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t o = idx[j][u] >= 0 ? lbase + (uint32_t)idx[j][u] * 32u : (uint32_t)(16 * q);
-                    x[u] = *reinterpret_cast<const float4*>(xs + o);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(pad + (uint32_t)(idx[j][u] + 1) * 32u);
-            }
-            bsum += gv[j];
-            static_for<8>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
-                static_for<HB>([&](auto hc) {
-                    constexpr int h = decltype(hc)::value;
-                    constexpr int ab = u * HB + h;
-                    acc[0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].x, acc[0][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 1) acc[1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].y, acc[1][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 2) acc[2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].z, acc[2][h], CBSZ, ab, 0);
-                    if (DUAL || ncomp > 3) acc[3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[j], x[u].w, acc[3][h], CBSZ, ab, 0);
-                });
-            });
-        }
-        if (ci + 1 < nch) store_windows(parity ^ 1, ci + 1, fits_n);
-        __syncthreads();                          // next half filled; everybody is done reading this half
-    }
-    // fold waves in wave order (fixed => reproducible)
-    float* mine = sacc + lane * (NA + 1);
-    for (int w = 0; w < WG_WAVES; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int h = 0; h < HB; ++h)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = (c * HB + h) * 4 + i;
-                        mine[e] = (w == 0) ? acc[c][h][i] : mine[e] + acc[c][h][i];
-                    }
-        }
-        __syncthreads();
-    }
-    __shared__ float sbias[WG_WAVES][16];
-    {
-        float t = bsum;
-#pragma unroll
-        for (int m = COUT; m < 8 * COUT; m <<= 1) t += __shfl_xor(t, m, 64);
-        const int slot = DUAL ? ((lane >> 5) * 4 + (lane & 3)) : (lane % COUT);
-        if ((lane & 31) < COUT && (DUAL || lane < 32)) sbias[wave][slot] = t;
-        __syncthreads();
-    }
-    {
-        float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
-        const int tid = threadIdx.x;
-        if (tid < (DUAL ? 8 : COUT)) {
-            float t = sbias[0][tid];
-            for (int w = 1; w < WG_WAVES; ++w) t += sbias[w][tid];
-            if (DUAL) dst[(tid < 4 ? d.b_off : dd.b_off1) + (tid & 3)] = t;
-            else dst[d.b_off + tid] = t;
-        }
-        if constexpr (DUAL) {
-            for (int e = tid; e < 2 * 432; e += WG_WAVES * 64) {
-                const int t = e / 432, r = e - 432 * t;
-                dst[(t ? dd.w_off1 : d.w_off) + r] = sacc[(32 * t + (r >> 4)) * (NA + 1) + (r & 15)];
-            }
-        } else {
-            const int cinv = d.cin_valid;
-            const int per_k = cinv * COUT, total = 27 * per_k;
-            for (int e = tid; e < total; e += WG_WAVES * 64) {
-                const int kq = e / per_k, r = e - kq * per_k;
-                const int ci = r / COUT, co = r - ci * COUT;
-                dst[d.w_off + e] = sacc[(2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * HB + (co >> 2)) * 4 + (co & 3)];
-            }
-        }
-    }
-}
-
-// The op-level entries use it whenever a window table is passed; the executor only under LINR_WGRAD_LDS=1.  Measured (same box, loot10): 2.82 ms/step against 2.56 with the direct-gather kernel - the
-// staging removes two thirds of the vector-memory instructions but the chunk barrier, the LDS bank conflicts of 27
-// unrelated rows per read and the extra address arithmetic cost more than that saves; kept as a tested alternative.
 // ---- weight gradients with COALESCED gathers and an LDS transpose --------------------------------------------------------------
 // All weight-gradient kernels above take ~20 us per row pass whatever their MFMA count (8->8: 64 MFMAs per group, 8->4 and the
 // dual 4->4: 32): they are bound by the L1 return path.  With lane = (tap, channel quad) a gather instruction delivers 54
@@ -1290,8 +797,10 @@ __global__ __launch_bounds__(WG_WAVES * 64) void spconv_wgrad_lds_k(WgradSrc S, 
 // bytes.  Here the gather of an 8-row group is laid out the convolutions' way - lane = (tap t of 4, row u of 8, quad q): one
 // instruction fetches 4 taps x 8 CONSECUTIVE rows, i.e. four 256-byte runs - into a wave-private tap-major LDS image
 // [tap][row][quad] with a tap pitch of 8 x 32 + 32 bytes, and every (tap, quad) lane reads its eight rows back with
-// ds_read_b128: the pitch makes the 16-byte slot index (2 tap + quad + 2 row) mod 16 = (lane + 2 row) mod 16, conflict-free for
-// the hardware's 16-lane groups; the writes are 128 contiguous bytes per 8 lanes.  No block barrier (LDS operations of one wave
+// ds_read_b128: the pitch makes the 16-byte slot index (2 tap + quad + 2 row) mod 16 = (lane + 2 row) mod 16, distinct inside each of
+// the hardware's 16-lane groups; the writes are 128 contiguous bytes per 8 lanes.  (SQ_LDS_BANK_CONFLICT still reads 3.4e5 cycles
+// per launch, profiles/r02_pmc_wgrad_variants.txt: a few per cent of the LDS cycles, not attributed - the fold epilogue's
+// stride-(NA + 1) accesses are the candidate, the row loop's accesses are conflict-free by construction.)  No block barrier (LDS operations of one wave
 // execute in order).  Indices come from a second tiled table (linr_kmap_tile8t: [group][tap of 4][row][tap group j] so that a
 // lane's seven indices are 32 contiguous bytes).  Pipeline: while the MFMAs of group t run, the gathers of group t+1 and the
 // indices of group t+2 are in flight.  Same groups, same order, same MFMAs => same partial sums, bit for bit.
@@ -1504,45 +1013,28 @@ extern "C" int linr_kmap_tile8t(const int32_t* nbr, int64_t ld, int64_t n, int32
     return linr_launch_rc();
 }
 
-bool linr_wgrad_lds_enabled() {
-    static const int v = getenv("LINR_WGRAD_LDS") ? atoi(getenv("LINR_WGRAD_LDS")) : 0;
-    return v != 0;
-}
-
 int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gout_ld, const int32_t* nbr, int64_t nbr_ld,
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp,
-                          int ngroups, const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
-                          const int32_t* tile8t) {
+                          int ngroups, const int32_t* tile8t) {
     if (in_ld != 8 && in_ld != 4) return LINR_EINVAL;  // the kernels address gathered rows by a shift: 32- or 16-byte rows
-    const bool al = (nbr_ld % 4 == 0);
-    const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
-    const int32_t* tab = idx == 2 ? lo : nbr;
+    const int idx = (nbr_ld % 4 == 0 && linr_aligned16(nbr)) ? 1 : 0;
     const Grp g0 = gp ? *gp : Grp();
     const dim3 grid(nblocks, ngroups);
     WgradSrc S = {in, in_ld, gout, gout_ld, nullptr, 0};
     WgradDual dd = {0, 0};
     d.cin_valid = cin;
-#define GO(XQ, CO)                                                                                                           \
-    do {                                                                                                                     \
-        if (tile8 && idx != 2) spconv_wgrad_mfma_k<XQ, CO, false, 3><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8, mask, nbr_ld, n, d, dd, g0); \
-        else if (idx == 2) spconv_wgrad_mfma_k<XQ, CO, false, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
-        else if (idx == 1) spconv_wgrad_mfma_k<XQ, CO, false, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0); \
-        else spconv_wgrad_mfma_k<XQ, CO, false, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, g0);         \
-        return linr_launch_rc();                                                                                             \
-    } while (0)
-    // rows staged through LDS: 32-byte rows (in_ld 8), indices from the 16-byte aligned neighbour table
     // coalesced gathers + LDS transpose: 32-byte rows, the transposed tiled table
     if (tile8t && in_ld == 8 && cin <= 8 && (cout == 8 || (cout == 4 && cin == 8)) && linr_aligned16(in) && linr_aligned16(tile8t)) {
         if (cout == 8) spconv_wgrad_t_k<8, false><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8t, n, d, dd, g0);
         else spconv_wgrad_t_k<4, false><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8t, n, d, dd, g0);
         return linr_launch_rc();
     }
-    if (ranges && nblocks == LINR_WG_BLOCKS && in_ld == 8 && cin <= 8 && (cout == 8 || (cout == 4 && cin == 8)) && al &&
-        linr_aligned16(nbr) && linr_aligned16(in) && linr_aligned16(ranges)) {
-        if (cout == 8) spconv_wgrad_lds_k<8, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, g0);
-        else spconv_wgrad_lds_k<4, false><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, g0);
-        return linr_launch_rc();
-    }
+#define GO(XQ, CO)                                                                                                           \
+    do {                                                                                                                     \
+        if (idx == 1) spconv_wgrad_mfma_k<XQ, CO, false, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);   \
+        else spconv_wgrad_mfma_k<XQ, CO, false, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, g0);            \
+        return linr_launch_rc();                                                                                             \
+    } while (0)
     if (cin == 8 && cout == 8) GO(2, 8);
     if (cin == 8 && cout == 4) GO(2, 4);
     if (cin == 4 && cout == 4) GO(1, 4);
@@ -1555,32 +1047,19 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp, int ngroups,
-                            const int32_t* lo, const uint32_t* mask, const int32_t* ranges, const int32_t* tile8,
                             const int32_t* tile8t) {
-    const bool al = (nbr_ld % 4 == 0);
-    const int idx = (lo && mask && al && linr_aligned16(lo) && linr_aligned16(mask)) ? 2 : (al && linr_aligned16(nbr)) ? 1 : 0;
-    const int32_t* tab = idx == 2 ? lo : nbr;
+    const int idx = (nbr_ld % 4 == 0 && linr_aligned16(nbr)) ? 1 : 0;
     const Grp grp = gp ? *gp : Grp();
     const dim3 grid(nblocks, ngroups);
     WgradSrc S = {H, 8, g0, g0_ld, g1, g1_ld};
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     WgradDual dd = {w_off1, b_off1};
     if (tile8t && linr_aligned16(H) && linr_aligned16(tile8t)) {
-        const Grp grp_t = gp ? *gp : Grp();
-        WgradSrc St = {H, 8, g0, g0_ld, g1, g1_ld};
-        LinrWgradDst dt = {big, block_stride, w_off0, b_off0, 4};
-        WgradDual ddt = {w_off1, b_off1};
-        spconv_wgrad_t_k<4, true><<<dim3(nblocks, ngroups), WG_WAVES * 64, 0, s>>>(St, tile8t, n, dt, ddt, grp_t);
+        spconv_wgrad_t_k<4, true><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8t, n, d, dd, grp);
         return linr_launch_rc();
     }
-    if (ranges && nblocks == LINR_WG_BLOCKS && al && linr_aligned16(nbr) && linr_aligned16(H) && linr_aligned16(ranges)) {
-        spconv_wgrad_lds_k<4, true><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, ranges, d, dd, grp);
-        return linr_launch_rc();
-    }
-    if (tile8 && idx != 2) spconv_wgrad_mfma_k<2, 4, true, 3><<<grid, WG_WAVES * 64, 0, s>>>(S, tile8, mask, nbr_ld, n, d, dd, grp);
-    else if (idx == 2) spconv_wgrad_mfma_k<2, 4, true, 2><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
-    else if (idx == 1) spconv_wgrad_mfma_k<2, 4, true, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
-    else spconv_wgrad_mfma_k<2, 4, true, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, tab, mask, nbr_ld, n, d, dd, grp);
+    if (idx == 1) spconv_wgrad_mfma_k<2, 4, true, 1><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
+    else spconv_wgrad_mfma_k<2, 4, true, 0><<<grid, WG_WAVES * 64, 0, s>>>(S, nbr, nbr_ld, n, d, dd, grp);
     return linr_launch_rc();
 }
 
@@ -1782,13 +1261,10 @@ int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, c
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
     const dim3 grid(linr_grid(n, LINR_CONV_BLOCK), ngroups);
-    static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;   // 2 = MFMA + LDS staging (measured equal)
+    static const int use_mfma = getenv("LINR_CONV_MFMA") ? atoi(getenv("LINR_CONV_MFMA")) : 1;   // 0: the VALU kernel (bitwise reference)
 #define GO(GI, GO_, B, LW)                                                                                              \
     do {                                                                                                                \
-        if (use_mfma == 2 && (GO_ == 4 || GO_ == 8))                                                                    \
-            cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW, 0, true><<<grid, LINR_CONV_BLOCK, 0, s>>>(              \
-                in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
-        else if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                    \
+        if (use_mfma && (GO_ == 4 || GO_ == 8))                                                                    \
             cconv_mfma_k<GI, (GO_ == 4 || GO_ == 8) ? GO_ : 8, B, LW><<<grid, LINR_CONV_BLOCK, 0, s>>>(                       \
                 in, in_ld, lo, mask, ld, n, W, bias, res, res_ld, act, act_ld, out, out_ld, flags, HeadArgs(), PwArgs(), g0);  \
         else                                                                                                            \
@@ -1912,14 +1388,13 @@ extern "C" int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_
 }
 
 extern "C" int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g0_ld, const float* g1, int32_t g1_ld,
-                                        const int32_t* nbr, const int32_t* lo, const uint32_t* mask, const int32_t* ranges,
-                                        const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream) {
+                                        const int32_t* nbr, const int32_t* tile8t, int64_t ld, int64_t n, float* slab, void* stream) {
     if (n < 0 || ld < n || g0_ld < 4 || g1_ld < 4) return LINR_EINVAL;
     if (n == 0) return 0;
-    if (!H || !g0 || !g1 || !nbr || !slab || (lo == nullptr) != (mask == nullptr)) return LINR_EINVAL;
+    if (!H || !g0 || !g1 || !nbr || !slab) return LINR_EINVAL;
     if (!linr_aligned16(H)) return LINR_EALIGN;
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     // per block: [W01 432 | b01 4 | W11 432 | b11 4]
     return linr_conv3_wgrad_dual44(H, g0, g0_ld, g1, g1_ld, nbr, ld, n, slab, 872, 0, 432, 436, 868, LINR_WG_BLOCKS,
-                                   (hipStream_t)stream, nullptr, 1, lo, mask, ranges, nullptr, tile8t);
+                                   (hipStream_t)stream, nullptr, 1, tile8t);
 }

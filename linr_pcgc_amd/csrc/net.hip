@@ -41,9 +41,7 @@ struct Arena {
     float *C[8], *HH[8], *Z[8], *P[8];
     // backward scratch
     float *gZ, *gHH, *gXG, *gX0, *gHID;
-    float *gC[8], *gO[8], *gI[8], *gA[8], *gH[8], *gM[8];   // one set per stage / block: weight-gradient kernels run on a
-                                                           // second stream and may still read them when the chain moves on
-    float* WPAD;                 // [7][27][8][8] first-conv kernels of the outter blocks zero-extended to 8 input channels
+    float *gC[8], *gO[8], *gI[8], *gA[8], *gH[8], *gM[8];   // one set per stage / block (the grouped launches need them side by side)
     float* BIG;                  // [LINR_WG_BLOCKS][n_params] per-block partial weight gradients
     float* GSUM;                 // [n_params] their fixed-order sum (the gradient of this backward call)
     int64_t n_params;
@@ -88,7 +86,6 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params, in
     a.n_params = n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;
     a.GSUM = base ? base + a.cur : nullptr; a.cur += (n_params + 15) & ~(int64_t)15;
-    a.WPAD = base ? base + a.cur : nullptr; a.cur += 7 * 27 * 64;
     a.BIG = base ? base + a.cur : nullptr; a.cur += (int64_t)LINR_WG_BLOCKS * n_params;
     a.cur = (a.cur + 15) & ~(int64_t)15;                     // 64-byte alignment for the slab (doubles inside)
     a.slab = base ? (void*)(base + a.cur) : nullptr;
@@ -109,27 +106,9 @@ extern "C" size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers) {
 
 struct PadList { int64_t off[200]; int w[200]; int n; };
 
-__global__ void zero_pads_k(float* __restrict__ base, PadList pl) {
-    const int b = blockIdx.x;
-    if (b < pl.n && (int)threadIdx.x < pl.w[b]) base[pl.off[b] + threadIdx.x] = 0.0f;
-}
-
-// mix[r] = [emb(8) | offset_feat[r](7) | 0]
-__global__ __launch_bounds__(LINR_BLOCK) void sce_mix_k(const float* __restrict__ emb, const float* __restrict__ off,
-                                                        int64_t n, float* __restrict__ mix) {
-    const int64_t idx = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (idx >= n * 16) return;
-    const int64_t r = idx >> 4;
-    const int c = (int)(idx & 15);
-    float v = 0.0f;
-    if (c < 8) v = emb[c];
-    else if (c < 15) v = off[r * 7 + (c - 8)];
-    mix[idx] = v;
-}
-
 // Scale context of all scales in one launch (model_core.py:48-53): x0[r] = W2 relu(W1 [emb | offset_feat[r]] + b1) + b2 with
-// the weights of r's scale.  Same fmaf chains as sce_mix_k + linear_k<15,16> + linear_k<16,8> (bias first, inputs
-// ascending), so both routes give the same bits.  MIX and HID are kept for the backward pass.
+// the weights of r's scale: fmaf chains with the bias first and the inputs ascending, like linear_k<15,16> + linear_k<16,8> on
+// [emb | offset_feat | 0].  MIX and HID are kept for the backward pass.
 struct SceArgs {
     int64_t row_off[MAX_SCALES + 1];
     int64_t emb[MAX_SCALES], w1[MAX_SCALES], b1[MAX_SCALES], w2[MAX_SCALES], b2[MAX_SCALES];   // parameter offsets per scale
@@ -142,8 +121,8 @@ __device__ __forceinline__ int sce_scale_of(const SceArgs& a, int64_t r) {
     return s;
 }
 
-// The blocks behind the last row block clear the arena's pad rows (PadList; one pad per 32 threads) - the job of zero_pads_k,
-// without its launch: the first kernel that reads a pad row comes after this one on the stream.
+// The blocks behind the last row block clear the arena's pad rows (PadList; one pad per 32 threads): the first kernel that reads
+// a pad row comes after this one on the stream.
 __global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
                                                         int64_t n, float* __restrict__ mix, float* __restrict__ hid,
                                                         float* __restrict__ x0, float* __restrict__ pad_base, PadList pl) {
@@ -247,15 +226,6 @@ __global__ void sce_emb_grad_all_k(const float* __restrict__ P, float* __restric
     }
 }
 
-__global__ void sce_emb_grad_k(const float* __restrict__ gb1, const float* __restrict__ W1, float* __restrict__ gemb) {
-    const int t = threadIdx.x;
-    if (t < 8) {
-        float s = 0.0f;
-        for (int m = 0; m < 16; ++m) s = fmaf(gb1[m], W1[m * 15 + t], s);
-        gemb[t] = s;
-    }
-}
-
 // gsum[p] = sum_b big[b][p] in a fixed association (RED_SPLIT threads per parameter, each 8 interleaved partial sums over
 // its quarter of the slab rows in ascending order, quarters added in order) => bit-reproducible.  One thread per
 // parameter alone would be 214 blocks of latency-bound streaming on 256 CUs.
@@ -294,8 +264,7 @@ struct Ctx {
     const float* P;
     Arena A;
     Layout L;
-    hipStream_t s;           // the caller's stream: forward and the backward data chain
-    hipStream_t ws;          // weight-gradient kernels (== s, or the auxiliary stream when overlapping)
+    hipStream_t s;           // the caller's stream
     int64_t R;
     int64_t nbr_ld;
     int nb;                  // persistent blocks of the weight-gradient kernels = partial rows of the slab for this frame
@@ -308,85 +277,31 @@ struct Ctx {
 // 128 -> 2.285; 373 k rows (andrew10): 512 -> 2.626, 256 -> 2.614, 160 -> 2.656; 54 k rows (sphere8): 384 -> 0.566, 256 -> 0.533,
 // 192 -> 0.532, 128 -> 0.506, 96 -> 0.509, 64 -> 0.531 (profiles/r02_ab_wg_blocks.txt).  The block count decides how the partial
 // sums associate, i.e. the rounding of the gradients; nothing else depends on it (tests: test_block_count_changes_only_the_rounding).
-// The LDS-staged kernel (LINR_WGRAD_LDS=1) has its window table built for the 512-block partition.
 static int wg_blocks_for(int64_t rows) {
     static const int forced = getenv("LINR_WG_BLOCKS") ? atoi(getenv("LINR_WG_BLOCKS")) : 0;
     if (forced >= 32 && forced <= LINR_WG_BLOCKS && forced % 32 == 0) return forced;
-    if (linr_wgrad_lds_enabled()) return LINR_WG_BLOCKS;
     return rows >= 100000 ? 256 : 128;
 }
 
-// Weight-gradient kernels only feed the final reduction, so they CAN run on a second stream next to the backward data
-// chain (optional, see aux_init).  The stream and a small event pool are created once per process.
-static hipStream_t g_aux = nullptr;
-static hipEvent_t g_ev[64];
-static int g_ev_next = 0;
-static bool g_aux_ok = false;
-static std::mutex g_aux_mu;          // the pool is process-wide; executor calls may come from several host threads
-
-// Second-stream policy (LINR_WGRAD_STREAM: 1 = every weight-gradient launch, 0 = none, unset = auto).  Since block_in rides in
-// the grouped launches (join_block_in) the step has no single weight-gradient launches left, and auto = ONE stream:
-//   * small frames (sphere8, 54 k rows): 0.545 ms/step on one stream vs 0.554 with the weight gradients on a second one;
-//   * large frames (loot10, 337 k rows): 2.311 on one stream vs 2.321 with LINR_WGRAD_STREAM=1 LINR_FWD_OVERLAP=1 (the grouped
-//     weight-gradient launches beside the backward-data chain, the shared occupancy conv beside [scale context -> block_in's
-//     first conv]); a schedule that still hands the scale context's weight gradients to the second stream measured 2.353
-//     against 2.329 for everything on it - the event hand-offs cost more than the overlap of chip-filling grouped launches
-//     brings (profiles/r02_ab_overlap_policy.txt).  One stream also keeps every kernel timeable on its own.
-// The schedule with block_in's single launches (LINR_JOIN_BLOCK_IN=0, block_layers > 1) keeps the round-1 rule: its single
-// launches on the second stream, the grouped ones too for frames below LINR_AUX_ROWS (150,000) rows.
-// Results are bit-identical either way (tests/test_gpu_parity.py: switch test).
-static int aux_policy() {
-    static const int v = getenv("LINR_WGRAD_STREAM") ? atoi(getenv("LINR_WGRAD_STREAM")) : -1;
-    return v;
-}
-static int64_t aux_rows() {
-    static const int64_t v = getenv("LINR_AUX_ROWS") ? atoll(getenv("LINR_AUX_ROWS")) : 150000;
-    return v;
-}
-
-// the auxiliary stream (created on first use), or nullptr when switched off / unavailable
-static hipStream_t aux_stream() {
-    if (aux_policy() == 0) return nullptr;
-    std::lock_guard<std::mutex> lk(g_aux_mu);
-    if (g_aux_ok) return g_aux;
-    if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    for (int i = 0; i < 64; ++i)
-        if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    g_aux_ok = true;
-    return g_aux;
-}
-// do the grouped weight-gradient launches go to the auxiliary stream?
-static bool aux_all(int64_t rows, bool join) {
-    const int pol = aux_policy();
-    return pol > 0 || (pol < 0 && !join && rows < aux_rows());
-}
-
-// everything issued on `from` so far happens-before whatever is issued on `to` next
-static int stream_order(hipStream_t from, hipStream_t to) {
-    if (from == to) return 0;
-    std::lock_guard<std::mutex> lk(g_aux_mu);
-    hipEvent_t ev = g_ev[g_ev_next];
-    g_ev_next = (g_ev_next + 1) & 63;
-    TRY(linr_hip_rc(hipEventRecord(ev, from)));
-    return linr_hip_rc(hipStreamWaitEvent(to, ev, 0));
-}
-
 // ---- live kernel timing for bench.py's roofline (include/linr_hip.h: linr_prof_*) --------------------------------------
-// While enabled, every launch of the two roofline kernels inside the executor (kind 0: spconv_wgrad_mfma_k<2,8>,
-// kind 1: cconv_mfma_k<8,8,fwd,plain epilogue>) is bracketed by an event pair on its own stream; `passes` counts the
-// row passes (groups) of a launch.  Measurement aid only: mutex-guarded, nothing is recorded (and no lock is taken) when disabled.
-#define LINR_PROF_MAX 2048
+// While enabled, the launches of a training step are bracketed by an event pair on their stream, by kernel class (the list is
+// in include/linr_hip.h); `passes` counts the row passes (groups) of a launch.  Measurement aid only: mutex-guarded, nothing is
+// recorded (and no lock is taken) when disabled.
+#define LINR_PROF_MAX 4096
+enum { PK_FUSED88 = 0, PK_CONV88 = 1, PK_FUSED_DUAL = 2, PK_FUSED_C00 = 3, PK_HEAD_FWD = 4, PK_CONVPW_FWD = 5, PK_DUAL_FWD = 6,
+       PK_OCC7 = 7, PK_HEAD_BWD = 8, PK_WGRAD = 9, PK_LIN_WGRAD = 10, PK_SCE = 11, PK_MISC = 12, PK_BWD_DATA = 13 };
 struct ProfRec { hipEvent_t e0, e1; int passes; };
 static std::atomic<bool> g_prof_on{false};
-static std::mutex g_prof_mu;                    // guards the two vectors below
-static std::vector<ProfRec> g_prof[4];          // used records
+static std::atomic<uint32_t> g_prof_mask{3u};
+static std::mutex g_prof_mu;                    // guards the vectors below
+static std::vector<ProfRec> g_prof[LINR_PROF_KINDS];          // used records
 static std::vector<ProfRec> g_prof_free;        // pre-created event pairs (creating events in the hot path costs ~20 us each)
 
 struct ProfScope {
     hipStream_t s; int kind; bool live;
     ProfRec r;
     ProfScope(hipStream_t s_, int kind_, int passes, bool want = true) : s(s_), kind(kind_), live(false) {
-        if (!want || !g_prof_on.load(std::memory_order_relaxed)) return;
+        if (!want || !g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> kind_) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_free.empty()) return;
         r = g_prof_free.back();
@@ -403,16 +318,21 @@ struct ProfScope {
     }
 };
 
+extern "C" int linr_prof_mask(uint32_t mask) { g_prof_mask = mask; return 0; }
+
 extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kept), 1: clear + start, 2: resume
     g_prof_on = false;
     if (mode == 0) return 0;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (mode == 1)
-        for (int k = 0; k < 4; ++k) {
+    size_t used = 0;
+    for (int k = 0; k < LINR_PROF_KINDS; ++k) {
+        if (mode == 1) {
             for (auto& r : g_prof[k]) g_prof_free.push_back(r);
             g_prof[k].clear();
         }
-    while (g_prof_free.size() + g_prof[0].size() + g_prof[1].size() + g_prof[2].size() + g_prof[3].size() < 2 * LINR_PROF_MAX) {
+        used += g_prof[k].size();
+    }
+    while (g_prof_free.size() + used < LINR_PROF_MAX) {
         ProfRec r;
         r.passes = 0;
         if (hipEventCreate(&r.e0) != hipSuccess) break;
@@ -424,7 +344,7 @@ extern "C" int linr_prof_enable(int32_t mode) {          // 0: stop (records kep
 }
 
 extern "C" int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes) {
-    if (kind < 0 || kind > 3 || !total_ms || !launches || !passes) return LINR_EINVAL;
+    if (kind < 0 || kind >= LINR_PROF_KINDS || !total_ms || !launches || !passes) return LINR_EINVAL;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double t = 0.0;
     int64_t np = 0;
@@ -465,15 +385,10 @@ static bool fused_bwd(const Ctx& c) {
     return v != 0 && c.f->nbr_lo && c.f->nbr_mask;
 }
 
-static bool fwd_overlap() {          // opt-in, see the second-stream policy above
-    static const int v = getenv("LINR_FWD_OVERLAP") ? atoi(getenv("LINR_FWD_OVERLAP")) : 0;
-    return v != 0;
-}
-
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
                  const float* res, int res_ld, const float* act, int act_ld, float* out, int out_ld, unsigned flags) {
     if (c.f->nbr_lo && c.f->nbr_mask) {
-        ProfScope ps(c.s, 1, 1, !bwd && cin == 8 && cout == 8);
+        ProfScope ps(c.s, bwd ? PK_BWD_DATA : PK_CONV88, 1);
         return linr_cconv_launch(bwd, in, in_ld, clo(c), cmk(c), c.nbr_ld, c.R, W, bias, cin, cout, res, res_ld,
                                  act, act_ld, out, out_ld, flags, c.s);
     }
@@ -481,45 +396,13 @@ static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, c
                              flags | LINR_PAD_ROW, c.s);
 }
 
-// LINR_WGRAD_CMAP=1: weight-gradient kernels decode the compressed map instead of reading the full nbr[27][ld] table.
-// The table costs 108 instead of 40 index bytes per row, the decode ~5 VALU instructions per index - and VALU
-// instructions share the FMA units with the f32 MFMAs: the table is 0.7 % faster end to end (same-box A/B).
-static bool wg_cmap() {
-    static const int v = getenv("LINR_WGRAD_CMAP") ? atoi(getenv("LINR_WGRAD_CMAP")) : 0;
-    return v != 0;
-}
-// 8-row tiled index table (linr_kmap_tile8) for the direct-gather weight-gradient kernels; LINR_WGRAD_TILE8=0 reads nbr[27][ld]
-static const int32_t* wg_t8(const Ctx& c) {
-    if (wg_cmap()) return nullptr;            // LINR_WGRAD_CMAP=1: every weight-gradient kernel decodes the compressed map
-    static const int v = getenv("LINR_WGRAD_TILE8") ? atoi(getenv("LINR_WGRAD_TILE8")) : 1;
-    return v ? c.f->nbr8 : nullptr;
-}
-
-// transposed tiled table for the coalesced-gather + LDS-transpose weight-gradient kernels (csrc/fused.hip: spconv_wgrad_t_k).
-// LINR_WGRAD_T: 2 (default) = every weight-gradient kernel, 1 = the 4-output kernels only (conv 8->4, dual 4->4), 0 = none.
-// First measurement (r2, 5-to-7-group schedule): 80.9 / 78.8 us per launch against 91.7 / 80.3 with direct gathers for the
-// 4-output kernels, but 105.0 against 102.7 for the 8->8 one.  After the LDS writes were pinned in front of the next gathers (no
-// register-pair copies) and the gathers went to saddr form, the 8->8 kernel wins too: 2.241 vs 2.253 ms/step (same box).
-static const int32_t* wg_t8t(const Ctx& c, int cout) {
-    if (wg_cmap() || linr_wgrad_lds_enabled()) return nullptr;      // (the launchers prefer this table over the other index sources)
-    static const int v = getenv("LINR_WGRAD_T") ? atoi(getenv("LINR_WGRAD_T")) : 2;
-    return (v >= 2 || (v == 1 && cout == 4)) ? c.f->nbr8t : nullptr;
-}
-// The 4-output kernels (conv 8->4 and the dual 4->4 pair: half the MFMAs per row) preferred the compressed map over the
-// plain table in round 1; with the 8-row tiled table + one-group pipeline (linr_kmap_tile8) they are 3.8 % of the whole
-// step faster still (2.537 -> 2.441 ms/step, same box), so the compressed map is only their fallback for frames without a
-// tiled table (and what LINR_WGRAD_CMAP=1 selects for all weight-gradient kernels).
-static bool wg_cmap4_impl(bool have_tile8) { return !have_tile8 || wg_cmap(); }
-#define wg_cmap4() wg_cmap4_impl(wg_t8(c) != nullptr)
-// window table of the LDS-staged weight-gradient kernels: only under LINR_WGRAD_LDS=1 (csrc/fused.hip has the measurement)
-static const int32_t* wg_rg(const Ctx& c) { return linr_wgrad_lds_enabled() ? c.f->wg_ranges : nullptr; }
+// transposed tiled table of the stand-alone weight-gradient kernels (csrc/fused.hip: spconv_wgrad_t_k), or NULL: indices from nbr
+static const int32_t* wg_t8t(const Ctx& c) { return c.f->nbr8t; }
 static int conv3_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int cin, int cout,
                        int64_t w_off, int64_t b_off) {
     LinrWgradDst d = {c.A.BIG, c.L.total, w_off, b_off, cin};
-    TRY(stream_order(c.s, c.ws));
-    ProfScope ps(c.ws, 0, 1, cout == 8 && in_ld >= 8);
-    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, c.nb, c.ws, nullptr, 1,
-                                 (cout == 4 ? wg_cmap4() : wg_cmap()) ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, cout));
+    ProfScope ps(c.s, PK_WGRAD, 1);
+    return linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, c.f->nbr, c.nbr_ld, c.R, cin, cout, d, c.nb, c.s, nullptr, 1, wg_t8t(c));
 }
 
 static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co, const float* bias,
@@ -532,8 +415,8 @@ static int linear(Ctx& c, const float* in, int in_ld, int64_t n, const float* W,
 static int linear_wgrad(Ctx& c, const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
                         int64_t w_off, int ws_ci, int ws_co, int64_t b_off) {
     LinrLinDst d = {c.A.BIG, c.L.total, w_off, ws_ci, ws_co, b_off};
-    TRY(stream_order(c.s, c.ws));
-    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, c.nb, c.ws);
+    ProfScope ps(c.s, PK_LIN_WGRAD, 1);
+    return linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, c.nb, c.s);
 }
 
 // Per-layer matrices of block slot b (0 = block_in, 1..7 = outter blocks): layer 0 uses the slot's own H/M/I, the extra
@@ -606,10 +489,8 @@ static int block_bwd(Ctx& c, const BlockP& bp, const float* in, int in_ld, int b
             TRY(linear(c, t.gI + 4, 8, c.R, P + q.c12_w, 1, 4, nullptr, 4, 4, nullptr, 0, t.M, 4, t.gM, 4, LINR_RELU_MASK));
         TRY(linear_wgrad(c, t.M, 4, t.gI + 4, 8, c.R, 4, 4, q.c12_w, 4, 1, q.c12_b));
         if (cm) {
-            TRY(stream_order(c.s, c.ws));
             TRY(linr_conv3_wgrad_dual44(t.H, t.gI, 8, t.gM, 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, c.L.total, q.c01_w, q.c01_b,
-                                        q.c11_w, q.c11_b, c.nb, c.ws, nullptr, 1, wg_cmap4() ? c.f->nbr_lo : nullptr,
-                                        c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+                                        q.c11_w, q.c11_b, c.nb, c.s, nullptr, 1, wg_t8t(c)));
             TRY(linr_dual44_bwd_launch(t.gI, t.gM, clo(c), cmk(c), c.nbr_ld, c.R, P + q.c01_w, P + q.c11_w, t.H, t.gH, c.s));
         } else {
             // I[:,0:4] = conv3(H0; c01) + X[:,0:4]
@@ -681,16 +562,6 @@ static SceArgs sce_args(const Ctx& c) {
     return a;
 }
 
-// WPAD[g][k][ci][co] = ci <= g ? W_a(outter block g)[k][ci][co] : 0     (block g has cin = g + 1)
-struct PadSrc { int64_t off[7]; };
-__global__ __launch_bounds__(LINR_BLOCK) void pad_weights_k(const float* __restrict__ P, PadSrc src, float* __restrict__ wpad) {
-    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (e >= 7 * 1728) return;
-    const int g = e / 1728, r = e % 1728;
-    const int k = r / 64, ci = (r / 8) % 8, co = r % 8, cin = g + 1;
-    wpad[e] = ci < cin ? P[src.off[g] + (k * cin + ci) * 8 + co] : 0.0f;
-}
-
 static void goffs(int64_t* dst, const float* const* ptrs, int n) {
     for (int i = 0; i < n; ++i) dst[i] = ptrs[i] - ptrs[0];
 }
@@ -700,7 +571,7 @@ static void goffs(int64_t* dst, const float* const* ptrs, int n) {
 // path below, so the decoder reproduces these probabilities bit for bit.
 // part 1: the occupancy-only layers of the outter blocks (first conv, conv0_0 | conv1_0, both 4->4 convs: they do not need
 // x_glob); part 2: everything that does (tail conv + x_glob, the 8 heads).  3 = both.
-static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3, bool join = false, hipStream_t occ_on = nullptr) {
+static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3, bool join = false) {
     Arena& a = c.A;
     const float* P = c.P;
     const Layout& L = c.L;
@@ -723,36 +594,24 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3,
         p_c12w[g] = P + bp.inc[0].c12_w; p_c12b[g] = P + bp.inc[0].c12_b; p_bw[g] = P + bp.b_w; p_bb[g] = P + bp.b_b;
     }
     if (part & 1) {
-    if (occ_on) {    // the shared occupancy conv was launched on `occ_on` beside the scale context + block_in's first conv
-        TRY(stream_order(occ_on, c.s));
-    } else
     {   // first conv of every outter block: A[b] = relu(conv3(occ[:, :b]; a) + a_b), one shared gather (csrc/fused.hip)
-        static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
-        if (shared) {
-            int64_t w_off[7], b_off[7], o_off[7];
-            for (int g = 0; g < 7; ++g) { w_off[g] = L.outter[g].a_w; b_off[g] = L.outter[g].a_b; o_off[g] = a.A[g + 1] - a.A[1]; }
-            TRY(linr_occ_conv7_launch(a.OCC, lo, mk, c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, c.s));
-        } else {
-            PadSrc ps;
-            for (int g = 0; g < 7; ++g) ps.off[g] = L.outter[g].a_w;
-            pad_weights_k<<<linr_grid(7 * 1728, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, ps, a.WPAD);
-            Grp gp = Grp();
-            for (int g = 0; g < 7; ++g) gp.w[g] = (int64_t)g * 1728;
-            goffs(gp.b, p_ab + o7, 7); goffs(gp.out, pA + o7, 7);
-            TRY(linr_cconv_launch(false, a.OCC, 8, lo, mk, c.nbr_ld, c.R, a.WPAD, p_ab[o7], 8, 8, nullptr, 0, nullptr, 0, a.A[1], 8,
-                                  LINR_RELU, c.s, &gp, 7));
-        }
+        int64_t w_off[7], b_off[7], o_off[7];
+        for (int g = 0; g < 7; ++g) { w_off[g] = L.outter[g].a_w; b_off[g] = L.outter[g].a_b; o_off[g] = a.A[g + 1] - a.A[1]; }
+        ProfScope ps(c.s, PK_OCC7, 7);
+        TRY(linr_occ_conv7_launch(a.OCC, lo, mk, c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, c.s));
     }
     {   // H = [relu(conv0_0(A)) | relu(conv1_0(A))]
         Grp gp = Grp();
         goffs(gp.in, pA, ng); goffs(gp.w, p_c00w, ng); goffs(gp.b, p_c00b, ng); goffs(gp.out, pH, ng);
         goffs(gp.e0, p_c10w, ng); goffs(gp.e1, p_c10b, ng);
+        ProfScope ps(c.s, PK_CONVPW_FWD, ng);
         TRY(linr_conv_pw_fwd_launch(pA[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c00b[0], p_c10w[0], p_c10b[0], a.H[g0], c.s, &gp, ng));
     }
     {   // both 4->4 convs + conv1_2 + residual -> M, I
         Grp gp = Grp();
         goffs(gp.in, pH, ng); goffs(gp.w, p_c01w, ng); goffs(gp.b, p_c01b, ng); goffs(gp.e1, p_c11w, ng); goffs(gp.e2, p_c11b, ng);
         goffs(gp.res, pA, ng); goffs(gp.e3, p_c12w, ng); goffs(gp.e4, p_c12b, ng); goffs(gp.e5, pM, ng); goffs(gp.out, pI, ng);
+        ProfScope ps(c.s, PK_DUAL_FWD, ng);
         TRY(linr_dual44_fwd_launch(pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c01b[0], p_c11w[0], p_c11b[0], pA[0], p_c12w[0],
                                    p_c12b[0], a.M[g0], a.I[g0], c.s, &gp, ng));
     }
@@ -763,7 +622,7 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3,
     {   // O[b] = conv3(I; b) + x_glob
         Grp gp = Grp();
         goffs(gp.in, pI + o7, 7); goffs(gp.w, p_bw + o7, 7); goffs(gp.b, p_bb + o7, 7); goffs(gp.out, pO + o7, 7);
-        ProfScope ps(c.s, 1, 7);
+        ProfScope ps(c.s, PK_CONV88, 7);
         TRY(linr_cconv_launch(false, pI[o7], 8, lo, mk, c.nbr_ld, c.R, p_bw[o7], p_bb[o7], 8, 8, a.O[0], 8, nullptr, 0, a.O[1], 8, 0,
                               c.s, &gp, 7));
     }
@@ -777,10 +636,14 @@ static int forward_batched(Ctx& c, float* probs, double* bits_acc, int part = 3,
         goffs(gp.in, hO, 8); goffs(gp.w, h_prw, 8); goffs(gp.b, h_prb, 8); goffs(gp.out, hC, 8);
         goffs(gp.e0, h_w1, 8); goffs(gp.e1, h_b1, 8); goffs(gp.e2, h_w2, 8); goffs(gp.e3, h_b2, 8); goffs(gp.e5, hP, 8);
         for (int k = 0; k < 8; ++k) { gp.e4[k] = k; gp.e6[k] = (int64_t)k * nblk; }
+        ProfScope ps(c.s, PK_HEAD_FWD, 8);
         TRY(linr_cconv_head_launch(a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], h_prb[0], a.C[0], h_w1[0], h_b1[0], h_w2[0], h_b2[0],
                                    a.OCC, 8, a.P[0], bits_acc ? (double*)a.slab : nullptr, c.s, &gp, 8));
     }
-    if (bits_acc) TRY(linr_bits_finish_launch((const double*)a.slab, (int)(8 * nblk), bits_acc, c.s));
+    if (bits_acc) {
+        ProfScope ps(c.s, PK_MISC, 0);
+        TRY(linr_bits_finish_launch((const double*)a.slab, (int)(8 * nblk), bits_acc, c.s));
+    }
     if (probs)
         for (int k = 0; k < 8; ++k)
             TRY(linr_hip_rc(hipMemcpyAsync(probs + (int64_t)k * c.R, a.P[k], (size_t)c.R * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
@@ -802,56 +665,24 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         TRY(linr_hip_rc(hipMemcpyAsync(a.OCC, f->occ, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
     const bool batched = grouped_enabled();
     const bool all_grouped = batched && stage_begin == 0 && stage_end == 8 && f->nbr_lo && f->nbr_mask;
-    hipStream_t occ_on = nullptr;
     if (stage_begin == 0) {
         PadList pl;
         pl.n = a.npad;
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
-        static const int sce_fused_ = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
-        if (!sce_fused_) zero_pads_k<<<a.npad, 32, 0, c.s>>>(a.base, pl);          // (the fused scale context clears them itself)
-        if (all_grouped && join_block_in(c) && fwd_overlap()) {
-            // The first convs of the outter blocks read the occupancy only: they run on the second stream while this one does
-            // the scale context and block_in's first conv (both single launches that leave most of the chip idle).
-            hipStream_t aux = aux_stream();
-            static const int shared = getenv("LINR_OCC_SHARED") ? atoi(getenv("LINR_OCC_SHARED")) : 1;
-            if (aux && shared) {
-                int64_t w_off[7], b_off[7], o_off[7];
-                for (int g = 0; g < 7; ++g) { w_off[g] = c.L.outter[g].a_w; b_off[g] = c.L.outter[g].a_b; o_off[g] = a.A[g + 1] - a.A[1]; }
-                TRY(stream_order(c.s, aux));
-                TRY(linr_occ_conv7_launch(a.OCC, clo(c), cmk(c), c.nbr_ld, c.R, P, w_off, b_off, a.A[1], o_off, aux));
-                occ_on = aux;
-            }
-        }
-        // scale context: one small MLP per scale (model_core.py:48-53)
-        static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
-        if (sce_fused) {
+        {   // scale context: one small MLP per scale (model_core.py:48-53), all scales in one launch; its spare blocks clear the pad rows
+            ProfScope ps(c.s, PK_SCE, 1);
             sce_fwd_k<<<linr_grid(c.R, LINR_BLOCK) + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
                 P, f->offset_feat, sce_args(c), c.R, a.MIX, a.HID, a.X0, a.base, pl);
-        } else
-        for (int s = 0; s < f->n_scales; ++s) {
-            const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
-            if (n == 0) continue;
-            const int si = f->scale_idx_h[s];
-            sce_mix_k<<<linr_grid(n * 16, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P + c.L.emb + si * 8, f->offset_feat + r0 * 7, n,
-                                                                             a.MIX + r0 * 16);
-            TRY(linear(c, a.MIX + r0 * 16, 16, n, P + c.L.m0_w[si], 1, 15, P + c.L.m0_b[si], 15, 16, nullptr, 0, nullptr, 0,
-                       a.HID + r0 * 16, 16, LINR_RELU));
-            TRY(linear(c, a.HID + r0 * 16, 16, n, P + c.L.m2_w[si], 1, 16, P + c.L.m2_b[si], 16, 8, nullptr, 0, nullptr, 0,
-                       a.X0 + r0 * 8, 8, 0));
         }
         if (all_grouped && join_block_in(c)) {
             // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
             const BlockP& bi = c.L.block_in;
-            if (occ_on)     // (not through conv3(): a launch that shares the chip must not enter the live roofline timing)
-                TRY(linr_cconv_launch(false, a.X0, 8, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0,
-                                      nullptr, 0, a.A[0], 8, LINR_RELU, c.s));
-            else
-                TRY(conv3(c, false, a.X0, 8, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0, nullptr, 0, a.A[0], 8, LINR_RELU));
+            TRY(conv3(c, false, a.X0, 8, P + bi.a_w, P + bi.a_b, bi.cin, 8, nullptr, 0, nullptr, 0, a.A[0], 8, LINR_RELU));
         } else {
             TRY(block_fwd(c, c.L.block_in, a.X0, 8, 0, nullptr));       // O[0] = x_glob
         }
     }
-    if (all_grouped) return forward_batched(c, probs, bits_acc, 3, join_block_in(c), occ_on);
+    if (all_grouped) return forward_batched(c, probs, bits_acc, 3, join_block_in(c));
     const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
     bool fused_bits = false;
     for (int k = stage_begin; k < stage_end; ++k) {
@@ -969,6 +800,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             goffs(gp.out, h_gC, 8);
             for (int k = 0; k < 8; ++k) gp.e1[k] = k;
             goffs_i(gp.e3, o_w1, 8); goffs_i(gp.e4, o_b1, 8); goffs_i(gp.e5, o_w2, 8); goffs_i(gp.e6, o_b2, 8);
+            ProfScope ps(c.s, PK_HEAD_BWD, 8);
             TRY(linr_head_bwd_launch(a.C[0], a.P[0], a.OCC, 8, h_w1[0], h_b1[0], h_w2[0], gz_scale, a.gC[0], c.R, a.BIG, L.total,
                                      o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8, c.nb));
         }
@@ -977,26 +809,27 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             goffs(gp.in, h_gC, 8); goffs(gp.res, hO, 8); goffs(gp.w, h_prw, 8); goffs(gp.out, h_gO, 8);
             goffs_i(gp.e3, o_prw, 8); goffs_i(gp.e4, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
-            ProfScope ps(c.s, 0, 8);
+            ProfScope ps(c.s, PK_FUSED88, 8);
             TRY(linr_conv88_bwd_wgrad_launch(a.gC[0], a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], a.gO[0], nullptr, d, c.nb, c.s, &gp, 8));
         } else {
         {   // C = conv3(prior_k; prune_k): weight gradients ...
             Grp gp = Grp();
             goffs(gp.in, hO, 8); goffs(gp.res, h_gC, 8); goffs_i(gp.w, o_prw, 8); goffs_i(gp.b, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
-            TRY(stream_order(c.s, c.ws));
-            ProfScope ps(c.ws, 0, 8);
-            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, 8, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+            ProfScope ps(c.s, PK_WGRAD, 8);
+            TRY(linr_conv3_wgrad_mfma(a.O[0], 8, a.gC[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.s, &gp, 8, wg_t8t(c)));
         }
         {   // ... and gO[k] = bwd(gC[k])
             Grp gp = Grp();
             goffs(gp.in, h_gC, 8); goffs(gp.w, h_prw, 8); goffs(gp.out, h_gO, 8);
+            ProfScope ps(c.s, PK_BWD_DATA, 8);
             TRY(linr_cconv_launch(true, a.gC[0], 8, lo, mk, c.nbr_ld, c.R, h_prw[0], nullptr, 8, 8, nullptr, 0, nullptr, 0, a.gO[0],
                                   8, 0, c.s, &gp, 8));
         }
         }
         Ptr8 src;
         for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
+        ProfScope ps(c.s, PK_MISC, 0);
         sum8_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(src, c.R * 8, a.gXG);
     }
     // outter blocks 1..7 (slot b = block b; gO[b] is the gradient of the block output) and, with `join`, block_in as slot 0
@@ -1024,21 +857,21 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng); goffs(gp.e2, p_gM, ng); goffs_i(gp.e3, o_bw, ng); goffs_i(gp.e4, o_bb, ng);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         PwArgs pw = {p_c12w[0], nullptr, pM[0], a.gM[g0]};
-        ProfScope ps(c.s, 0, ng);
+        ProfScope ps(c.s, PK_FUSED88, ng);
         TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng));
     } else {
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
         goffs(gp.in, pI, ng); goffs(gp.res, p_gO, ng); goffs_i(gp.w, o_bw, ng); goffs_i(gp.b, o_bb, ng);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
-        TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, ng);
-        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.ws, &gp, ng, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        ProfScope ps(c.s, PK_WGRAD, ng);
+        TRY(linr_conv3_wgrad_mfma(pI[0], 8, p_gO[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 8, d, c.nb, c.s, &gp, ng, wg_t8t(c)));
     }
     {   // gI = bwd(gO; b), gM = (gI[:,4:8] @ W12^T) * (M > 0)
         Grp gp = Grp();
         goffs(gp.in, p_gO, ng); goffs(gp.w, p_bw, ng); goffs(gp.out, p_gI, ng); goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng);
         goffs(gp.e2, p_gM, ng);
+        ProfScope ps(c.s, PK_BWD_DATA, ng);
         TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[g0], a.gM[g0], c.s, &gp, ng));
     }
     }
@@ -1046,41 +879,44 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         Grp gp = Grp();
         goffs(gp.in, pM, ng); goffs(gp.res, p_gI, ng); goffs_i(gp.w, o_c12w, ng); goffs_i(gp.b, o_c12b, ng);
         LinrLinDst d = {a.BIG, L.total, o_c12w[0], 4, 1, o_c12b[0]};
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.ws, &gp, ng));
+        ProfScope ps(c.s, PK_LIN_WGRAD, ng);
+        TRY(linr_linear_wgrad_partial(pM[0], 4, p_gI[0] + 4, 8, c.R, 4, 4, d, c.nb, c.s, &gp, ng));
     }
     if (fused_bwd(c)) {   // both 4->4 convs: gH and the two kernel / bias gradients from one gather of [gI[:,0:4] | gM]
         Grp gp = Grp();
         goffs(gp.in, p_gI, ng); goffs(gp.e5, p_gM, ng); goffs(gp.res, pH, ng); goffs(gp.w, p_c01w, ng); goffs(gp.e6, p_c11w, ng);
         goffs(gp.out, p_gH, ng); goffs_i(gp.e3, o_c01w, ng); goffs_i(gp.e4, o_c01b, ng); goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
-        ProfScope ps(c.s, 2, ng);
+        ProfScope ps(c.s, PK_FUSED_DUAL, ng);
         TRY(linr_dual44_bwd_wgrad_launch(p_gI[0], p_gM[0], pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], a.gH[g0], a.BIG, L.total,
                                          o_c01w[0], o_c01b[0], o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng));
     } else {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
         goffs(gp.in, pH, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, p_gM, ng); goffs_i(gp.w, o_c01w, ng); goffs_i(gp.b, o_c01b, ng);
         goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
-                                    o_c11w[0], o_c11b[0], c.nb, c.ws, &gp, ng, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+        {
+            ProfScope ps(c.s, PK_WGRAD, ng);
+            TRY(linr_conv3_wgrad_dual44(pH[0], p_gI[0], 8, p_gM[0], 4, c.f->nbr, c.nbr_ld, c.R, a.BIG, L.total, o_c01w[0], o_c01b[0],
+                                        o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng, wg_t8t(c)));
+        }
         Grp gq = Grp();
         goffs(gq.in, p_gI, ng); goffs(gq.out, p_gH, ng); goffs(gq.e0, p_gM, ng); goffs(gq.w, p_c01w, ng); goffs(gq.e1, p_c11w, ng);
         goffs(gq.act, pH, ng);
+        ProfScope ps(c.s, PK_BWD_DATA, ng);
         TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[g0], c.s, &gq, ng));
     }
     {   // conv1_0 (1x1 8->4) weight gradient
         Grp gq = Grp();
         goffs(gq.in, pA, ng); goffs(gq.res, p_gH, ng); goffs_i(gq.w, o_c10w, ng); goffs_i(gq.b, o_c10b, ng);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.ws, &gq, ng));
+        ProfScope ps(c.s, PK_LIN_WGRAD, ng);
+        TRY(linr_linear_wgrad_partial(pA[0], 8, p_gH[0] + 4, 8, c.R, 8, 4, dl, c.nb, c.s, &gq, ng));
     }
     if (fused_bwd(c)) {   // conv0_0 (8->4): gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0) and its weight gradient, one gather
         Grp gp = Grp();
         goffs(gp.in, p_gH, ng); goffs(gp.res, pA, ng); goffs(gp.w, p_c00w, ng); goffs(gp.act, p_gI, ng); goffs(gp.out, p_gA, ng);
         goffs(gp.e0, p_c10w, ng); goffs_i(gp.e3, o_c00w, ng); goffs_i(gp.e4, o_c00b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
-        ProfScope ps(c.s, 3, ng);
+        ProfScope ps(c.s, PK_FUSED_C00, ng);
         TRY(linr_conv84_bwd_wgrad_launch(p_gH[0], pA[0], p_gI[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], a.gA[g0], LINR_RELU_MASK, d,
                                          c.nb, c.s, &gp, ng));
     } else {
@@ -1088,13 +924,14 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         Grp gp = Grp();
         goffs(gp.in, pA, ng); goffs(gp.res, p_gH, ng); goffs_i(gp.w, o_c00w, ng); goffs_i(gp.b, o_c00b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.ws, &gp, ng, wg_cmap4() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 4)));
+        ProfScope ps(c.s, PK_WGRAD, ng);
+        TRY(linr_conv3_wgrad_mfma(pA[0], 8, p_gH[0], 8, c.f->nbr, c.nbr_ld, c.R, 8, 4, d, c.nb, c.s, &gp, ng, wg_t8t(c)));
     }
     {   // gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0)
         Grp gp = Grp();
         goffs(gp.in, p_gH, ng); goffs(gp.w, p_c00w, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, pA, ng); goffs(gp.out, p_gA, ng);
         goffs(gp.e0, p_c10w, ng); goffs(gp.e1, p_gH, ng);
+        ProfScope ps(c.s, PK_BWD_DATA, ng);
         TRY(linr_conv_bwd_ga_launch(p_gH[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], p_gI[0], pA[0], a.gA[g0], LINR_RELU_MASK, c.s, &gp, ng));
     }
     }
@@ -1107,9 +944,8 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         goffs(gp.in, p_in + s0, nq); goffs(gp.res, p_gA + s0, nq); goffs_i(gp.w, o_aw + s0, nq); goffs_i(gp.b, o_ab + s0, nq);
         for (int g = 0; g < nq; ++g) gp.e2[g] = (g0 + s0 + g == 0) ? 8 : g0 + s0 + g;
         LinrWgradDst d = {a.BIG, L.total, o_aw[s0], o_ab[s0], 1};
-        TRY(stream_order(c.s, c.ws));
-        ProfScope ps(c.ws, 0, nq, !fused_bwd(c));
-        TRY(linr_conv3_wgrad_mfma(p_in[s0], 8, p_gA[s0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.ws, &gp, nq, wg_cmap() ? c.f->nbr_lo : nullptr, c.f->nbr_mask, wg_rg(c), wg_t8(c), wg_t8t(c, 8)));
+        ProfScope ps(c.s, PK_WGRAD, nq);
+        TRY(linr_conv3_wgrad_mfma(p_in[s0], 8, p_gA[s0], 8, c.f->nbr, c.nbr_ld, c.R, 1, 8, d, c.nb, c.s, &gp, nq, wg_t8t(c)));
     }
     return 0;
 }
@@ -1120,12 +956,9 @@ static int backward_core(Ctx& c, float gscale) {
     Arena& a = c.A;
     const float* P = c.P;
     const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
-    const bool cm_ = c.f->nbr_lo && c.f->nbr_mask;
-    hipStream_t aux = cm_ ? aux_stream() : nullptr;
     const bool batched = grouped_enabled();
     const bool grouped = batched && c.f->nbr_lo && c.f->nbr_mask;
     const bool join = grouped && join_block_in(c);
-    c.ws = (aux && aux_all(c.R, join)) ? aux : c.s;
     if (grouped) TRY(backward_batched(c, gz_scale, join));
     for (int k = grouped ? -1 : 7; k >= 0; --k) {
         if (c.f->nbr_lo && c.f->nbr_mask) {
@@ -1147,10 +980,10 @@ static int backward_core(Ctx& c, float gscale) {
         axpy_k<<<linr_grid(c.R * 8, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.gO[k], c.R * 8, a.gXG, k == 7 ? 0 : 1);
         if (k > 0) TRY(block_bwd(c, c.L.outter[k - 1], a.OCC, 8, k, a.gO[k], nullptr));
     }
-    if (aux && (aux_all(c.R, join) || !join)) c.ws = aux;     // block_in (unless joined) and the scale context: single launches, overlapped with the data chain
     if (join && fused_bwd(c)) {      // first conv of block_in: input gradient and weight gradient from one gather of gA[0]
         const BlockP& bi = c.L.block_in;
         LinrWgradDst d = {a.BIG, c.L.total, bi.a_w, bi.a_b, 8};
+        ProfScope ps(c.s, PK_FUSED88, 1);
         TRY(linr_conv88_bwd_wgrad_launch(a.gA[0], a.X0, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, a.gX0, nullptr, d, c.nb, c.s));
     } else if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
         const BlockP& bi = c.L.block_in;
@@ -1162,10 +995,12 @@ static int backward_core(Ctx& c, float gscale) {
     int ns = 0, sl[MAX_SCALES];
     for (int s = 0; s < f->n_scales; ++s)
         if (f->row_off_h[s + 1] > f->row_off_h[s]) sl[ns++] = s;
-    static const int sce_fused = getenv("LINR_SCE_FUSED") ? atoi(getenv("LINR_SCE_FUSED")) : 1;
-    const bool sce_grouped = sce_fused && ns >= 1 && ns <= LINR_MAXG;
+    const bool sce_grouped = ns >= 1 && ns <= LINR_MAXG;          // more scales than one grouped launch holds: scale by scale
     if (sce_grouped) {
-        sce_bwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, sce_args(c), c.R, a.gX0, a.HID, a.gHID);
+        {
+            ProfScope ps(c.s, PK_SCE, 1);
+            sce_bwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, sce_args(c), c.R, a.gX0, a.HID, a.gHID);
+        }
         Grp g2 = Grp(), g0 = Grp();
         const int64_t r00 = f->row_off_h[sl[0]];
         const int si0 = f->scale_idx_h[sl[0]];
@@ -1180,9 +1015,9 @@ static int backward_core(Ctx& c, float gscale) {
         const int64_t nmax = f->rows;          // every group carries its own row count
         LinrLinDst d2 = {a.BIG, c.L.total, c.L.m2_w[si0], 1, 16, c.L.m2_b[si0]};
         LinrLinDst d0 = {a.BIG, c.L.total, c.L.m0_w[si0], 1, 15, c.L.m0_b[si0]};
-        TRY(stream_order(c.s, c.ws));
-        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, c.nb, c.ws, &g2, ns));
-        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, c.nb, c.ws, &g0, ns));
+        ProfScope ps(c.s, PK_LIN_WGRAD, 2);
+        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, c.nb, c.s, &g2, ns));
+        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, c.nb, c.s, &g0, ns));
     } else
     for (int s = 0; s < f->n_scales; ++s) {
         const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
@@ -1193,8 +1028,8 @@ static int backward_core(Ctx& c, float gscale) {
                    a.gHID + r0 * 16, 16, LINR_RELU_MASK));
         TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, c.L.m0_w[si], 1, 15, c.L.m0_b[si]));
     }
-    // one pass sums every parameter's per-block partials in fixed order (after the weight-gradient stream has drained)
-    TRY(stream_order(c.ws, c.s));
+    // one pass sums every parameter's per-block partials in fixed order
+    ProfScope ps_tail(c.s, PK_MISC, 0);
     {   // the scale embedding and the context MLPs of absent scales get no partials: the reduction writes their zeros itself
         ZeroRanges zr;
         zr.n = 0; zr.prefix = c.L.block_in.a_w;
@@ -1293,6 +1128,7 @@ extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* ar
             rg.bc2_sqrt[si] = (float)sqrt(1.0 - pow(beta2, (double)t));
         }
     }
+    ProfScope ps(c.s, PK_MISC, 0);
     return linr_adam_launch(params, c.A.GSUM, exp_avg, exp_avg_sq, c.L.total, lr / (1.0 - pow(beta1, (double)step)),
                             sqrt(1.0 - pow(beta2, (double)step)), beta1, beta2, eps, weight_decay,
                             scale_steps_h ? &rg : nullptr, c.s);

@@ -59,19 +59,7 @@ class Frame:
         self.nbr_mask = torch.zeros((self.nbr_ld,), dtype=torch.int32, device=device)      # padding columns: empty masks
         check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
                                             self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
-        # window table of the LDS-staged weight-gradient kernels: only that alternative (LINR_WGRAD_LDS=1) reads it
-        import os
-        self.wg_ranges = None
-        if os.environ.get('LINR_WGRAD_LDS', '0') not in ('', '0'):
-            nb = _lib.lib().linr_wgrad_ranges_bytes(R)
-            self.wg_ranges = torch.zeros(max(1, (nb + 3) // 4), dtype=torch.int32, device=device)
-            check(_lib.lib().linr_wgrad_ranges_build(self.nbr.data_ptr(), self.nbr_ld, R, self.wg_ranges.data_ptr(),
-                                                     self.wg_ranges.numel() * 4, _stream()), 'linr_wgrad_ranges_build')
-        # 8-row tiled copy of the kernel map for the DIRECT-gather weight-gradient kernels: only built when those are selected
-        # (LINR_WGRAD_T=0|1; the default transposing kernels read nbr8t) or when somebody asks for `frame.nbr8` (108 B per row)
-        self._nbr8 = None
-        if os.environ.get('LINR_WGRAD_T', '2') in ('0', '1'):
-            self._build_nbr8()
+        # the kernel map tiled by 8 rows in the gather-lane order of the stand-alone weight-gradient kernels (128 B per row)
         nb8t = _lib.lib().linr_kmap_tile8t_bytes(R)
         self.nbr8t = torch.empty(max(4, (nb8t + 3) // 4), dtype=torch.int32, device=device)
         check(_lib.lib().linr_kmap_tile8t(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr8t.data_ptr(), self.nbr8t.numel() * 4,
@@ -84,22 +72,7 @@ class Frame:
                                  row_off_h=self.row_off.ctypes.data, scale_idx_h=self.scale_idx.ctypes.data,
                                  nbr=self.nbr.data_ptr(), nbr_ld=self.nbr_ld, nbr_lo=self.nbr_lo.data_ptr(),
                                  nbr_mask=self.nbr_mask.data_ptr(), offset_feat=self.offset_feat.data_ptr(),
-                                 occ=self.occ.data_ptr(), wg_ranges=0 if self.wg_ranges is None else self.wg_ranges.data_ptr(), nbr8=0 if self._nbr8 is None else self._nbr8.data_ptr(), nbr8t=self.nbr8t.data_ptr())
-
-    def _build_nbr8(self):
-        nb8 = _lib.lib().linr_kmap_tile8_bytes(self.rows)
-        self._nbr8 = torch.empty(max(4, (nb8 + 3) // 4), dtype=torch.int32, device=self.device)
-        check(_lib.lib().linr_kmap_tile8(self.nbr.data_ptr(), self.nbr_ld, self.rows, self._nbr8.data_ptr(), self._nbr8.numel() * 4,
-                                         _stream()), 'linr_kmap_tile8')
-        if getattr(self, '_c', None) is not None:
-            self._c.nbr8 = self._nbr8.data_ptr()
-
-    @property
-    def nbr8(self):
-        """linr_kmap_tile8 over nbr, built on first use."""
-        if self._nbr8 is None:
-            self._build_nbr8()
-        return self._nbr8
+                                 occ=self.occ.data_ptr(), nbr8t=self.nbr8t.data_ptr())
 
     def alloc_arena(self):
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)

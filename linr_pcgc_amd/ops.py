@@ -185,25 +185,6 @@ def spconv_cmap(x, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None
     return out
 
 
-def wgrad_ranges(nbr, n=None):
-    """linr_wgrad_ranges_build: per-frame window table of the LDS-staged weight-gradient kernels (int32 tensor)."""
-    L = _lib.lib()
-    n = nbr.shape[1] if n is None else n
-    out = torch.zeros(max(1, (L.linr_wgrad_ranges_bytes(n) + 3) // 4), dtype=torch.int32, device=nbr.device)
-    check(L.linr_wgrad_ranges_build(nbr.data_ptr(), nbr.stride(0), n, out.data_ptr(), out.numel() * 4, _stream()),
-          'linr_wgrad_ranges_build')
-    return out
-
-
-def kmap_tile8(nbr, n=None):
-    """linr_kmap_tile8: 8-row tiled copy of the kernel map (int32 tensor)."""
-    L = _lib.lib()
-    n = nbr.shape[1] if n is None else n
-    out = torch.empty(max(4, (L.linr_kmap_tile8_bytes(n) + 3) // 4), dtype=torch.int32, device=nbr.device)
-    check(L.linr_kmap_tile8(nbr.data_ptr(), nbr.stride(0), n, out.data_ptr(), out.numel() * 4, _stream()), 'linr_kmap_tile8')
-    return out
-
-
 def kmap_tile8t(nbr, n=None):
     """linr_kmap_tile8t: the tiled copy of the kernel map in the lane order of the transposing weight-gradient kernel."""
     L = _lib.lib()
@@ -213,17 +194,17 @@ def kmap_tile8t(nbr, n=None):
     return out
 
 
-def spconv_wgrad_cmap(x, gout, nbr, lo, mask, n, cin, cout, slab=None, reduce=True, ranges=None, tile8=None, tile8t=None):
-    """The executor's backward-weight kernel (MFMA; indices from the compressed map, or from nbr when lo and mask are
-    None - the executor's default).  x: view buf[1:] of a [n+1, 8] buffer whose row 0 is zero.  Returns (gW [27,cin,cout], gb [cout]) summed over the per-block partials, or the raw slab with reduce=False."""
+def spconv_wgrad_cmap(x, gout, nbr, n, cin, cout, slab=None, reduce=True, tile8t=None):
+    """The stand-alone backward-weight kernel (MFMA): with tile8t (linr_kmap_tile8t) the transposing kernel with coalesced gathers,
+    without it the direct-gather kernel reading nbr.  x: view buf[1:] of a [n+1, 8] buffer whose row 0 is zero.
+    Returns (gW [27,cin,cout], gb [cout]) summed over the per-block partials, or the raw slab with reduce=False."""
     L = _lib.lib()
     nb = int(L.linr_spconv_wgrad_cmap_blocks())
     elems = (27 * cin + 1) * cout
     if slab is None:
         slab = torch.empty((nb, elems), dtype=torch.float32, device=x.device)
-    check(L.linr_spconv_wgrad_cmap(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(), _ptr(lo),
-                                   _ptr(mask), _ptr(ranges), _ptr(tile8), _ptr(tile8t), nbr.stride(0), n, cin, cout, slab.data_ptr(),
-                                   _stream()),
+    check(L.linr_spconv_wgrad_cmap(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(), _ptr(tile8t),
+                                   nbr.stride(0), n, cin, cout, slab.data_ptr(), _stream()),
           'linr_spconv_wgrad_cmap')
     if not reduce:
         return slab

@@ -1,6 +1,6 @@
 """Helper of test_gpu_parity.py: runs one forward + backward of the network on the golden shell and dumps the results.
 
-Executed as a child process so that the executor's env switches (LINR_BATCHED, LINR_WGRAD_STREAM, LINR_CONV_MFMA),
+Executed as a child process so that the executor's env switches (LINR_BATCHED, LINR_JOIN_BLOCK_IN, LINR_CONV_MFMA, LINR_FUSED_BWD),
 which the library reads once per process, can be compared against each other bit for bit.
 usage: python tests/_dump_net.py <golden npz> <out npz>
 """

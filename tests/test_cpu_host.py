@@ -54,8 +54,9 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_spconv_fwd(p16, 4, p16, 16, 16, p16, p16, 8, 8, None, 0, p16, 8, 0, None) == -1      # in_ld < cin
     assert lib.linr_spconv_cmap(0, p16, 5, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -1   # ld 5
     assert lib.linr_spconv_cmap(0, p16 + 4, 8, p16, p16, 16, 16, p16, p16, 8, 8, None, 0, None, 0, p16, 8, 0, None) == -3
-    assert lib.linr_spconv_wgrad_cmap(p16, 8, p16, 8, p16, p16, p16, None, None, None, 16, 16, 8, 5, p16, None) == -1              # cout 5
-    assert lib.linr_wgrad_ranges_build(p16, 4, 8, p16, 1 << 20, None) == -1 and lib.linr_wgrad_ranges_build(p16, 8, 8, p16, 16, None) == -2
+    assert lib.linr_spconv_wgrad_cmap(p16, 8, p16, 8, p16, None, 16, 16, 8, 5, p16, None) == -1              # cout 5
+    assert lib.linr_spconv_bwd_fused(p16, p16, p16, p16, 16, 16, p16, p16 + 4, p16, 32, None) == -3          # gin not 16-byte aligned
+    assert lib.linr_spconv_bwd_fused(p16, p16, p16, p16, 16, 16, p16, p16, p16, 0, None) == -1               # no slab rows
     assert lib.linr_spconv_bwd_weight(p16, 8, p16, 8, p16, 16, 16, 8, 8, p16, p16, 0, p16, 16, None) == -2             # ws short
     # whole network: NULL frame / parameters, stage range
     assert lib.linr_net_forward(None, p16, p16, 4096, 0, 8, None, None, None) == -1
@@ -68,7 +69,7 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_ac_encode_binary(None, None, 4, p16, 64) == -1
     assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
     tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
-    assert lib.linr_prof_read(4, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
+    assert lib.linr_prof_read(14, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
 
 
 def test_param_count_matches_reference_checkpoint(lib, golden_dir):

@@ -125,33 +125,22 @@ def test_inception_layer_forward_backward(env):
     _close(gX, (xo.grad + old) * (x_h > 0), 1e-4, 1e-4, 'masked accumulated input gradient')
     # weight gradients of the two 4->4 convolutions (one pass) and of the rest through the plain entries
     slab = torch.empty((512, 872), device=dev)
-    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, env['nbr'].data_ptr(),
-                                                env['lo'].data_ptr(), env['mask'].data_ptr(), None, None, env['ld'], n, slab.data_ptr(),
-                                                _stream()), 'linr_spconv_wgrad_dual44')
+    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, env['nbr'].data_ptr(), None,
+                                                env['ld'], n, slab.data_ptr(), _stream()), 'linr_spconv_wgrad_dual44')
     tot = slab.double().sum(0).cpu()
     _rel_own_max(tot[:432].view(27, 4, 4), wo['w01'].grad, 'gW01')
     _rel_own_max(tot[432:436], wo['b01'].grad, 'gb01')
     _rel_own_max(tot[436:868].view(27, 4, 4), wo['w11'].grad, 'gW11')
     _rel_own_max(tot[868:872], wo['b11'].grad, 'gb11')
-    slab2 = torch.empty_like(slab)
-    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, env['nbr'].data_ptr(), None, None, None, None,
-                                                env['ld'], n, slab2.data_ptr(), _stream()), 'wgrad_dual44 from the table')
-    assert torch.equal(slab, slab2), 'compressed map and neighbour table must give the same partials'
-    # ... and with the gathered rows staged through LDS (window table of linr_wgrad_ranges_build): needs ld % 4 == 0
+    # ... and with coalesced gathers + LDS transpose (linr_kmap_tile8t; needs ld % 4 == 0): the same partials
     from linr_pcgc_amd import ops
     ld4 = (n + 63) // 64 * 64
     nbr4 = torch.full((27, ld4), -1, dtype=torch.int32, device=dev)
     nbr4[:, :n] = env['nbr']
-    rg = ops.wgrad_ranges(nbr4, n)
-    slab3 = torch.empty_like(slab)
-    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, nbr4.data_ptr(), None, None,
-                                                rg.data_ptr(), None, ld4, n, slab3.data_ptr(), _stream()), 'wgrad_dual44 through LDS')
-    assert torch.equal(slab, slab3), 'LDS-staged rows must give the same partials'
-    # ... and with coalesced gathers + LDS transpose (linr_kmap_tile8t)
     t8t = ops.kmap_tile8t(nbr4, n)
     slab4 = torch.empty_like(slab)
-    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, nbr4.data_ptr(), None, None, None,
-                                                t8t.data_ptr(), ld4, n, slab4.data_ptr(), _stream()), 'wgrad_dual44 transposing')
+    env['lib'].check(L.linr_spconv_wgrad_dual44(H.data_ptr(), gI.data_ptr(), 8, gM.data_ptr(), 4, nbr4.data_ptr(), t8t.data_ptr(),
+                                                ld4, n, slab4.data_ptr(), _stream()), 'wgrad_dual44 transposing')
     assert torch.equal(slab, slab4), 'the transposing kernel must give the same partials'
 
 
@@ -257,7 +246,7 @@ def test_scale_context_forward_backward(env, golden_dir):
     R = int(row_off[-1])
     off_feat = torch.cat(offs).to(dev).contiguous()
     fr = env['lib'].LinrFrame(rows=R, n_scales=3, model_scale_num=5, block_layers=2, flags=0, row_off_h=row_off.ctypes.data,
-                              scale_idx_h=sidx.ctypes.data, nbr=0, nbr_ld=R, nbr_lo=0, nbr_mask=0, offset_feat=off_feat.data_ptr(), occ=0, wg_ranges=0, nbr8=0, nbr8t=0)
+                              scale_idx_h=sidx.ctypes.data, nbr=0, nbr_ld=R, nbr_lo=0, nbr_mask=0, offset_feat=off_feat.data_ptr(), occ=0, nbr8t=0)
     mix, hid, x0 = (torch.empty((R, c), device=dev) for c in (16, 16, 8))
     env['lib'].check(L.linr_sce_fwd(model.flat_parameters().data_ptr(), ctypes.byref(fr), mix.data_ptr(), hid.data_ptr(), x0.data_ptr(),
                                     _stream()), 'linr_sce_fwd')

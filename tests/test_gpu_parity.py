@@ -577,32 +577,37 @@ def base_dumps(golden_dir, tmp_path_factory):
     return get
 
 
-# every executor switch the library reads from the environment (README.md): each one alone, and the two extreme
-# combinations, must reproduce the default path's probabilities, bits and all gradients BIT FOR BIT.  The LDS-staged
-# weight-gradient kernel works on the 512-block row partition only, so it is compared with the default executor at 512
-# persistent blocks (the partition decides the association of the per-block partial sums).
-B512 = {'LINR_WG_BLOCKS': '512'}
-SWITCHES = [({'LINR_JOIN_BLOCK_IN': '0'}, {}), ({'LINR_WGRAD_STREAM': '1', 'LINR_FWD_OVERLAP': '1'}, {}),
-            ({'LINR_JOIN_BLOCK_IN': '0', 'LINR_WGRAD_STREAM': '0'}, {}), ({'LINR_WGRAD_LDS': '1'}, B512), ({'LINR_WGRAD_T': '0'}, {}),
-            ({'LINR_WGRAD_T': '1'}, {}), ({'LINR_WGRAD_T': '0', 'LINR_WGRAD_TILE8': '0'}, {}), ({'LINR_BATCHED': '0'}, {}),
-            ({'LINR_SCE_FUSED': '0'}, {}), ({'LINR_OCC_SHARED': '0'}, {}), ({'LINR_CONV_MFMA': '0'}, {}), ({'LINR_CONV_MFMA': '2'}, {}),
-            ({'LINR_WGRAD_CMAP': '1'}, {}), ({'LINR_WGRAD_STREAM': '1'}, {}),
-            ({'LINR_BATCHED': '0', 'LINR_WGRAD_STREAM': '0', 'LINR_SCE_FUSED': '0', 'LINR_WGRAD_CMAP': '1', 'LINR_OCC_SHARED': '0',
-              'LINR_WGRAD_LDS': '1'}, B512),
-            ({'LINR_BATCHED': '1', 'LINR_WGRAD_STREAM': '1', 'LINR_CONV_MFMA': '2', 'LINR_WGRAD_CMAP': '1'}, {})]
+# Every executor switch the library reads from the environment (README.md).  Probabilities and bits must be BIT FOR BIT those of
+# the default executor under every switch - that is what lets the stage-serial decoder reproduce the encoder.  Gradients: the
+# schedules that differ from the default only in how launches are grouped reproduce it bit for bit ONCE the fused backward
+# (one gather for backward-data + weight gradient, csrc/fused_bwd.hip) is switched off on both sides: the fused kernels sum the
+# weight gradients over other row partitions, and the stage-by-stage / single-launch schedules do not use them.  Against the
+# default (fused) executor the same gradients agree to rounding.
+NOFUSE = {'LINR_FUSED_BWD': '0'}
+SWITCHES = [({'LINR_JOIN_BLOCK_IN': '0'}, NOFUSE), ({'LINR_BATCHED': '0'}, NOFUSE), ({'LINR_CONV_MFMA': '0'}, NOFUSE),
+            ({'LINR_BATCHED': '0', 'LINR_CONV_MFMA': '0', 'LINR_JOIN_BLOCK_IN': '0'}, NOFUSE), ({'LINR_FUSED_CUS': '64'}, None)]
 
 
-@pytest.mark.parametrize('env,base', SWITCHES, ids=lambda e: ','.join('%s=%s' % (k[5:], v) for k, v in e.items()) or 'default')
+@pytest.mark.parametrize('env,base', SWITCHES, ids=lambda e: ','.join('%s=%s' % (k[5:], v) for k, v in (e or {}).items()) or 'default')
 def test_executor_switch_is_bit_identical_to_default(pkg, golden_dir, tmp_path, base_dumps, env, base):
     """The grouped executor (one launch per layer for block_in + the 7 outter blocks / 8 heads / all scales of the scale
-    context) against every alternative path it can be switched to - stage by stage and scale by scale, block_in as single
-    launches, VALU or LDS-staged convolutions, compressed-map weight gradients, weight gradients on a second stream: same
-    bits everywhere, which is what lets the stage-serial decoder reproduce the encoder's probabilities."""
-    ref = base_dumps(base)
-    got = _dump_under(dict(base, **env), golden_dir, str(tmp_path / 'switched.npz'))
-    for key in ('probs', 'bits', 'grads'):
-        assert np.array_equal(ref[key], got[key]), key
+    context) against every alternative path it can be switched to - stage by stage, block_in as single launches, VALU
+    convolutions: same probabilities and bits everywhere; gradients bit for bit against the matching base, to rounding against
+    the default executor with its fused backward."""
+    default = base_dumps({})
+    got = _dump_under(dict(base or {}, **env), golden_dir, str(tmp_path / 'switched.npz'))
+    for key in ('probs', 'bits'):
+        assert np.array_equal(default[key], got[key]), key
+    scale = float(np.abs(default['grads']).max())
+    assert float(np.abs(default['grads'] - got['grads']).max()) <= 2e-5 * scale
+    if base is not None:
+        ref = base_dumps(base)
+        assert np.array_equal(ref['grads'], got['grads']), 'grads'
+        assert np.array_equal(ref['probs'], got['probs'])
     assert float(np.abs(got['grads']).max()) > 0
+
+
+B512 = {'LINR_WG_BLOCKS': '512'}
 
 
 def test_block_count_changes_only_the_rounding(pkg, golden_dir, tmp_path, base_dumps):
@@ -679,27 +684,21 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     bo = torch.zeros(1, cout, requires_grad=True)
     onet.conv3(x, torch.from_numpy(sc['nbr']).long(), wo, bo).backward(go)
     nbr = ops.kmap_build(torch.from_numpy(sc['coord']).to(dev))
-    lo, mask = ops.kmap_compress(nbr)
     xb = torch.zeros((n + 1, 8), device=dev)
     xb[1:, :cin] = x.to(dev)
-    gw, gb = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout)
+    gw, gb = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, n, cin, cout)                      # direct gathers, indices from nbr
     _close(gw, wo.grad, 0, 1e-4 * float(wo.grad.abs().max()) + 1e-6, 'wgrad cmap')
     _close(gb, bo.grad.reshape(-1), 0, 1e-4 * float(bo.grad.abs().max()) + 1e-6, 'bias grad cmap')
-    gw_t, gb_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, None, None, n, cin, cout)      # indices from the nbr table
-    assert torch.equal(gw_t, gw) and torch.equal(gb_t, gb)
-    slab1 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
-    # rows staged through LDS (window table; needs a 16-byte friendly leading dimension): bit-identical partials
+    slab1 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, n, cin, cout, reduce=False)
+    # 16-byte friendly leading dimension (16-byte index loads) and the transposing kernel: bit-identical partials
     ld4 = (n + 63) // 64 * 64
     nbr4 = torch.full((27, ld4), -1, dtype=torch.int32, device=dev)
     nbr4[:, :n] = nbr
-    slab_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False)
-    slab_l = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, ranges=ops.wgrad_ranges(nbr4, n))
-    assert torch.equal(slab_t, slab_l), 'LDS-staged weight gradients must equal the direct gathers bit for bit'
-    slab_8 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, tile8=ops.kmap_tile8(nbr4, n))
-    assert torch.equal(slab_t, slab_8), 'tiled-index pipelined weight gradients must equal the table kernel bit for bit'
-    slab_tt = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, None, None, n, cin, cout, reduce=False, tile8t=ops.kmap_tile8t(nbr4, n))
+    slab_t = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, n, cin, cout, reduce=False)
+    assert torch.equal(slab1, slab_t), 'scalar and 16-byte index loads must give the same partials'
+    slab_tt = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr4, n, cin, cout, reduce=False, tile8t=ops.kmap_tile8t(nbr4, n))
     assert torch.equal(slab_t, slab_tt), 'coalesced-gather + LDS-transpose weight gradients must equal the table kernel bit for bit'
-    slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, lo, mask, n, cin, cout, reduce=False)
+    slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of an environment switch on the default bench:  gpurun -- 'bash tools/ab_env.sh LINR_WGRAD_LDS=0 [steps]'
+# same-box A/B of an environment switch on the default bench:  gpurun -- 'bash tools/ab_env.sh LINR_FUSED_BWD=0 [steps]'
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 SW=$1; ST=${2:-96}
 b(){ LINR_SKIP_ROOFLINE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-sequence --steps $ST 2>/tmp/ab_err.txt | python3 -c "

@@ -1,13 +1,14 @@
 #!/bin/bash
-# HBM traffic of the two roofline kernels: separate --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch).
+# HBM traffic of the kernels of a training step, executor configuration (grouped launches): separate --pmc passes for FETCH_SIZE and
+# WRITE_SIZE (KB per dispatch; FETCH_SIZE is doubled for gfx950 as MI355X_MICROARCH.md prescribes), averaged per kernel name.
+#   gpurun -- 'bash tools/traffic_pmc.sh'   ->  gpurun_out/pmc_traffic.txt, gpurun_out/traffic.json  (copy the latter to profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_traffic.txt
 : > $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$c
-  timeout -k 10 200 rocprofv3 --kernel-trace --kernel-include-regex "wgrad_t_k|wgrad_mfma|cconv_mfma" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 5 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
-  python3 $R/tools/pmc_summary.py /tmp/tr_$c "wgrad_t_k,wgrad_mfma,cconv_mfma" >> $OUT
+  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "conv_bwd_wgrad_k|cconv_mfma_k|cconv_dual44_k|spconv_wgrad_t_k|occ_conv7_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
   echo "pass $c done"
 done
-cat $OUT
+python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic.json | tee -a $OUT

@@ -1,0 +1,23 @@
+"""Per-kernel HBM bytes per dispatch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB); writes traffic.json."""
+import collections, csv, glob, json, sys
+
+
+def load(d, counter):
+    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+            agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    return agg
+
+
+fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+out = {'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/traffic_probe.py: 3 training steps of the '
+                 'executor on frame 0 of loot10, every dispatch of a step; bytes = 2 x FETCH_SIZE (gfx950: the counter tallies '
+                 '128-B requests as 64 B) + WRITE_SIZE, mean per dispatch of that kernel name', 'kernels': {}}
+for name in sorted(fetch):
+    f, w = fetch[name], write.get(name, [0.0])
+    fb, wb = 2.0 * 1024.0 * sum(f) / len(f), 1024.0 * sum(w) / len(w)
+    out['kernels'][name] = {'dispatches': len(f), 'fetch_bytes_x2': int(fb), 'write_bytes': int(wb), 'bytes_per_dispatch': int(fb + wb)}
+    print('%-60s n=%3d  2xFETCH %8.1f MB  WRITE %7.1f MB' % (name[:60], len(f), fb / 1e6, wb / 1e6))
+json.dump(out, open(sys.argv[3], 'w'), indent=1)
