@@ -230,10 +230,12 @@ LINR_API int linr_net_backward(const linr_frame* f, const float* params, float* 
 /* One iteration of main.py:305-321 in a single call: forward (bits added into bits_acc), backward of
  * gscale * bits (gscale = 1/point_num), deterministic gradient reduction and the fused Adam update of `params`
  * (torch.optim.Adam with L2 weight decay; `step` = this update's 1-based count, bias corrections computed in double).
- * scale_steps_h: HOST [model_scale_num] 1-based step counts of the per-scale context MLPs, or NULL.  With it the
- * update follows torch.optim.Adam's handling of parameters without a gradient: the MLP of a scale this frame does not
- * contain (custom_dataset.py:325) is skipped entirely and the others use their own step count; NULL updates every
- * parameter with `step` (a zero gradient still decays weights and moments).  Nothing synchronises with the host. */
+ * scale_steps_h: HOST [model_scale_num] update counts of the per-scale context MLPs INCLUDING this update, or NULL.  With it the
+ * update follows torch.optim.Adam (the reference pins torch 1.13.1, enviroment.yaml:30): an MLP whose count is 0 - no frame so far
+ * contained its scale (custom_dataset.py:325), its .grad is still None - is skipped entirely; every other MLP is updated with
+ * its own step count, with a zero gradient when this frame lacks the scale (optimizer.zero_grad() of main.py:320 leaves zero
+ * tensors, so weight decay and moment decay keep acting).  A scale of this frame with count 0 is an error.  NULL updates every
+ * parameter with `step`.  Nothing synchronises with the host. */
 LINR_API int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
                         float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
                         double beta1, double beta2, double eps, double weight_decay, double* bits_acc, void* stream);

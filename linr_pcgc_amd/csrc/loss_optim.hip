@@ -100,10 +100,11 @@ extern "C" int linr_bce_bits_bwd(const float* p, const float* target, int32_t ta
 
 // torch.optim.Adam single-tensor update (amsgrad=False, maximize=False), L2 weight decay folded into the gradient.
 // Optional per-range schedule (LinrAdamRanges): torch.optim.Adam skips a parameter whose .grad is None and keeps a step
-// counter per parameter.  The scale-context MLP of a scale that a frame does not contain (custom_dataset.py:325 stops
-// early on min_point_num) gets no gradient in the reference (zero_grad(set_to_none=True) is torch 2's default), so its
-// 392 parameters are left untouched on that frame - no weight decay, no moment decay - and their bias corrections follow
-// their own step count.  Range r covers [begin + r*len, begin + (r+1)*len); everything outside uses the global scalars.
+// counter per parameter.  The scale-context MLP of a scale that no frame so far has contained (custom_dataset.py:325 stops
+// early on min_point_num) has no gradient yet: its 392 parameters are left untouched - no weight decay, no moment decay.
+// Once it has had one, the pinned torch 1.13.1 keeps a zero tensor in .grad (zero_grad() of main.py:320), so it is updated on
+// every step with its own step count.  Range r covers [begin + r*len, begin + (r+1)*len); everything outside uses the global
+// scalars; `active` and the per-range scalars come from the caller's counters (linr_net_train_step).
 __global__ __launch_bounds__(LINR_BLOCK) void adam_k(float* __restrict__ params, const float* __restrict__ grads,
                                                      float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                      float step_size, float bc2_sqrt, float beta1, float omb1, float beta2,

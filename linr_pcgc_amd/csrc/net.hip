@@ -1106,9 +1106,15 @@ extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* ar
                                    double beta1, double beta2, double eps, double weight_decay, double* bits_acc,
                                    void* stream) {
     if (!exp_avg || !exp_avg_sq || !bits_acc || step < 1) return LINR_EINVAL;
-    TRY(linr_net_forward(f, params, arena, arena_bytes, 0, 8, nullptr, bits_acc, stream));
     Ctx c;
     TRY(check_frame(f, params, arena, arena_bytes, c));
+    if (scale_steps_h) {          // checked before anything is launched
+        for (int s = 0; s < c.L.S; ++s)
+            if (scale_steps_h[s] < 0) return LINR_EINVAL;
+        for (int j = 0; j < f->n_scales; ++j)          // a scale of this frame cannot be "never started"
+            if (f->row_off_h[j + 1] > f->row_off_h[j] && scale_steps_h[f->scale_idx_h[j]] < 1) return LINR_EINVAL;
+    }
+    TRY(linr_net_forward(f, params, arena, arena_bytes, 0, 8, nullptr, bits_acc, stream));
     c.s = (hipStream_t)stream;
     if (c.R == 0) return 0;
     TRY(backward_core(c, gscale));
@@ -1117,15 +1123,14 @@ extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* ar
     rg.count = 0; rg.begin = c.L.m0_w[0]; rg.len = c.L.S > 1 ? c.L.m0_w[1] - c.L.m0_w[0] : c.L.block_in.a_w - c.L.m0_w[0];
     if (scale_steps_h) {
         rg.count = c.L.S;
-        for (int s = 0; s < c.L.S; ++s) { rg.active[s] = 0; rg.step_size[s] = 0.0f; rg.bc2_sqrt[s] = 1.0f; }
-        for (int j = 0; j < f->n_scales; ++j) {
-            if (f->row_off_h[j + 1] <= f->row_off_h[j]) continue;
-            const int si = f->scale_idx_h[j];
-            const int64_t t = scale_steps_h[si];
-            if (t < 1) return LINR_EINVAL;
-            rg.active[si] = 1;
-            rg.step_size[si] = (float)(lr / (1.0 - pow(beta1, (double)t)));
-            rg.bc2_sqrt[si] = (float)sqrt(1.0 - pow(beta2, (double)t));
+        // scale_steps_h[s] = updates applied to the context MLP of scale s INCLUDING this one; 0 = it has never had a gradient and
+        // is skipped (torch.optim.Adam skips .grad None; torch 1.13's zero_grad() leaves zeros afterwards, so a started scale is
+        // updated on every step - with the zero gradient the reduction writes for a scale this frame lacks)
+        for (int s = 0; s < c.L.S; ++s) {
+            const int64_t t = scale_steps_h[s];
+            rg.active[s] = t >= 1 ? 1 : 0;
+            rg.step_size[s] = t >= 1 ? (float)(lr / (1.0 - pow(beta1, (double)t))) : 0.0f;
+            rg.bc2_sqrt[s] = t >= 1 ? (float)sqrt(1.0 - pow(beta2, (double)t)) : 1.0f;
         }
     }
     ProfScope ps(c.s, PK_MISC, 0);

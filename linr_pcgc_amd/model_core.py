@@ -296,9 +296,14 @@ class FlatAdam:
         self.grad = torch.zeros_like(flat)
         self.t = 0                      # optimiser steps taken
         self.sched_steps = 0            # scheduler.step() calls (StepLR epoch counter)
-        # torch.optim.Adam keeps one step counter per parameter and skips parameters without a gradient: the context
-        # MLP of a scale that a frame lacks (custom_dataset.py:325) is not touched on that frame.  One counter per scale.
+        # torch.optim.Adam keeps one step counter per parameter and skips a parameter whose .grad is None.  The reference pins
+        # torch 1.13.1 (enviroment.yaml:30), whose optimizer.zero_grad() (main.py:320) leaves ZERO tensors behind, not None: the
+        # context MLP of a scale is therefore skipped only until a frame containing that scale has given it its first gradient
+        # (custom_dataset.py:325 drops the coarsest scales of small frames); from then on it is updated on every step, with a
+        # zero gradient on frames that lack the scale (weight decay and moment decay still act, its counter advances).
+        # t_scale[s] = Adam updates applied to scale s so far (0: never had a gradient).
         self.t_scale = np.zeros(model.scale_num, dtype=np.int64)
+        self._segments = None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -313,11 +318,47 @@ class FlatAdam:
         self.sched_steps = 0
         self.t_scale[:] = 0
 
-    def step(self):
-        self.t += 1
-        self.t_scale += 1                # a dense gradient buffer: every parameter is updated
-        ops.adam_step(self.model.flat_parameters(), self.grad, self.exp_avg, self.exp_avg_sq, self.t, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.weight_decay)
+    def advance(self, frame=None):
+        """Step counters of the next update: (t, t_scale) after an optimiser step on `frame` (None: a dense gradient, every scale
+        present).  Scales of the frame start their counter; started scales advance on every step (see __init__)."""
+        t_scale = self.t_scale.copy()
+        if frame is None:
+            t_scale += 1
+        else:
+            present = np.zeros(len(t_scale), dtype=bool)
+            for i in range(frame.n_scales):
+                if frame.row_off[i + 1] > frame.row_off[i]:
+                    present[frame.scale_idx[i]] = True
+            t_scale[present | (t_scale > 0)] += 1
+        return self.t + 1, t_scale
+
+    def _param_segments(self):
+        """[(begin, end, scale or -1)] over the flat buffer: maximal runs of parameters with the same owner."""
+        if self._segments is None:
+            segs, off = [], 0
+            for own, p in zip(self._scale_of_param(), self.model._plist):
+                n = p.numel()
+                if segs and segs[-1][2] == own:
+                    segs[-1][1] = off + n
+                else:
+                    segs.append([off, off + n, own])
+                off += n
+            self._segments = [tuple(x) for x in segs]
+        return self._segments
+
+    def step(self, frame=None):
+        """torch.optim.Adam.step() on the dense gradient buffer self.grad: the same update, segment by segment, that the fused
+        train_step applies in one launch (a scale's context MLP is skipped until its first gradient; `frame` says which scales
+        the gradient came from, None = all)."""
+        t, t_scale = self.advance(frame)
+        flat = self.model.flat_parameters()
+        for b, e, own in self._param_segments():
+            ts = t if own < 0 else int(t_scale[own])
+            if ts < 1:
+                continue
+            ops.adam_step(flat[b:e], self.grad[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], ts, self.lr,
+                          self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        self.t, self.t_scale = t, t_scale
 
     def scheduler_step(self):
         """StepLR.step(): multiply lr by gamma every `step_size` calls (chainable form, so a clamp persists)."""
@@ -388,11 +429,9 @@ def train_step(model, opt, frame, point_num, out=None):
     nothing synchronises with the host.  `out`: a zeroed float64[1] device tensor to add the bits into (e.g. one slot of a
     per-GOP vector that is cleared once per epoch) - saves the per-step allocation + fill."""
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device) if out is None else out
-    opt.t += 1
-    for i in range(frame.n_scales):                 # scales present in this frame advance their MLP's own counter
-        if frame.row_off[i + 1] > frame.row_off[i]:
-            opt.t_scale[frame.scale_idx[i]] += 1
-    engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), opt.t,
-                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=opt.t_scale)
+    t, t_scale = opt.advance(frame)
+    engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), t,
+                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=t_scale)
+    opt.t, opt.t_scale = t, t_scale              # committed only after the call returned without an error
     opt.scheduler_step()
     return bits

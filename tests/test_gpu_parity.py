@@ -920,34 +920,49 @@ def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
     assert 0 < enc['bpp']['point_bpp'] < 8 and enc['bpp']['model_bpp'] > 0      # tiny clouds: the 35 KB model dominates bpp_all
 
 
-def test_adam_skips_scales_a_frame_lacks(pkg, shell):
-    """torch.optim.Adam skips parameters whose .grad is None (zero_grad(set_to_none=True), torch 2's default) and keeps a
-    step counter per parameter: the context MLP of a scale that a frame does not contain (custom_dataset.py:325 stops
-    early on min_point_num) is left alone on that frame.  A 2-frame GOP whose second frame lacks the coarsest scale,
-    6 fused steps, against torch.optim.Adam on the oracle (grads of absent scales stay None there)."""
-    from linr_pcgc_amd.model_core import FlatAdam, train_step
+def test_adam_skips_a_scale_until_its_first_gradient(pkg, shell):
+    """torch.optim.Adam skips parameters whose .grad is None and keeps a step counter per parameter.  The reference pins torch
+    1.13.1 (enviroment.yaml:30), whose optimizer.zero_grad() (main.py:320) leaves ZERO tensors: the context MLP of a scale is left
+    alone only until a frame containing the scale gives it its first gradient (custom_dataset.py:325 drops the coarsest scales of
+    small frames); afterwards it is updated on every step, zero gradient or not.  Frames: 4 scales, 4 scales, 5 scales, 4 scales,
+    ... - the coarsest scale's MLP starts at step 3.  Fused steps against torch.optim.Adam on the oracle with
+    zero_grad(set_to_none=False), and against the package's own unfused path (net_backward + FlatAdam.step)."""
+    from linr_pcgc_amd import engine
+    from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model, train_step
     model, sd = _model_and_oracle(pkg, 5)
     full = shell['scales']
-    frames = [model.make_frame(full), model.make_frame(full[:-1])]
-    tscs = [onet.to_torch_scales(full), onet.to_torch_scales(full[:-1])]
+    frames = [model.make_frame(full[:-1]), model.make_frame(full[:-1]), model.make_frame(full), model.make_frame(full[:-1])]
+    tscs = [onet.to_torch_scales(full[:-1]), onet.to_torch_scales(full[:-1]), onet.to_torch_scales(full), onet.to_torch_scales(full[:-1])]
     opt = FlatAdam(model)
+    # second model on the unfused path: same parameters
+    model2 = LINR_PCGC_Model({'scale_num': 5, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
+                              'instage': 1}).cuda()
+    model2.load_state_dict(sd)
+    opt2 = FlatAdam(model2)
+    frames2 = [model2.make_frame(full[:-1]), model2.make_frame(full[:-1]), model2.make_frame(full), model2.make_frame(full[:-1])]
     sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
     names = list(sdo)
     opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
-    for it in range(6):
-        j = it % 2
+    for it in range(7):
+        j = it % 4
         train_step(model, opt, frames[j], shell['point_num'])
+        bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+        engine.net_forward(frames2[j], model2.flat_parameters(), 0, 8, None, bits)
+        opt2.zero_grad()
+        engine.net_backward(frames2[j], model2.flat_parameters(), opt2.grad, 1.0 / shell['point_num'])
+        opt2.step(frames2[j])
         (onet.frame_bits(sdo, tscs[j]) / shell['point_num']).backward()
-        if j == 1:
-            assert sdo['scale_mlp.4.0.weight'].grad is None           # the oracle's absent scale really has no gradient
+        if it < 2:
+            assert sdo['scale_mlp.4.0.weight'].grad is None           # not started yet: torch skips it
         opt_o.step()
-        opt_o.zero_grad()                                             # set_to_none=True
-    assert opt.t == 6 and opt.t_scale.tolist() == [6, 6, 6, 6, 3]
+        opt_o.zero_grad(set_to_none=False)                            # torch 1.13.1's default
+    assert opt.t == 7 and opt.t_scale.tolist() == [7, 7, 7, 7, 5] and opt2.t_scale.tolist() == [7, 7, 7, 7, 5]
     st = opt_o.state_dict()['state']
-    assert float(st[names.index('scale_mlp.4.0.weight')]['step']) == 3.0 and float(st[names.index('scale_mlp.0.0.weight')]['step']) == 6.0
+    assert float(st[names.index('scale_mlp.4.0.weight')]['step']) == 5.0 and float(st[names.index('scale_mlp.0.0.weight')]['step']) == 7.0
+    # the package's two training paths apply the same update
+    assert torch.equal(model.flat_parameters(), model2.flat_parameters()), 'fused train_step and net_backward + FlatAdam.step differ'
     flat_o = torch.cat([v.detach().reshape(-1) for v in sdo.values()])
-    _close(model.flat_parameters(), flat_o, 0, 3e-3, 'parameters after 6 Adam steps over frames with 5 / 4 scales')
-    # the absent scale's MLP is exactly where torch left it - closer than any update that also decayed it would be
+    _close(model.flat_parameters(), flat_o, 0, 3e-3, 'parameters after 7 Adam steps over frames with 4 / 5 scales')
     off = 0
     for n, v in sdo.items():
         if n.startswith('scale_mlp.4.'):
@@ -955,9 +970,9 @@ def test_adam_skips_scales_a_frame_lacks(pkg, shell):
             _close(mine, v.detach().reshape(-1), 0, 5e-4, n)
         off += v.numel()
     # and our own optimiser state round-trips through torch's format with the per-parameter steps intact
-    opt2 = FlatAdam(model)
-    opt2.load_state_dict(opt.state_dict())
-    assert opt2.t_scale.tolist() == [6, 6, 6, 6, 3] and torch.equal(opt2.exp_avg, opt.exp_avg)
+    opt3 = FlatAdam(model)
+    opt3.load_state_dict(opt.state_dict())
+    assert opt3.t_scale.tolist() == [7, 7, 7, 7, 5] and torch.equal(opt3.exp_avg, opt.exp_avg)
 
 
 def test_device_generator_equals_numpy_generator(pkg):
