@@ -118,13 +118,13 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     if rank == 0:
         try:
             ckpt = call(first_fn, groups[0], 0)
+            results[0] = ckpt.get('result') if isinstance(ckpt, dict) else None
+            tmp = ck_path + '.tmp.%d' % os.getpid()
+            torch.save(ckpt, tmp)
+            os.replace(tmp, ck_path)
         except BaseException:
-            open(err_path, 'w').close()                  # lets the waiting ranks fail instead of hanging
+            open(err_path, 'w').close()                  # training OR the checkpoint write failed: the waiting ranks fail too
             raise
-        results[0] = ckpt.get('result') if isinstance(ckpt, dict) else None
-        tmp = ck_path + '.tmp.%d' % os.getpid()
-        torch.save(ckpt, tmp)
-        os.replace(tmp, ck_path)
     else:
         # phase-A overlap: stage this rank's first GOP while rank 0 still trains GOP 0
         if schedule == 'static':
@@ -139,6 +139,24 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     def load():
         return torch.load(ck_path, map_location='cpu', weights_only=False)
 
+    try:
+        _phase_b(schedule, static_mine, first_claim, order, claim_dir, rank, groups, results, load, call, other_fn)
+    except BaseException:
+        open(os.path.join(work_dir, 'rank%d_failed' % rank), 'w').close()       # check_failures() lets the others skip the final reduce
+        raise
+    return results
+
+
+def check_failures(work_dir):
+    """Raises if any rank left a failure marker in work_dir - called before the final reductions so that the surviving ranks of
+    a job without kill-on-failure supervision do not wait in a collective for a rank that is gone."""
+    bad = sorted(f for f in os.listdir(work_dir) if f.endswith('_failed')) if os.path.isdir(work_dir) else []
+    if bad:
+        raise RuntimeError('ranks failed: %s' % ', '.join(bad))
+
+
+def _phase_b(schedule, static_mine, first_claim, order, claim_dir, rank, groups, results, load, call, other_fn):
+    ckpt = None
     if schedule == 'static':
         todo = static_mine
         if todo:

@@ -66,22 +66,65 @@ class Gop:
         return g
 
 
-def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None):
+class BestState:
+    """Device-side snapshot of (parameters, Adam moments, counters, lr) of the best epoch so far - what the reference keeps in
+    model.pth: it saves the checkpoint only when the epoch's mean loss improves (main.py:413-426,440-451), so the encoder codes
+    with, and the GOPs >= 1 warm-start from, the BEST epoch of an overfit, not the last one.  One D2D copy of 3 x n_params floats."""
+
+    def __init__(self, model, opt):
+        self.model, self.opt = model, opt
+        self.params = torch.empty_like(model.flat_parameters())
+        self.exp_avg, self.exp_avg_sq = torch.empty_like(opt.exp_avg), torch.empty_like(opt.exp_avg_sq)
+        self.epoch, self.loss, self.meta = -1, float('inf'), None
+
+    def offer(self, epoch, loss):
+        """Called at the end of an epoch, BEFORE the lr clamp (the reference saves first, main.py:413-437)."""
+        if not loss < self.loss:
+            return False
+        self.params.copy_(self.model.flat_parameters())
+        self.exp_avg.copy_(self.opt.exp_avg)
+        self.exp_avg_sq.copy_(self.opt.exp_avg_sq)
+        self.epoch, self.loss = epoch, loss
+        self.meta = (self.opt.t, self.opt.t_scale.copy(), self.opt.lr, self.opt.sched_steps)
+        return True
+
+    def restore(self):
+        if self.meta is None:
+            return
+        self.model.flat_parameters().copy_(self.params)
+        self.opt.exp_avg.copy_(self.exp_avg)
+        self.opt.exp_avg_sq.copy_(self.exp_avg_sq)
+        self.opt.t, self.opt.t_scale, self.opt.lr, self.opt.sched_steps = self.meta[0], self.meta[1].copy(), self.meta[2], self.meta[3]
+
+
+def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None, keep='best', info=None):
     """main.py:297-437: frames in fixed order, one optimiser + StepLR step per frame, lr clamp after each epoch.
-    Returns the per-epoch mean loss (bits per point), like the reference logs."""
+    keep='best' (the reference's policy, main.py:413-426,440-451): model and optimiser are left in the state at the end of the epoch
+    with the lowest mean loss; keep='last': in the state after the last epoch.  Returns the per-epoch mean loss (bits per point),
+    like the reference logs; `info` (a dict) receives 'coded_epoch' and 'coded_loss'."""
+    if keep not in ('best', 'last'):
+        raise ValueError("keep must be 'best' or 'last'")
     losses = []
     dev = gop.frames[0].device
     bits = torch.zeros(len(gop), dtype=torch.float64, device=dev)         # one slot per frame: no per-step torch kernels
     pns = torch.tensor([float(pn) for pn in gop.point_nums], dtype=torch.float64, device=dev)
+    best = BestState(model, opt) if keep == 'best' else None
     for epoch in range(epochs):
         bits.zero_()
         for j, (f, pn) in enumerate(zip(gop.frames, gop.point_nums)):
             train_step(model, opt, f, pn, out=bits[j:j + 1])
-        opt.clamp_lr(min_lr)
         loss_mean = float((bits / pns).sum()) / len(gop)     # the only host sync of the epoch
+        if best is not None:
+            best.offer(epoch, loss_mean)
+        opt.clamp_lr(min_lr)
         losses.append(loss_mean)
         if on_epoch is not None:
             on_epoch(epoch, loss_mean)
+    if best is not None:
+        best.restore()          # also when the last epoch is the best: the checkpoint holds the lr from before the clamp
+    if info is not None:
+        info['coded_epoch'] = best.epoch if best is not None else epochs - 1
+        info['coded_loss'] = best.loss if best is not None else (losses[-1] if losses else None)
     return losses
 
 

@@ -35,6 +35,8 @@ def parse(argv=None):
     ap.add_argument('--seed', type=int, default=8807)
     ap.add_argument('--out', default='/tmp/linr_out')
     ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
+    ap.add_argument('--keep', default='best', choices=['best', 'last'],
+                    help="which epoch's model is coded / handed to the next GOPs: the one with the lowest mean loss (the reference: main.py:413-426) or the last")
     ap.add_argument('--decode', action='store_true', help='decode every GOP again and check it is lossless')
     return ap.parse_args(argv)
 
@@ -71,7 +73,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         opt = make_opt(model)
         if ckpt is not None:
             overfit.warm_start(model, opt, ckpt)                 # main.py:241-248
-        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr)
+        info = {}
+        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info)
         torch.cuda.synchronize()
         t1 = time.time()
         enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)), gop, 8)
@@ -90,14 +93,15 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         torch.cuda.synchronize()
         t3 = time.time()
         result = {'gop': gop_parallel.gop_name(group), 'frames': len(group), 'epochs': epochs, 'loss': losses,
+                  'coded_epoch': info['coded_epoch'], 'coded_loss': info['coded_loss'],
                   'bpp': enc['bpp'], 'points': enc['point_num'], 'lossless': ok, 'stage_s': stage_s, 'overfit_s': t1 - t0,
                   'encode_s': t2 - t1, 'decode_s': t3 - t2, 'seconds': stage_s + (t3 - t0), 'rank': rank}
         del gop
-        return model, opt, losses, result
+        return model, opt, losses, result, info
 
     def first_fn(group, staged=None):
-        model, opt, losses, result = run_gop(group, args.first_epoch, None, staged)
-        ck = overfit.checkpoint(model, opt, args.first_epoch - 1, losses[-1])
+        model, opt, losses, result, info = run_gop(group, args.first_epoch, None, staged)
+        ck = overfit.checkpoint(model, opt, info['coded_epoch'], info['coded_loss'])      # the state overfit_gop left: the kept epoch
         ck['result'] = result
         return ck
 
@@ -120,6 +124,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                                         prepare_fn=stage, schedule=schedule, prepared=prepared)
     torch.cuda.synchronize()
     my_wall = time.time() - t0
+    gop_parallel.check_failures(os.path.join(args.out, 'output'))          # a failed rank left a marker: do not wait for it below
     wall = gop_parallel.max_over_ranks(my_wall, dist, 'cuda')
     # phase A = rank 0's GOP 0; phase B = the rest of the wall.  Phase-B efficiency = busy GPU-seconds of the GOPs >= 1
     # over (ranks x phase-B wall): what SURVEY.md section 8e asks to be reported next to the whole-sequence wall.

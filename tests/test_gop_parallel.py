@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: GOP sharding, the GOP-0 checkpoint hand-off and the MAX-over-ranks timing."""
+"""CPU, world_size 2 and 8 over gloo: GOP sharding, the GOP-0 checkpoint hand-off and the MAX-over-ranks timing."""
 import os
 import tempfile
 
@@ -110,3 +110,70 @@ def test_rank0_failure_releases_waiting_ranks(tmp_path):
         gp.run_sequence(groups, work, boom, lambda g, c: None, rank=0, world=2)
     with pytest.raises(RuntimeError):
         gp.run_sequence(groups, work, boom, lambda g, c: None, rank=1, world=2)
+
+
+def _pull8_worker(rank, world, init_file, work_dir, out_dir, fail):
+    """The real BASELINE config[2] split (300 frames, GOP 32: 10 GOPs, the last one short) on 8 ranks with schedule='pull'."""
+    import time
+    dist.init_process_group('gloo', init_method='file://' + init_file, rank=rank, world_size=world)
+    groups = gp.split_gops(300, 32)
+    ck_path = os.path.join(work_dir, gp.gop_name(groups[0]), 'model.pth')
+    staged = []
+
+    def prepare_fn(group):
+        staged.append((group[0], not os.path.exists(ck_path), time.time()))
+        return group[0]
+
+    def first_fn(group, prepared):
+        time.sleep(1.0)                                      # the seven other ranks stage their first GOP meanwhile
+        if fail:
+            raise ValueError('gop 0 failed')
+        return {'model': {'w': torch.ones(2)}, 'result': {'t_done': time.time()}}
+
+    def other_fn(group, ckpt, prepared):
+        assert prepared == group[0] and float(ckpt['model']['w'][0]) == 1.0
+        time.sleep(0.1 * len(group) / 32.0)
+        return {'rank': rank, 'first': group[0], 't_start': time.time()}
+
+    err = None
+    try:
+        res = gp.run_sequence(groups, work_dir, first_fn, other_fn, rank, world, dist, prepare_fn=prepare_fn, schedule='pull')
+    except (ValueError, RuntimeError) as e:
+        res, err = {}, type(e).__name__
+    torch.save({'res': res, 'staged': staged, 'err': err}, os.path.join(out_dir, 'q%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_pull_on_the_config2_split():
+    """north_star's 8-GPU case without the hardware: every GOP exactly once, rank 0 joins the queue after GOP 0, all seven idle
+    ranks stage a GOP before the checkpoint exists, the two GOPs left over go to whoever is free first."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_pull8_worker, args=(8, os.path.join(tmp, 'init'), os.path.join(tmp, 'work'), tmp, False), nprocs=8, join=True)
+        r = [torch.load(os.path.join(tmp, 'q%d.pt' % k), weights_only=False) for k in range(8)]
+        assert all(x['err'] is None for x in r)
+        done = sorted(g for x in r for g in x['res'])
+        assert done == list(range(10))                                       # GOP 0 + every GOP >= 1 exactly once
+        assert 0 in r[0]['res']
+        t_ck = r[0]['res'][0]['t_done']
+        for k in range(1, 8):
+            assert r[k]['staged'] and r[k]['staged'][0][1], 'rank %d did not stage before the checkpoint existed' % k
+            assert len(r[k]['res']) >= 1
+            assert all(v['t_start'] >= t_ck for v in r[k]['res'].values())   # nobody trains a GOP >= 1 before the hand-off
+        first = sorted(x['staged'][0][0] for x in r[1:])
+        assert first == [32 * g for g in range(1, 8)]                        # longest first: GOPs 1..7 claimed in phase A
+        later = [g for x in r for g in x['res'] if g in (8, 9)]
+        assert sorted(later) == [8, 9]                                       # the rest (incl. the short last GOP) in phase B
+        assert abs(gp.ideal_speedup(gp.split_gops(300, 32), 8) - 300 / 76.0) < 1e-9
+
+
+def test_eight_rank_rank0_failure_releases_seven_waiters():
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_pull8_worker, args=(8, os.path.join(tmp, 'init'), os.path.join(tmp, 'work'), tmp, True), nprocs=8, join=True)
+        r = [torch.load(os.path.join(tmp, 'q%d.pt' % k), weights_only=False) for k in range(8)]
+        assert r[0]['err'] == 'ValueError'
+        assert all(x['err'] == 'RuntimeError' and not x['res'] for x in r[1:])
+        assert os.path.exists(os.path.join(tmp, 'work', 'rank0_failed'))
+        import pytest
+        with pytest.raises(RuntimeError):
+            gp.check_failures(os.path.join(tmp, 'work'))

@@ -864,6 +864,41 @@ def test_overfit_is_run_to_run_deterministic(pkg):
     assert a[4]['frames'] == b[4]['frames'] and a[4]['model_bin'] == b[4]['model_bin']
 
 
+def test_best_epoch_checkpoint_policy(pkg):
+    """The reference writes model.pth only when the epoch's mean loss improves (main.py:413-426,440-451): the encoder codes with,
+    and the GOPs >= 1 warm-start from, the BEST epoch.  With a learning rate far too large the later epochs are worse than an
+    earlier one: overfit_gop(keep='best') must leave model and optimiser exactly as they were at the end of that epoch
+    (re-run with that many epochs and keep='last': same bits), keep='last' must not."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sphere_shell(7, 40 + t) for t in range(3)]
+
+    def run(epochs, keep):
+        gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+        model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+        opt = FlatAdam(model, lr=0.3, gamma=1.3, step_size=1)           # grows every frame: the overfit diverges
+        info = {}
+        losses = overfit.overfit_gop(model, opt, gop, epochs, keep=keep, info=info)
+        return gop, model, opt, losses, info
+
+    gop, model, opt, losses, info = run(8, 'best')
+    k = int(np.argmin(losses))
+    assert k < 7, 'the test needs an overfit whose last epoch is not the best: %s' % losses
+    assert info['coded_epoch'] == k and info['coded_loss'] == losses[k]
+    _, m_ref, o_ref, l_ref, _ = run(k + 1, 'last')
+    assert l_ref == losses[:k + 1]
+    assert torch.equal(model.flat_parameters(), m_ref.flat_parameters())
+    assert torch.equal(opt.exp_avg, o_ref.exp_avg) and torch.equal(opt.exp_avg_sq, o_ref.exp_avg_sq)
+    assert opt.t == o_ref.t == 3 * (k + 1) and opt.t_scale.tolist() == o_ref.t_scale.tolist()
+    _, m_last, _, l_last, i_last = run(8, 'last')
+    assert l_last == losses and i_last['coded_epoch'] == 7
+    assert not torch.equal(m_last.flat_parameters(), model.flat_parameters())
+    # the kept model is the one that gets coded: fewer bits than the last epoch's
+    enc_best = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    enc_last = codec.encode_gop(m_last, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    assert enc_best['bpp']['point_bpp'] < enc_last['bpp']['point_bpp']
+
+
 def test_threaded_gop_decode_equals_serial(pkg):
     """codec.decode_gop(workers=3): frames decoded concurrently on their own streams give the serial result."""
     from linr_pcgc_amd import codec, overfit, synthetic
