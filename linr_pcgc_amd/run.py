@@ -37,6 +37,8 @@ def parse(argv=None):
     ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
     ap.add_argument('--keep', default='best', choices=['best', 'last'],
                     help="which epoch's model is coded / handed to the next GOPs: the one with the lowest mean loss (the reference: main.py:413-426) or the last")
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
+                    help='arithmetic of the coding forward: f32, or bf16 features with the uint8 weight codes de-quantised in-kernel (BASELINE config[4]); travels in side_info.json')
     ap.add_argument('--decode', action='store_true', help='decode every GOP again and check it is lossless')
     return ap.parse_args(argv)
 
@@ -77,7 +79,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info)
         torch.cuda.synchronize()
         t1 = time.time()
-        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)), gop, 8)
+        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)), gop, 8,
+                               precision=getattr(args, 'precision', 'f32'))
         res_dir = os.path.join(args.out, 'result_enc', gop_parallel.gop_name(group))
         codec.write_gop(enc, res_dir)
         torch.cuda.synchronize()

@@ -172,6 +172,26 @@ def test_config4_owlii11_bf16_lossless():
     assert torch.equal(dec[0], ref), 'bf16 decode must be bit-exact'
 
 
+def test_config4_owlii11_gop64_sequence_bf16(tmp_path):
+    """BASELINE config[4] at its own GOP size: 64 frames of the Owlii stand-in (11-bit, ~2.9 M points, ~1.25 M rows each: ~27 GB of
+    kernel maps and inputs resident in HBM) as ONE GOP through the sequence driver - one epoch of fp32 overfit, the bf16 /
+    uint8-weight codec to the reference's file layout, 3 frames decoded from the files alone (the precision travels in
+    side_info.json): lossless."""
+    import os
+    from linr_pcgc_amd import codec, run
+    out = str(tmp_path / 'owlii')
+    args = run.parse(['--config', 'owlii11', '--frames', '64', '--gop', '64', '--first-epoch', '1', '--others-epoch', '1',
+                      '--out', out, '--decode', '--precision', 'bf16'])
+    summary, results = run.run_sequence_job(args, decode_frames=3)
+    assert summary['gops'] == 1 and summary['frames'] == 64 and summary['lossless'] is True
+    r = results[0]
+    assert r['frames'] == 64 and r['lossless'] is True and r['points'] > 64 * 2800000
+    assert 0.0 < r['bpp']['bpp_all'] < 4.0 and len(r['loss']) == 1
+    res_dir = os.path.join(out, 'result_enc', 'gop_0_63')
+    back = codec.read_gop(res_dir)
+    assert back['side_info']['precision'] == 'bf16' and len(back['frames']) == 64 and len(back['frames'][0]) == 8
+
+
 @pytest.mark.parametrize('n', [1, 2, 63, 65])
 def test_bf16_tiny_and_ragged_frames(n):
     """Edge cases of the bf16 executor: a single voxel, row counts around the wave size, a zero-row scale next to it: the

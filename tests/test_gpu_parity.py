@@ -802,8 +802,8 @@ def test_config3_andrew10_dense_shell_properties(pkg):
 
 
 def test_config4_owlii11_size_properties(pkg):
-    """BASELINE config[4] stand-in geometry: 11-bit sphere (~2.9 M points, 8 scales, ~1.24 M rows) through the fp32 path
-    (the bf16 / int8-weight variant of that config is not built yet)."""
+    """BASELINE config[4] stand-in geometry: 11-bit sphere (~2.9 M points, 8 scales, ~1.24 M rows) through the fp32 path (its
+    bf16 / uint8-weight codec and the gop_size = 64 flow: tests/test_gpu_bf16.py)."""
     from linr_pcgc_amd import overfit, synthetic
     pts = synthetic.sequence_frame('owlii11', 0)
     gop = overfit.Gop(None, [pts], None, 64, 'cuda')

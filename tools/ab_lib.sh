@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-box A/B of lab builds of the library on the default bench:  gpurun -- 'bash tools/ab_lib.sh tools/_lab/liblinr_fb_10.so ...'
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+b(){ LINR_SKIP_ROOFLINE=1 LINR_SKIP_BPP_SEEDS=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-sequence --steps 96 2>/tmp/ab_err.txt | python3 -c "
+import json,sys
+t=sys.stdin.read()
+try:
+    d=json.loads(t.strip().splitlines()[-1]); print(d['ms_per_step'], d['bits_per_point'])
+except Exception as e:
+    print('FAILED', repr(e)); print(open('/tmp/ab_err.txt').read()[-800:])"; }
+echo "default : $(b)"
+for lib in "$@"; do echo "$lib : $(LINR_HIP_LIB=$R/$lib bash -c "$(declare -f b); b")"; done
+echo "default : $(b)"
