@@ -272,6 +272,22 @@ LINR_API int linr_net_decode_stages(const linr_frame* f, const float* params, co
                            const int64_t* stream_len_h, float* probs, float* p_pinned, uint8_t* s_pinned, uint8_t* s_dev,
                            void* stream);
 
+/* One scale of the decoder as one call - the body of decoder.decode_one_frame's loop (decoder.py:153-176): kernel map of the
+ * level's coordinates, the 7-neighbour features read off it (instead of qscTensor.set_offset_tensor's 7 searches), the 8 decode
+ * stages of linr_net_decode_stages, and octree_level.upper_layer (models/module_utils.py:117-127): the coordinates of the next finer
+ * level = children 2 p + (dx, dy, dz) of every decoded octant 4 dx + 2 dy + dz, sorted x-major (radix sort of child_bits-bit-per-
+ * axis keys).  coord: DEVICE int32 [n][3], sorted x-major, unique; streams_h / stream_len_h: the 8 stage streams of this scale
+ * (HOST); ws: DEVICE workspace of linr_decode_scale_ws_bytes(n, block_layers, codes != NULL) bytes, 256-byte aligned; p_pinned /
+ * s_pinned: pinned HOST buffers of n floats / n bytes; child_xyz: DEVICE int32 [child_cap][3] (8 n is always enough); *child_n_h
+ * receives the number of children.  params (fp32 executor) or codes + min / max (bf16 / uint8-weight executor).  Synchronises the
+ * stream.  Between two scales the caller only allocates the next workspace. */
+LINR_API size_t linr_decode_scale_ws_bytes(int64_t n, int32_t block_layers, int32_t bf16);
+LINR_API int linr_decode_scale(const int32_t* coord, int64_t n, int32_t scale_idx, int32_t model_scale_num, int32_t block_layers,
+                      int32_t child_bits, const float* params, const uint8_t* codes, float min_param, float max_param,
+                      const uint8_t* const* streams_h, const int64_t* stream_len_h, void* ws, size_t ws_bytes,
+                      float* p_pinned, uint8_t* s_pinned, int32_t* child_xyz, int64_t child_cap, int64_t* child_n_h,
+                      void* stream);
+
 /* ---- the executor's fused layers as stand-alone ops ------------------------------------------------------------
  * What linr_net_forward / _backward launch for one layer, callable (and testable) on its own.  All of them work on the
  * compressed kernel map (linr_kmap_compress) and follow the LINR_PAD_ROW contract: every matrix that a kernel GATHERS

@@ -96,6 +96,9 @@ _PROTOS = {
     'linr_ac_decode_binary': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_net_decode_stages': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
                                               c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_decode_scale_ws_bytes': (c_size, [c_i64, c_i32, c_i32]),
+    'linr_decode_scale': (ctypes.c_int, [c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_f32, c_f32, c_ptr, c_ptr, c_ptr, c_size,
+                                         c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_cdf16': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
     'linr_ac_encode_binary_batch': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32]),

@@ -128,9 +128,21 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
 
 
 def decode_one_frame(model, frame_enc_bytes, xyz_low):
-    """decoder.decode_one_frame (decoder.py:153-176): coarse to fine, 8 AC-decoded stages per scale.  The 7-neighbour
-    occupancy the reference rebuilds with qscTensor.set_offset_tensor comes out of the scale's kernel map instead
-    (linr_kmap_offset_feat), so a scale costs one kernel-map build, 8 stage forwards and 8 host round trips."""
+    """decoder.decode_one_frame (decoder.py:153-176): coarse to fine, 8 AC-decoded stages per scale.  A scale is ONE call into the
+    library (model.decode_scale -> linr_decode_scale: kernel map, the 7-neighbour occupancy read off it instead of
+    qscTensor.set_offset_tensor's searches, the 8 stage forwards with their host round trips, upper_layer), so the Python side of a
+    frame is seven buffer allocations."""
+    lowx = unique_sorted(xyz_low)
+    bits = max(1, int(xyz_low.max()).bit_length()) if xyz_low.numel() else 1       # coordinates of the coarsest level
+    for s_idx in range(len(frame_enc_bytes) - 1, -1, -1):
+        bits = min(bits + 1, 21)
+        lowx = model.decode_scale(lowx, s_idx, frame_enc_bytes[s_idx], bits)
+    return {'dec_coord': lowx}
+
+
+def decode_one_frame_stagewise(model, frame_enc_bytes, xyz_low):
+    """The same through the reference-shaped surface (model.decode per scale + octree_level.upper_layer in torch): kept as the
+    cross-check of decode_one_frame."""
     lowx = unique_sorted(xyz_low)
     for s_idx in range(len(frame_enc_bytes) - 1, -1, -1):
         occ_lst = model.decode({'enc_bytes': frame_enc_bytes[s_idx], 'coord': lowx, 'offset_tensor': None,

@@ -232,6 +232,36 @@ class LINR_PCGC_Model(nn.Module):
         frame = self.make_frame([s], with_arena=self._precision(None) == 'f32')
         return self.decode_frame(frame, [streams])
 
+    @torch.no_grad()
+    def decode_scale(self, coord, scale_idx, enc_bytes, child_bits):
+        """One scale of decoder.decode_one_frame (decoder.py:153-176) as ONE C call that does not hold the GIL
+        (linr_decode_scale): kernel map of `coord` (int32 [n,3] on the GPU, sorted x-major), the 8 decode stages against the
+        packed stream `enc_bytes`, octree_level.upper_layer.  Returns the next finer level's coordinates (int32 [m,3])."""
+        import ctypes
+        L = _lib.lib()
+        n = int(coord.shape[0])
+        if n == 0:
+            return coord.new_zeros((0, 3))
+        coord = coord.contiguous()
+        streams = unpack_bitstream(enc_bytes)
+        bufs = [np.frombuffer(b, dtype=np.uint8) for b in streams]
+        ptrs = (ctypes.c_void_p * 8)(*[b.ctypes.data if b.size else None for b in bufs])
+        lens = (ctypes.c_int64 * 8)(*[int(b.size) for b in bufs])
+        bf16 = self._precision(None) == 'bf16'
+        need = L.linr_decode_scale_ws_bytes(n, self.block_layers, 1 if bf16 else 0)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=coord.device)
+        base = (ws.data_ptr() + 255) & ~255
+        child = torch.empty((8 * n, 3), dtype=torch.int32, device=coord.device)
+        p_host, s_host = self._host_buffers(n)
+        m = ctypes.c_int64(0)
+        codes, lo, hi, params = (self._qcodes.data_ptr(), float(self._qrange[0]), float(self._qrange[1]), None) if bf16 else \
+            (None, 0.0, 0.0, self._flat.data_ptr())
+        _lib.check(L.linr_decode_scale(coord.data_ptr(), n, int(scale_idx), self.scale_num, self.block_layers, int(child_bits), params,
+                                       codes, lo, hi, ptrs, lens, base, need, p_host.data_ptr(), s_host.data_ptr(),
+                                       child.data_ptr(), 8 * n, ctypes.byref(m), torch.cuda.current_stream().cuda_stream),
+                   'linr_decode_scale')
+        return child[:m.value]
+
     def _host_buffers(self, rows):
         """Pinned staging buffers of the staged decoder (probabilities down, decoded symbols up), grown on demand."""
         import threading

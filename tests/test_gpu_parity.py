@@ -914,6 +914,57 @@ def test_threaded_gop_decode_equals_serial(pkg):
         assert torch.equal(a, ref)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_decode_scale_call_equals_stagewise_decode(pkg, precision):
+    """linr_decode_scale (kernel map + 8 decode stages + upper_layer of a scale in one C call) against the reference-shaped
+    path (model.decode per scale, octree_level.upper_layer in torch): the same coordinates, level by level; a child buffer that
+    is too small is refused."""
+    import ctypes
+    from linr_pcgc_amd import _lib, codec, overfit, synthetic
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    from linr_pcgc_amd.module_utils import unique_sorted
+    clouds = [synthetic.sphere_shell(7, 41), synthetic.sphere_shell(7, 47)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision=precision)
+    side = dict(enc['side_info'])
+    side.pop('arith_version', None)
+    side['final_bytes'] = enc['model_bin']
+    m, _ = Model_Estimate().decompress_model(overfit.gen_model(gop.scale_num, 'cuda'), side)
+    m.inference_precision = precision
+    lows, mins = codec.dec_all_frame_low_xyz(enc['low_enc_bytes'])
+    for i in range(2):
+        xyz_low = torch.tensor(lows[i].astype(np.int32), device='cuda')
+        a = codec.decode_one_frame(m, list(enc['frames'][i]), xyz_low)['dec_coord']
+        b = codec.decode_one_frame_stagewise(m, list(enc['frames'][i]), xyz_low)['dec_coord']
+        assert torch.equal(a, b)
+        ref = torch.as_tensor(gop.infos[i]['ori']).cuda()
+        assert torch.equal(a, ref)
+    # argument checks of the entry: capacity of the child buffer, alignment of the workspace
+    L = _lib.lib()
+    lowx = unique_sorted(torch.tensor(lows[0].astype(np.int32), device='cuda')).contiguous()
+    n = lowx.shape[0]
+    from linr_pcgc_amd.function_utils import unpack_bitstream
+    streams = [np.frombuffer(b, dtype=np.uint8) for b in unpack_bitstream(enc['frames'][0][-1])]
+    ptrs = (ctypes.c_void_p * 8)(*[b.ctypes.data if b.size else None for b in streams])
+    lens = (ctypes.c_int64 * 8)(*[int(b.size) for b in streams])
+    need = L.linr_decode_scale_ws_bytes(n, 1, 1 if precision == 'bf16' else 0)
+    ws = torch.empty(need + 512, dtype=torch.uint8, device='cuda')
+    base = (ws.data_ptr() + 255) & ~255
+    p_host, s_host = m._host_buffers(n)
+    child = torch.empty((8 * n, 3), dtype=torch.int32, device='cuda')
+    cnt = ctypes.c_int64(0)
+    params = None if precision == 'bf16' else m.flat_parameters().data_ptr()
+    codes = m._qcodes.data_ptr() if precision == 'bf16' else None
+    lo, hi = (float(m._qrange[0]), float(m._qrange[1])) if precision == 'bf16' else (0.0, 0.0)
+    args = lambda ws_ptr, cap: (lowx.data_ptr(), n, gop.scale_num - 1, gop.scale_num, 1, 8, params, codes, lo, hi, ptrs, lens, ws_ptr, need,
+                                p_host.data_ptr(), s_host.data_ptr(), child.data_ptr(), cap, ctypes.byref(cnt),
+                                torch.cuda.current_stream().cuda_stream)
+    assert L.linr_decode_scale(*args(base + 8, 8 * n)) == -3
+    assert L.linr_decode_scale(*args(base, 1)) == -2
+    assert L.linr_decode_scale(*args(base, 8 * n)) == 0 and 0 < cnt.value <= 8 * n
+
+
 def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
     """main.overfit_enc_dec in miniature: GOP 0 from scratch -> checkpoint -> GOP 1 warm start (model + Adam state) ->
     encode -> reference directory layout on disk -> decode from the files alone -> lossless; model codec round trip."""
