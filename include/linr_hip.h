@@ -340,10 +340,11 @@ LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g
 /* The backward of an Inception layer's two convolution pairs in the same form (models/resnet.py:55-60; gM comes from the
  * caller: the tail convolution's epilogue or a pointwise op):
  *   gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)  with dW01, db01, dW11, db11  (one gather of [gI[:, 0:4] | gM]), then
- *   gX = (bwd(gH[:, 0:4]; W00) + gI (+ old gX: LINR_ACCUM) + gH[:, 4:8] @ W10^T) (* (x > 0): LINR_RELU_MASK)  with dW00, db00.
- * gH and gX are bit-identical to linr_inception_bwd_data's.  slab: [nblocks][1744] per-block partials
- * [W00 864 | b00 4 | W01 432 | b01 4 | W11 432 | b11 4 | pad 4], every row written; sum over the rows = the gradients.
- * The pointwise kernels' gradients (conv1_0, conv1_2) are linr_linear_bwd_weight's job.  gI, gH, gX, x, H: [n][8], gM: [n][4], all
+ *   gX = (bwd(gH[:, 0:4]; W00) + gI (+ old gX: LINR_ACCUM) + gH[:, 4:8] @ W10^T) (* (x > 0): LINR_RELU_MASK)  with dW00, db00 and,
+ *        on lanes the 11-tap last chunk leaves idle, dW10 = x^T gH[:, 4:8], db10 of the 1x1 conv1_0.
+ * gH and gX are bit-identical to linr_inception_bwd_data's.  slab: [nblocks][1776] per-block partials
+ * [W00 864 | b00 4 | W01 432 | b01 4 | W11 432 | b11 4 | W10 32 | b10 4], every row written; sum over the rows = the gradients.
+ * conv1_2's gradient (M^T gI[:, 4:8]) is linr_linear_bwd_weight's job.  gI, gH, gX, x, H: [n][8], gM: [n][4], all
  * 16-byte aligned; gI, gM and gH need the zero row at index -1. */
 LINR_API int linr_inception_bwd_fused(const float* gI, const float* gM, const float* x, const float* H, const int32_t* lo,
                              const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gH, float* gX,

@@ -137,21 +137,24 @@ int linr_conv3_wgrad_mfma(const float* in, int in_ld, const float* gout, int gou
                           int64_t n, int cin, int cout, LinrWgradDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr,
                           int ngroups = 1, const int32_t* tile8t = nullptr);
 struct PwArgs;
+__attribute__((visibility("hidden")))
+int linr_fused_bwd_rows(int64_t n, int nb, int ngroups);
 // backward-data + weight gradient of a conv 8->8 from one gather (csrc/fused_bwd.hip); pw != nullptr: gM epilogue
 __attribute__((visibility("hidden")))
 int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                                  const float* W, float* out, const PwArgs* pw, LinrWgradDst d, int nb, hipStream_t s,
-                                 const Grp* gp = nullptr, int ngroups = 1);
+                                 const Grp* gp = nullptr, int ngroups = 1, int* rows_written = nullptr);
 // ... of the two 4->4 convolutions of an Inception layer (gH, masked by H > 0) and of conv0_0 8->4 (gA with cconv_mfma_k's EPI 4)
 __attribute__((visibility("hidden")))
 int linr_dual44_bwd_wgrad_launch(const float* gI, const float* gM, const float* H, const int32_t* lo, const uint32_t* mask,
                                  int64_t ld, int64_t n, const float* w01, const float* w11, float* gH, float* big,
                                  int64_t block_stride, int64_t w_off0, int64_t b_off0, int64_t w_off1, int64_t b_off1, int nb,
-                                 hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
+                                 hipStream_t s, const Grp* gp = nullptr, int ngroups = 1, int* rows_written = nullptr);
 __attribute__((visibility("hidden")))
 int linr_conv84_bwd_wgrad_launch(const float* gH, const float* A, const float* gI, const int32_t* lo, const uint32_t* mask,
                                  int64_t ld, int64_t n, const float* w00, const float* w10, float* gA, unsigned flags,
-                                 LinrWgradDst d, int nb, hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
+                                 LinrWgradDst d, int64_t w10_off, int64_t b10_off, int nb, hipStream_t s, const Grp* gp = nullptr,
+                                 int ngroups = 1, int* rows_written = nullptr);
 __attribute__((visibility("hidden")))
 int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const float* g1, int g1_ld, const int32_t* nbr,
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,

@@ -79,11 +79,11 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
     __shared__ float4 smem[FB_WAVES * FB_WAVE_BYTES / 16];
     __shared__ float sbias[FB_WAVES][8];
     {   // group offsets: in = g, e5 = g1, res = xin, w = W, e6 = W1, act = res, out; e0..e2 = pointwise epilogue (KIND 0 / 2) or
-        // e0 / e1 = slab offsets of the second convolution (KIND 1); e3 / e4 = slab offsets of kernel / bias
+        // e0 / e1 = slab offsets of the second convolution (KIND 1), e1 / e2 = of conv1_0 (KIND 2); e3 / e4 = slab offsets of kernel / bias
         const int gi = blockIdx.y;
         a.g += gp.in[gi]; a.xin += gp.res[gi]; a.W += gp.w[gi]; a.out += gp.out[gi];
         if constexpr (KIND == 1) { a.g1 += gp.e5[gi]; a.W1 += gp.e6[gi]; d2.w_off1 += gp.e0[gi]; d2.b_off1 += gp.e1[gi]; }
-        if constexpr (KIND == 2) { if (a.res) a.res += gp.act[gi]; pw.w += gp.e0[gi]; }
+        if constexpr (KIND == 2) { if (a.res) a.res += gp.act[gi]; pw.w += gp.e0[gi]; d2.w_off1 += gp.e1[gi]; d2.b_off1 += gp.e2[gi]; }
         if constexpr (EPI == 3) { pw.w += gp.e0[gi]; pw.aux += gp.e1[gi]; pw.aux_out += gp.e2[gi]; }
         d.w_off += gp.e3[gi]; d.b_off += gp.e4[gi];
     }
@@ -355,6 +355,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
                         });
                     }
                 });
+                if constexpr (KIND == 2 && kk == 26 && !(FB_LAB & 8)) {
+                    // conv1_0 (1x1, 8 -> 4) rides along: its weight gradient sum_rows A[row]^T gH[row][4:8] is the product the idle
+                    // lanes of the last chunk (11 taps on 16 slots) would compute if slot 11 held the rows' OWN gH[:, 4:8] - which
+                    // the epilogue has in registers anyway (e2).  One LDS write per tile instead of a pointwise weight-gradient launch.
+                    *reinterpret_cast<float4*>(imgW + ((NCH - 1) & 1) * FB_BUF + 11 * FB_HP) = e2;
+                    if (live) { bsum[4] += e2.x; bsum[5] += e2.y; bsum[6] += e2.z; bsum[7] += e2.w; }
+                }
                 if constexpr (kk == 26) read_next();
                 if constexpr (k == 13) {                           // the centre tap is the row's own gradient: bias gradient
                     if (live) {
@@ -455,7 +462,8 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
             for (int i = 0; i < 4; ++i) mine[c * 4 + i] = wacc[ch][c][i];
         __syncthreads();
         constexpr int per_tap = KIND == 0 ? 64 : 32;              // outputs per tap (KIND 1: both convolutions)
-        for (int e = tid; e < ntaps * per_tap; e += FB_WAVES * 64) {
+        constexpr int nslots = ntaps + ((KIND == 2 && ch == NCH - 1) ? 1 : 0);        // KIND 2: slot 11 of the last chunk = conv1_0
+        for (int e = tid; e < nslots * per_tap; e += FB_WAVES * 64) {
             const int slot = e / per_tap, r = e % per_tap;
             int kp, idx, dofs;
             const int kk = CT * ch + slot;
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
             } else {                            // r = ci * 4 + co; lane slot, accumulator (co, ci / 4), register ci % 4
                 const int ci = r >> 2, co = r & 3;
                 kp = slot; idx = (co * 2 + (ci >> 2)) * 4 + (ci & 3);
-                dofs = (int)d.w_off + k * 32 + r;
+                dofs = slot < ntaps ? (int)d.w_off + k * 32 + r : (int)d2.w_off1 + r;          // conv1_0.kernel [8][4]
             }
             float t = 0.0f;
 #pragma unroll
@@ -482,10 +490,10 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
         }
         __syncthreads();
     });
-    if (tid < 4 * XN) {
+    if (tid < (KIND == 2 ? 8 : 4 * XN)) {
         const float t = ((sbias[0][tid] + sbias[1][tid]) + sbias[2][tid]) + sbias[3][tid];
-        if constexpr (KIND == 1) dst[(tid < 4 ? d.b_off : d2.b_off1) + (tid & 3)] = t;
-        else dst[d.b_off + tid] = t;
+        if constexpr (KIND == 0) dst[d.b_off + tid] = t;
+        else dst[(tid < 4 ? d.b_off : d2.b_off1) + (tid & 3)] = t;          // KIND 1: second convolution; KIND 2: conv1_0
     }
     for (int64_t r = (int64_t)blockIdx.x + gridDim.x; r < a.nb_slab; r += gridDim.x) {
         float* z = d.base + r * d.block_stride;
@@ -495,8 +503,9 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
         }
         if (tid < T::BELEMS) {
             z[d.b_off + tid] = 0.0f;
-            if constexpr (KIND == 1) z[d2.b_off1 + tid] = 0.0f;
+            if constexpr (KIND != 0) z[d2.b_off1 + tid] = 0.0f;
         }
+        if constexpr (KIND == 2) { if (tid < 32) z[d2.w_off1 + tid] = 0.0f; }
     }
 }
 
@@ -525,16 +534,27 @@ static inline void fb_grid(int64_t n, int nb, int ngroups, int& tiles_per_wave, 
     if (blocks < 1) blocks = 1;
 }
 
-// g: output gradient (gathered), xin: the convolution's input, W: its kernel; out: input gradient; slab partials into d
-// (rows 0 .. nb - 1 of the slab are all written: the blocks beyond the grid's get zeros).  pw != nullptr selects the gM epilogue.
+// slab rows a fused launch over `ngroups` groups writes (= its blocks per group)
+int linr_fused_bwd_rows(int64_t n, int nb, int ngroups) {
+    int tpw = 1, blocks = 1;
+    fb_grid(n, nb, ngroups, tpw, blocks);
+    return blocks;
+}
+
+// g: output gradient (gathered), xin: the convolution's input, W: its kernel; out: input gradient; slab partials into d.
+// rows_written == nullptr: rows 0 .. nb - 1 of the slab are all written (the rows beyond the grid's blocks get zeros);
+// otherwise only the grid's rows are written and *rows_written tells the caller how many (its reduction must stop there).
+// pw != nullptr selects the gM epilogue.
 int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                                  const float* W, float* out, const PwArgs* pw, LinrWgradDst d, int nb, hipStream_t s,
-                                 const Grp* gp, int ngroups) {
+                                 const Grp* gp, int ngroups, int* rows_written) {
+    if (rows_written) *rows_written = 0;
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
-    FbArgs a = {g, nullptr, xin, W, nullptr, nullptr, out, 0u, 1, nb};
+    FbArgs a = {g, nullptr, xin, W, nullptr, nullptr, out, 0u, 1, rows_written ? 0 : nb};
     int blocks = 1;
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
+    if (rows_written) *rows_written = blocks;
     const dim3 grid(blocks, ngroups);
     if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{0, 0}, g0);
     else conv_bwd_wgrad_k<0, 0><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
@@ -546,29 +566,35 @@ int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t
 int linr_dual44_bwd_wgrad_launch(const float* gI, const float* gM, const float* H, const int32_t* lo, const uint32_t* mask,
                                  int64_t ld, int64_t n, const float* w01, const float* w11, float* gH, float* big,
                                  int64_t block_stride, int64_t w_off0, int64_t b_off0, int64_t w_off1, int64_t b_off1, int nb,
-                                 hipStream_t s, const Grp* gp, int ngroups) {
+                                 hipStream_t s, const Grp* gp, int ngroups, int* rows_written) {
+    if (rows_written) *rows_written = 0;
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
-    FbArgs a = {gI, gM, H, w01, w11, nullptr, gH, 0u, 1, nb};
+    FbArgs a = {gI, gM, H, w01, w11, nullptr, gH, 0u, 1, rows_written ? 0 : nb};
     int blocks = 1;
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
+    if (rows_written) *rows_written = blocks;
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
     conv_bwd_wgrad_k<1, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
     return linr_launch_rc();
 }
 
 // conv0_0 (8->4) of an Inception layer: gA = (bwd(gH[:, 0:4]; W00) + gI (+ old gA: LINR_ACCUM) + gH[:, 4:8] @ W10^T) (* (A > 0):
-// LINR_RELU_MASK) and the kernel / bias gradient of conv0_0 from one gather of gH[:, 0:4]
+// LINR_RELU_MASK) and the kernel / bias gradient of conv0_0 from one gather of gH[:, 0:4]; the kernel / bias gradient of the 1x1
+// conv1_0 (A^T gH[:, 4:8]) comes out of the same launch (slab offsets w10_off / b10_off)
 int linr_conv84_bwd_wgrad_launch(const float* gH, const float* A, const float* gI, const int32_t* lo, const uint32_t* mask,
                                  int64_t ld, int64_t n, const float* w00, const float* w10, float* gA, unsigned flags,
-                                 LinrWgradDst d, int nb, hipStream_t s, const Grp* gp, int ngroups) {
+                                 LinrWgradDst d, int64_t w10_off, int64_t b10_off, int nb, hipStream_t s, const Grp* gp, int ngroups,
+                                 int* rows_written) {
+    if (rows_written) *rows_written = 0;
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
-    FbArgs a = {gH, nullptr, A, w00, nullptr, gI, gA, flags & (LINR_RELU_MASK | LINR_ACCUM), 1, nb};
+    FbArgs a = {gH, nullptr, A, w00, nullptr, gI, gA, flags & (LINR_RELU_MASK | LINR_ACCUM), 1, rows_written ? 0 : nb};
     int blocks = 1;
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
+    if (rows_written) *rows_written = blocks;
     PwArgs pw = {w10, nullptr, nullptr, nullptr};
-    conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{0, 0}, g0);
+    conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
     return linr_launch_rc();
 }
 
@@ -580,12 +606,12 @@ extern "C" int linr_spconv_bwd_fused(const float* gout, const float* in, const i
     if (!linr_aligned16(gout) || !linr_aligned16(gin)) return LINR_EALIGN;
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull || ld >= ((int64_t)1 << 26)) return LINR_EINVAL;
     LinrWgradDst d = {slab, 1736, 0, 1728, 8};
-    return linr_conv88_bwd_wgrad_launch(gout, in, lo, mask, ld, n, W, gin, nullptr, d, nblocks, (hipStream_t)stream, nullptr, 1);
+    return linr_conv88_bwd_wgrad_launch(gout, in, lo, mask, ld, n, W, gin, nullptr, d, nblocks, (hipStream_t)stream, nullptr, 1, nullptr);
 }
 
 // The Inception layer's backward with its two conv pairs fused (what the executor launches): gM by the caller (tail conv
-// epilogue or linr_linear), then [gH + dW01, db01, dW11, db11], then [gX + dW00, db00].  slab: [nblocks][1744] =
-// [W00 864 | b00 4 | W01 432 | b01 4 | W11 432 | b11 4 | pad 4]
+// epilogue or linr_linear), then [gH + dW01, db01, dW11, db11], then [gX + dW00, db00, dW10, db10].  slab: [nblocks][1776] =
+// [W00 864 | b00 4 | W01 432 | b01 4 | W11 432 | b11 4 | W10 32 | b10 4]
 extern "C" int linr_inception_bwd_fused(const float* gI, const float* gM, const float* x, const float* H, const int32_t* lo,
                                         const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gH,
                                         float* gX, uint32_t flags, float* slab, int32_t nblocks, void* stream) {
@@ -597,9 +623,9 @@ extern "C" int linr_inception_bwd_fused(const float* gI, const float* gM, const 
         !linr_aligned16(x)) return LINR_EALIGN;
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull || ld >= ((int64_t)1 << 26)) return LINR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    int rc = linr_dual44_bwd_wgrad_launch(gI, gM, H, lo, mask, ld, n, q->w01, q->w11, gH, slab, 1744, 868, 1300, 1304, 1736, nblocks, s,
-                                          nullptr, 1);
+    int rc = linr_dual44_bwd_wgrad_launch(gI, gM, H, lo, mask, ld, n, q->w01, q->w11, gH, slab, 1776, 868, 1300, 1304, 1736, nblocks, s,
+                                          nullptr, 1, nullptr);
     if (rc) return rc;
-    LinrWgradDst d = {slab, 1744, 0, 864, 8};
-    return linr_conv84_bwd_wgrad_launch(gH, x, gI, lo, mask, ld, n, q->w00, q->w10, gX, flags, d, nblocks, s, nullptr, 1);
+    LinrWgradDst d = {slab, 1776, 0, 864, 8};
+    return linr_conv84_bwd_wgrad_launch(gH, x, gI, lo, mask, ld, n, q->w00, q->w10, gX, flags, d, 1740, 1772, nblocks, s, nullptr, 1, nullptr);
 }

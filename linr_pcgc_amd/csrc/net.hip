@@ -234,8 +234,12 @@ __global__ void sce_emb_grad_all_k(const float* __restrict__ P, float* __restric
 // the context MLPs of scales the frame does not contain - lie in [0, prefix): `zr` lists those ranges and the reduction
 // writes 0 for them WITHOUT reading the slab, which therefore needs no clearing pass (a 2-D memset of nb rows per step).
 struct ZeroRanges { int n; int64_t prefix; int64_t b[MAX_SCALES + 1], e[MAX_SCALES + 1]; };
+// Parameter ranges whose producer (a fused backward launch: one round of long-lived blocks, csrc/fused_bwd.hip) wrote only the
+// first rows[i] rows of the slab: the reduction stops there instead of having the producer fill the other rows with zeros.
+#define MAX_SHORT 24
+struct ShortRanges { int n; int64_t b[MAX_SHORT], e[MAX_SHORT]; int rows[MAX_SHORT]; };
 __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
-                                                             float* __restrict__ gsum, ZeroRanges zr) {
+                                                             float* __restrict__ gsum, ZeroRanges zr, ShortRanges sr) {
     __shared__ float part[RED_SPLIT][LINR_BLOCK / RED_SPLIT];
     const int lp = threadIdx.x % (LINR_BLOCK / RED_SPLIT), q = threadIdx.x / (LINR_BLOCK / RED_SPLIT);
     const int64_t p = (int64_t)blockIdx.x * (LINR_BLOCK / RED_SPLIT) + lp;
@@ -248,9 +252,14 @@ __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __rest
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = 0.0f;
         const int per = nblocks / RED_SPLIT;                 // nblocks is a multiple of 8 * RED_SPLIT
-        for (int b = q * per; b < (q + 1) * per; b += 8) {
+        int rows = nblocks;
+        for (int i = 0; i < sr.n; ++i)
+            if (p >= sr.b[i] && p < sr.e[i]) rows = sr.rows[i];
+        const int hi = (q + 1) * per < rows ? (q + 1) * per : rows;
+        for (int b = q * per; b < hi; b += 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] += big[(int64_t)(b + i) * total + p];
+            for (int i = 0; i < 8; ++i)
+                if (b + i < hi) a[i] += big[(int64_t)(b + i) * total + p];
         }
         s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
@@ -268,6 +277,17 @@ struct Ctx {
     int64_t R;
     int64_t nbr_ld;
     int nb;                  // persistent blocks of the weight-gradient kernels = partial rows of the slab for this frame
+    struct Short { int64_t b, e; int rows; };
+    std::vector<Short> shortr;      // parameter ranges of this backward pass that hold fewer than nb slab rows (fused launches)
+    // a fused launch wrote `rows` slab rows for parameters [b, e): the final reduction stops there (more ranges than the table
+    // holds cannot happen: 8 blocks x 2 + prune convs + block_in's first conv = 18)
+    // a fused launch writes only `rows` slab rows for parameters [b, e) (no zero fill): the final reduction stops there.  The
+    // table holds every range of a backward pass: 8 blocks x 2 + the prune convs + block_in's first conv = 18
+    void note_short(int64_t b, int64_t e, int rows) {
+        if (rows >= nb) return;
+        if ((int)shortr.size() >= MAX_SHORT) abort();          // cannot happen (see above); a silent drop would read unwritten rows
+        shortr.push_back({b, e, rows});
+    }
 };
 
 // Persistent blocks per weight-gradient launch (multiples of 32: wgrad_reduce_k's association).  Every block ends with a fold
@@ -757,7 +777,9 @@ int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float*
     if (total <= 0) return 0;
     ZeroRanges zr;
     zr.n = 0; zr.prefix = 0;
-    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(big, nblocks, total, gsum, zr);
+    ShortRanges sr;
+    sr.n = 0;
+    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(big, nblocks, total, gsum, zr, sr);
     return linr_launch_rc();
 }
 
@@ -810,7 +832,9 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             goffs_i(gp.e3, o_prw, 8); goffs_i(gp.e4, o_prb, 8);
             LinrWgradDst d = {a.BIG, L.total, o_prw[0], o_prb[0], 8};
             ProfScope ps(c.s, PK_FUSED88, 8);
-            TRY(linr_conv88_bwd_wgrad_launch(a.gC[0], a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], a.gO[0], nullptr, d, c.nb, c.s, &gp, 8));
+            int rows = 0;
+            TRY(linr_conv88_bwd_wgrad_launch(a.gC[0], a.O[0], lo, mk, c.nbr_ld, c.R, h_prw[0], a.gO[0], nullptr, d, c.nb, c.s, &gp, 8, &rows));
+            c.note_short(L.pr_w[0], L.pr_b[7] + 8, rows);
         } else {
         {   // C = conv3(prior_k; prune_k): weight gradients ...
             Grp gp = Grp();
@@ -858,7 +882,9 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         PwArgs pw = {p_c12w[0], nullptr, pM[0], a.gM[g0]};
         ProfScope ps(c.s, PK_FUSED88, ng);
-        TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng));
+        int rows = 0;
+        TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng, &rows));
+        for (int g = 0; g < ng; ++g) c.note_short(o_bw[g], o_bb[g] + 8, rows);
     } else {
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
@@ -887,8 +913,9 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         goffs(gp.in, p_gI, ng); goffs(gp.e5, p_gM, ng); goffs(gp.res, pH, ng); goffs(gp.w, p_c01w, ng); goffs(gp.e6, p_c11w, ng);
         goffs(gp.out, p_gH, ng); goffs_i(gp.e3, o_c01w, ng); goffs_i(gp.e4, o_c01b, ng); goffs_i(gp.e0, o_c11w, ng); goffs_i(gp.e1, o_c11b, ng);
         ProfScope ps(c.s, PK_FUSED_DUAL, ng);
+        int rows_inc = 0;
         TRY(linr_dual44_bwd_wgrad_launch(p_gI[0], p_gM[0], pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], a.gH[g0], a.BIG, L.total,
-                                         o_c01w[0], o_c01b[0], o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng));
+                                         o_c01w[0], o_c01b[0], o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng, &rows_inc));
     } else {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
         goffs(gp.in, pH, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, p_gM, ng); goffs_i(gp.w, o_c01w, ng); goffs_i(gp.b, o_c01b, ng);
@@ -904,7 +931,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         ProfScope ps(c.s, PK_BWD_DATA, ng);
         TRY(linr_dual44_bwd_launch(p_gI[0], p_gM[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], pH[0], a.gH[g0], c.s, &gq, ng));
     }
-    {   // conv1_0 (1x1 8->4) weight gradient
+    if (!fused_bwd(c)) {   // conv1_0 (1x1 8->4) weight gradient (the fused conv0_0 launch below produces it on the side)
         Grp gq = Grp();
         goffs(gq.in, pA, ng); goffs(gq.res, p_gH, ng); goffs_i(gq.w, o_c10w, ng); goffs_i(gq.b, o_c10b, ng);
         LinrLinDst dl = {a.BIG, L.total, o_c10w[0], 4, 1, o_c10b[0]};
@@ -914,11 +941,16 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
     if (fused_bwd(c)) {   // conv0_0 (8->4): gA = (bwd(gH[:,0:4]; W00) + gI + gH[:,4:8] @ W10^T) * (A > 0) and its weight gradient, one gather
         Grp gp = Grp();
         goffs(gp.in, p_gH, ng); goffs(gp.res, pA, ng); goffs(gp.w, p_c00w, ng); goffs(gp.act, p_gI, ng); goffs(gp.out, p_gA, ng);
-        goffs(gp.e0, p_c10w, ng); goffs_i(gp.e3, o_c00w, ng); goffs_i(gp.e4, o_c00b, ng);
+        goffs(gp.e0, p_c10w, ng); goffs_i(gp.e3, o_c00w, ng); goffs_i(gp.e4, o_c00b, ng); goffs_i(gp.e1, o_c10w, ng); goffs_i(gp.e2, o_c10b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_c00w[0], o_c00b[0], 8};
         ProfScope ps(c.s, PK_FUSED_C00, ng);
+        int rows_c00 = 0;
         TRY(linr_conv84_bwd_wgrad_launch(p_gH[0], pA[0], p_gI[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], a.gA[g0], LINR_RELU_MASK, d,
-                                         c.nb, c.s, &gp, ng));
+                                         o_c10w[0], o_c10b[0], c.nb, c.s, &gp, ng, &rows_c00));
+        // conv0_0, conv0_1, conv1_0, conv1_1 are contiguous in the parameter vector and come from the two fused launches of the
+        // layer, which write the same number of slab rows (same rows, same groups)
+        if (rows_c00 != linr_fused_bwd_rows(c.R, c.nb, ng)) return LINR_EINVAL;
+        for (int g = 0; g < ng; ++g) c.note_short(o_c00w[g], o_c12w[g], rows_c00);
     } else {
     {   // conv0_0 (8->4) weight gradient
         Grp gp = Grp();
@@ -984,7 +1016,9 @@ static int backward_core(Ctx& c, float gscale) {
         const BlockP& bi = c.L.block_in;
         LinrWgradDst d = {a.BIG, c.L.total, bi.a_w, bi.a_b, 8};
         ProfScope ps(c.s, PK_FUSED88, 1);
-        TRY(linr_conv88_bwd_wgrad_launch(a.gA[0], a.X0, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, a.gX0, nullptr, d, c.nb, c.s));
+        int rows = 0;
+        TRY(linr_conv88_bwd_wgrad_launch(a.gA[0], a.X0, clo(c), cmk(c), c.nbr_ld, c.R, P + bi.a_w, a.gX0, nullptr, d, c.nb, c.s, nullptr, 1, &rows));
+        c.note_short(bi.a_w, bi.a_b + 8, rows);
     } else if (join) {      // everything but the input gradient of its first conv was part of the grouped launches
         const BlockP& bi = c.L.block_in;
         TRY(conv3(c, true, a.gA[0], 8, P + bi.a_w, nullptr, bi.cin, 8, nullptr, 0, nullptr, 0, a.gX0, 8, 0));
@@ -1042,7 +1076,10 @@ static int backward_core(Ctx& c, float gscale) {
                 zr.e[zr.n] = si + 1 < c.L.S ? c.L.m0_w[si + 1] : c.L.block_in.a_w;
                 ++zr.n;
             }
-        wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM, zr);
+        ShortRanges sr;
+        sr.n = (int)c.shortr.size();
+        for (int i = 0; i < sr.n; ++i) { sr.b[i] = c.shortr[i].b; sr.e[i] = c.shortr[i].e; sr.rows[i] = c.shortr[i].rows; }
+        wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM, zr, sr);
     }
     if (ns > 0) {
         EmbArgs ea;

@@ -305,7 +305,7 @@ def test_conv88_backward_fused_one_gather(env, nblocks):
 @pytest.mark.parametrize('nblocks,flags', [(256, 0), (3, 6)])
 def test_inception_backward_fused_pairs(env, nblocks, flags):
     """linr_inception_bwd_fused (both conv pairs of an Inception layer's backward, each from ONE gather): gH and gX are
-    bit-identical to linr_inception_bwd_data's, the kernel / bias gradients of conv0_0, conv0_1 and conv1_1 match autograd through
+    bit-identical to linr_inception_bwd_data's, the kernel / bias gradients of conv0_0, conv0_1, conv1_1 and conv1_0 match autograd through
     oracle.network.inception (models/resnet.py:55-60); flags 6 = LINR_ACCUM | LINR_RELU_MASK (block_in's layer 0)."""
     L, dev, n = env['L'], env['dev'], env['n']
     gen = torch.Generator().manual_seed(23 + nblocks)
@@ -335,12 +335,12 @@ def test_inception_backward_fused_pairs(env, nblocks, flags):
     _, gH2 = _empty_padded(n, 8, dev)
     _, gX2 = _empty_padded(n, 8, dev)
     gX2[:] = old
-    slab = torch.full((nblocks, 1744), float('nan'), device=dev)
+    slab = torch.full((nblocks, 1776), float('nan'), device=dev)
     env['lib'].check(L.linr_inception_bwd_fused(gI.data_ptr(), gM.data_ptr(), x.data_ptr(), H.data_ptr(), env['lo'].data_ptr(),
                                                 env['mask'].data_ptr(), env['ld'], n, ctypes.byref(q), gH2.data_ptr(), gX2.data_ptr(),
                                                 flags, slab.data_ptr(), nblocks, _stream()), 'linr_inception_bwd_fused')
     assert torch.equal(gH, gH2) and torch.equal(gX, gX2)
-    assert bool(torch.isfinite(slab[:, :1740]).all()), 'slab rows left unwritten'
+    assert bool(torch.isfinite(slab).all()), 'slab rows left unwritten'
     tot = slab.double().sum(0).cpu()
     _rel_own_max(tot[:864].view(27, 8, 4), wo['w00'].grad, 'gW00')
     _rel_own_max(tot[864:868], wo['b00'].grad, 'gb00')
@@ -348,3 +348,5 @@ def test_inception_backward_fused_pairs(env, nblocks, flags):
     _rel_own_max(tot[1300:1304], wo['b01'].grad, 'gb01')
     _rel_own_max(tot[1304:1736].view(27, 4, 4), wo['w11'].grad, 'gW11')
     _rel_own_max(tot[1736:1740], wo['b11'].grad, 'gb11')
+    _rel_own_max(tot[1740:1772].view(8, 4), wo['w10'].grad, 'gW10 (conv1_0 rides in the conv0_0 launch)')
+    _rel_own_max(tot[1772:1776], wo['b10'].grad, 'gb10')
