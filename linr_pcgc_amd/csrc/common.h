@@ -143,7 +143,8 @@ int linr_fused_bwd_rows(int64_t n, int nb, int ngroups);
 __attribute__((visibility("hidden")))
 int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                                  const float* W, float* out, const PwArgs* pw, LinrWgradDst d, int nb, hipStream_t s,
-                                 const Grp* gp = nullptr, int ngroups = 1, int* rows_written = nullptr);
+                                 const Grp* gp = nullptr, int ngroups = 1, int* rows_written = nullptr, int64_t w12_off = 0,
+                                 int64_t b12_off = 0);
 // ... of the two 4->4 convolutions of an Inception layer (gH, masked by H > 0) and of conv0_0 8->4 (gA with cconv_mfma_k's EPI 4)
 __attribute__((visibility("hidden")))
 int linr_dual44_bwd_wgrad_launch(const float* gI, const float* gM, const float* H, const int32_t* lo, const uint32_t* mask,

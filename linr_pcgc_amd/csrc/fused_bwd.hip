@@ -79,12 +79,13 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
     __shared__ float4 smem[FB_WAVES * FB_WAVE_BYTES / 16];
     __shared__ float sbias[FB_WAVES][8];
     {   // group offsets: in = g, e5 = g1, res = xin, w = W, e6 = W1, act = res, out; e0..e2 = pointwise epilogue (KIND 0 / 2) or
-        // e0 / e1 = slab offsets of the second convolution (KIND 1), e1 / e2 = of conv1_0 (KIND 2); e3 / e4 = slab offsets of kernel / bias
+        // e0 / e1 = slab offsets of the second convolution (KIND 1), e1 / e2 = of conv1_0 (KIND 2), e5 / e6 = of conv1_2 (EPI 3);
+        // e3 / e4 = slab offsets of kernel / bias
         const int gi = blockIdx.y;
         a.g += gp.in[gi]; a.xin += gp.res[gi]; a.W += gp.w[gi]; a.out += gp.out[gi];
         if constexpr (KIND == 1) { a.g1 += gp.e5[gi]; a.W1 += gp.e6[gi]; d2.w_off1 += gp.e0[gi]; d2.b_off1 += gp.e1[gi]; }
         if constexpr (KIND == 2) { if (a.res) a.res += gp.act[gi]; pw.w += gp.e0[gi]; d2.w_off1 += gp.e1[gi]; d2.b_off1 += gp.e2[gi]; }
-        if constexpr (EPI == 3) { pw.w += gp.e0[gi]; pw.aux += gp.e1[gi]; pw.aux_out += gp.e2[gi]; }
+        if constexpr (EPI == 3) { pw.w += gp.e0[gi]; pw.aux += gp.e1[gi]; pw.aux_out += gp.e2[gi]; d2.w_off1 += gp.e5[gi]; d2.b_off1 += gp.e6[gi]; }
         d.w_off += gp.e3[gi]; d.b_off += gp.e4[gi];
     }
     const int lane = threadIdx.x & 63;
@@ -233,6 +234,11 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
 #pragma unroll
         for (int j = 0; j < 16; ++j) w12[j] = pw.w[j];
     }
+    // EPI 3: conv1_2 (1x1, 4 -> 4) rides along: its weight gradient sum_rows M[row]^T gI[row][4:8] is a product of two OWN-row
+    // quantities the epilogue holds anyway - 16 + 4 per-lane accumulators (plain VALU, 20 FMAs per tile), one wave reduction per block
+    float g12[20];
+#pragma unroll
+    for (int j = 0; j < 20; ++j) g12[j] = 0.0f;
     float w10[32];                               // KIND 2: conv1_0's 1x1 kernel [8][4] of the epilogue, read once
 #pragma unroll
     for (int j = 0; j < 32; ++j) w10[j] = 0.0f;
@@ -395,6 +401,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
                         gm[i] = mv[i] > 0.0f ? t : 0.0f;
                     }
                     *reinterpret_cast<float4*>(pw.aux_out + row * 4) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) g12[i * 4 + q] = fmaf(mv[i], o[4 + q], g12[i * 4 + q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g12[16 + q] += o[4 + q];
                 }
                 if constexpr (KIND == 1) {         // gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)
                     const float hv[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
@@ -451,6 +463,21 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
     }
     float* dst = d.base + (int64_t)blockIdx.x * d.block_stride;
     const int tid = threadIdx.x;
+    if constexpr (EPI == 3) {          // conv1_2's gradients: fixed shuffle tree inside the wave, the four waves in order
+        __shared__ float s12[FB_WAVES][20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            float t = g12[j];
+#pragma unroll
+            for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_xor(t, dd, 64);
+            if (lane == 0) s12[wave][j] = t;
+        }
+        __syncthreads();
+        if (tid < 20) {
+            const float t = ((s12[0][tid] + s12[1][tid]) + s12[2][tid]) + s12[3][tid];
+            dst[(tid < 16 ? d2.w_off1 + tid : d2.b_off1 + (tid - 16))] = t;
+        }
+    }
     static_for<NCH>([&](auto chc) {
         constexpr int ch = decltype(chc)::value;
         constexpr int ntaps = T::ntaps(ch);
@@ -506,6 +533,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
             if constexpr (KIND != 0) z[d2.b_off1 + tid] = 0.0f;
         }
         if constexpr (KIND == 2) { if (tid < 32) z[d2.w_off1 + tid] = 0.0f; }
+        if constexpr (EPI == 3) { if (tid < 20) z[(tid < 16 ? d2.w_off1 + tid : d2.b_off1 + (tid - 16))] = 0.0f; }
     }
 }
 
@@ -544,10 +572,11 @@ int linr_fused_bwd_rows(int64_t n, int nb, int ngroups) {
 // g: output gradient (gathered), xin: the convolution's input, W: its kernel; out: input gradient; slab partials into d.
 // rows_written == nullptr: rows 0 .. nb - 1 of the slab are all written (the rows beyond the grid's blocks get zeros);
 // otherwise only the grid's rows are written and *rows_written tells the caller how many (its reduction must stop there).
-// pw != nullptr selects the gM epilogue.
+// pw != nullptr selects the gM epilogue, which also produces conv1_2's kernel / bias gradient (M^T gin[:, 4:8]; slab offsets
+// w12_off / b12_off).
 int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                                  const float* W, float* out, const PwArgs* pw, LinrWgradDst d, int nb, hipStream_t s,
-                                 const Grp* gp, int ngroups, int* rows_written) {
+                                 const Grp* gp, int ngroups, int* rows_written, int64_t w12_off, int64_t b12_off) {
     if (rows_written) *rows_written = 0;
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
@@ -556,7 +585,7 @@ int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     const dim3 grid(blocks, ngroups);
-    if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{0, 0}, g0);
+    if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
     else conv_bwd_wgrad_k<0, 0><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
     return linr_launch_rc();
 }

@@ -879,12 +879,16 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         Grp gp = Grp();
         goffs(gp.in, p_gO, ng); goffs(gp.res, pI, ng); goffs(gp.w, p_bw, ng); goffs(gp.out, p_gI, ng);
         goffs(gp.e0, p_c12w, ng); goffs(gp.e1, pM, ng); goffs(gp.e2, p_gM, ng); goffs_i(gp.e3, o_bw, ng); goffs_i(gp.e4, o_bb, ng);
+        goffs_i(gp.e5, o_c12w, ng); goffs_i(gp.e6, o_c12b, ng);
         LinrWgradDst d = {a.BIG, L.total, o_bw[0], o_bb[0], 8};
         PwArgs pw = {p_c12w[0], nullptr, pM[0], a.gM[g0]};
         ProfScope ps(c.s, PK_FUSED88, ng);
         int rows = 0;
-        TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng, &rows));
-        for (int g = 0; g < ng; ++g) c.note_short(o_bw[g], o_bb[g] + 8, rows);
+        TRY(linr_conv88_bwd_wgrad_launch(p_gO[0], pI[0], lo, mk, c.nbr_ld, c.R, p_bw[0], a.gI[g0], &pw, d, c.nb, c.s, &gp, ng, &rows,
+                                         o_c12w[0], o_c12b[0]));
+        // everything of a block behind its first conv comes from fused launches over the same groups (conv1_2 rides in this one,
+        // conv0_0 / conv0_1 / conv1_0 / conv1_1 come below): one contiguous range of `rows` slab rows per block
+        for (int g = 0; g < ng; ++g) c.note_short(o_c00w[g], o_bb[g] + 8, rows);
     } else {
     {   // O = conv3(I; b): weight gradient
         Grp gp = Grp();
@@ -901,7 +905,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         TRY(linr_conv_bwd_gm_launch(p_gO[0], lo, mk, c.nbr_ld, c.R, p_bw[0], p_c12w[0], pM[0], a.gI[g0], a.gM[g0], c.s, &gp, ng));
     }
     }
-    {   // conv1_2 weight gradient: M^T gI[:,4:8]
+    if (!fused_bwd(c)) {   // conv1_2 weight gradient: M^T gI[:,4:8]  (the fused tail-conv launch above produces it on the side)
         Grp gp = Grp();
         goffs(gp.in, pM, ng); goffs(gp.res, p_gI, ng); goffs_i(gp.w, o_c12w, ng); goffs_i(gp.b, o_c12b, ng);
         LinrLinDst d = {a.BIG, L.total, o_c12w[0], 4, 1, o_c12b[0]};
@@ -916,6 +920,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         int rows_inc = 0;
         TRY(linr_dual44_bwd_wgrad_launch(p_gI[0], p_gM[0], pH[0], lo, mk, c.nbr_ld, c.R, p_c01w[0], p_c11w[0], a.gH[g0], a.BIG, L.total,
                                          o_c01w[0], o_c01b[0], o_c11w[0], o_c11b[0], c.nb, c.s, &gp, ng, &rows_inc));
+        if (rows_inc != linr_fused_bwd_rows(c.R, c.nb, ng)) return LINR_EINVAL;        // (its parameters were registered with the tail conv)
     } else {   // both 4->4 convs: weight gradients, then gH
         Grp gp = Grp();
         goffs(gp.in, pH, ng); goffs(gp.res, p_gI, ng); goffs(gp.act, p_gM, ng); goffs_i(gp.w, o_c01w, ng); goffs_i(gp.b, o_c01b, ng);
@@ -947,10 +952,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         int rows_c00 = 0;
         TRY(linr_conv84_bwd_wgrad_launch(p_gH[0], pA[0], p_gI[0], lo, mk, c.nbr_ld, c.R, p_c00w[0], p_c10w[0], a.gA[g0], LINR_RELU_MASK, d,
                                          o_c10w[0], o_c10b[0], c.nb, c.s, &gp, ng, &rows_c00));
-        // conv0_0, conv0_1, conv1_0, conv1_1 are contiguous in the parameter vector and come from the two fused launches of the
-        // layer, which write the same number of slab rows (same rows, same groups)
-        if (rows_c00 != linr_fused_bwd_rows(c.R, c.nb, ng)) return LINR_EINVAL;
-        for (int g = 0; g < ng; ++g) c.note_short(o_c00w[g], o_c12w[g], rows_c00);
+        if (rows_c00 != linr_fused_bwd_rows(c.R, c.nb, ng)) return LINR_EINVAL;       // (registered with the tail conv)
     } else {
     {   // conv0_0 (8->4) weight gradient
         Grp gp = Grp();
