@@ -362,9 +362,12 @@ LINR_API int linr_occ_conv7(const float* occ, const int32_t* lo, const uint32_t*
  * (models/module_utils.py:8-40; callers models/upsample.py:224-237,275; models/model_core.py:204-208) and by the
  * model stream (model_compression/model_size_est.py:470-482,545-563).  Follows torchac 0.9.3's published
  * coder (un-vendored, pinned in enviroment.yaml:32); the one known-answer vector the reference ships (the model stream of
- * loot/gop_32_62) is met to the byte under a 90-bit header and sits one byte off under today's 82-bit header formula
- * (tests/test_oracle_golden.py::test_model_stream_known_answer has the derivation) - real torchac is not installable here,
- * so byte-compatibility beyond that vector is by construction, not by test.
+ * loot/gop_32_62: 282,642 bits) is consistent with this coder in two ways that cannot be told apart offline - 35,319 bytes with
+ * the CPU's Laplace pdf plus a 90-bit header of an older revision, or 35,320 bytes plus today's 82-bit header if the CUDA pdf
+ * the reference builds its CDF from differs in the last bit (tests/test_oracle_golden.py::test_model_stream_known_answer).
+ * Consequence for interop: a model.bin whose CDF was built on another device decodes only if that device's expf agrees to the
+ * last bit on the 256 pdf values.  Real torchac is not installable here, so byte-compatibility beyond that vector is by
+ * construction, not by test.
  * All pointers here are HOST pointers.  Return: bytes written (>= 0) or a negative LINR_E* code. */
 LINR_API int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym_h, int64_t n, uint8_t* out_h, int64_t cap);
 LINR_API int     linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h);

@@ -44,6 +44,9 @@ def dec_all_frame_low_xyz(low_byte):
     return [np.frombuffer(c, dtype=np.uint8).reshape(-1, 3) for c in chunks], mins
 
 
+EXTRA_SIDE_BITS = 16          # arith_version + precision in side_info.json, beyond the reference's side information
+
+
 def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32'):
     """encoder.encode_one_gop: quantise the model, then per frame ONE forward over all scales and 8 x scales
     independent arithmetic-coded streams (thread pool).  precision='bf16': the forward runs on the bf16 / uint8-weight
@@ -122,9 +125,10 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
     occ_bits = 8 * sum(len(b) for fb in frames_bytes for b in fb)
     return {'frames': frames_bytes, 'model_bin': comp['final_bytes'], 'side_info': side_info, 'low_enc_bytes': low,
             'point_num': points, 'bits_est': bits_est,
-            'bpp': {'point_bpp': occ_bits / points, 'model_bpp': comp['bit_real'] / points,
+            # the two side-info fields this codec adds (arithmetic version, precision: one byte each) are counted with the model
+            'bpp': {'point_bpp': occ_bits / points, 'model_bpp': (comp['bit_real'] + EXTRA_SIDE_BITS) / points,
                     'xyzlow_bpp': len(low) * 8 / points,
-                    'bpp_all': (occ_bits + comp['bit_real'] + len(low) * 8) / points}}       # test_utils.py:146-157
+                    'bpp_all': (occ_bits + comp['bit_real'] + EXTRA_SIDE_BITS + len(low) * 8) / points}}       # test_utils.py:146-157
 
 
 def decode_one_frame(model, frame_enc_bytes, xyz_low):

@@ -1,5 +1,6 @@
 // Arithmetic-coder feed (host side).  Produces / consumes streams in torchac 0.9.3's format, following its published coder
-// (byte-compatibility is by construction + the reference's one known-answer vector, see include/linr_hip.h), as the
+// (byte-compatibility is by construction; the reference's one known-answer vector is consistent with it in two ways,
+// include/linr_hip.h; cross-device model.bin interop depends on the last bit of expf), as the
 // reference uses it: BinaryArithmeticCoding (models/module_utils.py:8-40, cdf = [0, 1-p, 1]) and the Laplace model stream
 // (model_compression/model_size_est.py:470-482,545-563).  32-bit range coder with carry-less pending-bit handling
 // over 16-bit cumulative frequencies; bits are packed MSB first, the tail is zero padded.

@@ -2,7 +2,8 @@
 
 Restates model_compression/model_size_est.py: quant_uniform2 :72-91, Laplace parameters :409-410,
 the CDF construction with its trailing-zero quirk :466-482 and de-quantisation :566-568.
-Pinned by loot/gop_32_62/70/side_info.json and the 35,320-byte stream implied by 70/result.json.
+Pinned by loot/gop_32_62/70/side_info.json and the model stream implied by 70/result.json (35,319 bytes with the CPU's pdf; the
+artefact is also consistent with 35,320 bytes from a CUDA pdf that differs in the last bit: tests/test_oracle_golden.py).
 """
 import numpy as np
 import torch

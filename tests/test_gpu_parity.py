@@ -965,6 +965,26 @@ def test_decode_scale_call_equals_stagewise_decode(pkg, precision):
     assert L.linr_decode_scale(*args(base, 8 * n)) == 0 and 0 < cnt.value <= 8 * n
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_committed_stream_still_decodes(pkg, golden_dir, precision):
+    """The fp32 evaluation order of the forward is part of the stream format (codec.ARITH_VERSION).  A stream coded by the build
+    that set the current version is committed (tests/golden/stream_v*.npz, written by tests/golden/make_stream_golden.py on a
+    MI355X): this build must decode it to the same geometry - a change of the arithmetic without a version bump fails here."""
+    import ast
+    from linr_pcgc_amd import codec, overfit
+    path = os.path.join(golden_dir, 'stream_v%d.npz' % codec.ARITH_VERSION)
+    assert os.path.exists(path), 'no committed stream for ARITH_VERSION %d: run tests/golden/make_stream_golden.py' % codec.ARITH_VERSION
+    g = np.load(path)
+    assert int(g['arith_version']) == codec.ARITH_VERSION
+    n_scales = int(g['scale_num'])
+    frames = [[g['%s_f%d_s%d' % (precision, fi, si)].tobytes() for si in range(n_scales)] for fi in range(2)]
+    enc = {'frames': frames, 'model_bin': g[precision + '_model_bin'].tobytes(), 'low_enc_bytes': g[precision + '_low'].tobytes(),
+           'side_info': ast.literal_eval(str(g[precision + '_side']))}
+    dec = codec.decode_gop(overfit.gen_model(n_scales, 'cuda'), enc, 'cuda')
+    for i in range(2):
+        assert torch.equal(dec[i].cpu(), torch.from_numpy(g['ref%d' % i])), 'frame %d of the committed stream decodes to other geometry' % i
+
+
 def test_gop_flow_checkpoint_warm_start_files(pkg, tmp_path):
     """main.overfit_enc_dec in miniature: GOP 0 from scratch -> checkpoint -> GOP 1 warm start (model + Adam state) ->
     encode -> reference directory layout on disk -> decode from the files alone -> lossless; model codec round trip."""
