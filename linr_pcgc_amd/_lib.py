@@ -45,6 +45,8 @@ _PROTOS = {
     'linr_kmap_tile8t': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),
     'linr_prof_mask': (ctypes.c_int, [c_u32]),
     'linr_prof_enable': (ctypes.c_int, [c_i32]),
+    'linr_debug_poison': (ctypes.c_int, [c_u32]),
+    'linr_debug_poison_now': (ctypes.c_int, [c_ptr]),
     'linr_prof_read': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr]),
     'linr_octree_occupancy': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'linr_kmap_offset_feat': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
@@ -125,8 +127,34 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.linr_abi_version() != ABI_VERSION:
             raise LinrError('liblinr_hip.so ABI %d != binding ABI %d' % (handle.linr_abi_version(), ABI_VERSION))
+        if os.environ.get('LINR_DEBUG_POISON'):
+            handle = _Poisoned(handle)
         _lib = handle
     return _lib
+
+
+class _Poisoned:
+    """LINR_DEBUG_POISON=1 (test aid, tools/README.md): every GPU entry point is called with the LDS and vector registers of all
+    CUs freshly filled with a NaN pattern (linr_debug_poison_now in front of it, linr_debug_poison(all classes) for the launches
+    inside the executors).  The test suite must pass unchanged under it: no kernel may read on-chip state it did not write."""
+    _HOST = ('linr_ac_', 'linr_prof_', 'linr_debug_', 'linr_abi_version')
+
+    def __init__(self, handle):
+        self._h = handle
+        handle.linr_debug_poison(0xFFFF)
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name.startswith(self._HOST) or name.endswith('_bytes'):
+            return fn
+        h = self._h
+
+        def call(*a):
+            import torch
+            if torch.cuda.is_available():
+                h.linr_debug_poison_now(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return fn(*a)
+        return call
 
 
 _ERR = {-1: 'LINR_EINVAL (bad argument)', -2: 'LINR_ENOSPC (buffer too small)', -3: 'LINR_EALIGN (misaligned pointer)'}

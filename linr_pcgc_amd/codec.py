@@ -155,12 +155,15 @@ def decode_one_frame_stagewise(model, frame_enc_bytes, xyz_low):
     return {'dec_coord': lowx}
 
 
-def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1):
+def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1, timing=None):
     """decoder.decode_one_gop: rebuild the model from model.bin, then every frame from its streams alone.
+    `timing` (a dict) receives 'setup_s': the once-per-GOP part (model.bin -> parameters, the coarsest coordinates).
     Frames are independent once the model is known; with workers > 1 they are decoded by a host thread pool, each
     thread on its own HIP stream (a frame's own chain - 56 stage forwards with a serial range decode in between - cannot
     be parallelised, but the range decoding of one frame overlaps the stage forwards and copies of the others; the
     C calls release the GIL)."""
+    import time
+    t_setup = time.time()
     side = dict(enc['side_info'])
     coded_with = int(side.pop('arith_version', 1))
     if coded_with != ARITH_VERSION:
@@ -173,6 +176,10 @@ def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1):
     model.inference_precision = side.get('precision', 'f32')
     lows, mins = dec_all_frame_low_xyz(enc['low_enc_bytes'])
     todo = list(range(len(enc['frames'])) if frames is None else frames)
+    if timing is not None:
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        timing['setup_s'] = time.time() - t_setup
 
     def one(i):
         xyz_low = torch.tensor(lows[i].astype(np.int32), device=device)

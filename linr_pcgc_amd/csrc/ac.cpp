@@ -14,6 +14,9 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "../../include/linr_hip.h"
 
 namespace {
@@ -153,7 +156,17 @@ struct BitSinkFast {
 constexpr int AC_CHUNK = 256;
 
 inline void c1_block(const float* p, int n, uint32_t* c1) {
-    for (int i = 0; i < n; ++i) c1[i] = binary_c1(p[i]);
+    int i = 0;
+#if defined(__SSE2__)
+    // binary_c1 four at a time: cvtps2dq rounds to nearest even under the default MXCSR, like lrintf; |scaled| <= 65534 fits
+    const __m128 one = _mm_set1_ps(1.0f), scale = _mm_set1_ps(65534.0f);
+    const __m128i inc = _mm_set1_epi32(1), m16 = _mm_set1_epi32(0xFFFF);
+    for (; i + 4 <= n; i += 4) {
+        const __m128i v = _mm_cvtps_epi32(_mm_mul_ps(_mm_sub_ps(one, _mm_loadu_ps(p + i)), scale));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(c1 + i), _mm_and_si128(_mm_add_epi32(v, inc), m16));
+    }
+#endif
+    for (; i < n; ++i) c1[i] = binary_c1(p[i]);
 }
 
 }  // namespace
@@ -208,10 +221,44 @@ extern "C" int64_t linr_ac_encode_binary(const float* prob_h, const uint8_t* sym
     return sink.len <= cap ? sink.len : (int64_t)LINR_ENOSPC;
 }
 
+namespace {
+
+// Bit window of the binary decoder: 64 bits, MSB-aligned, refilled eight bytes at a time while eight whole bytes remain
+// (byte by byte in the tail; past the end the stream reads as zeros, as torchac's does).
+struct BitWindow {
+    const uint8_t* in; int64_t len; int64_t pos = 0; uint64_t buf = 0; int nbuf = 0;
+    BitWindow(const uint8_t* i, int64_t l) : in(i), len(l) {}
+    inline void refill() {                                   // afterwards nbuf >= 56
+        if (__builtin_expect(pos + 8 <= len, 1)) {
+            uint64_t w;
+            std::memcpy(&w, in + pos, 8);
+            buf |= __builtin_bswap64(w) >> nbuf;             // bits of a partly taken byte are OR-ed again, unchanged
+            pos += (63 - nbuf) >> 3;
+            nbuf |= 56;
+        } else {
+            while (nbuf <= 56) {
+                const uint64_t byte = pos < len ? in[pos] : 0u;
+                ++pos;
+                buf |= byte << (56 - nbuf);
+                nbuf += 8;
+            }
+        }
+    }
+    inline uint32_t take(int n) {                            // n in 0..32 (0 gives 0); needs nbuf >= n
+        const uint32_t v = (uint32_t)((buf >> 1) >> (63 - n));
+        buf <<= n;
+        nbuf -= n;
+        return v;
+    }
+};
+
+}  // namespace
+
 extern "C" int linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8_t* in_h, int64_t in_len, uint8_t* sym_h) {
     if (n < 0 || in_len < 0 || (n > 0 && (!prob_h || !sym_h)) || (in_len > 0 && !in_h)) return LINR_EINVAL;
-    BitSource src(in_h, in_len);
-    uint32_t low = 0, high = 0xFFFFFFFFu, value = src.bits(32);
+    BitWindow src(in_h, in_len);
+    src.refill();
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = src.take(32);
     uint32_t c1[AC_CHUNK];
     for (int64_t base = 0; base < n; base += AC_CHUNK) {
         const int m = (int)(n - base < AC_CHUNK ? n - base : AC_CHUNK);
@@ -229,22 +276,23 @@ extern "C" int linr_ac_decode_binary(const float* prob_h, int64_t n, const uint8
             const uint32_t lt = low + t;
             high = (high & one) | ((lt - 1u) & ~one);
             low = (lt & one) | (low & ~one);
-            for (;;) {
+            // Renormalisation.  torchac shifts one bit at a time: first while the top bits of low and high agree, then while
+            // the interval straddles the middle with low = 01.., high = 10.. (each such step also takes 2^30 off value).  Both
+            // runs are done at once: k agreeing bits, then j straddle steps (the top bits differ after the first run and after
+            // every straddle step, so the first run cannot resume); j steps leave value = (value << j | bits) - 2^31 mod 2^32.
+            // Most symbols of a trained model need neither, which the one branch below predicts.
+            while (__builtin_expect((((low ^ high) ^ 0x80000000u) | ((low & ~high) << 1)) & 0x80000000u, 0)) {
+                if (src.nbuf < 32) src.refill();
                 const uint32_t diff = low ^ high;
-                if (diff < 0x80000000u) {
-                    int k = diff ? __builtin_clz(diff) : 31;
-                    if (k > 31) k = 31;
-                    low <<= k;
-                    high = (high << k) | ((1u << k) - 1u);
-                    value = (value << k) | src.bits(k);
-                } else if (low >= 0x40000000u && high < 0xC0000000u) {
-                    low = (low << 1) & 0x7FFFFFFFu;
-                    high = (high << 1) | 0x80000001u;
-                    value -= 0x40000000u;
-                    value = (value << 1) | src.bits(1);
-                } else {
-                    break;
-                }
+                int k = __builtin_clz(diff | 1u);           // 0 when the top bits differ already
+                low <<= k;
+                high = (high << k) | ((1u << k) - 1u);
+                value = (value << k) | src.take(k);
+                if (src.nbuf < 32) src.refill();
+                const int j = __builtin_clz(~((low & ~high) << 1));          // leading positions below the top with low 1, high 0
+                low = (low << j) & 0x7FFFFFFFu;
+                high = (high << j) | 0x80000000u | ((1u << j) - 1u);
+                value = ((value << j) | src.take(j)) ^ (j ? 0x80000000u : 0u);
             }
         }
     }

@@ -161,3 +161,7 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
                             int64_t nbr_ld, int64_t n, float* big, int64_t block_stride, int64_t w_off0, int64_t b_off0,
                             int64_t w_off1, int64_t b_off1, int nblocks, hipStream_t s, const Grp* gp = nullptr,
                             int ngroups = 1, const int32_t* tile8t = nullptr);
+
+// test hook (include/linr_hip.h: linr_debug_poison): poisons LDS and vector registers of every CU on `s` when bit `kind` of the
+// mask is set; kinds 0..13 = the linr_prof_* classes of the fp32 executor, 14 = the bf16 executor, 15 = the decoder's own kernels
+__attribute__((visibility("hidden"))) void linr_poison_hook(hipStream_t s, int kind);

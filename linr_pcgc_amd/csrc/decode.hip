@@ -126,6 +126,7 @@ extern "C" int linr_decode_scale(const int32_t* coord, int64_t n, int32_t scale_
     if (rc) return rc;
     rc = linr_hip_rc(hipMemsetAsync(lo, 0, w.mask + (size_t)w.ld * 4 - w.lo, s));            // lo and mask are adjacent
     if (rc) return rc;
+    linr_poison_hook(s, 15);
     rc = linr_kmap_build(coord, n, nbr, w.ld, 0, base + w.kws, linr_kmap_workspace_bytes(n), stream);
     if (rc) return rc;
     rc = linr_kmap_compress(nbr, w.ld, n, lo, mask, w.ld, stream);
@@ -144,6 +145,7 @@ extern "C" int linr_decode_scale(const int32_t* coord, int64_t n, int32_t scale_
                                 p_pinned, s_pinned, s_dev, stream);
     if (rc) return rc;
     // upper_layer: children of the occupied octants, sorted x-major
+    linr_poison_hook(s, 15);
     child_count_k<<<linr_grid(n + 1, LINR_BLOCK), LINR_BLOCK, 0, s>>>(occ, n, cnt);
     size_t cb = w.cub_bytes;
     rc = linr_hip_rc(hipcub::DeviceScan::ExclusiveSum(base + w.cub, cb, cnt, pos, (int)(n + 1), s));

@@ -261,8 +261,12 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
             if constexpr (KIND == 0) xl_load(tile << 6, xl);
 #pragma unroll
             for (int u = 0; u < PF; ++u) gather(off[LINR_TAP(u)], x[u]);
-            // step 0: row 0 of "the last chunk of the previous tile" (zeros)
-            bq[0][0] = *reinterpret_cast<const float4*>(KIND == 0 ? imgR3 : imgR + ((NCH - 1) & 1) * FB_BUF);
+            // step 0 multiplies the first rows of "the last chunk of the previous tile" (the zeroed buffer; xlp = 0): EVERY register
+            // it will feed to the matrix cores is loaded - 0 x (whatever the register held) is only 0 while that is finite
+            constexpr int nr0 = T::prows(NCH - 1) / T::ntaps(0);
+#pragma unroll
+            for (int j = 0; j < nr0; ++j)
+                bq[0][j] = *reinterpret_cast<const float4*>((KIND == 0 ? imgR3 : imgR + ((NCH - 1) & 1) * FB_BUF) + j * 16);
         }
         for (; tile < tb1; tile += FB_WAVES) {
             const int64_t row_raw = (tile << 6) + lane;

@@ -317,10 +317,53 @@ static std::mutex g_prof_mu;                    // guards the vectors below
 static std::vector<ProfRec> g_prof[LINR_PROF_KINDS];          // used records
 static std::vector<ProfRec> g_prof_free;        // pre-created event pairs (creating events in the hot path costs ~20 us each)
 
+// ---- test hook: on-chip state poisoning (include/linr_hip.h: linr_debug_poison) ------------------------------------------
+// A kernel must never read LDS (or rely on register contents) it did not write itself: what is left there belongs to whatever
+// ran on the CU before - on a GPU shared with another process that can be a NaN pattern, and 0 x NaN poisons a gradient that
+// 0 x (own finite leftovers) never would.  While enabled, every launch of the executor is preceded by a kernel that fills the
+// LDS of every CU (and most of the vector registers) with 0xFFFFFFFF; tests then demand bitwise unchanged results.
+static std::atomic<uint32_t> g_poison{0u};          // bit k: poison in front of the launches of kernel class k (linr_prof_* classes)
+__global__ __launch_bounds__(1024) void poison_onchip_k(uint32_t pattern, uint32_t* sink) {
+    extern __shared__ uint32_t pl[];
+    for (int i = threadIdx.x; i < 40960; i += 1024) pl[i] = pattern;
+    // v8 .. v127 of every wave: 16 waves x 128 registers = the four SIMDs' 512-row register files
+    asm volatile(
+                 "v_mov_b32 v8, %0\n v_mov_b32 v9, %0\n v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n v_mov_b32 v14, %0\n v_mov_b32 v15, %0\n"
+                 "v_mov_b32 v16, %0\n v_mov_b32 v17, %0\n v_mov_b32 v18, %0\n v_mov_b32 v19, %0\n v_mov_b32 v20, %0\n v_mov_b32 v21, %0\n v_mov_b32 v22, %0\n v_mov_b32 v23, %0\n"
+                 "v_mov_b32 v24, %0\n v_mov_b32 v25, %0\n v_mov_b32 v26, %0\n v_mov_b32 v27, %0\n v_mov_b32 v28, %0\n v_mov_b32 v29, %0\n v_mov_b32 v30, %0\n v_mov_b32 v31, %0\n"
+                 "v_mov_b32 v32, %0\n v_mov_b32 v33, %0\n v_mov_b32 v34, %0\n v_mov_b32 v35, %0\n v_mov_b32 v36, %0\n v_mov_b32 v37, %0\n v_mov_b32 v38, %0\n v_mov_b32 v39, %0\n"
+                 "v_mov_b32 v40, %0\n v_mov_b32 v41, %0\n v_mov_b32 v42, %0\n v_mov_b32 v43, %0\n v_mov_b32 v44, %0\n v_mov_b32 v45, %0\n v_mov_b32 v46, %0\n v_mov_b32 v47, %0\n"
+                 "v_mov_b32 v48, %0\n v_mov_b32 v49, %0\n v_mov_b32 v50, %0\n v_mov_b32 v51, %0\n v_mov_b32 v52, %0\n v_mov_b32 v53, %0\n v_mov_b32 v54, %0\n v_mov_b32 v55, %0\n"
+                 "v_mov_b32 v56, %0\n v_mov_b32 v57, %0\n v_mov_b32 v58, %0\n v_mov_b32 v59, %0\n v_mov_b32 v60, %0\n v_mov_b32 v61, %0\n v_mov_b32 v62, %0\n v_mov_b32 v63, %0\n"
+                 "v_mov_b32 v64, %0\n v_mov_b32 v65, %0\n v_mov_b32 v66, %0\n v_mov_b32 v67, %0\n v_mov_b32 v68, %0\n v_mov_b32 v69, %0\n v_mov_b32 v70, %0\n v_mov_b32 v71, %0\n"
+                 "v_mov_b32 v72, %0\n v_mov_b32 v73, %0\n v_mov_b32 v74, %0\n v_mov_b32 v75, %0\n v_mov_b32 v76, %0\n v_mov_b32 v77, %0\n v_mov_b32 v78, %0\n v_mov_b32 v79, %0\n"
+                 "v_mov_b32 v80, %0\n v_mov_b32 v81, %0\n v_mov_b32 v82, %0\n v_mov_b32 v83, %0\n v_mov_b32 v84, %0\n v_mov_b32 v85, %0\n v_mov_b32 v86, %0\n v_mov_b32 v87, %0\n"
+                 "v_mov_b32 v88, %0\n v_mov_b32 v89, %0\n v_mov_b32 v90, %0\n v_mov_b32 v91, %0\n v_mov_b32 v92, %0\n v_mov_b32 v93, %0\n v_mov_b32 v94, %0\n v_mov_b32 v95, %0\n"
+                 "v_mov_b32 v96, %0\n v_mov_b32 v97, %0\n v_mov_b32 v98, %0\n v_mov_b32 v99, %0\n v_mov_b32 v100, %0\n v_mov_b32 v101, %0\n v_mov_b32 v102, %0\n v_mov_b32 v103, %0\n"
+                 "v_mov_b32 v104, %0\n v_mov_b32 v105, %0\n v_mov_b32 v106, %0\n v_mov_b32 v107, %0\n v_mov_b32 v108, %0\n v_mov_b32 v109, %0\n v_mov_b32 v110, %0\n v_mov_b32 v111, %0\n"
+                 "v_mov_b32 v112, %0\n v_mov_b32 v113, %0\n v_mov_b32 v114, %0\n v_mov_b32 v115, %0\n v_mov_b32 v116, %0\n v_mov_b32 v117, %0\n v_mov_b32 v118, %0\n v_mov_b32 v119, %0\n"
+                 "v_mov_b32 v120, %0\n v_mov_b32 v121, %0\n v_mov_b32 v122, %0\n v_mov_b32 v123, %0\n v_mov_b32 v124, %0\n v_mov_b32 v125, %0\n v_mov_b32 v126, %0\n v_mov_b32 v127, %0\n"
+                 :: "v"(pattern) : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    __syncthreads();
+    const uint32_t t = pl[(threadIdx.x * 37u) % 40960u];
+    if (t == 0x12345u && sink) *sink = t;             // never true for the pattern used: keeps the LDS stores alive
+}
+static void poison_onchip(hipStream_t s) {          // failures are ignored: a test hook
+    static const bool ok = hipFuncSetAttribute((const void*)poison_onchip_k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) == hipSuccess;
+    if (!ok) return;
+    poison_onchip_k<<<1024, 1024, 163840, s>>>(0xFFFFFFFFu, nullptr);
+}
+extern "C" int linr_debug_poison(uint32_t kind_mask) { g_poison = kind_mask; return 0; }
+extern "C" int linr_debug_poison_now(void* stream) { poison_onchip((hipStream_t)stream); return linr_launch_rc(); }
+void linr_poison_hook(hipStream_t s, int kind) {          // common.h: for the executors outside this file
+    if ((g_poison.load(std::memory_order_relaxed) >> kind) & 1u) poison_onchip(s);
+}
+
 struct ProfScope {
     hipStream_t s; int kind; bool live;
     ProfRec r;
     ProfScope(hipStream_t s_, int kind_, int passes, bool want = true) : s(s_), kind(kind_), live(false) {
+        if ((g_poison.load(std::memory_order_relaxed) >> kind_) & 1u) poison_onchip(s_);
         if (!want || !g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> kind_) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof_free.empty()) return;

@@ -396,6 +396,7 @@ static BArgs base_args(const BCtx& c) {
 
 template <int MODE>
 static int blaunch(const BCtx& c, const BArgs& a, int groups) {
+    linr_poison_hook(c.s, 14);
     bconv_k<MODE><<<dim3(linr_grid(c.R, LINR_BLOCK), groups), LINR_BLOCK, 0, c.s>>>(a);
     return linr_launch_rc();
 }
@@ -515,6 +516,7 @@ extern "C" int linr_net_forward_bf16(const linr_frame* f, const uint8_t* codes, 
             sa.emb[s] = L.emb + si * 8; sa.w1[s] = L.m0_w[si]; sa.b1[s] = L.m0_b[si]; sa.w2[s] = L.m2_w[si]; sa.b2[s] = L.m2_b[si];
         }
         sa.row_off[f->n_scales] = f->rows;
+        linr_poison_hook(c.s, 14);
         sce_bf16_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(a.PF, f->offset_feat, sa, c.R, a.X0);
         TRY(bblock(c, L.block_in, a.X0, 0, nullptr));                                   // O[0] = x_glob
     }

@@ -165,6 +165,28 @@ def test_cpp_binary_coder_bit_exact_with_oracle(lib, n):
     assert (oac.decode_binary(p, data) == s).all()
 
 
+@pytest.mark.parametrize('seed', [0, 1])
+def test_cpp_binary_decoder_skewed_streams_and_truncation(lib, seed):
+    """Streams of a trained model are skewed (most symbols cost ~0.1 bit: long runs without renormalisation, then many shifts
+    and straddle steps at once), and a truncated stream reads as zeros past its end: the product decoder follows the oracle's
+    (one bit at a time, like torchac) in both."""
+    from linr_pcgc_amd.module_utils import BinaryArithmeticCoding
+    rng = np.random.default_rng(seed)
+    n = 60001
+    z = rng.normal(-5.5, 2.5, n)
+    p = (1 / (1 + np.exp(-z))).astype(np.float32)
+    p = np.where(rng.random(n) < 0.5, 1 - p, p).astype(np.float32)
+    p[::97] = 0.5 + (rng.random(len(p[::97])).astype(np.float32) - 0.5) * 1e-4          # straddles of the middle
+    s = (rng.random(n) < p).astype(np.int16)
+    bac = BinaryArithmeticCoding()
+    data = bac.encode(torch.from_numpy(p).reshape(-1, 1), torch.from_numpy(s))
+    assert data == oac.encode_binary(p, s)
+    assert (bac.decode(torch.from_numpy(p), data).numpy() == s).all()
+    for cut in (len(data) - 1, len(data) // 2, 3, 0):
+        short = data[:cut]
+        assert (bac.decode(torch.from_numpy(p), short).numpy() == oac.decode_binary(p, short)).all()
+
+
 def test_cpp_generic_coder_model_stream(lib, golden_dir):
     from linr_pcgc_amd import model_codec
     g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))

@@ -559,7 +559,7 @@ def _dump_under(env, golden_dir, out):
     import sys
     script = os.path.join(os.path.dirname(__file__), '_dump_net.py')
     golden = os.path.join(golden_dir, 'octree_shell128.npz')
-    clean = {k: v for k, v in os.environ.items() if not k.startswith('LINR_')}
+    clean = {k: v for k, v in os.environ.items() if not k.startswith('LINR_') or k == 'LINR_DEBUG_POISON'}
     subprocess.run([sys.executable, script, golden, out], check=True, env=dict(clean, **env), timeout=600)
     return np.load(out)
 
@@ -605,6 +605,43 @@ def test_executor_switch_is_bit_identical_to_default(pkg, golden_dir, tmp_path, 
         assert np.array_equal(ref['grads'], got['grads']), 'grads'
         assert np.array_equal(ref['probs'], got['probs'])
     assert float(np.abs(got['grads']).max()) > 0
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_leftover_onchip_state(pkg, golden_dir, tmp_path, base_dumps):
+    """A kernel may not read LDS or registers it did not write: what is left there belongs to whatever ran on the CU before - one's
+    own finite numbers in a process that has the GPU to itself, possibly a NaN pattern on a GPU shared with another process, and
+    0 x NaN poisons a gradient that 0 x finite never would (found by two ranks rehearsing on one GPU: a register of the fused
+    4->4 backward kernel's first pipeline step fed the matrix cores unloaded, against a zero operand).  With every launch
+    preceded by a kernel that fills the LDS and the vector registers of all CUs with 0xFFFFFFFF (linr_debug_poison), results must
+    not move by a bit: (a) forward + backward on the multi-scale golden shell under three executor schedules, in child processes;
+    (b) training steps at full size in this process.  LINR_DEBUG_POISON=1 runs the WHOLE suite that way (tools/README.md)."""
+    from linr_pcgc_amd import _lib, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    for i, base in enumerate(({}, NOFUSE, dict(NOFUSE, LINR_BATCHED='0', LINR_CONV_MFMA='0', LINR_JOIN_BLOCK_IN='0'))):
+        ref = base_dumps(base)
+        got = _dump_under(dict(base, LINR_DEBUG_POISON='1'), golden_dir, str(tmp_path / ('poison%d.npz' % i)))
+        for key in ('probs', 'bits', 'grads'):
+            assert np.array_equal(ref[key], got[key]), (base, key)
+    gop = overfit.Gop(None, [synthetic.sequence_frame_device('loot10', 0, 'cuda')], None, 64, 'cuda')
+    L = _lib.lib()
+
+    def run(mask):
+        m = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+        o = FlatAdam(m)
+        bits = torch.zeros(3, dtype=torch.float64, device='cuda')
+        L.linr_debug_poison(mask)
+        try:
+            for s in range(3):
+                train_step(m, o, gop.frames[0], gop.point_nums[0], out=bits[s:s + 1])
+            torch.cuda.synchronize()
+        finally:
+            L.linr_debug_poison(0xFFFF if os.environ.get('LINR_DEBUG_POISON') else 0)
+        return m.flat_parameters().clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), bits.cpu()
+    clean, dirty = run(0), run(0xFFFF)
+    assert bool(torch.isfinite(dirty[0]).all())
+    for a, b in zip(clean, dirty):
+        assert torch.equal(a, b)
 
 
 B512 = {'LINR_WG_BLOCKS': '512'}

@@ -77,6 +77,118 @@ __global__ __launch_bounds__(256) void gather_c(const float* __restrict__ x, con
     if (row < n) out[row] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// D  band staging: the neighbours of a tile of 256 consecutive rows lie, per (dx,dy) column, in one contiguous band of the matrix
+//    (x-major sorted rows: a shift by (dx,dy) preserves the order).  The block copies the 9 bands into LDS with coalesced 16-byte
+//    loads (288 B per row instead of 864 B through the L1's tag lookup) and gathers the 27 taps from LDS (two 16-byte planes per band:
+//    consecutive rows 16 B apart = conflict-free ds_read_b128).  Synthetic map: band q of tile t starts at 256 t + 700 dx + 27 dy - 1.
+constexpr int D_R = 264;          // band rows held per tile (256 + 2, padded)
+template <int T>
+__global__ __launch_bounds__(256) void gather_d(const float* __restrict__ x, const int* __restrict__ nbr, long ld, long n, float* out) {
+    extern __shared__ float4 lds[];             // [9][2][D_R] + one zero entry at the end
+    const long i0 = (long)blockIdx.x * 256;
+    const long row = i0 + threadIdx.x;
+    const long r = row < n ? row : n - 1;
+    const float4* xb = (const float4*)x;         // row j (-1 = pad) at xb[2 (j + 1)]
+    int bstart[9];
+    float4 v0[9], v1[9], v2[9];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {                 // all band loads in flight before the first LDS store
+        const int dy = q / 3 - 1, dx = q % 3 - 1;
+        const long b = i0 + 700L * dx + 27L * dy - 1;
+        bstart[q] = (int)b;
+        auto piece = [&](int pc) {
+            long j = b + (pc >> 1);
+            j = (j < -1 || j >= n) ? -1 : j;
+            return xb[2 * (j + 1) + (pc & 1)];
+        };
+        if (!(T & 2)) { v0[q] = piece(t); v1[q] = piece(t + 256); if (t < 4) v2[q] = piece(t + 512); }
+        else { v0[q] = v1[q] = v2[q] = make_float4(q, t, 0, 0); }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        lds[(q * 2 + (t & 1)) * D_R + (t >> 1)] = v0[q];
+        lds[(q * 2 + (t & 1)) * D_R + 128 + (t >> 1)] = v1[q];
+        if (t < 4) lds[(q * 2 + (t & 1)) * D_R + 256 + (t >> 1)] = v2[q];
+    }
+    if (threadIdx.x == 0) lds[18 * D_R] = make_float4(0, 0, 0, 0);
+    __syncthreads();
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 27; ++kk) {
+        const int q = kk / 3, dz = kk % 3, k = q + 9 * dz;
+        const int dyy = q / 3 - 1, dxx = q % 3 - 1;
+        const long tt = r + 700L * dxx + 27L * dyy + (dz - 1);
+        const bool present = ((r * 2654435761u + k * 40503u) >> 7) % 27 < 14 || k == 13;
+        const int v = (T & 1) ? ((present && tt >= 0 && tt < n) ? (int)tt : -1) : nbr[k * ld + r];
+        const int rel = v - bstart[q];
+        const int o0 = v < 0 ? 18 * D_R : (q * 2) * D_R + rel, o1 = v < 0 ? 18 * D_R : (q * 2 + 1) * D_R + rel;
+        const float4 a = lds[o0], b = lds[o1];
+        acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
+    }
+    if (row < n) out[row] = acc.x + acc.y + acc.z + acc.w;
+}
+
+// D2 = D as long-lived blocks with a software pipeline: the bands and indices of the next tile are loaded into registers while the
+//      current tile's taps are read from LDS (single LDS buffer, two blocks per CU).
+__global__ __launch_bounds__(256) void gather_d2(const float* __restrict__ x, const int* __restrict__ nbr, long ld, long n, float* out) {
+    extern __shared__ float4 lds[];
+    const float4* xb = (const float4*)x;
+    const int t = threadIdx.x;
+    const long ntiles = (n + 255) / 256;
+    float4 v0[9], v1[9], v2[9];
+    int idx[27], nidx[27];
+    auto load_tile = [&](long tile) {
+        const long i0 = tile * 256;
+        const long r = i0 + t < n ? i0 + t : n - 1;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int dy = q / 3 - 1, dx = q % 3 - 1;
+            const long b = i0 + 700L * dx + 27L * dy - 1;
+            auto piece = [&](int pc) {
+                long j = b + (pc >> 1);
+                j = (j < -1 || j >= n) ? -1 : j;
+                return xb[2 * (j + 1) + (pc & 1)];
+            };
+            v0[q] = piece(t); v1[q] = piece(t + 256);
+            if (t < 4) v2[q] = piece(t + 512);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 27; ++kk) {
+            const int q = kk / 3, dz = kk % 3, k = q + 9 * dz;
+            const int dy = q / 3 - 1, dx = q % 3 - 1;
+            const int v = nbr[k * ld + r];
+            const int b = (int)(i0 + 700L * dx + 27L * dy - 1);
+            nidx[kk] = v < 0 ? 18 * D_R : (q * 2) * D_R + (v - b);
+        }
+    };
+    if (t == 0) lds[18 * D_R] = make_float4(0, 0, 0, 0);
+    long tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                          // everyone has finished reading the previous tile
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            lds[(q * 2 + (t & 1)) * D_R + (t >> 1)] = v0[q];
+            lds[(q * 2 + (t & 1)) * D_R + 128 + (t >> 1)] = v1[q];
+            if (t < 4) lds[(q * 2 + (t & 1)) * D_R + 256 + (t >> 1)] = v2[q];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 27; ++kk) idx[kk] = nidx[kk];
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 27; ++kk) {
+            const int o0 = idx[kk], o1 = idx[kk] == 18 * D_R ? 18 * D_R : idx[kk] + D_R;
+            const float4 a = lds[o0], b = lds[o1];
+            acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
+        }
+        const long row = tile * 256 + t;
+        if (row < n) out[row] = acc.x + acc.y + acc.z + acc.w;
+    }
+}
+
 int main() {
     const long n = 336529, ld = (n + 63) / 64 * 64;
     std::vector<int> h(27 * ld, -1);
@@ -92,9 +204,14 @@ int main() {
     CK(hipMalloc(&nbr, h.size() * 4)); CK(hipMalloc(&x, (n + 1) * 32)); CK(hipMalloc(&out, n * 4));
     CK(hipMemcpy(nbr, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(x, 0, (n + 1) * 32));
+    CK(hipFuncSetAttribute((const void*)gather_d<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
+    CK(hipFuncSetAttribute((const void*)gather_d<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
+    CK(hipFuncSetAttribute((const void*)gather_d<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
+    CK(hipFuncSetAttribute((const void*)gather_d<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
+    CK(hipFuncSetAttribute((const void*)gather_d2, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int blocks = (int)((n + 255) / 256), iters = 50;
-    for (int v = 0; v < 7; ++v) {
+    for (int v = 0; v < 12; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) {
@@ -104,11 +221,16 @@ int main() {
                 else if (v == 3) gather_a<1><<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 4) gather_b<1><<<blocks, 256>>>(x, nbr, ld, n, out);
                 else if (v == 5) gather_a<1, 1><<<(blocks + 7) / 8 * 8, 256>>>(x, nbr, ld, n, out);
-                else gather_a<2><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else if (v == 6) gather_a<2><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else if (v == 7) gather_d<0><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else if (v == 8) gather_d2<<<512, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else if (v == 9) gather_d<1><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else if (v == 10) gather_d<2><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else gather_d<3><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const char* nm[7] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges", "A3 lane=row, taps x-slab-major (dx, dy, dz)"};
+            const char* nm[12] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges", "A3 lane=row, taps x-slab-major (dx, dy, dz)", "D  9 bands staged in LDS, taps from LDS", "D2 = D, long-lived blocks, next tile prefetched", "D without index loads (computed)", "D without band loads", "D without either (LDS + VALU only)"};
             if (rep) printf("%-40s %.2f us per pass (%ld rows, 27 taps x 32 B)\n", nm[v], ms * 1e3 / iters, n);
         }
     }
