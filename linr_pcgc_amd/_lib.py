@@ -164,3 +164,14 @@ def check(rc, what):
     """The reference's only error convention is Python assert/ValueError (encoder.py:86-87); we raise RuntimeError."""
     if rc != 0:
         raise LinrError('%s failed: %s' % (what, _ERR.get(rc, 'hipError_t %d' % rc)))
+
+
+def scratch(nbytes, device):
+    """Uninitialised device scratch (arenas, workspaces, slabs) that the library must initialise itself wherever it reads it.
+    Under LINR_DEBUG_POISON it comes filled with 0xFF bytes (NaN as float, -1 as int) instead of whatever the allocator returns -
+    mostly zeros from a fresh process, which is exactly what hides a missing initialisation."""
+    import torch
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if os.environ.get('LINR_DEBUG_POISON'):
+        t.fill_(0xFF)
+    return t

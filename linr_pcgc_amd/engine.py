@@ -76,13 +76,13 @@ class Frame:
 
     def alloc_arena(self):
         nbytes = _lib.lib().linr_net_arena_bytes(self.rows, self.block_layers)
-        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.arena = _lib.scratch(nbytes, self.device)
 
     def bf16_arena(self):
         """Arena of the bf16 / uint8-weight inference executor (allocated on first use, 64-byte aligned)."""
         if getattr(self, '_arena_bf16', None) is None:
             nbytes = _lib.lib().linr_net_bf16_arena_bytes(self.rows, self.block_layers)
-            self._arena_bf16 = torch.empty(nbytes + 64, dtype=torch.uint8, device=self.device)
+            self._arena_bf16 = _lib.scratch(nbytes + 64, self.device)
         return self._arena_bf16
 
     def cref(self):

@@ -249,7 +249,7 @@ class LINR_PCGC_Model(nn.Module):
         lens = (ctypes.c_int64 * 8)(*[int(b.size) for b in bufs])
         bf16 = self._precision(None) == 'bf16'
         need = L.linr_decode_scale_ws_bytes(n, self.block_layers, 1 if bf16 else 0)
-        ws = torch.empty(need + 256, dtype=torch.uint8, device=coord.device)
+        ws = _lib.scratch(need + 256, coord.device)
         base = (ws.data_ptr() + 255) & ~255
         child = torch.empty((8 * n, 3), dtype=torch.int32, device=coord.device)
         p_host, s_host = self._host_buffers(n)

@@ -47,7 +47,7 @@ def kmap_build_into(coords, nbr, row_base, validate=True):
         if int(bad.item()) != 0:
             raise ValueError('coord must be unique, non-negative (< 2^20) and sorted by the x-major ravel key '
                              '(models/module_utils.py:246-256)')
-    ws = torch.empty(L.linr_kmap_workspace_bytes(n), dtype=torch.uint8, device=coords.device)
+    ws = _lib.scratch(L.linr_kmap_workspace_bytes(n), coords.device)
     check(L.linr_kmap_build(coords.data_ptr(), n, nbr.data_ptr(), nbr.shape[1], row_base, ws.data_ptr(), ws.numel(),
                             _stream()), 'linr_kmap_build')
 
@@ -84,7 +84,7 @@ def spconv_bwd_weight(x, gout, nbr, cin, cout, pad_row=False):
     L = _lib.lib()
     gw = torch.empty((27, cin, cout), dtype=torch.float32, device=x.device)
     gb = torch.empty((1, cout), dtype=torch.float32, device=x.device)
-    ws = torch.empty(max(L.linr_spconv_bwd_weight_workspace_bytes(n, cin, cout), 4), dtype=torch.uint8, device=x.device)
+    ws = _lib.scratch(max(L.linr_spconv_bwd_weight_workspace_bytes(n, cin, cout), 4), x.device)
     check(L.linr_spconv_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(),
                                    nbr.stride(0), n, cin, cout, gw.data_ptr(), gb.data_ptr(), LINR_PAD_ROW if pad_row else 0,
                                    ws.data_ptr(),
@@ -123,7 +123,7 @@ def linear_bwd_weight(x, gout, cin, cout, layout):
     ws_ci, ws_co = (cout, 1) if layout == 'me' else (1, cin)
     gw = torch.empty((cin, cout) if layout == 'me' else (cout, cin), dtype=torch.float32, device=x.device)
     gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
-    ws = torch.empty(max(L.linr_linear_bwd_weight_workspace_bytes(n, cin, cout), 4), dtype=torch.uint8, device=x.device)
+    ws = _lib.scratch(max(L.linr_linear_bwd_weight_workspace_bytes(n, cin, cout), 4), x.device)
     check(L.linr_linear_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), n, cin, cout,
                                    gw.data_ptr(), ws_ci, ws_co, gb.data_ptr(), 0, ws.data_ptr(), ws.numel(),
                                    _stream()), 'linr_linear_bwd_weight')
@@ -136,7 +136,7 @@ def bce_bits_fwd(z, target):
     L = _lib.lib()
     p = torch.empty((n,), dtype=torch.float32, device=z.device)
     bits = torch.zeros(1, dtype=torch.float64, device=z.device)
-    ws = torch.empty(max(L.linr_bce_workspace_bytes(n), 8), dtype=torch.uint8, device=z.device)
+    ws = _lib.scratch(max(L.linr_bce_workspace_bytes(n), 8), z.device)
     check(L.linr_bce_bits_fwd(z.data_ptr(), target.data_ptr(), target.stride(0), n, p.data_ptr(), bits.data_ptr(),
                               ws.data_ptr(), ws.numel(), _stream()), 'linr_bce_bits_fwd')
     return p, bits
@@ -202,7 +202,7 @@ def spconv_wgrad_cmap(x, gout, nbr, n, cin, cout, slab=None, reduce=True, tile8t
     nb = int(L.linr_spconv_wgrad_cmap_blocks())
     elems = (27 * cin + 1) * cout
     if slab is None:
-        slab = torch.empty((nb, elems), dtype=torch.float32, device=x.device)
+        slab = _lib.scratch(nb * elems * 4, x.device).view(torch.float32).view(nb, elems)
     check(L.linr_spconv_wgrad_cmap(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), nbr.data_ptr(), _ptr(tile8t),
                                    nbr.stride(0), n, cin, cout, slab.data_ptr(), _stream()),
           'linr_spconv_wgrad_cmap')
@@ -234,7 +234,7 @@ def octree_occupancy(child, parent):
     L = _lib.lib()
     m, n = child.shape[0], parent.shape[0]
     occ = torch.empty((n, 8), dtype=torch.float32, device=child.device)
-    ws = torch.empty(max(L.linr_kmap_workspace_bytes(m), 8), dtype=torch.uint8, device=child.device)
+    ws = _lib.scratch(max(L.linr_kmap_workspace_bytes(m), 8), child.device)
     check(L.linr_octree_occupancy(child.data_ptr(), m, parent.data_ptr(), n, occ.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
           'linr_octree_occupancy')
     return occ

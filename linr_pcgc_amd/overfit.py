@@ -50,7 +50,7 @@ class Gop:
             max_rows = max(max_rows, f.rows)
         # one activation arena shared by all frames of the GOP (a step finishes before the next begins)
         from . import _lib
-        arena = torch.empty(_lib.lib().linr_net_arena_bytes(max_rows, self.block_layers), dtype=torch.uint8, device=device)
+        arena = _lib.scratch(_lib.lib().linr_net_arena_bytes(max_rows, self.block_layers), device)
         for f in self.frames:
             f.arena = arena
 
