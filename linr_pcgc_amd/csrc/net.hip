@@ -109,16 +109,22 @@ struct PadList { int64_t off[200]; int w[200]; int n; };
 // Scale context of all scales in one launch (model_core.py:48-53): x0[r] = W2 relu(W1 [emb | offset_feat[r]] + b1) + b2 with
 // the weights of r's scale: fmaf chains with the bias first and the inputs ascending, like linear_k<15,16> + linear_k<16,8> on
 // [emb | offset_feat | 0].  MIX and HID are kept for the backward pass.
+// A workgroup never straddles two scales (blk_off: first workgroup of every scale), so the scale - and with it every weight
+// address - is uniform: the weights come through the scalar cache into SGPRs (s_load + v_fmac with an SGPR operand) instead of
+// ~400 broadcast vector loads per row (46.8 -> ~12 us for the forward kernel at 337 k rows, 18.9 -> ~9 for the backward one).
 struct SceArgs {
     int64_t row_off[MAX_SCALES + 1];
     int64_t emb[MAX_SCALES], w1[MAX_SCALES], b1[MAX_SCALES], w2[MAX_SCALES], b2[MAX_SCALES];   // parameter offsets per scale
+    int blk_off[MAX_SCALES + 1];
     int n_scales;
 };
 
-__device__ __forceinline__ int sce_scale_of(const SceArgs& a, int64_t r) {
-    int s = 0;
-    for (int i = 1; i < a.n_scales; ++i) s += (r >= a.row_off[i]) ? 1 : 0;
-    return s;
+// scale of workgroup b and the row of this thread (-1: none)
+__device__ __forceinline__ int64_t sce_row_of(const SceArgs& a, int b, int& s) {
+    s = 0;
+    for (int i = 1; i < a.n_scales; ++i) s += (b >= a.blk_off[i]) ? 1 : 0;
+    const int64_t r = a.row_off[s] + (int64_t)(b - a.blk_off[s]) * LINR_BLOCK + threadIdx.x;
+    return r < a.row_off[s + 1] ? r : -1;
 }
 
 // The blocks behind the last row block clear the arena's pad rows (PadList; one pad per 32 threads): the first kernel that reads
@@ -126,15 +132,15 @@ __device__ __forceinline__ int sce_scale_of(const SceArgs& a, int64_t r) {
 __global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
                                                         int64_t n, float* __restrict__ mix, float* __restrict__ hid,
                                                         float* __restrict__ x0, float* __restrict__ pad_base, PadList pl) {
-    const int64_t row_blocks = (n + LINR_BLOCK - 1) / LINR_BLOCK;
-    if ((int64_t)blockIdx.x >= row_blocks) {
-        const int b = (int)((int64_t)blockIdx.x - row_blocks) * (LINR_BLOCK / 32) + (int)(threadIdx.x >> 5), t = threadIdx.x & 31;
+    const int row_blocks = a.blk_off[a.n_scales];
+    if ((int)blockIdx.x >= row_blocks) {
+        const int b = ((int)blockIdx.x - row_blocks) * (LINR_BLOCK / 32) + (int)(threadIdx.x >> 5), t = threadIdx.x & 31;
         if (b < pl.n && t < pl.w[b]) pad_base[pl.off[b] + t] = 0.0f;
         return;
     }
-    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (r >= n) return;
-    const int s = sce_scale_of(a, r);
+    int s;
+    const int64_t r = sce_row_of(a, (int)blockIdx.x, s);
+    if (r < 0) return;
     const float* emb = P + a.emb[s];
     const float* W1 = P + a.w1[s];
     const float* b1 = P + a.b1[s];
@@ -177,9 +183,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict_
 __global__ __launch_bounds__(LINR_BLOCK) void sce_bwd_k(const float* __restrict__ P, SceArgs a, int64_t n,
                                                         const float* __restrict__ gx0, const float* __restrict__ hid,
                                                         float* __restrict__ ghid) {
-    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (r >= n) return;
-    const float* W2 = P + a.w2[sce_scale_of(a, r)];
+    int s;
+    const int64_t r = sce_row_of(a, (int)blockIdx.x, s);
+    if (r < 0) return;
+    const float* W2 = P + a.w2[s];
     const float4 g0 = *reinterpret_cast<const float4*>(gx0 + r * 8);
     const float4 g1 = *reinterpret_cast<const float4*>(gx0 + r * 8 + 4);
     const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -256,10 +263,22 @@ __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __rest
         for (int i = 0; i < sr.n; ++i)
             if (p >= sr.b[i] && p < sr.e[i]) rows = sr.rows[i];
         const int hi = (q + 1) * per < rows ? (q + 1) * per : rows;
-        for (int b = q * per; b < hi; b += 8) {
+        if (per == 64) {
+            // the usual slab (256 rows): the thread's 64 loads are all in flight before the first add (the rolled loop waits
+            // for memory eight times); same adds in the same order
+            const float* src = big + (int64_t)(q * 64) * total + p;
+            float v[64];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (b + i < hi) a[i] += big[(int64_t)(b + i) * total + p];
+            for (int j = 0; j < 64; ++j) v[j] = (q * 64 + j < hi) ? src[(int64_t)j * total] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                if (q * 64 + j < hi) a[j & 7] += v[j];
+        } else {
+            for (int b = q * per; b < hi; b += 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (b + i < hi) a[i] += big[(int64_t)(b + i) * total + p];
+            }
         }
         s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
@@ -622,6 +641,9 @@ static SceArgs sce_args(const Ctx& c) {
         a.emb[s] = c.L.emb + si * 8; a.w1[s] = c.L.m0_w[si]; a.b1[s] = c.L.m0_b[si]; a.w2[s] = c.L.m2_w[si]; a.b2[s] = c.L.m2_b[si];
     }
     a.row_off[c.f->n_scales] = c.f->rows;
+    a.blk_off[0] = 0;
+    for (int s = 0; s < c.f->n_scales; ++s)
+        a.blk_off[s + 1] = a.blk_off[s] + (int)linr_grid(a.row_off[s + 1] - a.row_off[s], LINR_BLOCK);
     return a;
 }
 
@@ -734,8 +756,9 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         for (int i = 0; i < a.npad; ++i) { pl.off[i] = a.pad_off[i]; pl.w[i] = a.pad_w[i]; }
         {   // scale context: one small MLP per scale (model_core.py:48-53), all scales in one launch; its spare blocks clear the pad rows
             ProfScope ps(c.s, PK_SCE, 1);
-            sce_fwd_k<<<linr_grid(c.R, LINR_BLOCK) + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
-                P, f->offset_feat, sce_args(c), c.R, a.MIX, a.HID, a.X0, a.base, pl);
+            const SceArgs sa = sce_args(c);
+            sce_fwd_k<<<sa.blk_off[sa.n_scales] + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
+                P, f->offset_feat, sa, c.R, a.MIX, a.HID, a.X0, a.base, pl);
         }
         if (all_grouped && join_block_in(c)) {
             // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
@@ -798,8 +821,9 @@ extern "C" int linr_sce_fwd(const float* params, const linr_frame* f, float* mix
     if (!params || !f->offset_feat || !mix || !hid || !x0) return LINR_EINVAL;
     if (!linr_aligned16(mix) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
     c.f = f;
-    sce_fwd_k<<<linr_grid(f->rows, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sce_args(c), f->rows,
-                                                                                     mix, hid, x0, nullptr, PadList{{}, {}, 0});
+    const SceArgs sa = sce_args(c);
+    sce_fwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sa, f->rows, mix, hid, x0, nullptr,
+                                                                              PadList{{}, {}, 0});
     return linr_launch_rc();
 }
 
@@ -811,7 +835,8 @@ extern "C" int linr_sce_bwd(const float* params, const linr_frame* f, const floa
     if (!params || !gx0 || !hid || !ghid) return LINR_EINVAL;
     if (!linr_aligned16(gx0) || !linr_aligned16(hid) || !linr_aligned16(ghid)) return LINR_EALIGN;
     c.f = f;
-    sce_bwd_k<<<linr_grid(f->rows, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(params, sce_args(c), f->rows, gx0, hid, ghid);
+    const SceArgs sa = sce_args(c);
+    sce_bwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, sa, f->rows, gx0, hid, ghid);
     return linr_launch_rc();
 }
 
@@ -1078,7 +1103,8 @@ static int backward_core(Ctx& c, float gscale) {
     if (sce_grouped) {
         {
             ProfScope ps(c.s, PK_SCE, 1);
-            sce_bwd_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(P, sce_args(c), c.R, a.gX0, a.HID, a.gHID);
+            const SceArgs sa = sce_args(c);
+            sce_bwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, c.s>>>(P, sa, c.R, a.gX0, a.HID, a.gHID);
         }
         Grp g2 = Grp(), g0 = Grp();
         const int64_t r00 = f->row_off_h[sl[0]];
