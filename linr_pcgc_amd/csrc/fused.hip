@@ -568,10 +568,13 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __re
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t row_raw = (int64_t)blockIdx.x * LINR_CONV_BLOCK + threadIdx.x;
+    const char* pad = reinterpret_cast<const char*>(occ - 8);
+    // the 27 KB weight image is built once per workgroup: the launch gives every workgroup several row tiles (linr_occ_conv7_launch)
+    const int64_t tiles = (n + LINR_CONV_BLOCK - 1) / LINR_CONV_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t row_raw = tile * LINR_CONV_BLOCK + threadIdx.x;
     const bool live = row_raw < n;
     const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
-    const char* pad = reinterpret_cast<const char*>(occ - 8);
     uint32_t off[27];
     decode_offsets<false>(lo, mask, ld, row, 32u, off);
     f32x4 acc[7][2];
@@ -612,14 +615,16 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __re
         });
         __builtin_amdgcn_sched_barrier(0);
     });
-    if (!live) return;
+    if (live) {
 #pragma unroll
-    for (int g = 0; g < 7; ++g) {
-        float* op = out + a.out[g] + row * 8;
-        *reinterpret_cast<float4*>(op) = make_float4(fmaxf(acc[g][0][0], 0.0f), fmaxf(acc[g][0][1], 0.0f),
-                                                     fmaxf(acc[g][0][2], 0.0f), fmaxf(acc[g][0][3], 0.0f));
-        *reinterpret_cast<float4*>(op + 4) = make_float4(fmaxf(acc[g][1][0], 0.0f), fmaxf(acc[g][1][1], 0.0f),
-                                                         fmaxf(acc[g][1][2], 0.0f), fmaxf(acc[g][1][3], 0.0f));
+        for (int g = 0; g < 7; ++g) {
+            float* op = out + a.out[g] + row * 8;
+            *reinterpret_cast<float4*>(op) = make_float4(fmaxf(acc[g][0][0], 0.0f), fmaxf(acc[g][0][1], 0.0f),
+                                                         fmaxf(acc[g][0][2], 0.0f), fmaxf(acc[g][0][3], 0.0f));
+            *reinterpret_cast<float4*>(op + 4) = make_float4(fmaxf(acc[g][1][0], 0.0f), fmaxf(acc[g][1][1], 0.0f),
+                                                             fmaxf(acc[g][1][2], 0.0f), fmaxf(acc[g][1][3], 0.0f));
+        }
+    }
     }
 }
 
@@ -630,7 +635,20 @@ int linr_occ_conv7_launch(const float* occ, const int32_t* lo, const uint32_t* m
     if (n == 0) return 0;
     Occ7Args a;
     for (int g = 0; g < 7; ++g) { a.w[g] = w_off[g]; a.b[g] = b_off[g]; a.out[g] = out_off[g]; }
-    occ_conv7_k<<<linr_grid(n, LINR_CONV_BLOCK), LINR_CONV_BLOCK, 0, s>>>(occ, lo, mask, ld, n, P, a, out);
+    // MFMA-bound (1512 per 64 rows): two workgroups per CU keep the matrix cores fed, and each amortises its weight image over
+    // tiles / grid row tiles (same-box A/B at 337 k rows, ms/step: one tile per workgroup 1.732, three workgroups per CU 1.725,
+    // two 1.716, one 1.720)
+    constexpr int per_cu = 2;
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        return v;
+    }();
+    const int64_t tiles = linr_grid(n, LINR_CONV_BLOCK);
+    const int64_t want = (int64_t)cus * per_cu;
+    const int64_t per = (tiles + want - 1) / want;                 // tiles per workgroup
+    const int64_t grid = (tiles + per - 1) / per;
+    occ_conv7_k<<<(unsigned)grid, LINR_CONV_BLOCK, 0, s>>>(occ, lo, mask, ld, n, P, a, out);
     return linr_launch_rc();
 }
 
