@@ -88,7 +88,7 @@ KERNEL_CLASSES = [
     (6, 'cconv_dual44_k<fwd> both 4->4 convs + conv1_2 + residual', 280 + 32),
     (7, 'occ_conv7_k first convs of the 7 outter blocks (one gather; 7 layer passes)', 156),
     (8, 'head_bwd_k head MLP backward (data + weights)', 2 * 228),
-    (9, 'spconv_wgrad_t_k stand-alone conv weight gradients (first convs of the outter blocks)', 156),
+    (9, 'occ_wgrad7_k weight gradients of the first convs of the 7 outter blocks (one gather; 7 layer passes)', 156),
     (10, 'xtg_wgrad_k pointwise weight gradients', None),
     (11, 'sce_fwd_k / sce_bwd_k scale context', None),
     (12, 'sum8_k, wgrad_reduce_k, sce_emb_grad, adam_k, bits finish', None),

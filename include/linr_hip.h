@@ -143,7 +143,7 @@ LINR_API int linr_spconv_bwd_fused(const float* gout, const float* in, const int
  *   0 fused backward 8->8 (conv_bwd_wgrad_k<0>)   1 conv 8->8 forward, plain epilogue   2 fused backward of the two 4->4 convs
  *   3 fused backward of conv0_0 8->4              4 prune conv + head forward           5 conv0_0 | conv1_0 forward
  *   6 both 4->4 convs forward                     7 shared occupancy conv               8 head backward
- *   9 stand-alone conv weight gradients          10 pointwise weight gradients         11 scale context (forward, backward)
+ *   9 first-conv / stand-alone weight gradients  10 pointwise weight gradients         11 scale context (forward, backward)
  *  12 sums, reduction, Adam                      13 stand-alone backward-data convolutions (schedules without the fused backward)
  * linr_prof_mask selects the classes that are recorded (default: 0 and 1; an event pair costs a few microseconds of stream
  * time).  linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
@@ -355,6 +355,15 @@ LINR_API int linr_spconv_wgrad_dual44(const float* H, const float* g0, int32_t g
 LINR_API int linr_inception_bwd_fused(const float* gI, const float* gM, const float* x, const float* H, const int32_t* lo,
                              const uint32_t* mask, int64_t ld, int64_t n, const linr_inception_params* q, float* gH, float* gX,
                              uint32_t flags, float* slab, int32_t nblocks, void* stream);
+
+/* Weight gradients of the FIRST convolutions of the 7 outter blocks (block b = 1..7: conv3(occ[:, :b] -> 8) on the same occupancy
+ * rows, models/upsample.py:206-214; ME: seven MinkowskiConvolution backward-weight calls) from ONE gather of the occupancy rows:
+ *   gW_b[k][ci][co] = sum_r occ[nbr(r, k)][ci] * gout7[b - 1][r][co]  (ci < b),   gb_b[co] = sum_r gout7[b - 1][r][co].
+ * occ [n][8] with the zero row at index -1; gout7_h: HOST array of 7 device pointers [n][8] (the gradients behind the ReLU);
+ * everything 16-byte aligned.  slab: [nblocks][6104] per-block partials, for b = 1..7: kernel [27][b][8] then bias [8]; only the
+ * first *rows_written_h (<= nblocks) rows are written - sum over those rows = the gradients. */
+LINR_API int linr_occ_wgrad7(const float* occ, const float* const* gout7_h, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                    int64_t n, float* slab, int32_t nblocks, int32_t* rows_written_h, void* stream);
 /* First convolutions of the 7 outter blocks (models/upsample.py:206-214 -> make_block's first conv + ReLU): block g + 1
  * computes relu(conv3(occ[:, :g+1]; kernel [27][g+1][8]) + bias) on the SAME gathered occupancy rows, so one gather feeds
  * all seven.  occ [n][8] (gathered); kernel / bias of block g at params + w_off_h[g] / b_off_h[g]; result of block g at

@@ -6,7 +6,7 @@ OUT=../liblinr_hip.so
 mkdir -p _obj
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall"
 pids=()
-for f in kmap spconv linear loss_optim net fused fused_bwd net_bf16 decode; do
+for f in kmap spconv linear loss_optim net fused fused_bwd occ_wgrad net_bf16 decode; do
   if [ ! -f _obj/$f.o ] || [ $f.hip -nt _obj/$f.o ] || [ common.h -nt _obj/$f.o ] || [ conv_common.h -nt _obj/$f.o ] || [ layout.h -nt _obj/$f.o ] || [ ../../include/linr_hip.h -nt _obj/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o _obj/$f.o &
     pids+=($!)
@@ -17,5 +17,5 @@ if [ ! -f _obj/ac.o ] || [ ac.cpp -nt _obj/ac.o ] || [ ../../include/linr_hip.h 
   pids+=($!)
 fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o _obj/fused_bwd.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o _obj/fused_bwd.o _obj/occ_wgrad.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
 echo "built $(realpath $OUT)"

@@ -165,3 +165,8 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
 // test hook (include/linr_hip.h: linr_debug_poison): poisons LDS and vector registers of every CU on `s` when bit `kind` of the
 // mask is set; kinds 0..13 = the linr_prof_* classes of the fp32 executor, 14 = the bf16 executor, 15 = the decoder's own kernels
 __attribute__((visibility("hidden"))) void linr_poison_hook(hipStream_t s, int kind);
+// csrc/occ_wgrad.hip: weight gradients of the first convolutions of the 7 outter blocks from one gather of the occupancy rows
+__attribute__((visibility("hidden")))
+int linr_occ_wgrad7_launch(const float* occ, const float* const* g, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                           float* big, int64_t block_stride, const int64_t* w_off, const int64_t* b_off, int nb, hipStream_t s,
+                           int* rows_written);

@@ -243,7 +243,7 @@ __global__ void sce_emb_grad_all_k(const float* __restrict__ P, float* __restric
 struct ZeroRanges { int n; int64_t prefix; int64_t b[MAX_SCALES + 1], e[MAX_SCALES + 1]; };
 // Parameter ranges whose producer (a fused backward launch: one round of long-lived blocks, csrc/fused_bwd.hip) wrote only the
 // first rows[i] rows of the slab: the reduction stops there instead of having the producer fill the other rows with zeros.
-#define MAX_SHORT 24
+#define MAX_SHORT 32
 struct ShortRanges { int n; int64_t b[MAX_SHORT], e[MAX_SHORT]; int rows[MAX_SHORT]; };
 __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
                                                              float* __restrict__ gsum, ZeroRanges zr, ShortRanges sr) {
@@ -298,10 +298,9 @@ struct Ctx {
     int nb;                  // persistent blocks of the weight-gradient kernels = partial rows of the slab for this frame
     struct Short { int64_t b, e; int rows; };
     std::vector<Short> shortr;      // parameter ranges of this backward pass that hold fewer than nb slab rows (fused launches)
-    // a fused launch wrote `rows` slab rows for parameters [b, e): the final reduction stops there (more ranges than the table
-    // holds cannot happen: 8 blocks x 2 + prune convs + block_in's first conv = 18)
     // a fused launch writes only `rows` slab rows for parameters [b, e) (no zero fill): the final reduction stops there.  The
-    // table holds every range of a backward pass: 8 blocks x 2 + the prune convs + block_in's first conv = 18
+    // table holds every range of a backward pass: 8 blocks x 2 + the prune convs + block_in's first conv + the 7 outter first
+    // convs = 25
     void note_short(int64_t b, int64_t e, int rows) {
         if (rows >= nb) return;
         if ((int)shortr.size() >= MAX_SHORT) abort();          // cannot happen (see above); a silent drop would read unwritten rows
@@ -1042,6 +1041,16 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
         // (with the fused backward block_in's first conv - slot 0 - gets its weight gradient from the launch that also produces
         // its input gradient, backward_core; the grouped launch then covers the outter blocks only)
         const int s0 = (join && fused_bwd(c)) ? 1 : 0, nq = ng - s0;
+        bool same_in = nq == 7 && g0 + s0 == 1;
+        for (int g = 0; g < nq && same_in; ++g) same_in = p_in[s0 + g] == a.OCC;
+        if (same_in && fused_bwd(c)) {
+            // the 7 outter blocks read the SAME occupancy rows: all seven weight gradients from one gather (csrc/occ_wgrad.hip)
+            ProfScope ps(c.s, PK_WGRAD, nq);
+            int rows = 0;
+            TRY(linr_occ_wgrad7_launch(a.OCC, p_gA + s0, lo, mk, c.nbr_ld, c.R, a.BIG, L.total, o_aw + s0, o_ab + s0, c.nb, c.s, &rows));
+            for (int g = 0; g < nq; ++g) c.note_short(o_aw[s0 + g], o_ab[s0 + g] + 8, rows);
+            return 0;
+        }
         Grp gp = Grp();
         goffs(gp.in, p_in + s0, nq); goffs(gp.res, p_gA + s0, nq); goffs_i(gp.w, o_aw + s0, nq); goffs_i(gp.b, o_ab + s0, nq);
         for (int g = 0; g < nq; ++g) gp.e2[g] = (g0 + s0 + g == 0) ? 8 : g0 + s0 + g;

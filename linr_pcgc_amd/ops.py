@@ -227,6 +227,25 @@ def spconv_bwd_fused(gout, x, lo, mask, n, kernel, nblocks=256, reduce=True):
     return gin, tot[:1728].view(27, 8, 8), tot[1728:]
 
 
+def occ_wgrad7(occ, gouts, lo, mask, n, nblocks=256):
+    """linr_occ_wgrad7: weight gradients of the first convolutions of the 7 outter blocks from one gather of the occupancy rows.
+    occ: view buf[1:] of a [n+1, 8] buffer whose row 0 is zero; gouts: 7 tensors [n, 8].
+    Returns ([gW_b [27, b, 8] for b = 1..7], [gb_b [8]]) summed over the slab rows the kernel wrote."""
+    import ctypes
+    assert len(gouts) == 7
+    slab = torch.full((nblocks, 6104), float('nan'), dtype=torch.float32, device=occ.device)
+    ptrs = (ctypes.c_void_p * 7)(*[g.data_ptr() for g in gouts])
+    rows = ctypes.c_int32(0)
+    check(_lib.lib().linr_occ_wgrad7(occ.data_ptr(), ptrs, lo.data_ptr(), mask.data_ptr(), lo.stride(0), n, slab.data_ptr(), nblocks,
+                                     ctypes.byref(rows), _stream()), 'linr_occ_wgrad7')
+    tot = slab[:rows.value].double().sum(dim=0).float()
+    gw, gb, cur = [], [], 0
+    for b in range(1, 8):
+        gw.append(tot[cur:cur + 27 * b * 8].view(27, b, 8)); cur += 27 * b * 8
+        gb.append(tot[cur:cur + 8]); cur += 8
+    return gw, gb
+
+
 def octree_occupancy(child, parent):
     """occ float32 [N,8] of the parents (sorted unique floor(child/2)) of a sorted unique child list (int32 [M,3])."""
     _dev(child, torch.int32, 'child')

@@ -302,6 +302,32 @@ def test_conv88_backward_fused_one_gather(env, nblocks):
     assert torch.equal(slab, slab2) and torch.equal(gin, gin2)
 
 
+@pytest.mark.parametrize('nblocks', [256, 2])
+def test_outter_first_conv_weight_gradients_one_gather(env, nblocks):
+    """linr_occ_wgrad7 (weight gradients of the first convolutions of the 7 outter blocks, conv3(occ[:, :b] -> 8) for b = 1..7,
+    from ONE gather of the occupancy rows; models/upsample.py:206-214): kernel and bias gradients match autograd of seven oracle
+    convolutions (MinkowskiConvolution backward-weight, a18); only the rows the kernel reports are written; reproducible."""
+    from linr_pcgc_amd import ops
+    dev, n = env['dev'], env['n']
+    gen = torch.Generator().manual_seed(911 + nblocks)
+    occ_h = (torch.rand(n, 8, generator=gen) < 0.4).float()
+    gos_h = [torch.randn(n, 8, generator=gen) for _ in range(7)]
+    refs = []
+    for b in range(1, 8):
+        w = (torch.randn(27, b, 8, generator=gen) * 0.2).requires_grad_()
+        bias = torch.zeros(1, 8, requires_grad=True)
+        onet.conv3(occ_h[:, :b].contiguous(), env['nbr_t'], w, bias).backward(gos_h[b - 1])
+        refs.append((w.grad, bias.grad.reshape(-1)))
+    _, occ = _padded(occ_h, dev)
+    gos = [g.to(dev).contiguous() for g in gos_h]
+    gw, gb = ops.occ_wgrad7(occ, gos, env['lo'], env['mask'], n, nblocks=nblocks)
+    for b in range(7):
+        _rel_own_max(gw[b], refs[b][0], 'kernel gradient of block %d' % (b + 1))
+        _rel_own_max(gb[b], refs[b][1], 'bias gradient of block %d' % (b + 1))
+    gw2, gb2 = ops.occ_wgrad7(occ, gos, env['lo'], env['mask'], n, nblocks=nblocks)
+    assert all(torch.equal(a, b) for a, b in zip(gw + gb, gw2 + gb2))
+
+
 @pytest.mark.parametrize('nblocks,flags', [(256, 0), (3, 6)])
 def test_inception_backward_fused_pairs(env, nblocks, flags):
     """linr_inception_bwd_fused (both conv pairs of an Inception layer's backward, each from ONE gather): gH and gX are
