@@ -130,33 +130,43 @@ __global__ __launch_bounds__(XTG_WAVES * 64) void xtg_wgrad_k(const float* __res
     per = (per + 15) & ~(int64_t)15;
     const int64_t b0 = (int64_t)blockIdx.x * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
-    for (int64_t c0 = b0 + 16 * wave; c0 < b1; c0 += 16 * XTG_WAVES) {
-        float av[4][MT], bv[4][NT];
+    // two 16-row chunks per iteration: their loads are all in flight before the first MFMA (the kernel streams X and G once and
+    // is bound by the latency of these 4-byte loads); chunks are accumulated in the same order as one by one
+    for (int64_t c0 = b0 + 16 * wave; c0 < b1; c0 += 2 * 16 * XTG_WAVES) {
+        float av[2][4][MT], bv[2][4][NT];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int64_t row = c0 + 4 * s4 + rr;
-            const bool ok = row < b1;
+        for (int u = 0; u < 2; ++u) {
+            const int64_t cu = c0 + (int64_t)u * 16 * XTG_WAVES;
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int m = 16 * a + mm;
-                float v = 0.0f;
-                if (ok && m < M) v = X[row * x_ld + m];
-                if (ok && m == M) v = 1.0f;
-                av[s4][a] = v;
-            }
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int64_t row = cu + 4 * s4 + rr;
+                const bool ok = row < b1;
 #pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int nn = 16 * b + mm;
-                bv[s4][b] = (ok && nn < N) ? G[row * g_ld + nn] : 0.0f;
+                for (int a = 0; a < MT; ++a) {
+                    const int m = 16 * a + mm;
+                    float v = 0.0f;
+                    if (ok && m < M) v = X[row * x_ld + m];
+                    if (ok && m == M) v = 1.0f;
+                    av[u][s4][a] = v;
+                }
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const int nn = 16 * b + mm;
+                    bv[u][s4][b] = (ok && nn < N) ? G[row * g_ld + nn] : 0.0f;
+                }
             }
         }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && c0 + 16 * XTG_WAVES >= b1) break;          // wave-uniform: the second chunk does not exist (zeros anyway)
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
+            for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][a], bv[s4][b], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s4][a], bv[u][s4][b], acc[a][b], 0, 0, 0);
+        }
     }
     float* mine = sacc + lane * (MT * NT * 4 + 1);
     for (int w = 0; w < XTG_WAVES; ++w) {
