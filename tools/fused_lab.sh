@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   mkdir -p $R/tools/_lab
   for m in $2; do
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -DFB_LAB=$m -c fused_bwd.hip -o $R/tools/_lab/fused_bwd_$m.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/liblinr_fb_$m.so _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o $R/tools/_lab/fused_bwd_$m.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
+    hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/liblinr_fb_$m.so _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o $R/tools/_lab/fused_bwd_$m.o _obj/occ_wgrad.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
   done
   ls $R/tools/_lab/*.so
 else
