@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 3
+#define LINR_ABI_VERSION 4
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/pmc_traffic.txt
 : > $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$c
-  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "conv_bwd_wgrad_k|cconv_mfma_k|cconv_dual44_k|spconv_wgrad_t_k|occ_conv7_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "conv_bwd_wgrad_k|cconv_mfma_k|cconv_dual44_k|spconv_wgrad_t_k|occ_conv7_k|occ_wgrad7_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
   echo "pass $c done"
 done
 python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic.json | tee -a $OUT
