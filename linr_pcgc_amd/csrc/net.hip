@@ -34,13 +34,13 @@ struct Arena {
     int pad_w[200];
     int npad;
     // forward (saved for backward)
-    float *MIX, *HID, *X0, *OCC;
+    float *HID, *X0, *OCC;
     float *A[8], *H[8], *M[8], *I[8], *O[8];
     float *Hx[MAX_BL - 1], *Mx[MAX_BL - 1], *Ix[MAX_BL - 1];        // Inception layers 1.. of block_in (block_layers > 1)
     float *gIx[MAX_BL - 1], *gMx[MAX_BL - 1], *gHx[MAX_BL - 1];
     float *C[8], *HH[8], *Z[8], *P[8];
     // backward scratch
-    float *gZ, *gHH, *gXG, *gX0, *gHID;
+    float *gZ, *gHH, *gXG, *gX0;
     float *gC[8], *gO[8], *gI[8], *gA[8], *gH[8], *gM[8];   // one set per stage / block (the grouped launches need them side by side)
     float* BIG;                  // [LINR_WG_BLOCKS][n_params] per-block partial weight gradients
     float* GSUM;                 // [n_params] their fixed-order sum (the gradient of this backward call)
@@ -63,7 +63,7 @@ static size_t slab_need(int64_t rows) {
 
 static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params, int block_layers = 1) {
     a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
-    a.MIX = arena_mat(a, 16); a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
+    a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
     for (int b = 0; b < 8; ++b) {
         a.A[b] = arena_mat(a, 8); a.H[b] = arena_mat(a, 8); a.M[b] = arena_mat(a, 4);
         a.I[b] = arena_mat(a, 8); a.O[b] = arena_mat(a, 8);
@@ -71,7 +71,7 @@ static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params, in
     for (int k = 0; k < 8; ++k) {
         a.C[k] = arena_mat(a, 8); a.HH[k] = arena_mat(a, 24); a.Z[k] = arena_mat(a, 1); a.P[k] = arena_mat(a, 1);
     }
-    a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gXG = arena_mat(a, 8); a.gX0 = arena_mat(a, 8); a.gHID = arena_mat(a, 16);
+    a.gZ = arena_mat(a, 1); a.gHH = arena_mat(a, 24); a.gXG = arena_mat(a, 8); a.gX0 = arena_mat(a, 8);
     for (int i = 0; i < 8; ++i) {
         a.gC[i] = arena_mat(a, 8); a.gO[i] = arena_mat(a, 8); a.gI[i] = arena_mat(a, 8); a.gA[i] = arena_mat(a, 8);
         a.gH[i] = arena_mat(a, 8); a.gM[i] = arena_mat(a, 4);
@@ -108,7 +108,7 @@ struct PadList { int64_t off[200]; int w[200]; int n; };
 
 // Scale context of all scales in one launch (model_core.py:48-53): x0[r] = W2 relu(W1 [emb | offset_feat[r]] + b1) + b2 with
 // the weights of r's scale: fmaf chains with the bias first and the inputs ascending, like linear_k<15,16> + linear_k<16,8> on
-// [emb | offset_feat | 0].  MIX and HID are kept for the backward pass.
+// [emb | offset_feat | 0].  HID is kept for the backward pass (sce_bwd_all_k); the op-level entry also returns the MLP input.
 // A workgroup never straddles two scales (blk_off: first workgroup of every scale), so the scale - and with it every weight
 // address - is uniform: the weights come through the scalar cache into SGPRs (s_load + v_fmac with an SGPR operand) instead of
 // ~400 broadcast vector loads per row (46.8 -> ~12 us for the forward kernel at 337 k rows, 18.9 -> ~9 for the backward one).
@@ -116,6 +116,7 @@ struct SceArgs {
     int64_t row_off[MAX_SCALES + 1];
     int64_t emb[MAX_SCALES], w1[MAX_SCALES], b1[MAX_SCALES], w2[MAX_SCALES], b2[MAX_SCALES];   // parameter offsets per scale
     int blk_off[MAX_SCALES + 1];
+    int wg_off[MAX_SCALES + 1];          // sce_bwd_all_k: first workgroup of every scale (= its slab rows in front)
     int n_scales;
 };
 
@@ -152,9 +153,11 @@ __global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 7; ++i) x[8 + i] = off[r * 7 + i];
     x[15] = 0.0f;
-    float4* mp = reinterpret_cast<float4*>(mix + r * 16);
+    if (mix) {                                 // only the op-level entry wants the MLP input back (uniform)
+        float4* mp = reinterpret_cast<float4*>(mix + r * 16);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) mp[v] = make_float4(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]);
+        for (int v = 0; v < 4; ++v) mp[v] = make_float4(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]);
+    }
     float h[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) h[o] = b1[o];
@@ -207,6 +210,133 @@ __global__ __launch_bounds__(LINR_BLOCK) void sce_bwd_k(const float* __restrict_
     }
 }
 
+// The whole backward of the scale context in ONE launch (grid: slab rows x scales): per row ghid = (W2^T gx0) * (hid > 0) with the
+// scale's weights from the scalar cache (the fmaf chain of sce_bwd_k), and all four parameter gradients as X^T G products with the
+// rows as the K dimension of v_mfma_f32_16x16x4_f32 (xtg_wgrad_k's scheme):
+//   gW1[m][i] = sum_r ghid[r][m] * [emb | offset_feat | 1][r][i]   (column 15 = the bias gradient gb1),
+//   gW2[o][i] = sum_r gx0[r][o] * hid[r][i],   gb2[o] = sum_r gx0[r][o]  (per-lane sums, fixed shuffle tree)
+// Each wave passes its 64 rows through a wave-private LDS tile [row][ghid 16 | x 16 | gx0 8 | hid 16] to turn "lane = row" into
+// the fragment layout.  Neither ghid nor the MLP input is written to memory (round 2/3: a 64 B/row matrix each, read back by two
+// pointwise weight-gradient launches).  One slab row per workgroup and scale, the four waves folded in order.
+#define SB_LD 57
+#define SB_WAVES 4          // (8 waves per workgroup = one workgroup per CU: 63.6 instead of 50.3 us per step for the two scale-context kernels)
+__global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
+                                                            const float* __restrict__ gx0, const float* __restrict__ hid,
+                                                            float* __restrict__ big, int64_t block_stride) {
+    __shared__ float sT[SB_WAVES * 64 * SB_LD];
+    __shared__ float sfold[64 * 9];
+    __shared__ float sb2[SB_WAVES * 8];
+    int s = 0;                                                 // scale of this workgroup: uniform
+    for (int i = 1; i < a.n_scales; ++i) s += ((int)blockIdx.x >= a.wg_off[i]) ? 1 : 0;
+    const int sb = (int)blockIdx.x - a.wg_off[s], nsb = a.wg_off[s + 1] - a.wg_off[s];          // slab row, rows of this scale
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mm = lane & 15, rr = lane >> 4;
+    const float* emb = P + a.emb[s];
+    const float* W2 = P + a.w2[s];
+    const int64_t r0 = a.row_off[s], n = a.row_off[s + 1] - r0;
+    int64_t per = (n + nsb - 1) / nsb;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t b0 = (int64_t)sb * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    float* T = sT + wave * 64 * SB_LD;
+    // W2 in VECTOR registers: 128 uniform values are more than the scalar file holds beside the rest (the compiler spilled them
+    // into register lanes: 742 v_readlane per tile, 40 us per launch) - the empty asm pins each into a VGPR
+    float w2v[128];
+#pragma unroll
+    for (int j = 0; j < 128; ++j) { w2v[j] = W2[j]; asm volatile("" : "+v"(w2v[j])); }
+    f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f}, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = 0.0f;
+    for (int64_t c0 = b0 + 64 * wave; c0 < b1; c0 += 64 * SB_WAVES) {
+        const int64_t row = c0 + lane;
+        const bool live = row < b1;
+        const int64_t r = r0 + (live ? row : b1 - 1);
+        const float4 g0 = *reinterpret_cast<const float4*>(gx0 + r * 8), g1 = *reinterpret_cast<const float4*>(gx0 + r * 8 + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        float h[16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 t = *reinterpret_cast<const float4*>(hid + r * 16 + 4 * v);
+            h[4 * v] = t.x; h[4 * v + 1] = t.y; h[4 * v + 2] = t.z; h[4 * v + 3] = t.w;
+        }
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = emb[i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) x[8 + i] = off[r * 7 + i];
+        x[15] = 1.0f;                                          // the bias gradient's pseudo input
+        float gh[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) gh[o] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int o = 0; o < 16; ++o) gh[o] = fmaf(g[i], w2v[i * 16 + o], gh[o]);
+        float* Tr = T + lane * SB_LD;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) Tr[o] = (live && h[o] > 0.0f) ? gh[o] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Tr[16 + i] = live ? x[i] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Tr[32 + j] = live ? g[j] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Tr[40 + i] = live ? h[i] : 0.0f;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs[j] += g[j];
+        }
+        // wave-private tile: LDS operations of a wave execute in order, no barrier
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float* Tq = T + (4 * s4 + rr) * SB_LD;
+            const float a1 = Tq[mm], b1v = Tq[16 + mm];
+            const float a2 = (mm < 8) ? Tq[32 + mm] : 0.0f, b2v = Tq[40 + mm];
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2v, acc2, 0, 0, 0);
+        }
+    }
+    // fold the 4 waves in wave order, then one partial per destination element (C/D map: row = (lane >> 4) * 4 + reg, col = lane & 15)
+    float* mine = sfold + lane * 9;
+    for (int w = 0; w < SB_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mine[j] = (w == 0) ? acc1[j] : mine[j] + acc1[j];
+                mine[4 + j] = (w == 0) ? acc2[j] : mine[4 + j] + acc2[j];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) bs[j] += __shfl_xor(bs[j], dd, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sb2[wave * 8 + j] = bs[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = big + (int64_t)sb * block_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = rr * 4 + j;
+            if (mm < 15) dst[a.w1[s] + m * 15 + mm] = mine[j];
+            else dst[a.b1[s] + m] = mine[j];
+            if (m < 8) dst[a.w2[s] + m * 16 + mm] = mine[4 + j];
+        }
+        if (lane < 8) {
+            float t = sb2[lane];
+#pragma unroll
+            for (int w = 1; w < SB_WAVES; ++w) t += sb2[8 * w + lane];
+            dst[a.b2[s] + lane] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(LINR_BLOCK) void sigmoid_k(const float* __restrict__ z, int64_t n, float* __restrict__ p) {
     const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
     if (i < n) p[i] = 1.0f / (1.0f + expf(-z[i]));
@@ -243,7 +373,7 @@ __global__ void sce_emb_grad_all_k(const float* __restrict__ P, float* __restric
 struct ZeroRanges { int n; int64_t prefix; int64_t b[MAX_SCALES + 1], e[MAX_SCALES + 1]; };
 // Parameter ranges whose producer (a fused backward launch: one round of long-lived blocks, csrc/fused_bwd.hip) wrote only the
 // first rows[i] rows of the slab: the reduction stops there instead of having the producer fill the other rows with zeros.
-#define MAX_SHORT 32
+#define MAX_SHORT 48
 struct ShortRanges { int n; int64_t b[MAX_SHORT], e[MAX_SHORT]; int rows[MAX_SHORT]; };
 __global__ __launch_bounds__(LINR_BLOCK) void wgrad_reduce_k(const float* __restrict__ big, int nblocks, int64_t total,
                                                              float* __restrict__ gsum, ZeroRanges zr, ShortRanges sr) {
@@ -300,7 +430,7 @@ struct Ctx {
     std::vector<Short> shortr;      // parameter ranges of this backward pass that hold fewer than nb slab rows (fused launches)
     // a fused launch writes only `rows` slab rows for parameters [b, e) (no zero fill): the final reduction stops there.  The
     // table holds every range of a backward pass: 8 blocks x 2 + the prune convs + block_in's first conv + the 7 outter first
-    // convs = 25
+    // convs + up to 16 scale-context MLPs = 41
     void note_short(int64_t b, int64_t e, int rows) {
         if (rows >= nb) return;
         if ((int)shortr.size() >= MAX_SHORT) abort();          // cannot happen (see above); a silent drop would read unwritten rows
@@ -757,7 +887,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
             ProfScope ps(c.s, PK_SCE, 1);
             const SceArgs sa = sce_args(c);
             sce_fwd_k<<<sa.blk_off[sa.n_scales] + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
-                P, f->offset_feat, sa, c.R, a.MIX, a.HID, a.X0, a.base, pl);
+                P, f->offset_feat, sa, c.R, nullptr, a.HID, a.X0, a.base, pl);
         }
         if (all_grouped && join_block_in(c)) {
             // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
@@ -1108,39 +1238,22 @@ static int backward_core(Ctx& c, float gscale) {
     int ns = 0, sl[MAX_SCALES];
     for (int s = 0; s < f->n_scales; ++s)
         if (f->row_off_h[s + 1] > f->row_off_h[s]) sl[ns++] = s;
-    const bool sce_grouped = ns >= 1 && ns <= LINR_MAXG;          // more scales than one grouped launch holds: scale by scale
-    if (sce_grouped) {
-        {
-            ProfScope ps(c.s, PK_SCE, 1);
-            const SceArgs sa = sce_args(c);
-            sce_bwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, c.s>>>(P, sa, c.R, a.gX0, a.HID, a.gHID);
+    if (ns >= 1) {          // ghid and all four parameter gradients of every scale's context MLP in one launch
+        ProfScope ps(c.s, PK_SCE, 1);
+        SceArgs sa = sce_args(c);
+        // slab rows per scale: one workgroup per 256 rows, at most nb; a scale with fewer leaves a short range for the reduction
+        sa.wg_off[0] = 0;
+        for (int j = 0; j < f->n_scales; ++j) {
+            const int64_t nj = f->row_off_h[j + 1] - f->row_off_h[j];
+            int64_t wg = nj > 0 ? (nj + LINR_BLOCK - 1) / LINR_BLOCK : 0;
+            if (wg > c.nb) wg = c.nb;
+            sa.wg_off[j + 1] = sa.wg_off[j] + (int)wg;
+            if (wg > 0) {
+                const int si = f->scale_idx_h[j];
+                c.note_short(c.L.m0_w[si], c.L.m2_b[si] + 8, (int)wg);
+            }
         }
-        Grp g2 = Grp(), g0 = Grp();
-        const int64_t r00 = f->row_off_h[sl[0]];
-        const int si0 = f->scale_idx_h[sl[0]];
-        for (int j = 0; j < ns; ++j) {
-            const int64_t r0 = f->row_off_h[sl[j]], n = f->row_off_h[sl[j] + 1] - r0;
-            const int si = f->scale_idx_h[sl[j]];
-            g2.in[j] = (r0 - r00) * 16; g2.res[j] = (r0 - r00) * 8; g2.w[j] = c.L.m2_w[si] - c.L.m2_w[si0];
-            g2.b[j] = c.L.m2_b[si] - c.L.m2_b[si0]; g2.n[j] = n;
-            g0.in[j] = (r0 - r00) * 16; g0.res[j] = (r0 - r00) * 16; g0.w[j] = c.L.m0_w[si] - c.L.m0_w[si0];
-            g0.b[j] = c.L.m0_b[si] - c.L.m0_b[si0]; g0.n[j] = n;
-        }
-        const int64_t nmax = f->rows;          // every group carries its own row count
-        LinrLinDst d2 = {a.BIG, c.L.total, c.L.m2_w[si0], 1, 16, c.L.m2_b[si0]};
-        LinrLinDst d0 = {a.BIG, c.L.total, c.L.m0_w[si0], 1, 15, c.L.m0_b[si0]};
-        ProfScope ps(c.s, PK_LIN_WGRAD, 2);
-        TRY(linr_linear_wgrad_partial(a.HID + r00 * 16, 16, a.gX0 + r00 * 8, 8, nmax, 16, 8, d2, c.nb, c.s, &g2, ns));
-        TRY(linr_linear_wgrad_partial(a.MIX + r00 * 16, 16, a.gHID + r00 * 16, 16, nmax, 15, 16, d0, c.nb, c.s, &g0, ns));
-    } else
-    for (int s = 0; s < f->n_scales; ++s) {
-        const int64_t r0 = f->row_off_h[s], n = f->row_off_h[s + 1] - r0;
-        if (n == 0) continue;
-        const int si = f->scale_idx_h[s];
-        TRY(linear_wgrad(c, a.HID + r0 * 16, 16, a.gX0 + r0 * 8, 8, n, 16, 8, c.L.m2_w[si], 1, 16, c.L.m2_b[si]));
-        TRY(linear(c, a.gX0 + r0 * 8, 8, n, P + c.L.m2_w[si], 16, 1, nullptr, 8, 16, nullptr, 0, a.HID + r0 * 16, 16,
-                   a.gHID + r0 * 16, 16, LINR_RELU_MASK));
-        TRY(linear_wgrad(c, a.MIX + r0 * 16, 16, a.gHID + r0 * 16, 16, n, 15, 16, c.L.m0_w[si], 1, 15, c.L.m0_b[si]));
+        sce_bwd_all_k<<<sa.wg_off[f->n_scales], SB_WAVES * 64, 0, c.s>>>(P, f->offset_feat, sa, a.gX0, a.HID, a.BIG, c.L.total);
     }
     // one pass sums every parameter's per-block partials in fixed order
     ProfScope ps_tail(c.s, PK_MISC, 0);
