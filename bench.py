@@ -159,7 +159,10 @@ def kernel_roofline(gop, live, table_prof, table_steps, ms_per_step):
         tflops = ppl * mean_rows * flops_per_pass / dur_s / 1e12       # dense-27 flops the kernel executes on the matrix cores
         return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': tr, 'kernel': name,
-                'mfma_f32_view': {'achieved_tflops': round(tflops, 1), 'peak_tflops': 157.3, 'frac': round(tflops / 157.3, 4)},
+                'mfma_f32_view': {'achieved_tflops': round(tflops, 1), 'peak_tflops': 157.3, 'frac': round(tflops / 157.3, 4),
+                                  # v_mfma_f32_4x4x1 issues every 9.5-10 cycles, not 8 (profiles/r03_issue_probe.txt): what a
+                                  # stream of nothing but these instructions reaches
+                                  'issue_ceiling_tflops_4x4x1': 119.0, 'frac_of_issue_ceiling': round(tflops / 119.0, 4)},
                 'launches_timed': int(launches), 'passes_per_launch': round(ppl, 3), 'rows_per_pass': round(mean_rows, 1),
                 'alg_bytes_per_launch': int(alg), 'avg_launch_us': round(dur_s * 1e6, 2)}
 
