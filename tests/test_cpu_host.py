@@ -58,6 +58,14 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_spconv_bwd_fused(p16, p16, p16, p16, 16, 16, p16, p16 + 4, p16, 32, None) == -3          # gin not 16-byte aligned
     assert lib.linr_spconv_bwd_fused(p16, p16, p16, p16, 16, 16, p16, p16, p16, 0, None) == -1               # no slab rows
     assert lib.linr_spconv_bwd_weight(p16, 8, p16, 8, p16, 16, 16, 8, 8, p16, p16, 0, p16, 16, None) == -2             # ws short
+    rows = ctypes.c_int32(7)
+    g7 = (ctypes.c_void_p * 7)(*([p16] * 7))
+    assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 16, p16, 0, ctypes.byref(rows), None) == -1            # no slab rows
+    g7[3] = p16 + 4
+    assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 16, p16, 8, ctypes.byref(rows), None) == -3            # a gradient matrix misaligned
+    g7[3] = None
+    assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 16, p16, 8, ctypes.byref(rows), None) == -1 and rows.value == 0
+    assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 0, p16, 8, ctypes.byref(rows), None) == 0               # empty input is fine
     # whole network: NULL frame / parameters, stage range
     assert lib.linr_net_forward(None, p16, p16, 4096, 0, 8, None, None, None) == -1
     assert lib.linr_net_train_step(None, p16, p16, 4096, 1.0, None, None, 0.01, 1, None, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
