@@ -164,7 +164,7 @@ __global__ __launch_bounds__(OW_WAVES * 64, 1) void occ_wgrad7_k(OccWgArgs a, co
                 };
                 rd(0, 0, 0);
                 static_for<32>([&](auto hc) {
-                    constexpr int hh = decltype(hc)::value, rq = hh >> 1, half = hh & 1;
+                    constexpr int hh = decltype(hc)::value, half = hh & 1;          // row quad hh >> 1
                     __builtin_amdgcn_sched_barrier(0);          // keeps the reads of later row quads from being hoisted (registers)
                     if constexpr (hh + 1 < 32) rd((hh + 1) >> 1, (hh + 1) & 1, (hh + 1) & 1);
                     static_for<4>([&](auto ec) {
