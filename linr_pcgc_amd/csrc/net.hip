@@ -593,7 +593,8 @@ static bool join_block_in(const Ctx& c) {
 // two-kernel schedule (same input gradients bit for bit, weight gradients in another summation order)
 static bool fused_bwd(const Ctx& c) {
     static const int v = getenv("LINR_FUSED_BWD") ? atoi(getenv("LINR_FUSED_BWD")) : 1;
-    return v != 0 && c.f->nbr_lo && c.f->nbr_mask;
+    // (the fused kernels address the compressed map with 32-bit byte offsets: 9 x ld x 4 B < 2^32; larger maps take the two-kernel path)
+    return v != 0 && c.f->nbr_lo && c.f->nbr_mask && c.nbr_ld < ((int64_t)1 << 26);
 }
 
 static int conv3(Ctx& c, bool bwd, const float* in, int in_ld, const float* W, const float* bias, int cin, int cout,
