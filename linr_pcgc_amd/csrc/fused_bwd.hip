@@ -276,7 +276,6 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
             const int64_t nrow_raw = (ntile << 6) + lane;
             const int64_t nrow = nrow_raw < n ? nrow_raw : n - 1;
             f32x4 acc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
-            [[maybe_unused]] f32x4 accB[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
             // own-row operands of the epilogue, requested early (step 5): EPI 3: M; KIND 1: H; KIND 2: gI, gH[4:8], A
             float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0, e3 = e0, e4 = e0;
             __builtin_amdgcn_sched_barrier(0);
@@ -344,15 +343,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
                 static_for<NBW>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     if constexpr (!(FB_LAB & 4)) {
-                        if constexpr (KIND == 0 && (FB_LAB & 16)) {          // lab: four accumulation chains instead of two
-                            if constexpr (i % 2 == 0) {
-                                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], acc[0], 4, ab, 0);
-                                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], acc[1], 4, ab + 1, 0);
-                            } else {
-                                accB[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], accB[0], 4, ab, 0);
-                                accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], accB[1], 4, ab + 1, 0);
-                            }
-                        } else if constexpr (KIND == 0) {
+                        if constexpr (KIND == 0) {
                             acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], acc[0], 4, ab, 0);
                             acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], xk[i / 4][i % 4], acc[1], 4, ab + 1, 0);
                         } else if constexpr (KIND == 1) {
@@ -402,7 +393,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[4 * h + j] = (FB_LAB & 16) ? acc[h][j] + accB[h][j] : acc[h][j];
+                    for (int j = 0; j < 4; ++j) o[4 * h + j] = acc[h][j];
                 if constexpr (EPI == 3) {          // gM = (gin[4:8] @ W12^T) * (M > 0)   (W12 [4][4])
                     const float mv[4] = {e0.x, e0.y, e0.z, e0.w};
                     float gm[4];
