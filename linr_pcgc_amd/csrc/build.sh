@@ -12,6 +12,7 @@ for f in kmap spconv linear loss_optim net fused fused_bwd occ_wgrad net_bf16 de
     # one-wave-per-SIMD kernels (same box: 1.6445 -> 1.629 ms/step; bf16 forward 0.436 -> 0.422 ms); no gain for the other files
     EXTRA=""
     if [ $f = fused_bwd ] || [ $f = net_bf16 ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+    if [ $f = occ_wgrad ]; then EXTRA="-mllvm -amdgpu-sched-strategy=max-ilp"; fi          # -5 us/step (same box, twice); slower for fused.hip
     hipcc $FLAGS $EXTRA -c $f.hip -o _obj/$f.o &
     pids+=($!)
   fi
