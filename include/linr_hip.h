@@ -175,6 +175,9 @@ LINR_API size_t linr_linear_bwd_weight_workspace_bytes(int64_t n, int32_t cin, i
 LINR_API int linr_linear_bwd_weight(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, int64_t n,
                            int32_t cin, int32_t cout, float* gW, int32_t ws_ci, int32_t ws_co, float* gb,
                            uint32_t flags, void* ws, size_t ws_bytes, void* stream);
+/* dst[i] (+)= src[i] over n floats: the residual / gradient fan-in adds of the width-generic executor (linr_pcgc_amd/wide_net.py);
+ * torch's `x + y` in models/resnet.py:59,161 and autograd's accumulation. */
+LINR_API int linr_axpy(const float* src, int64_t n, float* dst, int32_t accumulate, void* stream);
 
 /* ---- occupancy head loss -------------------------------------------------------------------------------------
  * Replaces sigmoid + nn.BCELoss(reduction='sum') / ln 2 (models/upsample.py:160, models/model_core.py:14,76-81).

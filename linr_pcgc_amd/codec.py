@@ -136,6 +136,8 @@ def decode_one_frame(model, frame_enc_bytes, xyz_low):
     library (model.decode_scale -> linr_decode_scale: kernel map, the 7-neighbour occupancy read off it instead of
     qscTensor.set_offset_tensor's searches, the 8 stage forwards with their host round trips, upper_layer), so the Python side of a
     frame is seven buffer allocations."""
+    if getattr(model, '_wide', None) is not None:          # hidden_channel_conv 16 / 32: no single-call decoder scale
+        return decode_one_frame_stagewise(model, frame_enc_bytes, xyz_low)
     lowx = unique_sorted(xyz_low)
     bits = max(1, int(xyz_low.max()).bit_length()) if xyz_low.numel() else 1       # coordinates of the coarsest level
     for s_idx in range(len(frame_enc_bytes) - 1, -1, -1):

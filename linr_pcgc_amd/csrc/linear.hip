@@ -57,7 +57,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void linear_k(const float* __restrict__
     for (int o = 0; o < COUT; ++o) op[o] = acc[o];
 }
 
-#define LINR_LINEAR_SHAPES(X) X(15, 16) X(16, 8) X(8, 24) X(24, 1) X(8, 4) X(4, 4) /* forward shapes */ \
+#define LINR_LINEAR_SHAPES(X) X(15, 16) X(16, 8) X(8, 24) X(24, 1) X(8, 4) X(4, 4) X(8, 8) /* forward shapes; 8x8: the blocks of wider models */ \
                               X(8, 16) X(1, 24) X(24, 8) X(4, 8) X(16, 15)         /* transposed (bwd-data) */
 
 int linr_linear_launch(const float* in, int in_ld, int64_t n, const float* W, int ws_ci, int ws_co,

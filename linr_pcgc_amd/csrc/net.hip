@@ -349,6 +349,14 @@ __global__ __launch_bounds__(LINR_BLOCK) void axpy_k(const float* __restrict__ s
     if (i < n) dst[i] = accumulate ? dst[i] + src[i] : src[i];
 }
 
+extern "C" int linr_axpy(const float* src, int64_t n, float* dst, int32_t accumulate, void* stream) {
+    if (n < 0) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!src || !dst) return LINR_EINVAL;
+    axpy_k<<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(src, n, dst, accumulate ? 1 : 0);
+    return linr_launch_rc();
+}
+
 // gemb[i] = sum_m gb1[m] * W1[m][i]   (scale-embedding gradient through Linear(15,16); the embedding row is a
 // constant input of every row of its scale, so its gradient is W1[:, :8]^T applied to the bias gradient)
 struct EmbArgs { int64_t gb1[MAX_SCALES], w1[MAX_SCALES], gemb[MAX_SCALES]; };

@@ -45,12 +45,36 @@ class _NetBits(torch.autograd.Function):
         return (None, None) + (None,) * len(model._plist)
 
 
+class _WideBits(torch.autograd.Function):
+    """The same for hidden_channel_conv = 16 / 32 (wide_net.py: forward with the activations kept, hand-written backward)."""
+
+    @staticmethod
+    def forward(ctx, model, frame, *params):
+        bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
+        with torch.no_grad():
+            ctx.tape = model._wide.forward(frame, 0, 8, None, bits, keep=True)
+        ctx.model, ctx.frame = model, frame
+        return bits[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, frame = ctx.model, ctx.frame
+        model._ensure_grad_views()
+        keep = model._flat_grad.clone()                      # the wide backward WRITES the gradients: accumulate around it
+        with torch.no_grad():
+            model._flat_grad.zero_()
+            if ctx.tape is not None:
+                model._wide.backward(frame, ctx.tape, 1.0)
+            model._flat_grad.mul_(gout.to(torch.float32).reshape(1)).add_(keep)
+        return (None, None) + (None,) * len(model._plist)
+
+
 class LINR_PCGC_Model(nn.Module):
     """models/model_core.py:19-37.  inargs: scale_num, in_channel (=7), hidden_channel_conv (=8), block_layers (1..4),
     outstage (=8), instage (=1).  outstage / instage / in_channel are hard-coded by the reference's drivers
     (main.py:97,218); block_layers is its live --block_layers flag (main.py:521: the Inception layers of block_in's
-    ResNetBlock, with the extra skip of models/resnet.py:160-161 when > 1).  hidden_channel_conv (main.py:520) is NOT
-    supported at other widths: every kernel is specialised for 8-wide feature rows."""
+    ResNetBlock, with the extra skip of models/resnet.py:160-161 when > 1).  hidden_channel_conv (main.py:520): 8 runs on the
+    tuned kernels (every one is specialised for 8-wide feature rows), 16 and 32 on the channel-blocked executor of wide_net.py."""
 
     def __init__(self, inargs):
         super().__init__()
@@ -61,9 +85,11 @@ class LINR_PCGC_Model(nn.Module):
         if in_channel != 7 or inargs['outstage'] != 8 or inargs['instage'] != 1:
             raise ValueError('the gfx950 engine is specialised for in_channel=7, outstage=8, instage=1 (what main.py:97,218 '
                              'hard-code); got %r' % (inargs,))
-        if hidden != 8:
-            raise ValueError('hidden_channel_conv=%d is not supported: the gfx950 kernels are specialised for 8-wide rows '
-                             '(the reference default, main.py:520); a checkpoint trained at another width cannot be loaded' % hidden)
+        if hidden not in (8, 16, 32):
+            raise ValueError('hidden_channel_conv=%d is not supported: 8 (the reference default, main.py:520) runs on the tuned '
+                             'gfx950 kernels, 16 and 32 on the channel-blocked executor (wide_net.py); a checkpoint of another '
+                             'width cannot be loaded' % hidden)
+        self.hidden = hidden
         if not 1 <= block_layers <= 4:
             raise ValueError('block_layers must be in 1..4 (main.py:521 default 1), got %d' % block_layers)
         self.block_layers = block_layers
@@ -80,6 +106,10 @@ class LINR_PCGC_Model(nn.Module):
         self.inference_precision = 'f32'
         self._qcodes = None
         self._qrange = None
+        self._wide = None
+        if hidden != 8:
+            from .wide_net import WideNet
+            self._wide = WideNet(self, hidden)
         self._flatten()
 
     # ---- flat parameter buffer ------------------------------------------------------------------------------------
@@ -87,7 +117,7 @@ class LINR_PCGC_Model(nn.Module):
         """Re-home all parameters as views of one contiguous buffer in parameters() order (the kernels' layout)."""
         plist = list(self.parameters())
         total = sum(p.numel() for p in plist)
-        if plist and plist[0].is_cuda and total != _lib.lib().linr_param_count(self.scale_num, self.block_layers):
+        if plist and plist[0].is_cuda and self.hidden == 8 and total != _lib.lib().linr_param_count(self.scale_num, self.block_layers):
             raise _lib.LinrError('parameter layout mismatch with liblinr_hip.so')
         flat = torch.empty(total, dtype=torch.float32, device=plist[0].device)
         off = 0
@@ -100,6 +130,8 @@ class LINR_PCGC_Model(nn.Module):
                 off += n
         self._flat, self._plist, self._flat_grad = flat, plist, None
         self._frame_cache = {}
+        if getattr(self, '_wide', None) is not None:
+            self._wide._built = False                 # the parameter tensors were re-homed
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -144,7 +176,7 @@ class LINR_PCGC_Model(nn.Module):
     # ---- frames ----------------------------------------------------------------------------------------------------
     def make_frame(self, scales, validate=True, with_arena=True):
         """Batched multi-scale frame for the fast path.  scales: list of per-scale input dicts (see engine.Frame)."""
-        return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena, self.block_layers)
+        return engine.Frame(scales, self.scale_num, self._flat.device, validate, with_arena and self._wide is None, self.block_layers)
 
     def _scale_frame(self, d, need_occ=True):
         """Kernel map + arena for one scale's inputs.  Encoder-side inputs are cached by tensor identity; the cache
@@ -170,13 +202,18 @@ class LINR_PCGC_Model(nn.Module):
         """models/model_core.py:72-81: bits of one scale (0-dim float32, differentiable w.r.t. the parameters)."""
         frame = self._scale_frame(inargs)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
-            return _NetBits.apply(self, frame, *self._plist)
+            return (_WideBits if self._wide is not None else _NetBits).apply(self, frame, *self._plist)
         bits = torch.zeros(1, dtype=torch.float64, device=frame.device)
-        engine.net_forward(frame, self._flat, 0, 8, None, bits)
+        self._stage_forward(frame, 0, 8, None, bits, 'f32')
         return bits[0].to(torch.float32)
 
     def _stage_forward(self, frame, k0, k1, probs, bits, precision):
-        if precision == 'bf16':
+        if self._wide is not None:
+            if precision != 'f32':
+                raise _lib.LinrError('the bf16 / uint8-weight executor exists for hidden_channel_conv=8 only')
+            with torch.no_grad():
+                self._wide.forward(frame, k0, k1, probs, bits)
+        elif precision == 'bf16':
             engine.net_forward_bf16(frame, self._qcodes, self._qrange[0], self._qrange[1], k0, k1, probs, bits)
         else:
             engine.net_forward(frame, self._flat, k0, k1, probs, bits)
@@ -284,6 +321,22 @@ class LINR_PCGC_Model(nn.Module):
         s_dev = torch.empty(max(rows, 1), dtype=torch.uint8, device=frame.device)
         p_host, s_host = self._host_buffers(rows)
         precision = self._precision(precision)
+        if self._wide is not None:          # stage loop in Python: stage forward, D2H, range decoder, H2D
+            L = _lib.lib()
+            import ctypes
+            for k in range(8):
+                self._stage_forward(frame, k, k + 1, probs, None, precision)
+                p_host[:rows].copy_(probs[k])
+                for i in range(frame.n_scales):
+                    r0, r1 = int(frame.row_off[i]), int(frame.row_off[i + 1])
+                    if r1 == r0:
+                        continue
+                    buf = np.frombuffer(streams_per_scale[i][k], dtype=np.uint8)
+                    _lib.check(L.linr_ac_decode_binary(ctypes.c_void_p(p_host.data_ptr() + 4 * r0), r1 - r0,
+                                                       ctypes.c_void_p(buf.ctypes.data if buf.size else None), int(buf.size),
+                                                       ctypes.c_void_p(s_host.data_ptr() + r0)), 'linr_ac_decode_binary')
+                frame.occ[:, k].copy_(s_host[:rows].to(frame.device, torch.float32))
+            return [frame.occ[:, k:k + 1].clone() for k in range(8)]
         # the whole stage loop is one C call (csrc/net.hip: linr_net_decode_stages): no Python between the stages, no GIL held
         if precision == 'bf16':
             engine.net_decode_stages(frame, None, streams_per_scale, probs, p_host, s_host, s_dev, self._qcodes, self._qrange)
@@ -459,6 +512,17 @@ def train_step(model, opt, frame, point_num, out=None):
     nothing synchronises with the host.  `out`: a zeroed float64[1] device tensor to add the bits into (e.g. one slot of a
     per-GOP vector that is cleared once per epoch) - saves the per-step allocation + fill."""
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device) if out is None else out
+    if model._wide is not None:          # hidden_channel_conv 16 / 32: the channel-blocked executor + the segment-wise Adam
+        with torch.no_grad():
+            tape = model._wide.forward(frame, 0, 8, None, bits, keep=True)
+            model._ensure_grad_views()
+            model._flat_grad.zero_()
+            if tape is not None:
+                model._wide.backward(frame, tape, 1.0 / float(point_num))
+            opt.grad.copy_(model._flat_grad)
+            opt.step(frame)
+        opt.scheduler_step()
+        return bits
     t, t_scale = opt.advance(frame)
     engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), t,
                           opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=t_scale)

@@ -11,11 +11,11 @@ from .model_core import FlatAdam, LINR_PCGC_Model, train_step
 from .module_utils import prepare_frame
 
 
-def gen_model(scale_num, device='cuda', seed=None, block_layers=1):
-    """Gen_Model of main.py:97,218."""
+def gen_model(scale_num, device='cuda', seed=None, block_layers=1, hidden=8):
+    """Gen_Model of main.py:97,218 (hidden = --hidden_channel_conv, main.py:520: 8 on the tuned kernels, 16 / 32 channel-blocked)."""
     if seed is not None:
         torch.manual_seed(seed)
-    m = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': block_layers,
+    m = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': hidden, 'block_layers': block_layers,
                          'outstage': 8, 'instage': 1})
     return m.to(device)
 

@@ -32,6 +32,8 @@ def parse(argv=None):
     ap.add_argument('--min-lr', type=float, default=4e-4)
     ap.add_argument('--decay-rate', type=float, default=1e-4)
     ap.add_argument('--block-layers', type=int, default=1)
+    ap.add_argument('--hidden-channel-conv', type=int, default=8, choices=[8, 16, 32],
+                    help='main.py:520; 8 = the tuned kernels, 16 / 32 = the channel-blocked executor (several times slower)')
     ap.add_argument('--seed', type=int, default=8807)
     ap.add_argument('--out', default='/tmp/linr_out')
     ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
@@ -71,7 +73,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     def run_gop(group, epochs, ckpt, staged):
         gop, stage_s = staged if staged is not None else stage(group)
         t0 = time.time()
-        model = overfit.gen_model(gop.scale_num, device, seed=args.seed, block_layers=getattr(args, 'block_layers', 1))
+        model = overfit.gen_model(gop.scale_num, device, seed=args.seed, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8))
         opt = make_opt(model)
         if ckpt is not None:
             overfit.warm_start(model, opt, ckpt)                 # main.py:241-248
@@ -79,7 +81,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info)
         torch.cuda.synchronize()
         t1 = time.time()
-        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)), gop, 8,
+        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)), gop, 8,
                                precision=getattr(args, 'precision', 'f32'))
         res_dir = os.path.join(args.out, 'result_enc', gop_parallel.gop_name(group))
         codec.write_gop(enc, res_dir)
@@ -88,7 +90,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         ok = None
         if args.decode:
             todo = list(range(len(group))) if decode_frames is None else list(range(min(decode_frames, len(group))))
-            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1)),
+            dec = codec.decode_gop(overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)),
                                    codec.read_gop(res_dir), device, frames=todo, workers=4)
             ok = all(torch.equal(d, torch.as_tensor(gop.infos[i]['ori']).cuda() +
                                  torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32))

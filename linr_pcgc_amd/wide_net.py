@@ -1,0 +1,387 @@
+"""Executor for ``hidden_channel_conv`` = 16 / 32 (main.py:520; models/upsample.py:38-76 ``channels=``, models/resnet.py:12-51
+``channels // 2``): the same network with wider feature rows, run on the library's 8-wide kernels by CHANNEL BLOCKING.
+
+Every C-wide activation is kept as C / 8 separate [rows + 1][8] matrices (zero row in front, what the kernels gather from), so
+a convolution Ci -> Co is (Ci / 8) x (Co / 8) launches of the tuned 8 -> 8 compressed-map MFMA kernel (``linr_spconv_cmap``) that
+accumulate into the output block (``LINR_ACCUM``; bias with the first, residual / ReLU with the last), a pointwise layer the same
+with ``linr_linear_fwd`` on sub-blocks of its weight matrix (addressed through the kernel's weight strides, no copies), weight
+gradients block by block with ``linr_spconv_bwd_weight`` / ``linr_linear_bwd_weight``; concatenations are free.  Only data
+movement is left to torch (slices of the 3x3x3 kernels, the [emb | offsets] input of the scale MLP); every arithmetic
+instruction runs in liblinr_hip.so.  Deterministic (fixed launch order, no atomics); the forward is the same launches in
+training, encoding and stage-by-stage decoding, so streams decode losslessly.
+
+Not tuned: ~3.5x the convolution work of the 8-wide network in ~10x as many launches, unfused backward.  The 8-wide model
+(every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import LINR_ACCUM, LINR_NO_BIAS, LINR_RELU, LINR_RELU_MASK, check
+
+B = 8
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _blocks(n, nb, dev):
+    """nb zero-padded [n, 8] matrices (views buf[1:] of [n + 1, 8] buffers whose row 0 is zero)."""
+    buf = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
+    buf[:, 0].zero_()
+    return [buf[i, 1:] for i in range(nb)]
+
+
+def _lin(x, w, w_off, ws_ci, ws_co, bias, cin, cout, out, res=None, relu=False, accumulate=False):
+    """out (+)= x @ W[sub-block] (+ bias) (+ res) (ReLU): linr_linear_fwd with explicit weight strides."""
+    n = x.shape[0]
+    flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_NO_BIAS if bias is None else 0)
+    check(_lib.lib().linr_linear_fwd(x.data_ptr(), x.stride(0), n, w.data_ptr() + 4 * w_off, ws_ci, ws_co,
+                                     0 if bias is None else bias.data_ptr(), cin, cout, 0 if res is None else res.data_ptr(),
+                                     0 if res is None else res.stride(0), out.data_ptr(), out.stride(0), flags, _stream()),
+          'linr_linear_fwd')
+
+
+def _lin_bwd_data(gout, w, w_off, ws_ci, ws_co, cin, cout, out, act=None, accumulate=False):
+    n = gout.shape[0]
+    flags = (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0)
+    check(_lib.lib().linr_linear_bwd_data(gout.data_ptr(), gout.stride(0), n, w.data_ptr() + 4 * w_off, ws_ci, ws_co, cin, cout,
+                                          0 if act is None else act.data_ptr(), 0 if act is None else act.stride(0),
+                                          out.data_ptr(), out.stride(0), flags, _stream()), 'linr_linear_bwd_data')
+
+
+def _lin_bwd_weight(x, gout, cin, cout, gw, gw_off, ws_ci, ws_co, gb):
+    n = x.shape[0]
+    L = _lib.lib()
+    ws = _lib.scratch(max(L.linr_linear_bwd_weight_workspace_bytes(n, cin, cout), 4), x.device)
+    check(L.linr_linear_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), n, cin, cout,
+                                   gw.data_ptr() + 4 * gw_off, ws_ci, ws_co, 0 if gb is None else gb.data_ptr(), 0, ws.data_ptr(),
+                                   ws.numel(), _stream()), 'linr_linear_bwd_weight')
+
+
+def _axpy(src, dst, accumulate=True):
+    check(_lib.lib().linr_axpy(src.data_ptr(), src.numel(), dst.data_ptr(), 1 if accumulate else 0, _stream()), 'linr_axpy')
+
+
+class _Conv:
+    """A 3x3x3 convolution Ci -> Co on blocked activations.  xs: Ci / 8 blocks (or one block with Ci < 8 live channels)."""
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.ci, self.co = mod.kernel.shape[1], mod.kernel.shape[2]
+        self.nbi, self.nbo = (self.ci + B - 1) // B, self.co // B
+
+    def sub(self, bi, bo):
+        w = self.mod.kernel
+        return w[:, B * bi:min(B * bi + B, self.ci), B * bo:B * bo + B].contiguous()
+
+    def fwd(self, net, xs, relu=False, res=None):
+        n = xs[0].shape[0]
+        outs = _blocks(n, self.nbo, xs[0].device)
+        bias = self.mod.bias
+        for bo in range(self.nbo):
+            for bi in range(self.nbi):
+                last = bi == self.nbi - 1
+                ops.spconv_cmap(xs[bi], net.lo, net.mask, n, self.sub(bi, bo), bias[0, B * bo:B * bo + B] if bi == 0 else None,
+                                res=res[bo] if (res is not None and last) else None, relu=relu and last, out=outs[bo],
+                                accumulate=bi > 0)
+        return outs
+
+    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True):
+        """Parameter gradients into .grad; input gradient (masked by act > 0: the ReLU that produced xs) accumulated into
+        gins (list of (buffer, has_content)) or returned as fresh blocks."""
+        n = gouts[0].shape[0]
+        gk, gbias = self.mod.kernel.grad, self.mod.bias.grad
+        for bi in range(self.nbi):
+            cw = min(B, self.ci - B * bi)
+            for bo in range(self.nbo):
+                gw, gb = ops.spconv_bwd_weight(xs[bi], gouts[bo], net.nbr, cw, B, pad_row=True)
+                gk[:, B * bi:B * bi + cw, B * bo:B * bo + B].copy_(gw)
+                if bi == 0:
+                    gbias[0, B * bo:B * bo + B].copy_(gb.reshape(-1))
+        if not need_input_grad:
+            return None
+        fresh = gins is None
+        if fresh:
+            gins = [[g, False] for g in _blocks(n, self.nbi, gouts[0].device)]
+        for bi in range(self.nbi):
+            for bo in range(self.nbo):
+                last = bo == self.nbo - 1
+                ops.spconv_cmap(gouts[bo], net.lo, net.mask, n, self.sub(bi, bo), None, bwd=True,
+                                act=act[bi] if (act is not None and last) else None, out=gins[bi][0],
+                                accumulate=gins[bi][1] or bo > 0)
+            gins[bi][1] = True
+        return [g for g, _ in gins] if fresh else None
+
+
+class _Pointwise:
+    """A 1x1 convolution (ME layout [Cin][Cout]) or an nn.Linear (torch layout [Cout][Cin]) on blocked inputs; the output is
+    blocked when cout is a multiple of 8, else one [n, cout] matrix."""
+
+    def __init__(self, weight, bias, cin, cout, layout, blocked_out=True):
+        self.w, self.b, self.cin, self.cout, self.layout = weight, bias, cin, cout, layout
+        self.nbi = cin // B
+        self.blocked_out = blocked_out and cout % B == 0
+        self.nbo = cout // B if self.blocked_out else 1
+        self.cw = B if self.blocked_out else cout
+
+    def _addr(self, bi, bo):
+        if self.layout == 'me':
+            return (B * bi) * self.cout + self.cw * bo, self.cout, 1
+        return (self.cw * bo) * self.cin + B * bi, 1, self.cin
+
+    def fwd(self, xs, relu=False, res=None, padded=True):
+        n, dev = xs[0].shape[0], xs[0].device
+        outs = _blocks(n, self.nbo, dev) if (self.blocked_out and padded) else \
+            [torch.empty((n, self.cw), dtype=torch.float32, device=dev) for _ in range(self.nbo)]
+        bflat = self.b.reshape(-1)
+        for bo in range(self.nbo):
+            for bi in range(self.nbi):
+                off, ws_ci, ws_co = self._addr(bi, bo)
+                last = bi == self.nbi - 1
+                _lin(xs[bi], self.w, off, ws_ci, ws_co, bflat[self.cw * bo:self.cw * bo + self.cw] if bi == 0 else None, B, self.cw,
+                     outs[bo], res=res[bo] if (res is not None and bi == 0) else None, relu=relu and last, accumulate=bi > 0)
+        return outs
+
+    def bwd(self, xs, gouts, gins=None, act=None, need_input_grad=True):
+        n = gouts[0].shape[0]
+        gw, gb = self.w.grad, self.b.grad.reshape(-1)
+        for bi in range(self.nbi):
+            for bo in range(self.nbo):
+                off, ws_ci, ws_co = self._addr(bi, bo)
+                _lin_bwd_weight(xs[bi], gouts[bo], B, self.cw, gw, off, ws_ci, ws_co,
+                                gb[self.cw * bo:self.cw * bo + self.cw] if bi == 0 else None)
+        if not need_input_grad:
+            return None
+        fresh = gins is None
+        if fresh:
+            gins = [[g, False] for g in _blocks(n, self.nbi, gouts[0].device)]
+        for bi in range(self.nbi):
+            for bo in range(self.nbo):
+                off, ws_ci, ws_co = self._addr(bi, bo)
+                last = bo == self.nbo - 1
+                _lin_bwd_data(gouts[bo], self.w, off, ws_ci, ws_co, B, self.cw, gins[bi][0],
+                              act=act[bi] if (act is not None and last) else None, accumulate=gins[bi][1] or bo > 0)
+            gins[bi][1] = True
+        return [g for g, _ in gins] if fresh else None
+
+
+class _Block:
+    """make_block (models/upsample.py:88-97): conv3 -> ReLU -> ResNetBlock (Inception layers) -> conv3."""
+
+    def __init__(self, seq, C):
+        self.C, self.h = C, C // 2
+        self.first, self.tail = _Conv(seq[0]), _Conv(seq[3])
+        self.layers = []
+        for lay in seq[2].layers:
+            h = self.h
+            self.layers.append({'c00': _Conv(lay.conv0_0), 'c01': _Conv(lay.conv0_1),
+                                'c10': _Pointwise(lay.conv1_0.kernel, lay.conv1_0.bias, C, h, 'me'), 'c11': _Conv(lay.conv1_1),
+                                'c12': _Pointwise(lay.conv1_2.kernel, lay.conv1_2.bias, h, h, 'me')})
+
+    def fwd(self, net, xs, res=None):
+        nh = self.h // B
+        a = self.first.fwd(net, xs, relu=True)
+        tape = {'in': xs, 'a': a, 'layers': []}
+        x = a
+        for q in self.layers:
+            h0 = q['c00'].fwd(net, x, relu=True)
+            h1 = q['c10'].fwd(x, relu=True)
+            i_lo = q['c01'].fwd(net, h0, res=x[:nh])
+            m = q['c11'].fwd(net, h1, relu=True)
+            i_hi = q['c12'].fwd(m, res=x[nh:])
+            tape['layers'].append({'x': x, 'h0': h0, 'h1': h1, 'm': m})
+            x = i_lo + i_hi
+        if len(self.layers) > 1:           # ResNetBlock.forward: out += x (models/resnet.py:160-161)
+            for blk, ab in zip(x, a):
+                _axpy(ab, blk)
+        tape['il'] = x
+        return self.tail.fwd(net, x, res=res), tape
+
+    def bwd(self, net, tape, g_out, need_input_grad):
+        """g_out: gradient blocks of the block output.  Returns the input gradient blocks (or None)."""
+        nh = self.h // B
+        n, dev = g_out[0].shape[0], g_out[0].device
+        g_il = self.tail.bwd(net, tape['il'], g_out)
+        g_a = None
+        if len(self.layers) > 1:           # the extra skip: a receives g_il as well
+            g_a = _blocks(n, self.C // B, dev)
+            for s, d in zip(g_il, g_a):
+                _axpy(s, d, accumulate=False)
+        g_i = g_il
+        for q, t in zip(reversed(self.layers), reversed(tape['layers'])):
+            x = t['x']
+            # the layer's input gradient starts as the residual's share: a copy of g_i
+            g_x = _blocks(n, self.C // B, dev)
+            for s, d in zip(g_i, g_x):
+                _axpy(s, d, accumulate=False)
+            gx = [[g, True] for g in g_x]
+            g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
+            g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'])
+            q['c10'].bwd(x, g_h1, gins=gx)
+            g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'])
+            q['c00'].bwd(net, x, g_h0, gins=gx)
+            g_i = g_x
+        if g_a is not None:
+            for s, d in zip(g_a, g_i):
+                _axpy(s, d)
+        # g_i is the gradient of a = relu(first conv): mask and go through the first convolution
+        for g, ab in zip(g_i, tape['a']):
+            _mask_inplace(g, ab)
+        return self.first.bwd(net, tape['in'], g_i, need_input_grad=need_input_grad)
+
+
+def _mask_inplace(g, act):
+    """g *= (act > 0) through the pointwise kernel's ReLU-mask epilogue on an identity-free path: g = 0 * W + g masked."""
+    # linr_linear_bwd_data with cin = cout = 8, a zero weight block, accumulate and mask: out = (0 + old) * (act > 0)
+    z = _zeros_w(g.device)
+    _lin_bwd_data(g, z, 0, 8, 1, B, B, g, act=act, accumulate=True)
+
+
+_ZW = {}
+
+
+def _zeros_w(dev):
+    key = str(dev)
+    if key not in _ZW:
+        _ZW[key] = torch.zeros(64, dtype=torch.float32, device=dev)
+    return _ZW[key]
+
+
+class WideNet:
+    def __init__(self, model, hidden):
+        if hidden % 16 != 0 or hidden > 32:
+            raise ValueError('hidden_channel_conv must be 8 (the tuned kernels) or 16 / 32 (channel-blocked executor), got %d' % hidden)
+        self.model, self.C = model, hidden
+        self._built = False
+
+    def _build(self):
+        up = self.model.upsampler
+        C = self.C
+        self.block_in = _Block(up.block_in, C)
+        self.outter = [_Block(b, C) for b in up.outter_blocks]
+        self.prune = [_Conv(p[0].conv) for p in up.prune_blocks]
+        self.heads = []
+        for mlp in up.inner_mlps:
+            lin0, lin2 = mlp[0][0], mlp[0][2]                # PointwiseMLP([C, 24, 1]) = Linear, ReLU, Linear
+            self.heads.append((_Pointwise(lin0.weight, lin0.bias, C, 24, 'torch', blocked_out=False), lin2))
+        self._built = True
+
+    # ---- shared pieces ------------------------------------------------------------------------------------------------
+    def _bind(self, frame):
+        if not self._built:
+            self._build()
+        # the op-level wrappers take the row count from the table's width: a view of its first `rows` columns (same stride)
+        self.nbr, self.lo, self.mask = frame.nbr[:, :frame.rows], frame.nbr_lo, frame.nbr_mask
+        self.n = frame.rows
+
+    def _scale_context(self, frame, keep):
+        """x0 [rows, 8] (one block): PointwiseMLP([15, 16, 8]) of the rows' scale on [emb | offset features] (model_core.py:48-53)."""
+        m = self.model
+        x0 = _blocks(frame.rows, 1, frame.device)
+        tape = []
+        for j in range(frame.n_scales):
+            r0, r1 = int(frame.row_off[j]), int(frame.row_off[j + 1])
+            if r1 == r0:
+                continue
+            si = int(frame.scale_idx[j])
+            lin0, lin2 = m.scale_mlp[si][0], m.scale_mlp[si][2]
+            mix = torch.cat([m.scale_emb.weight[si].detach().unsqueeze(0).expand(r1 - r0, -1), frame.offset_feat[r0:r1]], dim=1).contiguous()
+            hid = ops.linear_fwd(mix, lin0.weight, lin0.bias, 15, 16, 'torch', relu=True)
+            ops.linear_fwd(hid, lin2.weight, lin2.bias, 16, 8, 'torch', out=x0[0][r0:r1])
+            if keep:
+                tape.append((si, r0, r1, mix, hid))
+        return x0, tape
+
+    def _occ_block(self, frame):
+        return [frame.occ]                     # [rows, 8] view of a buffer with the zero row in front (engine.Frame)
+
+    def _head(self, k, prior, frame, keep):
+        n = frame.rows
+        c = self.prune[k].fwd(self, prior)
+        lin0, lin2 = self.heads[k]
+        hh = lin0.fwd(c, relu=True, padded=False)[0]
+        z = ops.linear_fwd(hh, lin2.weight, lin2.bias, 24, 1, 'torch').reshape(n)
+        return z, ({'prior': prior, 'c': c, 'hh': hh} if keep else None)
+
+    # ---- forward ---------------------------------------------------------------------------------------------------------
+    def forward(self, frame, k0, k1, probs, bits, keep=False):
+        """Stages [k0, k1) teacher-forced on frame.occ (decoder: the columns decoded so far): probs [8, rows] rows k0..k1-1, bits
+        (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8)."""
+        self._bind(frame)
+        if frame.rows == 0:
+            return None
+        x0, sce_tape = self._scale_context(frame, keep)
+        xg, bin_tape = self.block_in.fwd(self, x0)
+        tape = {'sce': sce_tape, 'bin': bin_tape, 'xg': xg, 'stages': []} if keep else None
+        for k in range(k0, k1):
+            blk_tape = None
+            if k == 0:
+                prior = xg
+            else:
+                occ = self._occ_block(frame)
+                prior, blk_tape = self.outter[k - 1].fwd(self, occ, res=xg)
+            z, head_tape = self._head(k, prior, frame, keep)
+            target = frame.occ[:, k]
+            p, b = ops.bce_bits_fwd(z, target)
+            if probs is not None:
+                probs[k].copy_(p)
+            if bits is not None:
+                _axpy_f64(b, bits)
+            if keep:
+                head_tape.update({'p': p, 'blk': blk_tape})
+                tape['stages'].append(head_tape)
+        return tape
+
+    # ---- backward --------------------------------------------------------------------------------------------------------
+    def backward(self, frame, tape, gscale):
+        """d (gscale * bits) / d params into the parameters' .grad (model._ensure_grad_views(): views of the flat gradient)."""
+        self._bind(frame)
+        self.model._ensure_grad_views()
+        n, dev = frame.rows, frame.device
+        C = self.C
+        gz_scale = float(gscale) * 1.4426950408889634          # d(bits)/d(nats) = 1 / ln 2
+        g_xg = [[g, False] for g in _blocks(n, C // B, dev)]
+        for k in range(7, -1, -1):
+            st = tape['stages'][k]
+            lin0, lin2 = self.heads[k]
+            gz = ops.bce_bits_bwd(st['p'], frame.occ[:, k], gz_scale).reshape(n, 1)
+            gw2, gb2 = ops.linear_bwd_weight(st['hh'], gz, 24, 1, 'torch')
+            lin2.weight.grad.copy_(gw2)
+            lin2.bias.grad.copy_(gb2)
+            g_hh = ops.linear_bwd_data(gz, lin2.weight, 24, 1, 'torch', act=st['hh'])
+            g_c = lin0.bwd(st['c'], [g_hh])
+            if k == 0:
+                self.prune[k].bwd(self, st['prior'], g_c, gins=g_xg)
+            else:
+                g_prior = self.prune[k].bwd(self, st['prior'], g_c)
+                for s, d in zip(g_prior, g_xg):                     # prior_k = x_glob + block output: both receive g_prior
+                    _axpy(s, d[0], accumulate=d[1])
+                    d[1] = True
+                self.outter[k - 1].bwd(self, st['blk'], g_prior, need_input_grad=False)
+        g_x0 = self.block_in.bwd(self, tape['bin'], [g for g, _ in g_xg], need_input_grad=True)[0]
+        m = self.model
+        m.scale_emb.weight.grad.zero_()
+        for si, r0, r1, mix, hid in tape['sce']:
+            lin0, lin2 = m.scale_mlp[si][0], m.scale_mlp[si][2]
+            g = g_x0[r0:r1]
+            gw, gb = ops.linear_bwd_weight(hid, g, 16, 8, 'torch')
+            lin2.weight.grad.copy_(gw)
+            lin2.bias.grad.copy_(gb)
+            g_hid = ops.linear_bwd_data(g, lin2.weight, 16, 8, 'torch', act=hid)
+            gw, gb = ops.linear_bwd_weight(mix, g_hid, 15, 16, 'torch')
+            lin0.weight.grad.copy_(gw)
+            lin0.bias.grad.copy_(gb)
+            # the embedding row is a constant input of every row of its scale: its gradient is the column sums of the input
+            # gradient's first 8 channels = W1[:, :8]^T gb1 (what sce_emb_grad_all_k computes for the 8-wide model)
+            g_mix = ops.linear_bwd_data(g_hid, lin0.weight, 15, 16, 'torch')
+            ones = torch.ones((r1 - r0, 1), dtype=torch.float32, device=dev)
+            gemb, _ = ops.linear_bwd_weight(ones, g_mix[:, :8].contiguous(), 1, 8, 'me')
+            m.scale_emb.weight.grad[si].copy_(gemb.reshape(-1))
+
+
+def _axpy_f64(src, dst):
+    dst.add_(src)          # the float64[1] bits accumulator (two scalars; the per-row sums are linr_bce_bits_fwd's)

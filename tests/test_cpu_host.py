@@ -105,9 +105,11 @@ def test_state_dict_contract(golden_dir):
     m.load_state_dict(new)
     assert torch.equal(m.flat_parameters(), torch.from_numpy(g['flat']))          # parameters() order == flat order
     assert torch.equal(torch.cat([p.reshape(-1) for p in m.parameters()]), m.flat_parameters())
-    with pytest.raises(ValueError, match='hidden_channel_conv=16 is not supported'):
-        LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 16, 'block_layers': 1, 'outstage': 8,
+    with pytest.raises(ValueError, match='hidden_channel_conv=12 is not supported'):          # 8, 16, 32 are (tests/test_gpu_wide.py)
+        LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 12, 'block_layers': 1, 'outstage': 8,
                          'instage': 1})
+    wide = LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 16, 'block_layers': 1, 'outstage': 8, 'instage': 1})
+    assert wide.state_dict()['upsampler.block_in.3.kernel'].shape == (27, 16, 16) and wide.flat_parameters().numel() == 189944
     with pytest.raises(ValueError, match='block_layers'):
         LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 5, 'outstage': 8,
                          'instage': 1})

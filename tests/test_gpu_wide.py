@@ -1,0 +1,178 @@
+"""hidden_channel_conv = 16 (main.py:520; models/upsample.py:38-76, models/resnet.py:12-51): the channel-blocked executor
+(linr_pcgc_amd/wide_net.py) against the oracle - forward bits and probabilities, every parameter gradient against autograd,
+training steps against torch.optim.Adam on the oracle, and a lossless encode / decode round trip through the codec."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import network as onet          # noqa: E402
+from oracle import octree as ooct           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import linr_pcgc_amd
+    from linr_pcgc_amd import _lib
+    _lib.lib()
+    return linr_pcgc_amd
+
+
+@pytest.fixture(scope='module')
+def shell(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    scales = []
+    for s in range(int(g['scale_num'])):
+        c = g['s%d_coord' % s]
+        scales.append({'coord': c, 'occ': g['s%d_occ' % s], 'offset_tensor': g['s%d_offset' % s], 'scale_idx': s,
+                       'nbr': ooct.neighbour_table(c)})
+    return {'scales': scales, 'point_num': int(len(g['ori']))}
+
+
+def _model(hidden, scale_num=5, block_layers=1, seed=8807):
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    torch.manual_seed(seed)
+    model = LINR_PCGC_Model({'scale_num': scale_num, 'in_channel': 7, 'hidden_channel_conv': hidden, 'block_layers': block_layers,
+                             'outstage': 8, 'instage': 1})
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.cuda(), sd
+
+
+def test_wide_state_dict_has_the_reference_shapes(pkg):
+    """Names and shapes follow models/upsample.py:38-76 / models/resnet.py:12-51 with channels = 16."""
+    model, sd = _model(16)
+    assert sd['upsampler.block_in.0.kernel'].shape == (27, 8, 16)
+    assert sd['upsampler.block_in.2.layers.0.conv0_0.kernel'].shape == (27, 16, 8)
+    assert sd['upsampler.block_in.2.layers.0.conv1_0.kernel'].shape == (16, 8)
+    assert sd['upsampler.block_in.2.layers.0.conv1_2.kernel'].shape == (8, 8)
+    assert sd['upsampler.block_in.3.kernel'].shape == (27, 16, 16)
+    assert sd['upsampler.inner_mlps.3.0.0.weight'].shape == (24, 16)
+    assert sd['upsampler.prune_blocks.5.0.conv.kernel'].shape == (27, 16, 16)
+    assert sd['upsampler.outter_blocks.2.0.kernel'].shape == (27, 3, 16)
+    assert len(sd) == 181          # scale_num 5: 1 + 4 x 5 + 14 + 8 x 4 + 8 x 2 + 7 x 14 (189 at scale_num 7), as at width 8
+    with pytest.raises(ValueError):
+        _model(12)
+
+
+@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (16, 2), (32, 1)])
+def test_wide_forward_and_backward_match_the_oracle(pkg, shell, hidden, block_layers):
+    model, sd = _model(hidden, block_layers=block_layers)
+    frame = model.make_frame(shell['scales'])
+    probs, bits = model.frame_probs(frame)
+    tsc = onet.to_torch_scales(shell['scales'])
+    ref_bits = 0.0
+    for i, s in enumerate(tsc):
+        out = onet.forward_scale(sd, s)
+        sl = frame.scale_slice(i)
+        for k in range(8):
+            err = (probs[k, sl].double().cpu() - out['probs'][k].reshape(-1).double()).abs().max()
+            assert float(err) <= 1e-4, (i, k, float(err))
+        ref_bits += float(out['bits'])
+    assert abs(float(bits) - ref_bits) <= 1e-5 * ref_bits, (float(bits), ref_bits)
+    probs2, bits2 = model.frame_probs(frame)
+    assert torch.equal(probs, probs2) and torch.equal(bits, bits2), 'forward must be bit-reproducible'
+    # gradients through the executor's own tape against autograd of the oracle, every tensor against its own largest entry
+    gscale = 1.0 / shell['point_num']
+    model._ensure_grad_views()
+    model._flat_grad.zero_()
+    b = torch.zeros(1, dtype=torch.float64, device='cuda')
+    with torch.no_grad():
+        tape = model._wide.forward(frame, 0, 8, None, b, keep=True)
+        model._wide.backward(frame, tape, gscale)
+    grads = model._flat_grad.clone()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (onet.frame_bits(sdo, tsc) * gscale).backward()
+    off = 0
+    for name, v in sdo.items():
+        n = v.numel()
+        mine = grads[off:off + n].view(v.shape).double().cpu()
+        ref = torch.zeros_like(v).double() if v.grad is None else v.grad.double()
+        gmax = float(ref.abs().max())
+        assert float((mine - ref).abs().max()) <= 3e-3 * gmax + 1e-9, name
+        off += n
+    with torch.no_grad():
+        model._flat_grad.zero_()
+        tape = model._wide.forward(frame, 0, 8, None, b, keep=True)
+        model._wide.backward(frame, tape, gscale)
+    assert torch.equal(grads, model._flat_grad), 'backward must be bit-reproducible'
+
+
+def test_wide_model_surface_autograd(pkg, shell):
+    """loss = model(putin_args); loss.backward() like main.py:457-475, one scale."""
+    model, sd = _model(16)
+    s = shell['scales'][1]
+    dev = 'cuda'
+    inargs = {'coord': torch.as_tensor(s['coord']).to(dev), 'offset_tensor': torch.as_tensor(s['offset_tensor']).to(dev),
+              'occ_lst': [torch.as_tensor(s['occ'][:, k:k + 1].copy()).to(dev) for k in range(8)], 'scale_idx': 1}
+    loss = model(inargs) / 1000.0
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref = onet.forward_scale(sdo, onet.to_torch_scales([s])[0])['bits'] / 1000.0
+    assert abs(float(loss) - float(ref)) <= 1e-5 * float(ref)
+    ref.backward()
+    for (name, p) in model.named_parameters():
+        g = sdo[name].grad
+        g = torch.zeros_like(sdo[name]) if g is None else g
+        gmax = float(g.abs().max())
+        assert float((p.grad.cpu().double() - g.double()).abs().max()) <= 3e-3 * gmax + 1e-9, name
+
+
+def test_wide_train_steps_track_torch_adam_and_decode_losslessly(pkg, shell):
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, sd = _model(16)
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tsc = onet.to_torch_scales(shell['scales'])
+    pn = shell['point_num']
+    first = None
+    for it in range(4):
+        bits = train_step(model, opt, frame, pn)
+        opt_o.zero_grad()
+        b_o = onet.frame_bits(sdo, tsc)
+        (b_o / pn).backward()
+        opt_o.step()
+        assert abs(float(bits) - float(b_o)) <= 2e-4 * float(b_o), (it, float(bits), float(b_o))
+        first = float(bits) if first is None else first
+    assert first > 0          # (four Adam steps at lr 0.01 need not lower the loss yet; the oracle's trajectory is the criterion)
+    # encoder probabilities == the staged decoder's, decoded occupancy == the input
+    probs, _ = model.frame_probs(frame)
+    from linr_pcgc_amd.model_core import encode_streams
+    p_host = probs.cpu().numpy()
+    occ = np.concatenate([s['occ'] for s in shell['scales']], axis=0)
+    streams = []
+    for i in range(frame.n_scales):
+        sl = frame.scale_slice(i)
+        streams.append(encode_streams([p_host[k, sl] for k in range(8)], [occ[sl, k].astype(np.uint8) for k in range(8)]))
+    dec_frame = model.make_frame([{k: v for k, v in s.items() if k != 'occ'} for s in shell['scales']])
+    out = model.decode_frame(dec_frame, streams)
+    got = torch.cat(out, dim=1).cpu().numpy()
+    assert np.array_equal(got, occ)
+
+
+def test_wide_gop_encode_decode_roundtrip(pkg):
+    """A 2-frame GOP of the 8-bit sphere through overfit -> encode_gop -> decode_gop with hidden_channel_conv = 16: lossless."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model
+    clouds = [synthetic.sequence_frame_device('sphere8', t, 'cuda') for t in range(2)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+
+    def gen(seed=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        return LINR_PCGC_Model({'scale_num': gop.scale_num, 'in_channel': 7, 'hidden_channel_conv': 16, 'block_layers': 1,
+                                'outstage': 8, 'instage': 1}).cuda()
+    model = gen(8807)
+    losses = overfit.overfit_gop(model, FlatAdam(model), gop, 3)
+    assert losses[-1] < losses[0]
+    enc = codec.encode_gop(model, gen(), gop, 8)
+    dec = codec.decode_gop(gen(), enc, 'cuda', workers=1)
+    for i in range(2):
+        ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
+        assert torch.equal(dec[i], ref)
