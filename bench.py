@@ -568,6 +568,27 @@ def main():
         decode_pts[w] = best
     log('decode: %s' % {k: round(v, 4) for k, v in decode_pts.items()})
 
+    # --hidden_channel_conv 16 (main.py:520): the channel-blocked executor on the 8-wide kernels, a few training steps on frame 0.
+    # Reported beside the headline (which is the reference's default width 8), never instead of it.
+    wide_leg = None
+    if rank == 0 and not os.environ.get('LINR_SKIP_WIDE'):
+        try:
+            mw = overfit.gen_model(gop.scale_num, 'cuda', seed=8807, hidden=16)
+            ow = FlatAdam(mw)
+            bw = torch.zeros(1, dtype=torch.float64, device='cuda')
+            for _ in range(2):
+                train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(5):
+                train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
+            torch.cuda.synchronize()
+            wide_leg = {'hidden_channel_conv': 16, 'ms_per_step': round((time.time() - t0) * 1e3 / 5, 2), 'parameters': int(mw.flat_parameters().numel()),
+                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py): the 8-wide kernels on 8-channel blocks, not tuned'}
+            del mw, ow
+        except Exception as e:
+            wide_leg = {'error': repr(e)}
+        log('hidden_channel_conv 16: %s' % wide_leg)
     # bf16 / uint8-weight codec leg (BASELINE config[4]'s numerics on this workload): the SAME trained model coded with the
     # bf16 executor (features bf16, weights as the uint8 codes of model.bin, de-quantised in-kernel).  Reported beside the fp32
     # headline, never instead of it.
@@ -652,6 +673,7 @@ def main():
                                           'decode_s_per_frame_8_in_flight': round(decode_pts.get(8, 0.0), 4),
                                           'decode_gop_setup_s': round(decode_pts.get('gop_setup_s', 0.0), 4)},
                'bf16_codec': bf16_leg,
+               'hidden16': wide_leg,
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
