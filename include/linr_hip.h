@@ -123,6 +123,11 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
 LINR_API int64_t linr_spconv_wgrad_cmap_blocks(void);
 LINR_API int linr_spconv_wgrad_cmap(const float* in, int32_t in_ld, const float* gout, int32_t gout_ld, const int32_t* nbr,
                            const int32_t* tile8t, int64_t ld, int64_t n, int32_t cin, int32_t cout, float* slab, void* stream);
+/* Fixed-order sum over the rows of a [nblocks][elems] slab of per-block partials (the form linr_spconv_wgrad_cmap, _wgrad_dual44,
+ * _bwd_fused, linr_occ_wgrad7 ... return): elements [0, split) to dstA, [split, elems) to dstB (either may be NULL);
+ * LINR_ACCUM adds to the destination.  16 threads per element, slices added in order: bit-reproducible. */
+LINR_API int linr_slab_reduce(const float* slab, int32_t nblocks, int32_t elems, int32_t split, float* dstA, float* dstB,
+                     uint32_t flags, void* stream);
 /* The tiled copy of the kernel map in the lane order of the transposing kernel: tile8t[g][t][u][j] = nbr[tap(4 j + t)][8 g + u]
  * (-1 for position 27, j = 7, beyond n), tap(p) = p / 9 + 3 * ((p / 3) % 3) + 9 * (p % 3): the conv family's slab-major tap
  * sequence, so that the four taps of one gather instruction are neighbours in memory.  tile8t: linr_kmap_tile8t_bytes(n) bytes,

@@ -41,6 +41,7 @@ _PROTOS = {
     'linr_spconv_bwd_fused': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_ptr]),
     'linr_inception_bwd_fused': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
                                                 ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr, c_u32, c_ptr, c_i32, c_ptr]),
+    'linr_slab_reduce': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_u32, c_ptr]),
     'linr_axpy': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i32, c_ptr]),
     'linr_occ_wgrad7': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_ptr, c_ptr]),
     'linr_kmap_tile8t_bytes': (c_size, [c_i64]),

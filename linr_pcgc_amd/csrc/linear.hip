@@ -216,22 +216,33 @@ int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int
     return LINR_EINVAL;
 }
 
+#define LR_ELEMS 16
+#define LR_SLICES (LINR_BLOCK / LR_ELEMS)
+// 16 threads per element (block slices in four interleaved chains, slices added in order): as slab_reduce_k of spconv.hip
 __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* __restrict__ slab, int nblocks, int cin,
                                                                    int cout, float* __restrict__ gW, int ws_ci,
                                                                    int ws_co, float* __restrict__ gb, unsigned flags) {
-    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
+    __shared__ float part[LR_SLICES][LR_ELEMS + 1];
+    const int el = threadIdx.x % LR_ELEMS, sl = threadIdx.x / LR_ELEMS;
+    const int e = blockIdx.x * LR_ELEMS + el;
     const int elems = (cin + 1) * cout;
-    if (e >= elems) return;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += slab[(int64_t)(b + 0) * elems + e];
-        s1 += slab[(int64_t)(b + 1) * elems + e];
-        s2 += slab[(int64_t)(b + 2) * elems + e];
-        s3 += slab[(int64_t)(b + 3) * elems + e];
+    if (e < elems) {
+        int b = sl;
+        for (; b + 3 * LR_SLICES < nblocks; b += 4 * LR_SLICES) {
+            s0 += slab[(int64_t)(b + 0 * LR_SLICES) * elems + e];
+            s1 += slab[(int64_t)(b + 1 * LR_SLICES) * elems + e];
+            s2 += slab[(int64_t)(b + 2 * LR_SLICES) * elems + e];
+            s3 += slab[(int64_t)(b + 3 * LR_SLICES) * elems + e];
+        }
+        for (; b < nblocks; b += LR_SLICES) s0 += slab[(int64_t)b * elems + e];
     }
-    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * elems + e];
-    const float s = (s0 + s1) + (s2 + s3);
+    part[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || e >= elems) return;
+    float s = part[0][el];
+#pragma unroll
+    for (int q = 1; q < LR_SLICES; ++q) s += part[q][el];
     const int ci = e / cout, co = e % cout;
     float* d = (ci < cin) ? (gW ? gW + ci * ws_ci + co * ws_co : nullptr) : (gb ? gb + co : nullptr);
     if (d == nullptr) return;
@@ -262,7 +273,7 @@ extern "C" int linr_linear_bwd_weight(const float* in, int32_t in_ld, const floa
     LinrLinDst d = {(float*)ws, (int64_t)(cin + 1) * cout, 0, cout, 1, (int64_t)cin * cout};
     int rc = linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, nb, s);
     if (rc) return rc;
-    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, cin, cout, gW,
+    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LR_ELEMS), LINR_BLOCK, 0, s>>>((const float*)ws, nb, cin, cout, gW,
                                                                                        ws_ci, ws_co, gb, flags);
     return linr_launch_rc();
 }

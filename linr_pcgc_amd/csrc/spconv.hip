@@ -241,26 +241,47 @@ __global__ __launch_bounds__(LINR_BLOCK) void spconv_bwd_weight_k(
     }
 }
 
-// second pass: element e of the slab summed over blocks; consecutive lanes own consecutive elements (coalesced),
-// four fixed interleaved partial sums keep loads in flight; the association is fixed => bit-reproducible.
+// second pass: element e of the slab summed over blocks in a fixed association => bit-reproducible.  16 threads per element:
+// thread (element, slice) sums the blocks slice, slice + 16, ... in four interleaved chains, the 16 slices are added in order
+// through LDS.  (One thread per element - 7 workgroups of 512-step serial chains for a 8->8 kernel - took 41 us per call.)
+#define SR_ELEMS 16
+#define SR_SLICES (LINR_BLOCK / SR_ELEMS)
 __global__ __launch_bounds__(LINR_BLOCK) void slab_reduce_k(const float* __restrict__ slab, int nblocks, int elems,
                                                             int split, float* __restrict__ dstA,
                                                             float* __restrict__ dstB, unsigned flags) {
-    const int e = blockIdx.x * LINR_BLOCK + threadIdx.x;
-    if (e >= elems) return;
+    __shared__ float part[SR_SLICES][SR_ELEMS + 1];
+    const int el = threadIdx.x % SR_ELEMS, sl = threadIdx.x / SR_ELEMS;
+    const int e = blockIdx.x * SR_ELEMS + el;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += slab[(int64_t)(b + 0) * elems + e];
-        s1 += slab[(int64_t)(b + 1) * elems + e];
-        s2 += slab[(int64_t)(b + 2) * elems + e];
-        s3 += slab[(int64_t)(b + 3) * elems + e];
+    if (e < elems) {
+        int b = sl;
+        for (; b + 3 * SR_SLICES < nblocks; b += 4 * SR_SLICES) {
+            s0 += slab[(int64_t)(b + 0 * SR_SLICES) * elems + e];
+            s1 += slab[(int64_t)(b + 1 * SR_SLICES) * elems + e];
+            s2 += slab[(int64_t)(b + 2 * SR_SLICES) * elems + e];
+            s3 += slab[(int64_t)(b + 3 * SR_SLICES) * elems + e];
+        }
+        for (; b < nblocks; b += SR_SLICES) s0 += slab[(int64_t)b * elems + e];
     }
-    for (; b < nblocks; ++b) s0 += slab[(int64_t)b * elems + e];
-    const float s = (s0 + s1) + (s2 + s3);
+    part[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || e >= elems) return;
+    float s = part[0][el];
+#pragma unroll
+    for (int q = 1; q < SR_SLICES; ++q) s += part[q][el];
     float* d = e < split ? (dstA ? dstA + e : nullptr) : (dstB ? dstB + (e - split) : nullptr);
     if (d == nullptr) return;
     *d = (flags & LINR_ACCUM) ? *d + s : s;
+}
+
+// the fixed-order sum of a [nblocks][elems] slab of per-block partials (what every weight-gradient entry returns): elements
+// [0, split) go to dstA, the rest to dstB (kernel | bias)
+extern "C" int linr_slab_reduce(const float* slab, int32_t nblocks, int32_t elems, int32_t split, float* dstA, float* dstB,
+                                uint32_t flags, void* stream) {
+    if (nblocks < 1 || elems < 1 || split < 0 || split > elems) return LINR_EINVAL;
+    if (!slab || (!dstA && !dstB) || (flags & ~LINR_ACCUM)) return LINR_EINVAL;
+    slab_reduce_k<<<linr_grid(elems, SR_ELEMS), LINR_BLOCK, 0, (hipStream_t)stream>>>(slab, nblocks, elems, split, dstA, dstB, flags);
+    return linr_launch_rc();
 }
 
 // ---- backward-weight v3: no LDS staging, wave-per-row-group ---------------------------------------------------------
@@ -410,7 +431,7 @@ static int launch_bwd_weight(const float* in, int in_ld, const float* gout, int 
     const int nb = linr_reduce_blocks(n, BW_TILE);
     spconv_bwd_weight_k<CIN, COUT><<<nb, LINR_BLOCK, 0, s>>>(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, slab);
     const int elems = (27 * CIN + 1) * COUT;
-    slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>(slab, nb, elems, 27 * CIN * COUT, gW, gb, flags);
+    slab_reduce_k<<<linr_grid(elems, SR_ELEMS), LINR_BLOCK, 0, s>>>(slab, nb, elems, 27 * CIN * COUT, gW, gb, flags);
     return linr_launch_rc();
 }
 
@@ -433,7 +454,7 @@ extern "C" int linr_spconv_bwd_weight(const float* in, int32_t in_ld, const floa
         int rc = ((flags & LINR_PAD_ROW) && (in_ld == 4 || in_ld == 8)) ? linr_conv3_wgrad_mfma(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, s)
                                         : linr_conv3_wgrad_partial(in, in_ld, gout, gout_ld, nbr, nbr_ld, n, cin, cout, d, nb, flags, s);
         if (rc) return rc;
-        slab_reduce_k<<<linr_grid(elems, LINR_BLOCK), LINR_BLOCK, 0, s>>>((const float*)ws, nb, elems, 27 * cin * cout, gW, gb, flags);
+        slab_reduce_k<<<linr_grid(elems, SR_ELEMS), LINR_BLOCK, 0, s>>>((const float*)ws, nb, elems, 27 * cin * cout, gW, gb, flags);
         return linr_launch_rc();
     }
 #define LINR_BW_CASE(CI, CO) \

@@ -208,8 +208,10 @@ def spconv_wgrad_cmap(x, gout, nbr, n, cin, cout, slab=None, reduce=True, tile8t
           'linr_spconv_wgrad_cmap')
     if not reduce:
         return slab
-    tot = slab.sum(dim=0)
-    return tot[:27 * cin * cout].view(27, cin, cout), tot[27 * cin * cout:]
+    gw = torch.empty((27, cin, cout), dtype=torch.float32, device=x.device)
+    gb = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    check(L.linr_slab_reduce(slab.data_ptr(), nb, elems, 27 * cin * cout, gw.data_ptr(), gb.data_ptr(), 0, _stream()), 'linr_slab_reduce')
+    return gw, gb
 
 
 def spconv_bwd_fused(gout, x, lo, mask, n, kernel, nblocks=256, reduce=True):

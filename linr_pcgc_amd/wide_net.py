@@ -74,9 +74,14 @@ class _Conv:
         self.ci, self.co = mod.kernel.shape[1], mod.kernel.shape[2]
         self.nbi, self.nbo = (self.ci + B - 1) // B, self.co // B
 
-    def sub(self, bi, bo):
-        w = self.mod.kernel
-        return w[:, B * bi:min(B * bi + B, self.ci), B * bo:B * bo + B].contiguous()
+    def sub(self, net, bi, bo):
+        """Dense [27][<=8][8] copy of a block of the kernel, made once per step (forward and backward-data share it)."""
+        key = (id(self), bi, bo)
+        w = net.subs.get(key)
+        if w is None:
+            w = self.mod.kernel[:, B * bi:min(B * bi + B, self.ci), B * bo:B * bo + B].contiguous()
+            net.subs[key] = w
+        return w
 
     def fwd(self, net, xs, relu=False, res=None):
         n = xs[0].shape[0]
@@ -85,7 +90,7 @@ class _Conv:
         for bo in range(self.nbo):
             for bi in range(self.nbi):
                 last = bi == self.nbi - 1
-                ops.spconv_cmap(xs[bi], net.lo, net.mask, n, self.sub(bi, bo), bias[0, B * bo:B * bo + B] if bi == 0 else None,
+                ops.spconv_cmap(xs[bi], net.lo, net.mask, n, self.sub(net, bi, bo), bias[0, B * bo:B * bo + B] if bi == 0 else None,
                                 res=res[bo] if (res is not None and last) else None, relu=relu and last, out=outs[bo],
                                 accumulate=bi > 0)
         return outs
@@ -98,10 +103,12 @@ class _Conv:
         for bi in range(self.nbi):
             cw = min(B, self.ci - B * bi)
             for bo in range(self.nbo):
-                gw, gb = ops.spconv_bwd_weight(xs[bi], gouts[bo], net.nbr, cw, B, pad_row=True)
+                # the transposing weight-gradient kernel (coalesced gathers through the frame's tiled index table) + the fixed-order
+                # slab reduction
+                gw, gb = ops.spconv_wgrad_cmap(xs[bi], gouts[bo], net.nbr_full, n, cw, B, tile8t=net.tile8t)
                 gk[:, B * bi:B * bi + cw, B * bo:B * bo + B].copy_(gw)
                 if bi == 0:
-                    gbias[0, B * bo:B * bo + B].copy_(gb.reshape(-1))
+                    gbias[0, B * bo:B * bo + B].copy_(gb)
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -110,7 +117,7 @@ class _Conv:
         for bi in range(self.nbi):
             for bo in range(self.nbo):
                 last = bo == self.nbo - 1
-                ops.spconv_cmap(gouts[bo], net.lo, net.mask, n, self.sub(bi, bo), None, bwd=True,
+                ops.spconv_cmap(gouts[bo], net.lo, net.mask, n, self.sub(net, bi, bo), None, bwd=True,
                                 act=act[bi] if (act is not None and last) else None, out=gins[bi][0],
                                 accumulate=gins[bi][1] or bo > 0)
             gins[bi][1] = True
@@ -257,6 +264,7 @@ class WideNet:
             raise ValueError('hidden_channel_conv must be 8 (the tuned kernels) or 16 / 32 (channel-blocked executor), got %d' % hidden)
         self.model, self.C = model, hidden
         self._built = False
+        self.subs = {}
 
     def _build(self):
         up = self.model.upsampler
@@ -276,6 +284,7 @@ class WideNet:
             self._build()
         # the op-level wrappers take the row count from the table's width: a view of its first `rows` columns (same stride)
         self.nbr, self.lo, self.mask = frame.nbr[:, :frame.rows], frame.nbr_lo, frame.nbr_mask
+        self.nbr_full, self.tile8t = frame.nbr, frame.nbr8t
         self.n = frame.rows
 
     def _scale_context(self, frame, keep):
@@ -312,6 +321,7 @@ class WideNet:
         """Stages [k0, k1) teacher-forced on frame.occ (decoder: the columns decoded so far): probs [8, rows] rows k0..k1-1, bits
         (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8)."""
         self._bind(frame)
+        self.subs = {}                          # kernel blocks of this step (the parameters change between steps)
         if frame.rows == 0:
             return None
         x0, sce_tape = self._scale_context(frame, keep)
