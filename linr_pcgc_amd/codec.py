@@ -188,6 +188,8 @@ def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1, timing=Non
         dec = decode_one_frame(model, list(enc['frames'][i]), xyz_low)['dec_coord']
         return dec + torch.tensor(mins[i], device=device, dtype=torch.int32)
 
+    if getattr(model, '_wide', None) is not None:
+        workers = 1          # the channel-blocked executor keeps per-call state on the model: frames one after the other
     if workers <= 1 or len(todo) <= 1:
         return [one(i) for i in todo]
     from concurrent.futures import ThreadPoolExecutor
