@@ -848,18 +848,49 @@ def test_config4_owlii11_size_properties(pkg):
     _frame_properties(gop, overfit.gen_model(gop.scale_num, 'cuda', seed=8807), steps=2)
 
 
-@pytest.mark.parametrize('n', [1, 2, 63, 65])
+def _smallest_relu_input(sd, sc):
+    """Smallest |x| any ReLU of the network sees on this scale, from the oracle in float64.  Below ~3e-7 (inputs are O(1)) the sign of x - and with
+    it a whole term of the gradient - is decided by fp32 rounding order, so no two fp32 implementations need agree there."""
+    import types
+    seen = []
+
+    def relu(x):
+        if x.numel():
+            seen.append(float(x.detach().abs().min()))
+        return torch.relu(x)
+    shim = types.SimpleNamespace(relu=relu, linear=torch.nn.functional.linear,
+                                 binary_cross_entropy=torch.nn.functional.binary_cross_entropy)
+    keep, onet.F = onet.F, shim
+    try:
+        with torch.no_grad():
+            onet.forward_scale({k: v.double() for k, v in sd.items()}, onet.to_torch_scales([sc], torch.float64)[0])
+    finally:
+        onet.F = keep
+    return min(seen)
+
+
+@pytest.mark.parametrize('n', [1, 2, 17, 63, 64, 65, 127, 129, 255, 256, 257, 511, 1025])
 def test_tiny_and_ragged_frames(pkg, n):
-    """Edge cases: a scale with a single voxel, row counts around the wave size, and a zero-row scale."""
+    """Edge cases: a scale with a single voxel, row counts around the wave size (64), the workgroup tiles (256) and the kernels'
+    multi-tile boundaries, and a zero-row scale.  A cloud on which some ReLU input is a tie at fp32 resolution (n = 257 with the
+    first seed: 1.2e-9 at one hidden unit of head 6) is redrawn - the criterion is the oracle's, not the kernels'."""
     from linr_pcgc_amd import engine
-    rng = np.random.default_rng(n)
     model, sd = _model_and_oracle(pkg, 3)
-    c = ooct.unique_sorted(rng.integers(0, 6, size=(4 * n, 3)))[:n]
-    n = len(c)
-    scales = [{'coord': c, 'occ': (rng.random((n, 8)) < 0.5).astype(np.float32), 'offset_tensor': ooct.offset_tensor(c),
-               'scale_idx': 1},
-              {'coord': np.zeros((0, 3), np.int32), 'occ': np.zeros((0, 8), np.float32),
-               'offset_tensor': np.zeros((0, 7), np.float32), 'scale_idx': 0}]
+    side = max(6, int(round((3 * n) ** (1 / 3))) + 2)          # a box that holds n distinct voxels at ~1/3 occupancy
+    want = n
+    for attempt in range(6):
+        rng = np.random.default_rng(want + 1000 * attempt)
+        c = ooct.unique_sorted(rng.integers(0, side, size=(4 * want, 3)))[:want]
+        n = len(c)
+        scales = [{'coord': c, 'occ': (rng.random((n, 8)) < 0.5).astype(np.float32), 'offset_tensor': ooct.offset_tensor(c),
+                   'scale_idx': 1},
+                  {'coord': np.zeros((0, 3), np.int32), 'occ': np.zeros((0, 8), np.float32),
+                   'offset_tensor': np.zeros((0, 7), np.float32), 'scale_idx': 0}]
+        tie = dict(scales[0]); tie['nbr'] = ooct.neighbour_table(c)
+        if _smallest_relu_input(sd, tie) >= 3e-7:
+            break
+    else:
+        pytest.fail('six clouds in a row with a ReLU tie')
     frame = model.make_frame(scales)
     probs, bits = model.frame_probs(frame)
     sc = dict(scales[0]); sc['nbr'] = ooct.neighbour_table(c)
