@@ -31,6 +31,28 @@ __global__ __launch_bounds__(256) void gather_a(const float* __restrict__ x, con
     if (row < n) out[row] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// E  layout A3 with the loads of absent taps masked off (exec mask) instead of reading the zero row; MODE 1: index loads only
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_e(const float* __restrict__ x, const int* __restrict__ nbr, long ld, long n, float* out) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    const long r = row < n ? row : n - 1;
+    const char* base = (const char*)x;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 27; ++kk) {
+        const int k = (kk / 9) + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+        const int v = nbr[k * ld + r];
+        if (MODE == 1) { acc.x += __int_as_float(v); continue; }
+        float4 a = make_float4(0, 0, 0, 0), b = a;
+        if (v >= 0) {
+            const unsigned off = (unsigned)(v + 1) << 5;
+            a = *(const float4*)(base + off); b = *(const float4*)(base + off + 16);
+        }
+        acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
+    }
+    if (row < n) out[row] = acc.x + acc.y + acc.z + acc.w;
+}
+
 template <int ORD>
 __global__ __launch_bounds__(256) void gather_b(const float* __restrict__ x, const int* __restrict__ nbr, long ld, long n, float* out) {
     const int lane = threadIdx.x & 63;
@@ -200,7 +222,11 @@ int main() {
             h[k * ld + r] = (present && t >= 0 && t < n) ? (int)t : -1;
         }
     }
-    int* nbr; float *x, *out;
+    std::vector<int> h_all(27 * ld), h_none(27 * ld, -1);
+    for (int k = 0; k < 27; ++k) { const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1; for (long r = 0; r < n; ++r) { long t = r + 700L * dx + 27L * dy + dz; h_all[k * ld + r] = (int)(t < 0 ? 0 : t >= n ? n - 1 : t); } }
+    int *nbr, *nbr_all, *nbr_none; float *x, *out;
+    CK(hipMalloc(&nbr_all, h.size() * 4)); CK(hipMalloc(&nbr_none, h.size() * 4));
+    CK(hipMemcpy(nbr_all, h_all.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(nbr_none, h_none.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&nbr, h.size() * 4)); CK(hipMalloc(&x, (n + 1) * 32)); CK(hipMalloc(&out, n * 4));
     CK(hipMemcpy(nbr, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(x, 0, (n + 1) * 32));
@@ -211,7 +237,7 @@ int main() {
     CK(hipFuncSetAttribute((const void*)gather_d2, hipFuncAttributeMaxDynamicSharedMemorySize, (18 * D_R + 1) * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int blocks = (int)((n + 255) / 256), iters = 50;
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 18; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < iters; ++i) {
@@ -226,11 +252,17 @@ int main() {
                 else if (v == 8) gather_d2<<<512, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
                 else if (v == 9) gather_d<1><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
                 else if (v == 10) gather_d<2><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
-                else gather_d<3><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else if (v == 11) gather_d<3><<<blocks, 256, (18 * D_R + 1) * 16>>>(x, nbr, ld, n, out);
+                else if (v == 12) gather_e<0><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else if (v == 13) gather_e<1><<<blocks, 256>>>(x, nbr, ld, n, out);
+                else if (v == 14) gather_a<2><<<blocks, 256>>>(x, nbr_all, ld, n, out);
+                else if (v == 15) gather_a<2><<<blocks, 256>>>(x, nbr_none, ld, n, out);
+                else if (v == 16) gather_e<0><<<blocks, 256>>>(x, nbr_all, ld, n, out);
+                else gather_e<0><<<blocks, 256>>>(x, nbr_none, ld, n, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const char* nm[12] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges", "A3 lane=row, taps x-slab-major (dx, dy, dz)", "D  9 bands staged in LDS, taps from LDS", "D2 = D, long-lived blocks, next tile prefetched", "D without index loads (computed)", "D without band loads", "D without either (LDS + VALU only)"};
+            const char* nm[18] = {"A  lane=row, taps dz-major", "B  lane=(row,half), taps dz-major", "C  transposing layout", "A' lane=row, taps column-major", "B' lane=(row,half), taps column-major", "A'' = A' + XCD-contiguous tile ranges", "A3 lane=row, taps x-slab-major (dx, dy, dz)", "D  9 bands staged in LDS, taps from LDS", "D2 = D, long-lived blocks, next tile prefetched", "D without index loads (computed)", "D without band loads", "D without either (LDS + VALU only)", "E  = A3, absent taps masked off (no load)", "E index loads only", "A3, every tap present", "A3, every tap absent (all read the zero row)", "E, every tap present", "E, every tap absent (no gathers issued)"};
             if (rep) printf("%-40s %.2f us per pass (%ld rows, 27 taps x 32 B)\n", nm[v], ms * 1e3 / iters, n);
         }
     }
