@@ -91,10 +91,13 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     claim_dir = os.path.join(work_dir, 'claims')
     err_path = os.path.join(work_dir, 'rank0_failed')
     if rank == 0:
+        if os.path.isdir(work_dir) and (world == 1 or dist is not None):      # failure markers of an earlier run in this directory
+            for f in os.listdir(work_dir):
+                if f.endswith('_failed'):
+                    os.remove(os.path.join(work_dir, f))
         if dist is not None and world > 1:
-            for stale in (ck_path, err_path):
-                if os.path.exists(stale):
-                    os.remove(stale)
+            if os.path.exists(ck_path):
+                os.remove(ck_path)
             shutil.rmtree(claim_dir, ignore_errors=True)
         os.makedirs(ck_dir, exist_ok=True)
         os.makedirs(claim_dir, exist_ok=True)

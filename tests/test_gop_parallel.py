@@ -177,3 +177,17 @@ def test_eight_rank_rank0_failure_releases_seven_waiters():
         import pytest
         with pytest.raises(RuntimeError):
             gp.check_failures(os.path.join(tmp, 'work'))
+
+
+def test_stale_failure_markers_of_an_earlier_run_are_cleared():
+    """A job that died leaves rank*_failed files in its work directory; running again in the same directory must not trip over
+    them (run.py --out is reused in practice)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        work = os.path.join(tmp, 'work')
+        os.makedirs(work)
+        for name in ('rank0_failed', 'rank3_failed'):
+            open(os.path.join(work, name), 'w').close()
+        groups = gp.split_gops(5, 2)
+        res = gp.run_sequence(groups, work, lambda g: {'result': ('first', g[0])}, lambda g, ck: ('other', g[0]))
+        assert sorted(res) == [0, 1, 2]
+        gp.check_failures(work)          # nothing left to raise about
