@@ -1180,6 +1180,34 @@ def test_config2_sequence_300_frames_gop32(pkg, tmp_path):
     assert os.path.exists(os.path.join(out, 'result_enc', 'gop_288_299', 'bins', 'frame0011_scale0.bin'))
 
 
+def test_sequence_from_ply_files(pkg, tmp_path):
+    """The driver on a real file sequence (main.py:69-119 with a dataset directory): five PLY frames (ascii and binary, shuffled
+    vertex order, duplicated points - what read_ply_o3d + the voxel de-duplication of custom_dataset.py:259-270 accept), GOPs of
+    2 (the last one a single frame), every frame decoded from the written files and compared with the de-duplicated input."""
+    from linr_pcgc_amd import ply, run, synthetic
+    rng = np.random.default_rng(5)
+    files, clouds = [], []
+    for t in range(5):
+        xyz = synthetic.sphere_shell(7, 38 + t, centre=(64 + t, 60, 66))
+        clouds.append(xyz)
+        shuffled = np.concatenate([xyz, xyz[:100]], axis=0)[rng.permutation(len(xyz) + 100)]
+        path = str(tmp_path / ('frame_%04d.ply' % t))
+        ply.write_ply_xyz(path, shuffled, binary=bool(t % 2))
+        files.append(path)
+    out = str(tmp_path / 'seq_ply')
+    args = run.parse(['--input-glob', str(tmp_path / 'frame_*.ply'), '--frames', '5', '--gop', '2', '--first-epoch', '2',
+                      '--others-epoch', '1', '--out', out, '--decode'])
+    summary, results = run.run_sequence_job(args, 0, 1, None, files=files)
+    assert summary['gops'] == 3 and summary['lossless'] is True and sorted(results) == [0, 1, 2]
+    assert [results[g]['frames'] for g in range(3)] == [2, 2, 1]
+    assert sum(r['points'] for r in results.values()) == sum(len(c) for c in clouds)          # duplicates dropped, nothing else
+    # and once more from the files alone, like decoder.py: GOP 2 (one frame)
+    from linr_pcgc_amd import codec, overfit
+    enc = codec.read_gop(os.path.join(out, 'result_enc', 'gop_4_4'))
+    dec = codec.decode_gop(overfit.gen_model(len(enc['frames'][0]), 'cuda'), enc, 'cuda', workers=1)
+    assert np.array_equal(dec[0].cpu().numpy(), clouds[4])
+
+
 def test_config3_andrew10_two_gop_sequence(pkg, tmp_path):
     """BASELINE config[3] in miniature on one GPU: the MVUB andrew10 stand-in (10-bit 2-voxel-thick shell, 1.3 M points,
     K_eff 16-18: the densest kernel map of the configs), 64 frames in GOPs of 32, one epoch each: GOP 1 warm-starts from
