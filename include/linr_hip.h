@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 4
+#define LINR_ABI_VERSION 5
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -402,6 +402,16 @@ LINR_API int     linr_ac_decode_cdf16(const uint16_t* cdf_h, int32_t lp, int32_t
 LINR_API int linr_ac_encode_binary_batch(const float* const* prob_h, const uint8_t* const* sym_h, const int64_t* n,
                                 int32_t n_streams, uint8_t* const* out_h, const int64_t* cap,
                                 int64_t* out_len, int32_t n_threads);
+
+/* ---- frame input (host) ----------------------------------------------------------------------------------------------
+ * Body of an ASCII PLY (datautils/custom_dataset.py:9-14 read_ply_o3d - open3d's C++ reader - followed by :263-269, which keeps
+ * the rounded x, y, z).  text_h / len: the bytes BEHIND "end_header\n"; n_rows vertices of n_cols whitespace-separated numbers,
+ * one vertex per line (empty lines between vertices tolerated); cx, cy, cz: the columns of x, y, z.  xyz_h [n_rows][3] receives
+ * the values rounded to the nearest integer (ties to even, like numpy.rint).  Returns 0, or LINR_EINVAL for a short / malformed
+ * line, a non-finite coordinate or bad arguments; *rows_parsed_h (optional) = the vertices completed before the error.
+ * Host pointers only; no GPU involved; thread-safe (linr_pcgc_amd/ply.py reads the frames of a GOP on a thread pool). */
+LINR_API int linr_ply_parse_ascii(const char* text_h, size_t len, int64_t n_rows, int32_t n_cols, int32_t cx, int32_t cy,
+                         int32_t cz, int64_t* xyz_h, int64_t* rows_parsed_h);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -106,6 +106,7 @@ _PROTOS = {
                                          c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_ac_encode_cdf16': (c_i64, [c_ptr, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64]),
     'linr_ac_decode_cdf16': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
+    'linr_ply_parse_ascii': (ctypes.c_int, [c_ptr, c_size, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     'linr_ac_encode_binary_batch': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_i32]),
 }
 

@@ -21,6 +21,10 @@ if [ ! -f _obj/ac.o ] || [ ac.cpp -nt _obj/ac.o ] || [ ../../include/linr_hip.h 
   g++ -O3 -fno-math-errno -fPIC -std=c++17 -fvisibility=hidden -Wall -c ac.cpp -o _obj/ac.o &
   pids+=($!)
 fi
+if [ ! -f _obj/ply.o ] || [ ply.cpp -nt _obj/ply.o ] || [ ../../include/linr_hip.h -nt _obj/ply.o ]; then
+  g++ -O3 -fPIC -std=c++17 -fvisibility=hidden -Wall -c ply.cpp -o _obj/ply.o &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o _obj/fused_bwd.o _obj/occ_wgrad.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o _obj/fused_bwd.o _obj/occ_wgrad.o _obj/net_bf16.o _obj/decode.o _obj/ac.o _obj/ply.o -lpthread
 echo "built $(realpath $OUT)"

@@ -56,17 +56,37 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     groups = gop_parallel.split_gops(args.frames, args.gop)
     device = 'cuda'
 
-    def load_frame(t):
-        if files is not None:
-            return ply.read_points(files[t])
-        return synthetic.sequence_frame_device(args.config, t, device)
+    # file input: the frames of a GOP are read and parsed on a thread pool (ply.read_many), and where this rank's next GOP is known in
+    # advance (one rank, or the static deal) its files are read in the background while the current GOP trains
+    schedule = 'static' if stage_all else getattr(args, 'schedule', 'pull')
+    ahead = None
+    if files is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        if world == 1:
+            my_order = [0] + gop_parallel.phase_b_order(groups)
+        elif schedule == 'static':
+            my_order = ([0] if rank == 0 else []) + gop_parallel.assign_gops(groups, world)[rank]
+        else:
+            my_order = []
+        ahead = {'pool': ThreadPoolExecutor(max_workers=1), 'futures': {},
+                 'next': {tuple(groups[a]): groups[b] for a, b in zip(my_order, my_order[1:])}}
+
+    def load_group(group):
+        if files is None:
+            return [synthetic.sequence_frame_device(args.config, t, device) for t in group]
+        fut = ahead['futures'].pop(tuple(group), None)
+        clouds = fut.result() if fut is not None else ply.read_many([files[t] for t in group])
+        nxt = ahead['next'].get(tuple(group))
+        if nxt is not None and tuple(nxt) not in ahead['futures']:
+            ahead['futures'][tuple(nxt)] = ahead['pool'].submit(ply.read_many, [files[t] for t in nxt])
+        return clouds
 
     def make_opt(model):
         return FlatAdam(model, lr=args.learning_rate, weight_decay=args.decay_rate, step_size=args.step_size, gamma=args.gamma)
 
     def stage(group):
         t0 = time.time()
-        gop = overfit.Gop(None, [load_frame(t) for t in group], None, 64, device, block_layers=getattr(args, 'block_layers', 1))
+        gop = overfit.Gop(None, load_group(group), None, 64, device, block_layers=getattr(args, 'block_layers', 1))
         torch.cuda.synchronize()
         return gop, time.time() - t0
 
@@ -113,7 +133,6 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     def other_fn(group, ckpt, staged=None):
         return run_gop(group, args.others_epoch, ckpt, staged)[3]
 
-    schedule = 'static' if stage_all else getattr(args, 'schedule', 'pull')
     prepared = {}
     t_stage0 = time.time()
     if stage_all:
@@ -125,8 +144,12 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     if dist is not None:
         dist.barrier()
     t0 = time.time()
-    results = gop_parallel.run_sequence(groups, os.path.join(args.out, 'output'), first_fn, other_fn, rank, world, dist,
-                                        prepare_fn=stage, schedule=schedule, prepared=prepared)
+    try:
+        results = gop_parallel.run_sequence(groups, os.path.join(args.out, 'output'), first_fn, other_fn, rank, world, dist,
+                                            prepare_fn=stage, schedule=schedule, prepared=prepared)
+    finally:
+        if ahead is not None:
+            ahead['pool'].shutdown(wait=True)
     torch.cuda.synchronize()
     my_wall = time.time() - t0
     gop_parallel.check_failures(os.path.join(args.out, 'output'))          # a failed rank left a marker: do not wait for it below

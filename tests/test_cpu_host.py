@@ -320,3 +320,47 @@ def test_decoder_refuses_streams_of_another_arithmetic_version():
     for side in ({'arith_version': codec.ARITH_VERSION - 1}, {}):
         with pytest.raises(LinrError, match='arithmetic version'):
             codec.decode_gop(None, {'side_info': side, 'model_bin': b'', 'low_enc_bytes': b'', 'frames': []})
+
+
+def test_ascii_ply_parser_against_numpy(tmp_path):
+    """linr_ply_parse_ascii (include/linr_hip.h; read_ply_o3d of custom_dataset.py:9-14 for the ASCII files the data sets ship):
+    the same integers as numpy's text reader + rint on a loot-style body (x y z as floats, colours behind), on decimals, signs,
+    exponents, ties (round half to even), CRLF line ends, blank lines; malformed bodies raise with the line number."""
+    import ctypes
+    from linr_pcgc_amd import _lib, ply
+    rng = np.random.default_rng(11)
+    n = 5000
+    xyz = rng.integers(0, 1024, size=(n, 3))
+    cols = np.concatenate([rng.integers(0, 256, size=(n, 2)), xyz[:, 2:3], xyz[:, 0:1], rng.integers(0, 256, size=(n, 1)), xyz[:, 1:2]], axis=1)
+    head = ('ply\nformat ascii 1.0\ncomment generated\nelement vertex %d\nproperty uchar red\nproperty uchar green\nproperty float z\n'
+            'property float x\nproperty uchar blue\nproperty float y\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n' % n)
+    path = str(tmp_path / 'loot_like.ply')
+    with open(path, 'w') as f:
+        f.write(head)
+        for i, row in enumerate(cols):
+            if i % 3 == 0:
+                f.write('%d %d %.6f %.1f %d %d.000\r\n' % tuple(row))          # float spellings, CRLF
+            elif i % 3 == 1:
+                f.write('  %d\t%d %d %d  %d %d \n\n' % tuple(row))              # blanks, tabs, an empty line behind
+            else:
+                f.write('%d %d %de0 +%d %d %.3e\n' % tuple(row))               # exponent forms -> the strtod path
+    assert np.array_equal(ply.read_points(path), xyz)
+    assert all(np.array_equal(a, xyz) for a in ply.read_many([path] * 3, workers=2))
+    # rounding and signs, straight through the C entry
+    text = b'0.5 1.5 2.5\n-0.5 -1.5 -2.5\n2.4999 -7.50001 1e3\n'
+    out = np.empty((3, 3), dtype=np.int64)
+    done = ctypes.c_int64(0)
+    L = _lib.lib()
+    assert L.linr_ply_parse_ascii(text, len(text), 3, 3, 0, 1, 2, out.ctypes.data, ctypes.byref(done)) == 0 and done.value == 3
+    want = np.rint(np.loadtxt(text.decode().splitlines(), ndmin=2)).astype(np.int64)
+    assert np.array_equal(out, want) and out.tolist() == [[0, 2, 2], [0, -2, -2], [2, -8, 1000]]
+    # malformed: a short line, a word, a non-finite coordinate, fewer vertices than announced, bad column arguments
+    for bad, at in ((b'1 2 3\n4 5\n6 7 8\n', 1), (b'1 2 3\n4 x 6\n', 1), (b'1 2 nan\n', 0), (b'1 2 3\n', 1), (b'1 2 3 4\n5 6 7\n', 0)):
+        rc = L.linr_ply_parse_ascii(bad, len(bad), 2 if at else 1, 3, 0, 1, 2, out.ctypes.data, ctypes.byref(done))
+        assert rc == -1 and done.value == at, (bad, rc, done.value)
+    assert L.linr_ply_parse_ascii(text, len(text), 3, 3, 0, 1, 3, out.ctypes.data, None) == -1
+    assert L.linr_ply_parse_ascii(text, len(text), 3, 2, 0, 1, 1, out.ctypes.data, None) == -1
+    with open(str(tmp_path / 'short.ply'), 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6\n')
+    with pytest.raises(ValueError, match='line 3'):
+        ply.read_points(str(tmp_path / 'short.ply'))
