@@ -912,6 +912,48 @@ def test_tiny_and_ragged_frames(pkg, n):
         off += m
 
 
+def test_ragged_multi_scale_frame_with_colliding_coordinates(pkg):
+    """Three scales batched into one frame at row offsets that are no multiple of any tile (257 + 65 + 3 rows), drawn from the SAME
+    coordinate box: a voxel of one scale has the coordinates of another scale's neighbour, which must not become its neighbour
+    (main.py:457-475 runs the scales as separate sparse tensors).  Bits and every gradient against the per-scale oracle."""
+    from linr_pcgc_amd import engine
+    model, sd = _model_and_oracle(pkg, 3)
+    for attempt in range(6):
+        rng = np.random.default_rng(77 + attempt)
+        scales = []
+        for idx, n in ((0, 257), (1, 65), (2, 3)):
+            c = ooct.unique_sorted(rng.integers(0, 9, size=(4 * n, 3)))[:n]
+            scales.append({'coord': c, 'occ': (rng.random((len(c), 8)) < 0.5).astype(np.float32), 'offset_tensor': ooct.offset_tensor(c),
+                           'scale_idx': idx, 'nbr': ooct.neighbour_table(c)})
+        if min(_smallest_relu_input(sd, s) for s in scales) >= 3e-7:
+            break
+    else:
+        pytest.fail('six draws in a row with a ReLU tie')
+    frame = model.make_frame([{k: v for k, v in s.items() if k != 'nbr'} for s in scales])
+    assert frame.rows == 325
+    probs, bits = model.frame_probs(frame)
+    tsc = onet.to_torch_scales(scales)
+    ref = 0.0
+    for i, s in enumerate(tsc):
+        out = onet.forward_scale(sd, s)
+        sl = frame.scale_slice(i)
+        for k in range(8):
+            assert float((probs[k, sl].cpu() - out['probs'][k].reshape(-1)).abs().max()) <= 2e-6, (i, k)
+        ref += float(out['bits'])
+    assert abs(float(bits) - ref) <= 1e-5 * ref
+    grads = torch.zeros_like(model.flat_parameters())
+    engine.net_backward(frame, model.flat_parameters(), grads, 1.0)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    onet.frame_bits(sdo, tsc).backward()
+    off = 0
+    for name, v in sdo.items():
+        m = v.numel()
+        mine = grads[off:off + m].view(v.shape).cpu().double()
+        refg = torch.zeros_like(v).double() if v.grad is None else v.grad.double()
+        assert float((mine - refg).abs().max()) <= 2e-4 * float(refg.abs().max()) + 1e-6, name
+        off += m
+
+
 def test_overfit_is_run_to_run_deterministic(pkg):
     """No float atomics, fixed reduction orders: two overfits of the same GOP from the same seed end in the same bits
     (parameters, Adam moments, bitstreams)."""
