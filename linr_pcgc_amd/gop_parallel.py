@@ -80,8 +80,8 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     >= 1 call it for their first GOP BEFORE the checkpoint exists (phase-A overlap).  `prepared`: {gop index: object}
     already staged by the caller (bench.py stages everything before its timed region).
     Returns {gop_index: result} of THIS rank.  The checkpoint crosses ranks through
-    ``work_dir/<gop_0>/model.pth`` (atomic rename), like the reference.  With `dist`, rank 0 clears stale state of an
-    earlier run in work_dir behind a start-up barrier; without it the caller must pass a fresh directory."""
+    ``work_dir/<gop_0>/model.pth`` (atomic rename), like the reference.  With `dist` (behind a start-up barrier) or with a single rank,
+    rank 0 clears what an earlier run left in work_dir; several ranks without `dist` must be given a fresh directory."""
     if schedule not in ('static', 'pull'):
         raise ValueError('schedule must be static or pull')
     prepared = dict(prepared or {})
@@ -91,11 +91,14 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     claim_dir = os.path.join(work_dir, 'claims')
     err_path = os.path.join(work_dir, 'rank0_failed')
     if rank == 0:
-        if os.path.isdir(work_dir) and (world == 1 or dist is not None):      # failure markers of an earlier run in this directory
-            for f in os.listdir(work_dir):
-                if f.endswith('_failed'):
-                    os.remove(os.path.join(work_dir, f))
-        if dist is not None and world > 1:
+        if world == 1 or dist is not None:
+            # what an earlier run left in this directory: failure markers (any rank's), the GOP-0 checkpoint the other ranks poll for,
+            # and the claim files - with those in place a new run would find every GOP already taken and stop after GOP 0.  (Ranks
+            # without a barrier between them cannot clean up safely: such callers pass a fresh directory.)
+            if os.path.isdir(work_dir):
+                for f in os.listdir(work_dir):
+                    if f.endswith('_failed'):
+                        os.remove(os.path.join(work_dir, f))
             if os.path.exists(ck_path):
                 os.remove(ck_path)
             shutil.rmtree(claim_dir, ignore_errors=True)

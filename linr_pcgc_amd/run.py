@@ -37,6 +37,8 @@ def parse(argv=None):
     ap.add_argument('--seed', type=int, default=8807)
     ap.add_argument('--out', default='/tmp/linr_out')
     ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
+    ap.add_argument('--no-stage-ahead', dest='stage_ahead', action='store_false',
+                    help='stage a GOP (file parsing, octrees, kernel maps) only when it is about to run instead of in the background during the GOP before it')
     ap.add_argument('--keep', default='best', choices=['best', 'last'],
                     help="which epoch's model is coded / handed to the next GOPs: the one with the lowest mean loss (the reference: main.py:413-426) or the last")
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
@@ -56,11 +58,13 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     groups = gop_parallel.split_gops(args.frames, args.gop)
     device = 'cuda'
 
-    # file input: the frames of a GOP are read and parsed on a thread pool (ply.read_many), and where this rank's next GOP is known in
-    # advance (one rank, or the static deal) its files are read in the background while the current GOP trains
+    # Staging (file read + parse on a thread pool, octrees, kernel maps) of this rank's NEXT GOP runs in a background thread on its own
+    # HIP stream while the current GOP trains, wherever the next GOP is known in advance: one rank, or the static deal.  (With the
+    # pull queue and several ranks the next GOP belongs to whoever is free first, so nothing is claimed ahead of time.)
     schedule = 'static' if stage_all else getattr(args, 'schedule', 'pull')
     ahead = None
-    if files is not None:
+    dev_index = torch.cuda.current_device()
+    if not stage_all and getattr(args, 'stage_ahead', True):
         from concurrent.futures import ThreadPoolExecutor
         if world == 1:
             my_order = [0] + gop_parallel.phase_b_order(groups)
@@ -68,26 +72,40 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
             my_order = ([0] if rank == 0 else []) + gop_parallel.assign_gops(groups, world)[rank]
         else:
             my_order = []
-        ahead = {'pool': ThreadPoolExecutor(max_workers=1), 'futures': {},
-                 'next': {tuple(groups[a]): groups[b] for a, b in zip(my_order, my_order[1:])}}
+        if len(my_order) > 1:
+            ahead = {'pool': ThreadPoolExecutor(max_workers=1), 'futures': {}, 'stream': torch.cuda.Stream(),
+                     'next': {tuple(groups[a]): groups[b] for a, b in zip(my_order, my_order[1:])}}
 
     def load_group(group):
         if files is None:
             return [synthetic.sequence_frame_device(args.config, t, device) for t in group]
-        fut = ahead['futures'].pop(tuple(group), None)
-        clouds = fut.result() if fut is not None else ply.read_many([files[t] for t in group])
-        nxt = ahead['next'].get(tuple(group))
-        if nxt is not None and tuple(nxt) not in ahead['futures']:
-            ahead['futures'][tuple(nxt)] = ahead['pool'].submit(ply.read_many, [files[t] for t in nxt])
-        return clouds
+        return ply.read_many([files[t] for t in group])
+
+    def build_gop(group):
+        return overfit.Gop(None, load_group(group), None, 64, device, block_layers=getattr(args, 'block_layers', 1))
+
+    def build_gop_ahead(group):
+        torch.cuda.set_device(dev_index)       # a new thread starts on device 0, whatever the rank's device is
+        with torch.cuda.stream(ahead['stream']):
+            gop = build_gop(group)
+        ahead['stream'].synchronize()          # everything the GOP holds is complete before another stream reads it
+        return gop
 
     def make_opt(model):
         return FlatAdam(model, lr=args.learning_rate, weight_decay=args.decay_rate, step_size=args.step_size, gamma=args.gamma)
 
     def stage(group):
         t0 = time.time()
-        gop = overfit.Gop(None, load_group(group), None, 64, device, block_layers=getattr(args, 'block_layers', 1))
-        torch.cuda.synchronize()
+        fut = ahead['futures'].pop(tuple(group), None) if ahead is not None else None
+        if fut is not None:
+            gop = fut.result()                 # staged in the background (its wait is what is left of it)
+        else:
+            gop = build_gop(group)
+            torch.cuda.synchronize()
+        if ahead is not None:
+            nxt = ahead['next'].get(tuple(group))
+            if nxt is not None and tuple(nxt) not in ahead['futures']:
+                ahead['futures'][tuple(nxt)] = ahead['pool'].submit(build_gop_ahead, nxt)
         return gop, time.time() - t0
 
     def run_gop(group, epochs, ckpt, staged):

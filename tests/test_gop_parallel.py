@@ -188,6 +188,9 @@ def test_stale_failure_markers_of_an_earlier_run_are_cleared():
         for name in ('rank0_failed', 'rank3_failed'):
             open(os.path.join(work, name), 'w').close()
         groups = gp.split_gops(5, 2)
-        res = gp.run_sequence(groups, work, lambda g: {'result': ('first', g[0])}, lambda g, ck: ('other', g[0]))
+        res = gp.run_sequence(groups, work, lambda g: {'result': ('first', g[0])}, lambda g, ck: ('other', g[0]), schedule='pull')
         assert sorted(res) == [0, 1, 2]
         gp.check_failures(work)          # nothing left to raise about
+        # and again in the same directory: the claim files of the first run must not make the second one stop after GOP 0
+        res = gp.run_sequence(groups, work, lambda g: {'result': ('first', g[0])}, lambda g, ck: ('other', g[0]), schedule='pull')
+        assert sorted(res) == [0, 1, 2]
