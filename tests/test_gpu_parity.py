@@ -1222,6 +1222,48 @@ def test_config2_sequence_300_frames_gop32(pkg, tmp_path):
     assert os.path.exists(os.path.join(out, 'result_enc', 'gop_288_299', 'bins', 'frame0011_scale0.bin'))
 
 
+def test_mid_test_driver_writes_the_reference_result_files(pkg, tmp_path):
+    """test_utils.Test_one_gop (test_utils.py:16-163; main.py:365-380 calls it on a checkpoint): the reference's argument dict in,
+    result.json / side_info.json / bins out, the numbers consistent with the GOP encoder's (same model codec, same low-resolution
+    payload; one stream per scale instead of eight, so the occupancy rate agrees to the coder's termination overhead)."""
+    import json
+    from linr_pcgc_amd import codec, overfit, synthetic, test_utils
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sphere_shell(7, 40 + t) for t in range(2)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    gen = lambda: overfit.gen_model(gop.scale_num, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    opt = FlatAdam(model)
+    overfit.overfit_gop(model, opt, gop, 3)
+    ck_path = str(tmp_path / 'model.pth')
+    torch.save(overfit.checkpoint(model, opt, 2, 0.0), ck_path)
+    low = codec.enc_all_frame_low_xyz(gop)
+    reading = [{'all_input_info': fr['all_input_info'], 'point_num': fr['point_num']} for fr in gop.infos]
+    args = {'model_path': ck_path, 'Gen_Model': gen, 'frame_num': 2, 'compress_model_test': Model_Estimate().compress_test,
+            'reading_data': reading, 'result_dir': str(tmp_path / '2'), 'write_flag': True, 'low_enc_ret': low}
+    res = test_utils.Test_one_gop(args)
+    assert sorted(res) == ['bpp_all', 'dec_time', 'enc_mode', 'enc_time', 'model_bpp', 'point_bpp', 'point_bpp_val', 'xyzlow_bpp']
+    assert res == json.load(open(str(tmp_path / '2' / 'result.json')))
+    side = json.load(open(str(tmp_path / '2' / 'side_info.json')))
+    assert sorted(side) == ['b', 'enc_mode', 'max_param', 'min_param', 'mu', 'xlow_enc_flags', 'xlow_enc_modes']
+    for name in ('model.bin', 'low_enc_bytes.bin', 'frame0000_scale0.bin', 'frame0001_scale%d.bin' % (gop.scale_num - 1)):
+        assert os.path.getsize(str(tmp_path / '2' / 'bins' / name)) > 0
+    enc = codec.encode_gop(model, gen(), gop, 8)
+    points = sum(gop.point_nums)          # the GOP encoder also counts its two extra side-info bytes (arith_version, precision)
+    assert abs(res['model_bpp'] + codec.EXTRA_SIDE_BITS / points - enc['bpp']['model_bpp']) < 1e-9
+    assert abs(res['xyzlow_bpp'] - enc['bpp']['xyzlow_bpp']) < 1e-12
+    # 48 streams with their length fields instead of 6 per frame: a few per cent on clouds this small
+    assert res['point_bpp'] <= enc['bpp']['point_bpp'] <= 1.05 * res['point_bpp']
+    assert abs(res['point_bpp_val'] - res['point_bpp']) <= 0.02 * res['point_bpp']          # coded size tracks the loss
+    assert abs(res['bpp_all'] - (res['point_bpp'] + res['model_bpp'] + res['xyzlow_bpp'])) < 1e-12
+    assert res['enc_time'] > 0 and res['dec_time'] > 0
+    with pytest.raises(ValueError):
+        test_utils.Test_one_gop(dict(args, low_enc_ret=None))
+    res2 = test_utils.Test_one_gop(dict(args, write_flag=False, result_dir=str(tmp_path / 'nowrite')))
+    assert res2['bpp_all'] == res['bpp_all'] and not os.path.exists(str(tmp_path / 'nowrite' / 'bins' / 'model.bin'))
+
+
 def test_sequence_from_ply_files(pkg, tmp_path):
     """The driver on a real file sequence (main.py:69-119 with a dataset directory): five PLY frames (ascii and binary, shuffled
     vertex order, duplicated points - what read_ply_o3d + the voxel de-duplication of custom_dataset.py:259-270 accept), GOPs of
