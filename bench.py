@@ -24,7 +24,6 @@ CPU baseline computes anyway is compared with the HIP forward/backward tensor by
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

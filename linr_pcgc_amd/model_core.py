@@ -11,7 +11,6 @@ Two ways in:
   * fast path used by ``overfit.py`` / ``bench.py``: ``Frame`` with all scales batched + ``train_step`` (forward,
     backward and the fused Adam update without touching autograd).
 """
-import math
 import time
 
 import numpy as np

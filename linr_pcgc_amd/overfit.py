@@ -7,7 +7,7 @@ once per epoch.
 """
 import torch
 
-from .model_core import FlatAdam, LINR_PCGC_Model, train_step
+from .model_core import LINR_PCGC_Model, train_step
 from .module_utils import prepare_frame
 
 

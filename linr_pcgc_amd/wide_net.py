@@ -13,9 +13,6 @@ training, encoding and stage-by-stage decoding, so streams decode losslessly.
 Not tuned: ~3.5x the convolution work of the 8-wide network in ~10x as many launches, unfused backward.  The 8-wide model
 (every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
 """
-import ctypes
-
-import numpy as np
 import torch
 
 from . import _lib, ops
