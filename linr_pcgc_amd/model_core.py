@@ -133,9 +133,34 @@ class LINR_PCGC_Model(nn.Module):
             self._wide._built = False                 # the parameter tensors were re-homed
 
     def _apply(self, fn, *args, **kwargs):
-        out = super()._apply(fn, *args, **kwargs)
-        self._flatten()
-        return out
+        # .cuda() / .to(device) / .cpu(): ONE conversion of the flat buffer and 189 new views instead of nn.Module's per-tensor
+        # conversion followed by a second flattening (8.5 -> 3 ms per model; the drivers build three models per GOP).  Anything that
+        # changes the dtype, and modules with buffers, take the general road.
+        flat = None
+        if self._flat is not None and not any(True for _ in self.buffers()):
+            with torch.no_grad():
+                flat = fn(self._flat)
+            if flat.dtype != torch.float32 or flat.numel() != self._flat.numel() or not flat.is_contiguous():
+                flat = None
+        if flat is None:
+            out = super()._apply(fn, *args, **kwargs)
+            self._flatten()
+            return out
+        if flat.is_cuda and self.hidden == 8 and flat.numel() != _lib.lib().linr_param_count(self.scale_num, self.block_layers):
+            raise _lib.LinrError('parameter layout mismatch with liblinr_hip.so')
+        off = 0
+        with torch.no_grad():
+            for q in self._plist:
+                n = q.numel()
+                q.data = flat[off:off + n].view(q.shape)
+                q.grad = None
+                off += n
+        self._flat, self._flat_grad, self._frame_cache = flat, None, {}
+        if self._qcodes is not None:
+            self._qcodes = self._qcodes.to(flat.device)
+        if getattr(self, '_wide', None) is not None:
+            self._wide._built = False                 # the parameter tensors were re-homed
+        return self
 
     def _ensure_grad_views(self):
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
