@@ -566,7 +566,7 @@ def main():
         if w > len(gop):
             continue
         best = 1e9
-        for rep in range(2):
+        for rep in range(3):          # best of three: a shared host has bursts that last longer than one repetition
             shell = overfit.gen_model(gop.scale_num, 'cuda')
             tm = {}
             torch.cuda.synchronize()
