@@ -44,6 +44,11 @@ def parse(argv=None):
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
                     help='arithmetic of the coding forward: f32, or bf16 features with the uint8 weight codes de-quantised in-kernel (BASELINE config[4]); travels in side_info.json')
     ap.add_argument('--decode', action='store_true', help='decode every GOP again and check it is lossless')
+    ap.add_argument('--mid-test', action='store_true',
+                    help='main.py --mid_test: measure the model through Test_one_gop (model.codec) at epochs 0..9 and every --check-freq-th '
+                         'epoch of every GOP; results under <out>/output/<gop>/<epoch>/ and <out>/output/<gop>/result.json')
+    ap.add_argument('--check-freq', type=int, default=5, help='main.py --check_freq')
+    ap.add_argument('--write-real-bitstream', action='store_true', help='main.py --write_real_bitstream: the mid-test also writes its bins at every 50th epoch')
     return ap.parse_args(argv)
 
 
@@ -116,7 +121,37 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         if ckpt is not None:
             overfit.warm_start(model, opt, ckpt)                 # main.py:241-248
         info = {}
-        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info)
+        mid = []
+
+        def mid_test(epoch, loss_mean):
+            # main.py:341-411: with --mid_test the checkpoint is written at every tested epoch (epochs 0..9 and every check_freq-th)
+            # and Test_one_gop measures it through model.codec into <out>/output/<gop>/<epoch>/ (result.json, side_info.json; the
+            # bitstream files too at every 50th epoch with --write-real-bitstream); the per-epoch list goes to <gop>/result.json
+            entry = {'epoch': epoch, 'loss_mean': loss_mean}
+            if epoch < 10 or epoch % args.check_freq == 0:
+                from .model_codec import Model_Estimate
+                from .test_utils import Test_one_gop
+                gop_dir = os.path.join(args.out, 'output', gop_parallel.gop_name(group))
+                os.makedirs(gop_dir, exist_ok=True)
+                path = os.path.join(gop_dir, 'model_mid.pth')
+                torch.save(overfit.checkpoint(model, opt, epoch, loss_mean), path)
+                gen = lambda: overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1),
+                                                hidden=getattr(args, 'hidden_channel_conv', 8))
+                out = Test_one_gop({'model_path': path, 'Gen_Model': gen, 'frame_num': len(group),
+                                    'compress_model_test': Model_Estimate().compress_test,
+                                    'reading_data': [{'all_input_info': fr['all_input_info'], 'point_num': fr['point_num']} for fr in gop.infos],
+                                    'result_dir': os.path.join(gop_dir, str(epoch)),
+                                    'write_flag': bool(args.write_real_bitstream and epoch % 50 == 0),
+                                    'low_enc_ret': codec.enc_all_frame_low_xyz(gop)})
+                entry.update({'real_bpp_all': out['bpp_all'], 'real_point_bpp': out['point_bpp'], 'point_bpp_val': out['point_bpp_val'],
+                              'model_bpp': out['model_bpp'], 'xyzlow_bpp': out['xyzlow_bpp'], 'enc_time': out['enc_time'],
+                              'dec_time': out['dec_time'], 'enc_mode': out['enc_mode'], 'model_bitdepth_final': 8})
+                with open(os.path.join(gop_dir, 'result.json'), 'w') as f:
+                    json.dump(mid + [entry], f, indent=4)
+            mid.append(entry)
+
+        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info,
+                                     on_epoch=mid_test if getattr(args, 'mid_test', False) else None)
         torch.cuda.synchronize()
         t1 = time.time()
         enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)), gop, 8,
@@ -139,6 +174,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                   'coded_epoch': info['coded_epoch'], 'coded_loss': info['coded_loss'],
                   'bpp': enc['bpp'], 'points': enc['point_num'], 'lossless': ok, 'stage_s': stage_s, 'overfit_s': t1 - t0,
                   'encode_s': t2 - t1, 'decode_s': t3 - t2, 'seconds': stage_s + (t3 - t0), 'rank': rank}
+        if mid:
+            result['mid_test'] = mid
         del gop
         return model, opt, losses, result, info
 

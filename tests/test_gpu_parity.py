@@ -1264,6 +1264,28 @@ def test_mid_test_driver_writes_the_reference_result_files(pkg, tmp_path):
     assert res2['bpp_all'] == res['bpp_all'] and not os.path.exists(str(tmp_path / 'nowrite' / 'bins' / 'model.bin'))
 
 
+def test_run_with_mid_test_matches_the_plain_run(pkg, tmp_path):
+    """run.py --mid-test (main.py --mid_test, :341-411): Test_one_gop at every epoch < 10 into <out>/output/<gop>/<epoch>/ and the
+    per-epoch list in <gop>/result.json - and the training it observes is bit for bit the training of a run without it."""
+    import json
+    from linr_pcgc_amd import run
+    base = ['--config', 'sphere8', '--frames', '4', '--gop', '2', '--first-epoch', '3', '--others-epoch', '2']
+    s0, r0 = run.run_sequence_job(run.parse(base + ['--out', str(tmp_path / 'plain')]), 0, 1, None)
+    s1, r1 = run.run_sequence_job(run.parse(base + ['--out', str(tmp_path / 'mid'), '--mid-test']), 0, 1, None)
+    assert [r0[g]['loss'] for g in (0, 1)] == [r1[g]['loss'] for g in (0, 1)] and s0['bits_per_point'] == s1['bits_per_point']
+    for g, name, epochs in ((0, 'gop_0_1', 3), (1, 'gop_2_3', 2)):
+        lst = json.load(open(str(tmp_path / 'mid' / 'output' / name / 'result.json')))
+        assert [e['epoch'] for e in lst] == list(range(epochs)) and lst == r1[g]['mid_test']
+        for e in lst:
+            one = json.load(open(str(tmp_path / 'mid' / 'output' / name / str(e['epoch']) / 'result.json')))
+            assert one['bpp_all'] == e['real_bpp_all']
+            # the loss of the epoch is the mean over its steps, the mid-test sees the state behind the last one (quantised)
+            assert e['point_bpp_val'] < e['loss_mean'] and abs(e['real_point_bpp'] - e['point_bpp_val']) <= 0.03 * e['point_bpp_val']
+            assert not os.path.exists(str(tmp_path / 'mid' / 'output' / name / str(e['epoch']) / 'bins' / 'model.bin'))
+        assert lst[-1]['real_bpp_all'] < lst[0]['real_bpp_all']          # it is learning, and the mid-test sees it
+    assert 'mid_test' not in r0[0]
+
+
 def test_sequence_from_ply_files(pkg, tmp_path):
     """The driver on a real file sequence (main.py:69-119 with a dataset directory): five PLY frames (ascii and binary, shuffled
     vertex order, duplicated points - what read_ply_o3d + the voxel de-duplication of custom_dataset.py:259-270 accept), GOPs of
