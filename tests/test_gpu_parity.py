@@ -335,9 +335,9 @@ def _grads_close_per_tensor(grads, sdo, rtol=3e-3, floor=1e-9, sd64=None):
     return worst
 
 
-@pytest.mark.parametrize('block_layers', [1, 2, 3])
+@pytest.mark.parametrize('block_layers', [1, 2, 3, 4])
 def test_net_backward_matches_autograd(pkg, shell, block_layers):
-    """bits and all parameter gradients against autograd through the oracle, for --block_layers 1, 2, 3
+    """bits and all parameter gradients against autograd through the oracle, for --block_layers 1..4
     (main.py:521; models/resnet.py:156-162 incl. the extra skip when > 1)."""
     from linr_pcgc_amd import engine
     model, sd = _model_and_oracle(pkg, 5, block_layers=block_layers)
@@ -360,7 +360,7 @@ def test_net_backward_matches_autograd(pkg, shell, block_layers):
     assert torch.equal(grads, grads2), 'backward must be bit-reproducible'
 
 
-@pytest.mark.parametrize('block_layers', [2, 3])
+@pytest.mark.parametrize('block_layers', [2, 3, 4])
 def test_block_layers_train_and_lossless(pkg, shell, block_layers):
     """--block_layers > 1 end to end: 4 fused train steps track torch.optim.Adam on the oracle, the staged decoder
     reproduces the encoder's probabilities bit for bit and decodes the occupancy losslessly."""
