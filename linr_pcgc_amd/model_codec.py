@@ -115,6 +115,11 @@ def decompress_params(enc_out, n, with_symbols=False):
     return (out, np.asarray(q)) if with_symbols else out
 
 
+def esti_model_size(model):
+    """model_size_est.py:30-36: the uncompressed size of the model in bits (32 per parameter)."""
+    return 32 * sum(p.numel() for p in model.parameters())
+
+
 class Model_Estimate:
     """The call surface main.py / encoder.py / decoder.py / test_utils.py use (model_size_est.py:40-579)."""
 
@@ -143,6 +148,32 @@ class Model_Estimate:
     def decompress_model(self, new_model, enc_out):
         recon, q = decompress_params(enc_out, new_model.flat_parameters().numel(), with_symbols=True)
         return self._fill(new_model, recon, q, enc_out['min_param'], enc_out['max_param'], enc_out['bitdepth']), recon
+
+    @torch.no_grad()
+    def estibits(self, model, new_model, bitdepth=8):
+        """model_size_est.py:99-179 (main.py:20,293 binds it as esti_compress_model and checks it against compress_test before
+        training): the size ESTIMATE of the coded model - Laplace entropy of the codes + 2*bitdepth, against the zlib / raw bound -
+        without running the coder, and `new_model` filled with the de-quantised parameters."""
+        st1 = time.time()
+        flat = model.flat_parameters().detach().to('cpu', torch.float32)
+        codes, recon = quant_uniform2(flat, bitdepth)
+        self._fill(new_model, recon)
+        n = codes.numel()
+        mu = torch.round(codes.mean())
+        b = torch.round((codes - mu).abs().mean())
+        bits_laplace = float(-torch.sum(torch.log2(torch.exp(-torch.abs(codes - mu) / b) / (2 * b))))
+        bits = bits_laplace + 2 * bitdepth
+        np_type = np.uint8 if bitdepth <= 8 else (np.uint16 if bitdepth <= 16 else np.uint32)
+        zlib_bpp = len(zlib.compress(codes.numpy().astype(np_type).tobytes())) * 8 / n
+        bound = zlib_bpp if zlib_bpp < bitdepth else bitdepth
+        enc_mode, bit_real = 2, bits + 2 + 2 * 32
+        if bits / n > bound:
+            enc_mode = 0 if bound == bitdepth else 1
+            bit_real = bound * n + 2
+        dt = time.time() - st1
+        return {'new_model': new_model, 'bpp_real': bit_real / n, 'bit_real': bit_real, 'enc_mode': enc_mode,
+                'laplace_bpp': bits_laplace / n, 'zlib_bpp': zlib_bpp, 'final_bytes': b'0', 'min_param': flat.min(), 'max_param': flat.max(),
+                'mu': mu, 'b': b, 'enc_time': dt, 'dec_time': dt, 'recon_ret': recon}
 
     @torch.no_grad()
     def compress_test(self, model, new_model, bitdepth=8):

@@ -82,6 +82,15 @@ def unique_sorted(coord):
     return torch.stack([(key >> 42) - 1, ((key >> 21) & mask) - 1, (key & mask) - 1], dim=1).to(torch.int32)
 
 
+def sort_by_coord_sum_c(xyz, onlycoord=True):
+    """models/sort_functions.py:17-30: the rows in x-major order, duplicates kept (what the decoder compares against, decoder.py:10)."""
+    if not onlycoord:
+        raise ValueError('only the coordinate form is used by the drivers')
+    lo = xyz.min() - 1
+    c = xyz.to(torch.int64) - lo.to(torch.int64)
+    return xyz[torch.argsort((c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2], stable=True)]
+
+
 def contains(sorted_coord, query):
     """QuickSearchCoord.search with all-ones features (module_utils.py:260-275): float {0,1} column."""
     keys = ravel_key(sorted_coord)

@@ -9,6 +9,7 @@ import torch
 
 from oracle import ac as oac
 from oracle import model_codec as omc
+from oracle import octree as ooct
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -364,3 +365,73 @@ def test_ascii_ply_parser_against_numpy(tmp_path):
         f.write('ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6\n')
     with pytest.raises(ValueError, match='line 3'):
         ply.read_points(str(tmp_path / 'short.ply'))
+
+
+def test_model_size_estimate_agrees_with_the_real_model_codec():
+    """Model_Estimate.estibits (model_size_est.py:99-179): main.py:290-295 runs it next to compress_test before training and
+    asserts the two reconstructions equal; the estimated size must also sit within a per cent of the coded one in Laplace mode."""
+    from linr_pcgc_amd.model_codec import Model_Estimate, esti_model_size
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    cfg = {'scale_num': 3, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8, 'instage': 1}
+    torch.manual_seed(3)
+    model = LINR_PCGC_Model(cfg)
+    est = Model_Estimate().estibits(model, LINR_PCGC_Model(cfg), 8)
+    real = Model_Estimate().compress_test(model, LINR_PCGC_Model(cfg), 8)
+    assert int((est['recon_ret'] != real['recon_ret']).sum()) == 0
+    assert torch.equal(est['new_model'].flat_parameters(), real['new_model'].flat_parameters())
+    assert est['enc_mode'] == real['enc_mode'] and float(est['mu']) == real['mu'] and float(est['b']) == real['b']
+    if est['enc_mode'] == 2:
+        assert abs(est['bit_real'] - real['bit_real']) <= 0.01 * real['bit_real']
+    assert esti_model_size(model) == 32 * model.flat_parameters().numel()
+    assert sorted(est) == ['b', 'bit_real', 'bpp_real', 'dec_time', 'enc_mode', 'enc_time', 'final_bytes', 'laplace_bpp', 'max_param',
+                           'min_param', 'mu', 'new_model', 'recon_ret', 'zlib_bpp']
+
+
+def test_dataset_classes_of_the_drivers(tmp_path):
+    """datautils/custom_dataset.py's MyDataset / Read_Data / MytestDataset (main.py:73-78,110, encoder.py:47, decoder.py:118-131) on
+    this package's octree preparation, against the oracle's restatement: same per-scale inputs, scale_num fixed by frame 0, frames
+    cached in RAM, the decoder's sorted voxel list."""
+    from linr_pcgc_amd import custom_dataset as cd
+    rng = np.random.default_rng(21)
+    ori = tmp_path / 'ori'
+    ori.mkdir()
+    clouds = []
+    for t in range(3):
+        c = rng.integers(5, 69, size=(6000, 3))
+        c = np.concatenate([c, c[:50]], axis=0)[rng.permutation(6050)]          # duplicates, no order
+        clouds.append(c)
+        if t == 2:
+            cd.write_ply_ascii(str(ori / ('f%03d.ply' % t)), c)
+        np.save(str(ori / ('f%03d.npy' % t)), c)
+    (ori / 'subdir.npy').mkdir()
+    ds = cd.MyDataset(str(ori), str(tmp_path / 'handle'), None, 'npy', stage=8, derive_ori=True)
+    ds.set_prefix_data({'offsets_ini': [[0, 0, 0], [-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, -1], [0, 0, 1]], 'min_point_num': 64})
+    assert len(ds.all_files_path) == 3 and os.path.isdir(str(tmp_path / 'handle')) and ds.scale_num is None
+    first = ds[0]
+    assert ds.scale_num == len(first['all_input_info']) and ds[0] is first          # RAM cache: the same object
+    for t in range(3):
+        got, want = ds[t], ooct.prepare_frame(clouds[t], ds.scale_num, 64)
+        assert got['point_num'] == want['point_num'] and got['coord_data_min'] == [int(v) for v in want['coord_data_min']]
+        assert np.array_equal(got['ori'].cpu().numpy(), want['ori'])
+        assert len(got['all_input_info']) == len(want['scales'])
+        for a, b in zip(got['all_input_info'], want['scales']):
+            assert a['scale_idx'] == b['scale_idx']
+            assert np.array_equal(a['xyzqsc_t'].get_coord().cpu().numpy(), b['coord'])
+            assert np.array_equal(torch.cat(a['occ_lst'], dim=1).cpu().numpy(), b['occ']) and len(a['occ_lst']) == 8
+            assert np.array_equal(a['xyzqsc_t'].get_offset_tensor().cpu().numpy(), b['offset_tensor'])
+        low = got['all_input_info'][-1]['xyzqsc_t'].get_coord()
+        bd = int(np.ceil(np.log2(int(low.max()) + 1)))
+        assert got['xyzQ_low_bits'] == min(len(low), 8 ** bd - len(low)) * bd * 3
+    win = cd.Read_Data_with_cache(ds, [1, 2])
+    assert len(win) == 2 and win[0] is ds[1] and win[1] is ds[2]
+    assert len(cd.MyDataset(str(ori), None, 2, 'npy', stage=4)[0]['all_input_info'][0]['occ_lst']) == 4
+    test = cd.MytestDataset(str(ori), ori_type='ply')
+    assert len(test) == 1
+    srt = test[0].cpu().numpy()
+    key = lambda a: (a[:, 0].astype(np.int64) << 42) | (a[:, 1].astype(np.int64) << 21) | a[:, 2].astype(np.int64)
+    assert srt.shape == (6050, 3) and np.all(np.diff(key(srt)) >= 0) and np.array_equal(np.unique(srt, axis=0), np.unique(clouds[2], axis=0))
+    assert np.array_equal(cd.read_ply_o3d(str(ori / 'f002.ply')), clouds[2])
+    with pytest.raises(ValueError):
+        cd.MyDataset(str(tmp_path / 'handle'), None, None, 'npy')                     # no frame files there
+    with pytest.raises(ValueError):
+        ds.set_prefix_data({'offsets_ini': [[0, 0, 0], [2, 0, 0]]})
