@@ -95,3 +95,35 @@ def Test_one_gop(inargs):
 
 
 Test_one_gop.__test__ = False
+
+
+# ---- the coarsest level and the coordinate minima of a GOP (test_utils.py:199-262,299-312) ------------------------------
+def enc_oneframe_lowx(frame_data):
+    """test_utils.py:235-255: the coarsest scale's voxel coordinates of one frame as uint8 bytes (they must fit 8 bits)."""
+    import numpy as np
+    low = frame_data['all_input_info'][-1]['xyzqsc_t'].get_coord()
+    if int(np.ceil(np.log2(int(low.max()) + 1))) > 8:
+        raise AssertionError('downsampled xyzQ should be less than 8 bit')
+    return low.detach().cpu().numpy().astype(np.uint8).tobytes()
+
+
+def xyzlow_tail_handle(all_coord_data_min, all_xlow_info):
+    """test_utils.py:257-262: the per-frame payloads followed by all coordinate minima (int32), packed."""
+    import numpy as np
+    from .function_utils import pack_bitstream
+    mins = np.concatenate([np.asarray(m).reshape(-1) for m in all_coord_data_min], axis=0).astype(np.int32)
+    return pack_bitstream(list(all_xlow_info) + [mins.tobytes()])
+
+
+def enc_all_frame_low_xyz(reading_data, frame_num):
+    """test_utils.py:199-232."""
+    frames = [reading_data[i] for i in range(frame_num)]
+    return xyzlow_tail_handle([f['coord_data_min'] for f in frames], [enc_oneframe_lowx(f) for f in frames])
+
+
+def dec_all_frame_low_xyz(low_byte):
+    """test_utils.py:299-312: {'all_xyz_low': list of uint8 [n, 3] arrays, 'all_coord_data_min': int32 [frames, 3] tensor}."""
+    from . import codec
+    lows, mins = codec.dec_all_frame_low_xyz(low_byte)
+    dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+    return {'all_xyz_low': lows, 'all_coord_data_min': torch.tensor(mins.tolist(), dtype=torch.int32, device=dev).reshape(-1, 3)}

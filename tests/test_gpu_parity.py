@@ -1332,20 +1332,37 @@ def test_reference_driver_flow_on_the_mirrored_modules(pkg, tmp_path):
     assert epoch_loss[-1] < epoch_loss[0]
     ck = str(tmp_path / 'model.pth')
     torch.save({'model': model.state_dict(), 'epoch': 2, 'optimizer_state_dict': optim.state_dict(), 'loss': epoch_loss[-1], 'bitdepth': 8}, ck)
-    low = _low_xyz_bytes(reading)
+    low = test_utils.enc_all_frame_low_xyz(reading, 2)
+    assert low == _low_xyz_bytes(reading)
     res = test_utils.Test_one_gop({'model_path': ck, 'Gen_Model': gen, 'frame_num': 2, 'compress_model_test': Model_Estimate().compress_test,
                                    'reading_data': reading, 'result_dir': str(tmp_path / '2'), 'write_flag': False, 'low_enc_ret': low})
     assert 0 < res['point_bpp'] < 1.1 * epoch_loss[-1] + 0.5
-    # encode with the de-quantised model, decode from the streams and the coarsest coordinates alone, compare with the test data set
-    coded = Model_Estimate().compress_model(model, 8, True, gen())['new_model']
+    # encoder.encode / decoder.decode with the reference's argument dicts (main.py:110-115): files out, frames back from the files
+    # alone, compared with the test data set's sorted voxel lists and written as PLY
+    from linr_pcgc_amd import decoder, encoder
+    out_dir = tmp_path / 'output' / 'gop_0_1'
+    out_dir.mkdir(parents=True)
+    os.replace(ck, str(out_dir / 'model.pth'))
+    encoder.encode({'outputdir': str(tmp_path / 'output'), 'gop_names': ['gop_0_1'], 'Gen_Model': gen, 'dataset': dataset,
+                    'encode_dir': str(tmp_path / 'enc')})
+    for name in ('side_info.json', 'bins/model.bin', 'bins/low_enc_bytes.bin', 'bins/frame0001_scale0.bin'):
+        assert os.path.getsize(str(tmp_path / 'enc' / 'gop_0_1' / name)) > 0
     test_set = cd.MytestDataset(str(ori), ori_type='ply')
+    decoder.decode({'gop_names': ['gop_0_1'], 'Gen_Model': gen, 'result_enc_dir': str(tmp_path / 'enc'),
+                    'result_dec_dir': str(tmp_path / 'dec'), 'dataset': test_set, 'write_flag': True})
     for fi in range(2):
-        frame = reading[fi]
-        streams = [coded.encode(putin(inargs))['enc_bytes'] for inargs in frame['all_input_info']]
-        xyz_low = frame['all_input_info'][-1]['xyzqsc_t'].get_coord()
-        dec = codec.decode_one_frame(coded, streams, xyz_low)['dec_coord']
-        dec = dec + torch.tensor(frame['coord_data_min'], device=dec.device, dtype=dec.dtype)
-        assert torch.equal(dec.to(torch.int32), torch.unique(test_set[fi], dim=0))
+        back = cd.read_ply_o3d(str(tmp_path / 'dec' / ('frame%04d.ply' % fi)))
+        assert np.array_equal(back, synthetic.sphere_shell(7, 40 + fi))
+    low_dec = test_utils.dec_all_frame_low_xyz(low)
+    assert len(low_dec['all_xyz_low']) == 2 and low_dec['all_coord_data_min'].shape == (2, 3)
+    # a corrupted stream must be noticed by the decoder's comparison
+    path = str(tmp_path / 'enc' / 'gop_0_1' / 'bins' / 'frame0000_scale0.bin')
+    blob = bytearray(open(path, 'rb').read())
+    blob[len(blob) // 2] ^= 0x55
+    open(path, 'wb').write(bytes(blob))
+    with pytest.raises(AssertionError):
+        decoder.decode({'gop_names': ['gop_0_1'], 'Gen_Model': gen, 'result_enc_dir': str(tmp_path / 'enc'),
+                        'result_dec_dir': str(tmp_path / 'dec2'), 'dataset': test_set, 'write_flag': False})
 
 
 def _low_xyz_bytes(reading):
