@@ -658,10 +658,13 @@ def main():
         out = {'metric': 'encode_sec_per_frame', 'value': round(value, 5), 'unit': 's/frame', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'BASELINE config[1] stand-in: synthetic %s (10-bit sphere r~250, %d points and %d '
+               'config': {'workload': 'BASELINE config[%s] stand-in: synthetic %s (%d-bit sphere shell r~%d, %s voxel thick, %d points and %d '
                                       'parent rows in frame 0, %d scales), 1 GOP of %d frames per GPU, first_epoch=%d, '
                                       'lr 0.01 StepLR(32,0.992) Adam wd 1e-4, seed 8807'
-                                      % (args.config, gop.point_nums[0], gop.frames[0].rows, gop.scale_num, len(gop), EPOCHS),
+                                      % ({'sphere8': '0', 'loot10': '1', 'andrew10': '3', 'owlii11': '4'}.get(args.config, '?'), args.config,
+                                         synthetic.CONFIGS[args.config]['bitdepth'], synthetic.CONFIGS[args.config]['radius'],
+                                         '%g' % (2 * synthetic.CONFIGS[args.config]['thickness']), gop.point_nums[0], gop.frames[0].rows,
+                                         gop.scale_num, len(gop), EPOCHS),
                           'frames_per_gpu': len(gop), 'epochs': EPOCHS, 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
                'value_note': 'overfit (complete %d epochs) + the steady-state codec call, per frame; a process\'s FIRST codec call also '
                              'pays for pinned buffers and coder threads: value_cold below uses it' % EPOCHS,
