@@ -38,3 +38,50 @@ def decode_one_gop(inargs):
             name = 'frame%s.ply' % str(inargs['gop_bound'][0] + frame_idx).zfill(4)
             write_ply_ascii(os.path.join(inargs['result_dec_dir'], name), dec.cpu().numpy())
     return decoded
+
+
+def main(argv=None):
+    """python -m linr_pcgc_amd.decoder --enc-dir OUT/result_enc --dec-dir OUT/dec [--ori-dir frames --ori-type ply]
+    The decoder as its own program (decoder.py:179-200): every GOP under --enc-dir from its files alone, frames written as
+    frameXXXX.ply; with --ori-dir each one is also compared with the input.  The model's shape is not part of the stream
+    (the reference hard-codes it, decoder.py:189): the scale count is read off the stream files, width and block_layers are flags."""
+    import argparse
+    from .model_core import LINR_PCGC_Model
+    ap = argparse.ArgumentParser('linr_pcgc_amd.decoder')
+    ap.add_argument('--enc-dir', required=True)
+    ap.add_argument('--dec-dir', required=True)
+    ap.add_argument('--ori-dir', default=None)
+    ap.add_argument('--ori-type', default='ply', choices=['ply', 'npy'])
+    ap.add_argument('--hidden-channel-conv', type=int, default=8)
+    ap.add_argument('--block-layers', type=int, default=1)
+    args = ap.parse_args(argv)
+    names = sorted((n for n in os.listdir(args.enc_dir) if n.startswith('gop_')), key=lambda n: gop_bounds(n)[0])
+    if not names:
+        raise ValueError('no gop_* directory under %s' % args.enc_dir)
+    os.makedirs(args.dec_dir, exist_ok=True)
+    truth = None
+    if args.ori_dir is not None:
+        from .custom_dataset import MytestDataset
+        truth = MytestDataset(args.ori_dir, ori_type=args.ori_type)
+    dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+    frames = 0
+    for name in names:
+        first, last = gop_bounds(name)
+        enc = codec.read_gop(os.path.join(args.enc_dir, name))
+        gen = lambda: LINR_PCGC_Model({'scale_num': len(enc['frames'][0]), 'in_channel': 7, 'hidden_channel_conv': args.hidden_channel_conv,
+                                       'block_layers': args.block_layers, 'outstage': 8, 'instage': 1}).to(dev)
+        decoded = codec.decode_gop(gen(), enc, dev, workers=1 if args.hidden_channel_conv != 8 else 4)
+        if len(decoded) != last - first + 1:
+            raise ValueError('%s holds %d frames, its name says %d' % (name, len(decoded), last - first + 1))
+        for i, dec in enumerate(decoded):
+            if truth is not None:
+                want = torch.unique(truth[first + i], dim=0)
+                if dec.shape != want.shape or bool((dec.to(want.dtype) != want).any()):
+                    raise AssertionError('frame %d does not decode to the input' % (first + i))
+            write_ply_ascii(os.path.join(args.dec_dir, 'frame%s.ply' % str(first + i).zfill(4)), dec.cpu().numpy())
+            frames += 1
+    print('decoded %d frames of %d GOPs into %s%s' % (frames, len(names), args.dec_dir, '' if truth is None else ' (all equal to the input)'))
+
+
+if __name__ == '__main__':
+    main()

@@ -9,6 +9,7 @@ Integer / index / byte work (kernel map, streams, decoded geometry) is bit-exact
 """
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1371,6 +1372,33 @@ def _low_xyz_bytes(reading):
     chunks = [reading[i]['all_input_info'][-1]['xyzqsc_t'].get_coord().cpu().numpy().astype(np.uint8).tobytes() for i in range(len(reading))]
     chunks.append(np.asarray([reading[i]['coord_data_min'] for i in range(len(reading))], dtype=np.int32).reshape(-1).tobytes())
     return pack_bitstream(chunks)
+
+
+def test_decoder_as_a_separate_process(pkg, tmp_path):
+    """Encoder and decoder are different programs in practice: the streams written by this process are decoded by a fresh
+    interpreter (python -m linr_pcgc_amd.decoder: its own HIP context, other addresses, the library loaded anew) from the files
+    alone, compared there with the input files and written as PLY."""
+    import subprocess
+    from linr_pcgc_amd import custom_dataset as cd, ply, run, synthetic
+    ori = tmp_path / 'ori'
+    ori.mkdir()
+    files = []
+    for t in range(3):
+        path = str(ori / ('frame_%04d.ply' % t))
+        ply.write_ply_xyz(path, synthetic.sphere_shell(7, 39 + t, centre=(60 + t, 64, 66)), binary=False)
+        files.append(path)
+    out = str(tmp_path / 'seq')
+    args = run.parse(['--input-glob', str(ori / 'frame_*.ply'), '--frames', '3', '--gop', '2', '--first-epoch', '2', '--others-epoch', '1', '--out', out])
+    summary, _ = run.run_sequence_job(args, 0, 1, None, files=files)
+    assert summary['gops'] == 2 and summary['lossless'] is None          # nothing was decoded in this process
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    done = subprocess.run([sys.executable, '-m', 'linr_pcgc_amd.decoder', '--enc-dir', os.path.join(out, 'result_enc'), '--dec-dir',
+                           str(tmp_path / 'dec'), '--ori-dir', str(ori)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert 'decoded 3 frames of 2 GOPs' in done.stdout and 'all equal to the input' in done.stdout
+    for t in range(3):
+        assert np.array_equal(cd.read_ply_o3d(str(tmp_path / 'dec' / ('frame%04d.ply' % t))), synthetic.sphere_shell(7, 39 + t, centre=(60 + t, 64, 66)))
 
 
 def test_sequence_from_ply_files(pkg, tmp_path):
