@@ -195,7 +195,9 @@ def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
         scales.append({'coord': s['coord'].cpu().numpy(), 'occ': s['occ'].cpu().numpy(),
                        'offset_tensor': s['offset_tensor'].cpu().numpy(), 'scale_idx': s['scale_idx']})
     rows = sum(len(s['coord']) for s in scales)
-    tsc = onet.to_torch_scales(scales)
+    t0 = time.time()
+    tsc = onet.to_torch_scales(scales)          # builds the kernel maps (oracle.octree.neighbour_table: sorted-key searches in numpy)
+    t_kmap = time.time() - t0
     sd = {k: v.clone().requires_grad_() for k, v in model_sd.items()}
     flat_p = torch.cat([v.detach().reshape(-1) for v in sd.values()])
     m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
@@ -225,6 +227,7 @@ def cpu_baseline(model_sd, gop_info, point_num, sample_rows):
            'sample': '1 overfit step (%.2f s) + 1 forward (%.2f s) + range coding of its %d symbols (%.3f s, 1 thread, %d bytes) of '
                      'frame 0 (%d rows), x%d epochs of the step' % (t_step, t_fwd, 8 * rows, t_ac, ac_bytes, rows, EPOCHS),
            'train_step_s': round(t_step, 3), 'forward_s': round(t_fwd, 3), 'ac_s': round(t_ac, 4),
+           'kernel_map_s': round(t_kmap, 3),          # once per frame, outside `value` like the GPU side's staging
            'bits_frame0_init': float(bits.detach())}
     return out, float(bits.detach()), grads
 
