@@ -123,16 +123,24 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         info = {}
         mid = []
 
-        def mid_test(epoch, loss_mean):
-            # main.py:341-411: with --mid_test the checkpoint is written at every tested epoch (epochs 0..9 and every check_freq-th)
-            # and Test_one_gop measures it through model.codec into <out>/output/<gop>/<epoch>/ (result.json, side_info.json; the
-            # bitstream files too at every 50th epoch with --write-real-bitstream); the per-epoch list goes to <gop>/result.json
-            entry = {'epoch': epoch, 'loss_mean': loss_mean}
-            if epoch < 10 or epoch % args.check_freq == 0:
+        gop_dir = os.path.join(args.out, 'output', gop_parallel.gop_name(group))
+        os.makedirs(gop_dir, exist_ok=True)
+        log = open(os.path.join(args.out, 'info.log' if rank == 0 else 'info_rank%d.log' % rank), 'a')
+        log.write('=' * 40 + '\nprocess_file: %d %d\n' % (group[0], group[-1]))
+        clock = {'mark': time.time(), 'train': 0.0}
+
+        def on_epoch(epoch, loss_mean):
+            # main.py:327-338,428-430: the epoch's record in info.log and in <gop>/result.json (train_time: cumulative seconds of the
+            # frame loops of this GOP; train_time_avg: per frame).  overfit_gop has just read the loss, so the GPU is idle here.
+            clock['train'] += time.time() - clock['mark']
+            entry = {'epoch': epoch, 'loss': loss_mean, 'train_time': clock['train'], 'train_time_avg': clock['train'] / len(group)}
+            log.write('epoch: %d\nloss: %r\ntrain_time: %r\ntrain_time_avg: %r\n' % (epoch, loss_mean, entry['train_time'], entry['train_time_avg']))
+            if getattr(args, 'mid_test', False) and (epoch < 10 or epoch % args.check_freq == 0):
+                # main.py:341-411: with --mid_test the checkpoint is written at every tested epoch (epochs 0..9 and every
+                # check_freq-th) and Test_one_gop measures it through model.codec into <gop>/<epoch>/ (result.json, side_info.json;
+                # the bitstream files too at every 50th epoch with --write-real-bitstream)
                 from .model_codec import Model_Estimate
                 from .test_utils import Test_one_gop
-                gop_dir = os.path.join(args.out, 'output', gop_parallel.gop_name(group))
-                os.makedirs(gop_dir, exist_ok=True)
                 path = os.path.join(gop_dir, 'model_mid.pth')
                 torch.save(overfit.checkpoint(model, opt, epoch, loss_mean), path)
                 gen = lambda: overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1),
@@ -146,12 +154,19 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                 entry.update({'real_bpp_all': out['bpp_all'], 'real_point_bpp': out['point_bpp'], 'point_bpp_val': out['point_bpp_val'],
                               'model_bpp': out['model_bpp'], 'xyzlow_bpp': out['xyzlow_bpp'], 'enc_time': out['enc_time'],
                               'dec_time': out['dec_time'], 'enc_mode': out['enc_mode'], 'model_bitdepth_final': 8})
-                with open(os.path.join(gop_dir, 'result.json'), 'w') as f:
-                    json.dump(mid + [entry], f, indent=4)
+                for key in ('real_bpp_all', 'real_point_bpp', 'point_bpp_val', 'model_bpp', 'xyzlow_bpp', 'enc_time', 'dec_time', 'enc_mode'):
+                    log.write('%s: %r\n' % (key, entry[key]))
+            log.write('\n')
+            log.flush()
             mid.append(entry)
+            with open(os.path.join(gop_dir, 'result.json'), 'w') as f:
+                json.dump(mid, f, indent=4)
+            clock['mark'] = time.time()
 
-        losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info,
-                                     on_epoch=mid_test if getattr(args, 'mid_test', False) else None)
+        try:
+            losses = overfit.overfit_gop(model, opt, gop, epochs, args.min_lr, keep=getattr(args, 'keep', 'best'), info=info, on_epoch=on_epoch)
+        finally:
+            log.close()
         torch.cuda.synchronize()
         t1 = time.time()
         enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)), gop, 8,
@@ -174,7 +189,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                   'coded_epoch': info['coded_epoch'], 'coded_loss': info['coded_loss'],
                   'bpp': enc['bpp'], 'points': enc['point_num'], 'lossless': ok, 'stage_s': stage_s, 'overfit_s': t1 - t0,
                   'encode_s': t2 - t1, 'decode_s': t3 - t2, 'seconds': stage_s + (t3 - t0), 'rank': rank}
-        if mid:
+        if getattr(args, 'mid_test', False):
             result['mid_test'] = mid
         del gop
         return model, opt, losses, result, info

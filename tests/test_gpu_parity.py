@@ -1281,10 +1281,17 @@ def test_run_with_mid_test_matches_the_plain_run(pkg, tmp_path):
             one = json.load(open(str(tmp_path / 'mid' / 'output' / name / str(e['epoch']) / 'result.json')))
             assert one['bpp_all'] == e['real_bpp_all']
             # the loss of the epoch is the mean over its steps, the mid-test sees the state behind the last one (quantised)
-            assert e['point_bpp_val'] < e['loss_mean'] and abs(e['real_point_bpp'] - e['point_bpp_val']) <= 0.03 * e['point_bpp_val']
+            assert e['point_bpp_val'] < e['loss'] and abs(e['real_point_bpp'] - e['point_bpp_val']) <= 0.03 * e['point_bpp_val']
             assert not os.path.exists(str(tmp_path / 'mid' / 'output' / name / str(e['epoch']) / 'bins' / 'model.bin'))
         assert lst[-1]['real_bpp_all'] < lst[0]['real_bpp_all']          # it is learning, and the mid-test sees it
     assert 'mid_test' not in r0[0]
+    # info.log and the per-epoch list exist without --mid-test too, in the reference's format (main.py:327-338,428-430)
+    plain = json.load(open(str(tmp_path / 'plain' / 'output' / 'gop_0_1' / 'result.json')))
+    assert [sorted(e) for e in plain] == [['epoch', 'loss', 'train_time', 'train_time_avg']] * 3 and [e['loss'] for e in plain] == r0[0]['loss']
+    assert plain[2]['train_time'] > plain[0]['train_time'] > 0 and abs(plain[1]['train_time_avg'] - plain[1]['train_time'] / 2) < 1e-12
+    lines = open(str(tmp_path / 'plain' / 'info.log')).read().splitlines()
+    assert lines[0] == '=' * 40 and lines[1] == 'process_file: 0 1' and lines[2] == 'epoch: 0' and lines[3].startswith('loss: ')
+    assert 'process_file: 2 3' in lines and sum(1 for ln in lines if ln.startswith('epoch: ')) == 5
 
 
 def test_reference_driver_flow_on_the_mirrored_modules(pkg, tmp_path):
