@@ -22,20 +22,25 @@ def parse(argv=None):
     ap = argparse.ArgumentParser('linr_pcgc_amd.run')
     ap.add_argument('--config', default='loot10')
     ap.add_argument('--input-glob', default=None, help="PLY / npy frames of a real sequence (sorted by name), e.g. '/data/loot/Ply/*.ply'; replaces --config")
-    ap.add_argument('--frames', type=int, default=32)
-    ap.add_argument('--gop', type=int, default=32)
-    ap.add_argument('--first-epoch', type=int, default=10)
-    ap.add_argument('--others-epoch', type=int, default=10)
-    ap.add_argument('--learning-rate', type=float, default=0.01)
+    ap.add_argument('--frames', '--frame_num', dest='frames', type=int, default=32)
+    ap.add_argument('--gop', '--gop_size', dest='gop', type=int, default=32)
+    ap.add_argument('--first-epoch', '--first_epoch', dest='first_epoch', type=int, default=10)
+    ap.add_argument('--others-epoch', '--others_epoch', dest='others_epoch', type=int, default=10)
+    ap.add_argument('--learning-rate', '--learning_rate', dest='learning_rate', type=float, default=0.01)
     ap.add_argument('--gamma', type=float, default=0.992)
-    ap.add_argument('--step-size', type=int, default=32)
-    ap.add_argument('--min-lr', type=float, default=4e-4)
-    ap.add_argument('--decay-rate', type=float, default=1e-4)
-    ap.add_argument('--block-layers', type=int, default=1)
-    ap.add_argument('--hidden-channel-conv', type=int, default=8, choices=[8, 16, 32],
+    ap.add_argument('--step-size', '--step_size', dest='step_size', type=int, default=32)
+    ap.add_argument('--min-lr', '--min_lr', dest='min_lr', type=float, default=4e-4)
+    ap.add_argument('--decay-rate', '--decay_rate', dest='decay_rate', type=float, default=1e-4)
+    ap.add_argument('--block-layers', '--block_layers', dest='block_layers', type=int, default=1)
+    ap.add_argument('--hidden-channel-conv', '--hidden_channel_conv', dest='hidden_channel_conv', type=int, default=8, choices=[8, 16, 32],
                     help='main.py:520; 8 = the tuned kernels, 16 / 32 = the channel-blocked executor (several times slower)')
     ap.add_argument('--seed', type=int, default=8807)
-    ap.add_argument('--out', default='/tmp/linr_out')
+    ap.add_argument('--out', '--result_dir', dest='out', default='/tmp/linr_out')
+    ap.add_argument('--ori_dir', '--ori-dir', dest='ori_dir', default=None, help='main.py --ori_dir: a directory of frames (with --ori_dtype), sorted by name; same as --input-glob DIR/*.TYPE')
+    ap.add_argument('--ori_dtype', '--ori-dtype', dest='ori_dtype', default='ply', choices=['ply', 'npy'])
+    ap.add_argument('--min_point_num', '--min-point-num', dest='min_point_num', type=int, default=64, help='main.py --min_point_num: the octree stops below this many voxels')
+    ap.add_argument('--scale_num', '--scale-num', dest='scale_num', type=int, default=None, help='main.py --scale_num: at most this many scales (default: down to --min_point_num, fixed by frame 0 of a GOP)')
+    ap.add_argument('--model_bitdepth', '--model-bitdepth', dest='model_bitdepth', type=int, default=8, help='main.py --model_bitdepth: bits of the weight quantiser')
     ap.add_argument('--schedule', default='pull', choices=['pull', 'static'])
     ap.add_argument('--no-stage-ahead', dest='stage_ahead', action='store_false',
                     help='stage a GOP (file parsing, octrees, kernel maps) only when it is about to run instead of in the background during the GOP before it')
@@ -47,7 +52,7 @@ def parse(argv=None):
     ap.add_argument('--mid-test', action='store_true',
                     help='main.py --mid_test: measure the model through Test_one_gop (model.codec) at epochs 0..9 and every --check-freq-th '
                          'epoch of every GOP; results under <out>/output/<gop>/<epoch>/ and <out>/output/<gop>/result.json')
-    ap.add_argument('--check-freq', type=int, default=5, help='main.py --check_freq')
+    ap.add_argument('--check-freq', '--check_freq', dest='check_freq', type=int, default=5, help='main.py --check_freq')
     ap.add_argument('--write-real-bitstream', action='store_true', help='main.py --write_real_bitstream: the mid-test also writes its bins at every 50th epoch')
     return ap.parse_args(argv)
 
@@ -87,7 +92,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         return ply.read_many([files[t] for t in group])
 
     def build_gop(group):
-        return overfit.Gop(None, load_group(group), None, 64, device, block_layers=getattr(args, 'block_layers', 1))
+        return overfit.Gop(None, load_group(group), getattr(args, 'scale_num', None), getattr(args, 'min_point_num', 64), device,
+                           block_layers=getattr(args, 'block_layers', 1))
 
     def build_gop_ahead(group):
         torch.cuda.set_device(dev_index)       # a new thread starts on device 0, whatever the rank's device is
@@ -142,7 +148,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                 from .model_codec import Model_Estimate
                 from .test_utils import Test_one_gop
                 path = os.path.join(gop_dir, 'model_mid.pth')
-                torch.save(overfit.checkpoint(model, opt, epoch, loss_mean), path)
+                torch.save(overfit.checkpoint(model, opt, epoch, loss_mean, getattr(args, 'model_bitdepth', 8)), path)
                 gen = lambda: overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1),
                                                 hidden=getattr(args, 'hidden_channel_conv', 8))
                 out = Test_one_gop({'model_path': path, 'Gen_Model': gen, 'frame_num': len(group),
@@ -169,8 +175,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
             log.close()
         torch.cuda.synchronize()
         t1 = time.time()
-        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)), gop, 8,
-                               precision=getattr(args, 'precision', 'f32'))
+        enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, device, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8)), gop,
+                               getattr(args, 'model_bitdepth', 8), precision=getattr(args, 'precision', 'f32'))
         res_dir = os.path.join(args.out, 'result_enc', gop_parallel.gop_name(group))
         codec.write_gop(enc, res_dir)
         torch.cuda.synchronize()
@@ -196,7 +202,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
 
     def first_fn(group, staged=None):
         model, opt, losses, result, info = run_gop(group, args.first_epoch, None, staged)
-        ck = overfit.checkpoint(model, opt, info['coded_epoch'], info['coded_loss'])      # the state overfit_gop left: the kept epoch
+        ck = overfit.checkpoint(model, opt, info['coded_epoch'], info['coded_loss'], getattr(args, 'model_bitdepth', 8))      # the state overfit_gop left: the kept epoch
         ck['result'] = result
         return ck
 
@@ -243,6 +249,21 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     return summary, results
 
 
+def resolve_files(args):
+    """The frame files of --input-glob / --ori_dir + --ori_dtype (sorted by name, at most --frames of them; args.frames is set to
+    their count), or None for the synthetic configs."""
+    if getattr(args, 'ori_dir', None) and not args.input_glob:
+        args.input_glob = os.path.join(args.ori_dir, '*.' + args.ori_dtype)
+    if not args.input_glob:
+        return None
+    import glob
+    files = sorted(glob.glob(args.input_glob))[:args.frames]
+    if not files:
+        raise ValueError('no file matches %s' % args.input_glob)
+    args.frames = len(files)
+    return files
+
+
 def init_dist(local):
     import torch.distributed as dist
     backend = os.environ.get('LINR_BENCH_BACKEND', 'nccl')          # nccl = RCCL over xGMI; gloo only for 1-GPU rehearsals
@@ -265,13 +286,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = init_dist(local) if world > 1 else None
-    files = None
-    if args.input_glob:
-        import glob
-        files = sorted(glob.glob(args.input_glob))[:args.frames]
-        if not files:
-            raise ValueError('no file matches %s' % args.input_glob)
-        args.frames = len(files)
+    files = resolve_files(args)
     summary, results = run_sequence_job(args, rank, world, dist, files=files)
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, 'results_rank%d.json' % rank), 'w') as f:

@@ -1423,8 +1423,10 @@ def test_sequence_from_ply_files(pkg, tmp_path):
         ply.write_ply_xyz(path, shuffled, binary=bool(t % 2))
         files.append(path)
     out = str(tmp_path / 'seq_ply')
-    args = run.parse(['--input-glob', str(tmp_path / 'frame_*.ply'), '--frames', '5', '--gop', '2', '--first-epoch', '2',
-                      '--others-epoch', '1', '--out', out, '--decode'])
+    # the reference's spellings of the flags (main.py:480-534)
+    args = run.parse(['--ori_dir', str(tmp_path), '--ori_dtype', 'ply', '--frame_num', '9', '--gop_size', '2', '--first_epoch', '2',
+                      '--others_epoch', '1', '--result_dir', out, '--min_point_num', '64', '--model_bitdepth', '8', '--decode'])
+    assert run.resolve_files(args) == files and args.frames == 5
     summary, results = run.run_sequence_job(args, 0, 1, None, files=files)
     assert summary['gops'] == 3 and summary['lossless'] is True and sorted(results) == [0, 1, 2]
     assert [results[g]['frames'] for g in range(3)] == [2, 2, 1]
