@@ -100,10 +100,14 @@ def decompress_params(enc_out, n, with_symbols=False):
     """decompress_model (model_size_est.py:523-579): returns the de-quantised flat float32 vector (CPU)
     (and, with_symbols, the integer codes it was rebuilt from)."""
     mode, data, bitdepth = enc_out['enc_mode'], enc_out['final_bytes'], enc_out['bitdepth']
+    # the raw / zlib modes hold the codes in the integer type the encoder chose for the bit depth (model_size_est.py:434-441).  The
+    # reference reads them back as uint8 whatever the depth (:546-549), so its own decoder fails above 8 bits; up to 8 - its default,
+    # and every shipped stream - the two agree.
+    np_type = np.uint8 if bitdepth <= 8 else (np.uint16 if bitdepth <= 16 else np.uint32)
     if mode == 0:
-        q = np.frombuffer(data, dtype=np.uint8)
+        q = np.frombuffer(data, dtype=np_type)
     elif mode == 1:
-        q = np.frombuffer(zlib.decompress(data), dtype=np.uint8)
+        q = np.frombuffer(zlib.decompress(data), dtype=np_type)
     else:
         cdf = _laplace_cdf_u16(torch.tensor(float(enc_out['mu'])), torch.tensor(float(enc_out['b'])), bitdepth)
         q = _ac_decode(cdf, data, n)

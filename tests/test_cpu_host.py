@@ -435,3 +435,21 @@ def test_dataset_classes_of_the_drivers(tmp_path):
         cd.MyDataset(str(tmp_path / 'handle'), None, None, 'npy')                     # no frame files there
     with pytest.raises(ValueError):
         ds.set_prefix_data({'offsets_ini': [[0, 0, 0], [2, 0, 0]]})
+
+
+@pytest.mark.parametrize('bitdepth', [4, 6, 8, 10, 16])
+def test_model_codec_round_trip_at_other_bit_depths(bitdepth):
+    """--model_bitdepth (main.py:522): compress_test's own consistency check (coded -> decoded reconstruction == the encoder's) at
+    depths below and above the default 8; above 8 the codes travel as uint16 (raw / zlib modes - the reference's decoder reads them
+    as uint8 there and fails), and the quantisation error shrinks with the depth."""
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    from linr_pcgc_amd.model_core import LINR_PCGC_Model
+    cfg = {'scale_num': 3, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8, 'instage': 1}
+    torch.manual_seed(5)
+    model = LINR_PCGC_Model(cfg)
+    out = Model_Estimate().compress_test(model, LINR_PCGC_Model(cfg), bitdepth)          # asserts recon == decoded recon itself
+    flat = model.flat_parameters()
+    step = float(flat.max() - flat.min()) / (2 ** bitdepth - 1)
+    assert float((out['new_model'].flat_parameters() - flat).abs().max()) <= 0.5 * step + 1e-6          # + fp32 rounding of the affine map
+    assert out['enc_mode'] in (0, 1, 2) and (bitdepth <= 8 or out['enc_mode'] in (0, 1))
+    assert out['bit_real'] <= bitdepth * flat.numel() + 2 + 64 + 2 * bitdepth
