@@ -131,12 +131,12 @@ class Model_Estimate:
 
     @staticmethod
     def _fill(model, recon, symbols=None, min_param=None, max_param=None, bitdepth=8):
-        """Writes the de-quantised parameters into `model`.  With 8-bit codes it also hands the model the codes themselves
+        """Writes the de-quantised parameters into `model`.  With 8-bit codes (the default --model_bitdepth) it also hands the model the codes themselves
         (device uint8, parameters() order) + the two range floats: the bf16 inference path (linr_net_forward_bf16) runs
         straight from them."""
         with torch.no_grad():
             model.flat_parameters().copy_(recon.to(model.flat_parameters().device))
-        if symbols is not None and bitdepth <= 8:
+        if symbols is not None and bitdepth == 8:          # the kernels de-quantise 8-bit codes (q / 255 * range + min); other depths: fp32 only
             model.set_quantised(torch.as_tensor(np.ascontiguousarray(symbols).astype(np.uint8)), float(min_param), float(max_param))
         return model
 

@@ -189,8 +189,8 @@ class LINR_PCGC_Model(nn.Module):
         if precision not in ('f32', 'bf16'):
             raise ValueError("precision must be 'f32' or 'bf16'")
         if precision == 'bf16' and self._qcodes is None:
-            raise _lib.LinrError('the bf16 path runs from the uint8 weight codes: quantise the model first '
-                                 '(Model_Estimate.compress_model(..., derive_new_model=True) / decompress_model)')
+            raise _lib.LinrError('the bf16 path runs from the 8-bit weight codes: quantise the model first, at bitdepth 8 '
+                                 '(Model_Estimate.compress_model(model, 8, derive_new_model=True) / decompress_model)')
         return precision
 
     def flat_parameters(self):

@@ -124,8 +124,17 @@ def test_bf16_staged_equals_one_shot_and_decodes_losslessly(shell, block_layers)
 def test_bf16_needs_the_quantised_model():
     from linr_pcgc_amd import _lib, overfit
     model = overfit.gen_model(5, 'cuda', seed=1)
-    with pytest.raises(_lib.LinrError, match='uint8 weight codes'):
+    with pytest.raises(_lib.LinrError, match='8-bit weight codes'):
         model._precision('bf16')
+    # the kernels de-quantise 8-bit codes only: a model quantised at another --model_bitdepth keeps to fp32
+    from linr_pcgc_amd.model_codec import Model_Estimate
+    for depth, ok in ((6, False), (8, True), (10, False)):
+        coded = Model_Estimate().compress_model(model, depth, True, overfit.gen_model(5, 'cuda'))['new_model']
+        if ok:
+            assert coded._precision('bf16') == 'bf16'
+        else:
+            with pytest.raises(_lib.LinrError, match='8-bit weight codes'):
+                coded._precision('bf16')
 
 
 def test_bf16_gop_codec_files_roundtrip(tmp_path):
