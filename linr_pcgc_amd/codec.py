@@ -44,7 +44,13 @@ def dec_all_frame_low_xyz(low_byte):
     return [np.frombuffer(c, dtype=np.uint8).reshape(-1, 3) for c in chunks], mins
 
 
-EXTRA_SIDE_BITS = 16          # arith_version + precision in side_info.json, beyond the reference's side information
+EXTRA_SIDE_BITS = 40          # arith_version, precision and the model's shape (scale_num, block_layers, hidden_channel_conv: the reference's
+                              # decoder hard-codes it, decoder.py:189) in side_info.json, one byte each, beyond the reference's side information
+
+
+def model_shape(model):
+    """What a decoder needs to build the model a stream was coded with (the reference's decoder hard-codes it, decoder.py:189)."""
+    return {'scale_num': int(model.scale_num), 'block_layers': int(model.block_layers), 'hidden_channel_conv': int(model.hidden)}
 
 
 def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32'):
@@ -61,6 +67,7 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
     if precision != 'f32':
         side_info['precision'] = precision
     side_info['arith_version'] = ARITH_VERSION
+    side_info.update(model_shape(model))
     # Pipeline: the GPU forward + D2H of frame i+1 runs while host workers range-code earlier frames (the coder's C call
     # releases the GIL).  A frame has 8 x scales independent streams, but the 8 streams of its finest scale carry 73 % of the
     # symbols, so one frame keeps only ~8 threads busy: TWO frames are coded concurrently, each on half of the threads
@@ -173,6 +180,10 @@ def decode_gop(model_ori, enc, device='cuda', frames=None, workers=1, timing=Non
         raise LinrError('this stream was coded with network arithmetic version %d; this build decodes version %d (the fp32 '
                         'accumulation order of the convolutions is part of the stream format: decode with the build that '
                         'encoded it)' % (coded_with, ARITH_VERSION))
+    want = {k: side[k] for k in ('scale_num', 'block_layers', 'hidden_channel_conv') if k in side}
+    have = model_shape(model_ori)
+    if any(int(v) != have[k] for k, v in want.items()):
+        raise ValueError('the stream was coded with a model of shape %s; the model handed to the decoder has %s' % (want, have))
     side['final_bytes'] = enc['model_bin']
     model, _ = Model_Estimate().decompress_model(model_ori, side)
     model.inference_precision = side.get('precision', 'f32')

@@ -43,8 +43,9 @@ def decode_one_gop(inargs):
 def main(argv=None):
     """python -m linr_pcgc_amd.decoder --enc-dir OUT/result_enc --dec-dir OUT/dec [--ori-dir frames --ori-type ply]
     The decoder as its own program (decoder.py:179-200): every GOP under --enc-dir from its files alone, frames written as
-    frameXXXX.ply; with --ori-dir each one is also compared with the input.  The model's shape is not part of the stream
-    (the reference hard-codes it, decoder.py:189): the scale count is read off the stream files, width and block_layers are flags."""
+    frameXXXX.ply; with --ori-dir each one is also compared with the input.  The model's shape travels in side_info.json (the
+    reference hard-codes it, decoder.py:189); for streams without it the scale count is read off the stream files and width /
+    block_layers are flags."""
     import argparse
     from .model_core import LINR_PCGC_Model
     ap = argparse.ArgumentParser('linr_pcgc_amd.decoder')
@@ -68,9 +69,12 @@ def main(argv=None):
     for name in names:
         first, last = gop_bounds(name)
         enc = codec.read_gop(os.path.join(args.enc_dir, name))
-        gen = lambda: LINR_PCGC_Model({'scale_num': len(enc['frames'][0]), 'in_channel': 7, 'hidden_channel_conv': args.hidden_channel_conv,
-                                       'block_layers': args.block_layers, 'outstage': 8, 'instage': 1}).to(dev)
-        decoded = codec.decode_gop(gen(), enc, dev, workers=1 if args.hidden_channel_conv != 8 else 4)
+        side = enc['side_info']          # streams of this package carry the model's shape; others: the flags, and the most scales a frame has
+        shape = {'scale_num': int(side.get('scale_num', max(len(f) for f in enc['frames']))), 'in_channel': 7,
+                 'hidden_channel_conv': int(side.get('hidden_channel_conv', args.hidden_channel_conv)),
+                 'block_layers': int(side.get('block_layers', args.block_layers)), 'outstage': 8, 'instage': 1}
+        gen = lambda: LINR_PCGC_Model(shape).to(dev)
+        decoded = codec.decode_gop(gen(), enc, dev, workers=1 if shape['hidden_channel_conv'] != 8 else 4)
         if len(decoded) != last - first + 1:
             raise ValueError('%s holds %d frames, its name says %d' % (name, len(decoded), last - first + 1))
         for i, dec in enumerate(decoded):

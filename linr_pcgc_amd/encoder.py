@@ -68,6 +68,7 @@ def encode_one_gop(inargs):
         f.write(packed['final_bytes'])
     side_info = {'mu': packed['mu'], 'b': packed['b'], 'min_param': packed['min_param'], 'max_param': packed['max_param'],
                  'enc_mode': packed['enc_mode'], 'bitdepth': bitdepth, 'arith_version': codec.ARITH_VERSION}
+    side_info.update(codec.model_shape(trained))
     with open(os.path.join(result_dir, 'side_info.json'), 'w') as f:
         json.dump(side_info, f, indent=4)
     model = packed['new_model']

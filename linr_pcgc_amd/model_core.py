@@ -78,6 +78,9 @@ class LINR_PCGC_Model(nn.Module):
     def __init__(self, inargs):
         super().__init__()
         self.scale_num = int(inargs['scale_num'])
+        if not 1 <= self.scale_num <= 16:
+            raise ValueError('scale_num must be in 1..16 (the executor batches at most 16 scales per frame; the reference runs 6 to 8), '
+                             'got %d' % self.scale_num)
         in_channel = int(inargs['in_channel'])
         hidden = int(inargs['hidden_channel_conv'])
         block_layers = int(inargs['block_layers'])

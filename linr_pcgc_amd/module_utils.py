@@ -170,6 +170,10 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
     else:
         pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
     cmin = pts.min(dim=0).values
+    span = int((pts.max(dim=0).values - cmin).max()) if pts.numel() else 0
+    if span >= (1 << 20):
+        raise ValueError('the cloud spans %d voxels along an axis; the kernel map holds 20-bit coordinates (the data sets of the '
+                         'reference are 10 to 12 bit)' % (span + 1))
     cur = qscTensor(pts - cmin)
     ori = cur.get_coord()
     info = []

@@ -91,8 +91,18 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
             return [synthetic.sequence_frame_device(args.config, t, device) for t in group]
         return ply.read_many([files[t] for t in group])
 
+    # main.py:73-78: the scale count of the whole sequence is fixed by its FIRST frame (dataset[0]) unless --scale_num gives it; every
+    # GOP's model has that many scale embeddings / scale MLPs (GOPs >= 1 load GOP 0's checkpoint), frames that run out of voxels
+    # earlier simply have fewer scales, frames that could go deeper stop there.  Every rank derives it from frame 0 itself.
+    seq_scale_num = getattr(args, 'scale_num', None)
+    if seq_scale_num is None:
+        from .module_utils import prepare_frame
+        first = ply.read_points(files[0]) if files is not None else synthetic.sequence_frame_device(args.config, 0, device)
+        seq_scale_num = prepare_frame(first, None, getattr(args, 'min_point_num', 64), device=device, with_offsets=False)['scale_num']
+        del first
+
     def build_gop(group):
-        return overfit.Gop(None, load_group(group), getattr(args, 'scale_num', None), getattr(args, 'min_point_num', 64), device,
+        return overfit.Gop(None, load_group(group), seq_scale_num, getattr(args, 'min_point_num', 64), device,
                            block_layers=getattr(args, 'block_layers', 1))
 
     def build_gop_ahead(group):

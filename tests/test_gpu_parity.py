@@ -1251,7 +1251,7 @@ def test_mid_test_driver_writes_the_reference_result_files(pkg, tmp_path):
     for name in ('model.bin', 'low_enc_bytes.bin', 'frame0000_scale0.bin', 'frame0001_scale%d.bin' % (gop.scale_num - 1)):
         assert os.path.getsize(str(tmp_path / '2' / 'bins' / name)) > 0
     enc = codec.encode_gop(model, gen(), gop, 8)
-    points = sum(gop.point_nums)          # the GOP encoder also counts its two extra side-info bytes (arith_version, precision)
+    points = sum(gop.point_nums)          # the GOP encoder also counts its extra side-info bytes (arith_version, precision, model shape)
     assert abs(res['model_bpp'] + codec.EXTRA_SIDE_BITS / points - enc['bpp']['model_bpp']) < 1e-9
     assert abs(res['xyzlow_bpp'] - enc['bpp']['xyzlow_bpp']) < 1e-12
     # 48 streams with their length fields instead of 6 per frame: a few per cent on clouds this small
@@ -1406,6 +1406,57 @@ def test_decoder_as_a_separate_process(pkg, tmp_path):
     assert 'decoded 3 frames of 2 GOPs' in done.stdout and 'all equal to the input' in done.stdout
     for t in range(3):
         assert np.array_equal(cd.read_ply_o3d(str(tmp_path / 'dec' / ('frame%04d.ply' % t))), synthetic.sphere_shell(7, 39 + t, centre=(60 + t, 64, 66)))
+
+
+def _run_npy_sequence(tmp_path, tag, clouds, extra=()):
+    from linr_pcgc_amd import run
+    ori = tmp_path / (tag + '_ori')
+    ori.mkdir()
+    for i, c in enumerate(clouds):
+        np.save(str(ori / ('f%03d.npy' % i)), np.asarray(c))
+    args = run.parse(['--ori_dir', str(ori), '--ori_dtype', 'npy', '--frame_num', str(len(clouds)), '--gop_size', '2', '--first_epoch', '2',
+                      '--others_epoch', '1', '--result_dir', str(tmp_path / (tag + '_out')), '--decode'] + list(extra))
+    return run.run_sequence_job(args, 0, 1, None, files=run.resolve_files(args))
+
+
+def test_sequence_scale_count_is_fixed_by_the_first_frame(pkg, tmp_path):
+    """main.py:73-78: dataset[0] fixes scale_num for the WHOLE sequence; GOPs >= 1 load GOP 0's checkpoint, so their models must
+    have its shape whatever their own frames look like.  Here the frames of later GOPs would have more scales (growing clouds) or
+    fewer (a 3-voxel-radius blob leads a GOP) than frame 0 - the first used to build a larger model, the second a smaller one, and
+    the warm start failed.  Also: negative coordinates, and a frame list whose sizes differ by two orders of magnitude."""
+    from linr_pcgc_amd import synthetic
+    sph = lambda r: synthetic.sphere_shell(7, r)
+    s, r = _run_npy_sequence(tmp_path, 'grow', [sph(30) - 200, sph(31) - 200, sph(32) - 200])
+    assert s['lossless'] is True and sorted(r) == [0, 1]
+    s, r = _run_npy_sequence(tmp_path, 'mixed', [sph(40), sph(10), sph(3), sph(45)])
+    assert s['lossless'] is True and sorted(r) == [0, 1]
+    import json
+    side = json.load(open(str(tmp_path / 'mixed_out' / 'result_enc' / 'gop_2_3' / 'side_info.json')))
+    first = json.load(open(str(tmp_path / 'mixed_out' / 'result_enc' / 'gop_0_1' / 'side_info.json')))
+    assert side['scale_num'] == first['scale_num'] and side['block_layers'] == 1 and side['hidden_channel_conv'] == 8
+    # GOP 2..3 starts with the 3-voxel blob: its frame 0 has fewer scale streams than the model has scales
+    n_streams = len([f for f in os.listdir(str(tmp_path / 'mixed_out' / 'result_enc' / 'gop_2_3' / 'bins')) if f.startswith('frame0000_scale')])
+    assert n_streams < side['scale_num']
+
+
+def test_sequence_degenerate_clouds(pkg, tmp_path):
+    """A single point, two points, a few dozen scattered points, repeated points, float coordinates, a plane and a line: every one
+    goes through the whole flow losslessly (the rates are absurd - the model costs more than the points - but nothing breaks); a
+    cloud wider than the 20-bit coordinates of the kernel map is refused with a message that says so."""
+    from linr_pcgc_amd import synthetic
+    rng = np.random.default_rng(0)
+    sph = lambda r: synthetic.sphere_shell(7, r)
+    cases = {'tiny': [np.array([[5, 6, 7]]), np.array([[1, 2, 3], [1, 2, 4]])],
+             'few': [rng.integers(0, 64, size=(40, 3)), rng.integers(0, 64, size=(100, 3))],
+             'dups': [np.repeat(sph(20), 3, axis=0), sph(21)],
+             'floats': [sph(20).astype(np.float64) + 0.2, sph(21).astype(np.float32) - 0.3],
+             'flat': [np.stack([rng.integers(0, 128, 5000), rng.integers(0, 128, 5000), np.zeros(5000, np.int64)], 1), sph(21)],
+             'line': [np.stack([np.arange(300), np.zeros(300, np.int64), np.zeros(300, np.int64)], 1), sph(21)]}
+    for tag, clouds in cases.items():
+        s, _ = _run_npy_sequence(tmp_path, tag, clouds)
+        assert s['lossless'] is True, tag
+    with pytest.raises(ValueError, match='20-bit'):
+        _run_npy_sequence(tmp_path, 'wide', [sph(30) * 20000])
 
 
 def test_sequence_from_ply_files(pkg, tmp_path):
