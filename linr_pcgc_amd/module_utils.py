@@ -169,8 +169,10 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
         pts = points[:, :3].to(device=device, dtype=torch.int64)
     else:
         pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
+    if pts.shape[0] == 0:
+        raise ValueError('the frame has no points')
     cmin = pts.min(dim=0).values
-    span = int((pts.max(dim=0).values - cmin).max()) if pts.numel() else 0
+    span = int((pts.max(dim=0).values - cmin).max())
     if span >= (1 << 20):
         raise ValueError('the cloud spans %d voxels along an axis; the kernel map holds 20-bit coordinates (the data sets of the '
                          'reference are 10 to 12 bit)' % (span + 1))

@@ -453,3 +453,13 @@ def test_model_codec_round_trip_at_other_bit_depths(bitdepth):
     assert float((out['new_model'].flat_parameters() - flat).abs().max()) <= 0.5 * step + 1e-6          # + fp32 rounding of the affine map
     assert out['enc_mode'] in (0, 1, 2) and (bitdepth <= 8 or out['enc_mode'] in (0, 1))
     assert out['bit_real'] <= bitdepth * flat.numel() + 2 + 64 + 2 * bitdepth
+
+
+def test_prepare_frame_refuses_what_it_cannot_represent():
+    from linr_pcgc_amd.module_utils import prepare_frame
+    with pytest.raises(ValueError, match='no points'):
+        prepare_frame(np.zeros((0, 3), np.int64))
+    with pytest.raises(ValueError, match='20-bit'):
+        prepare_frame(np.array([[0, 0, 0], [1 << 20, 5, 5]]))
+    fr = prepare_frame(np.array([[0, 0, 0], [(1 << 20) - 1, 5, 5]]), device='cpu')          # the widest cloud that fits
+    assert fr['point_num'] == 2
