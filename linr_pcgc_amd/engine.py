@@ -27,6 +27,24 @@ class Frame:
         self.device = device
         self.model_scale_num = int(model_scale_num)
         self.block_layers = int(block_layers)
+        for i, s in enumerate(scales):          # shapes first: the per-scale dicts come from user code (the drivers' putin_args)
+            c = s['coord']
+            n = int(c.shape[0])
+            if c.ndim != 2 or c.shape[1] != 3:
+                raise ValueError("scale %d: 'coord' must be [N, 3], got %s" % (i, tuple(c.shape)))
+            if not 0 <= int(s['scale_idx']) < self.model_scale_num:
+                raise ValueError("scale %d: 'scale_idx' %d is outside the model's 0..%d" % (i, int(s['scale_idx']), self.model_scale_num - 1))
+            off = s.get('offset_tensor')
+            if off is not None and tuple(off.shape) != (n, 7):
+                raise ValueError("scale %d: 'offset_tensor' must be [%d, 7], got %s" % (i, n, tuple(off.shape)))
+            if s.get('occ') is not None:
+                if tuple(s['occ'].shape) != (n, 8):
+                    raise ValueError("scale %d: 'occ' must be [%d, 8], got %s" % (i, n, tuple(s['occ'].shape)))
+            elif s.get('occ_lst') is not None:
+                lst = s['occ_lst']
+                if len(lst) != 8 or any(int(torch.as_tensor(o).numel()) != n for o in lst):
+                    raise ValueError("scale %d: 'occ_lst' must hold 8 columns of %d values, got %d entries of sizes %s"
+                                     % (i, n, len(lst), sorted({int(torch.as_tensor(o).numel()) for o in lst})))
         ns = [int(s['coord'].shape[0]) for s in scales]
         self.row_off = np.zeros(len(scales) + 1, dtype=np.int64)
         self.row_off[1:] = np.cumsum(ns)

@@ -12,9 +12,16 @@ def pack_bitstream(bitstream_list, dtype='uint32'):
 
 def unpack_bitstream(bitstream_all, dtype='uint32'):
     width = np.dtype(dtype).itemsize
+    total = len(bitstream_all)
+    if total < width:
+        raise ValueError('bitstream container of %d bytes: too short for its count field' % total)
     num = int(np.frombuffer(bitstream_all[:width], dtype=dtype)[0])
+    if width * (1 + num) > total:
+        raise ValueError('bitstream container announces %d streams but holds %d bytes' % (num, total))
     lens = np.frombuffer(bitstream_all[width:width * (1 + num)], dtype=dtype)
     pos = width * (1 + num)
+    if pos + int(lens.astype(np.int64).sum()) > total:
+        raise ValueError('bitstream container is truncated: %d bytes announced, %d present' % (pos + int(lens.astype(np.int64).sum()), total))
     out = []
     for n in lens:
         out.append(bitstream_all[pos:pos + int(n)])

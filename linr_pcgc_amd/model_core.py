@@ -213,20 +213,25 @@ class LINR_PCGC_Model(nn.Module):
         s = {'coord': coord, 'offset_tensor': d.get('offset_tensor'), 'scale_idx': d['scale_idx']}
         if not need_occ:
             return self.make_frame([s])
-        occ0 = d['occ_lst'][0]
-        key = (coord.data_ptr(), int(coord.shape[0]), int(d['scale_idx']), d['offset_tensor'].data_ptr(), occ0.data_ptr())
+        occ_lst, off = d['occ_lst'], d.get('offset_tensor')
+        occ0 = occ_lst[0]
+        # identity AND shape of every input: slices of the cached tensors share their data pointers
+        key = (coord.data_ptr(), tuple(coord.shape), int(d['scale_idx']), None if off is None else (off.data_ptr(), tuple(off.shape)),
+               occ0.data_ptr(), len(occ_lst), tuple(tuple(o.shape) for o in occ_lst))
         hit = self._frame_cache.get(key)
         if hit is None:
             if len(self._frame_cache) >= 1024:
                 self._frame_cache.pop(next(iter(self._frame_cache)))
-            s['occ_lst'] = d['occ_lst']
-            hit = (self.make_frame([s]), coord, d['offset_tensor'], list(d['occ_lst']))
+            s['occ_lst'] = occ_lst
+            hit = (self.make_frame([s]), coord, off, list(occ_lst))
             self._frame_cache[key] = hit
         return hit[0]
 
     # ---- reference call surface --------------------------------------------------------------------------------------
     def forward(self, inargs):
         """models/model_core.py:72-81: bits of one scale (0-dim float32, differentiable w.r.t. the parameters)."""
+        if int(inargs['coord'].shape[0]) == 0:          # a scale without voxels costs nothing (and has nothing to differentiate)
+            return self._flat.sum() * 0.0
         frame = self._scale_frame(inargs)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
             return (_WideBits if self._wide is not None else _NetBits).apply(self, frame, *self._plist)

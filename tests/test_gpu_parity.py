@@ -1459,6 +1459,44 @@ def test_sequence_degenerate_clouds(pkg, tmp_path):
         _run_npy_sequence(tmp_path, 'wide', [sph(30) * 20000])
 
 
+def test_model_surface_rejects_malformed_inputs(pkg):
+    """model(putin_args) / encode / decode with the per-scale dicts user code builds (main.py:457-475): dtype and device conversions
+    are accepted, everything that cannot be right is refused with a message naming the field - including inputs that alias a
+    cached frame's tensors (slices share data pointers) - and a scale without voxels costs zero bits."""
+    from linr_pcgc_amd import overfit, synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    fr = prepare_frame(synthetic.sphere_shell(7, 30), None, 64, device='cuda')
+    model = overfit.gen_model(fr['scale_num'], 'cuda', seed=1)
+    s = fr['all_input_info'][0]
+    n = int(s['coord'].shape[0])
+
+    def putin(**over):
+        d = {'coord': s['coord'], 'offset_tensor': s['offset_tensor'], 'occ_lst': s['occ_lst'], 'scale_idx': 0}
+        d.update(over)
+        return d
+    with torch.no_grad():
+        base = float(model(putin()))
+        same = [putin(coord=s['coord'].long()), putin(offset_tensor=None), putin(occ_lst=[o.double() for o in s['occ_lst']]),
+                putin(occ_lst=[o.bool() for o in s['occ_lst']]),
+                putin(coord=s['coord'].cpu(), offset_tensor=s['offset_tensor'].cpu(), occ_lst=[o.cpu() for o in s['occ_lst']])]
+        assert all(float(model(d)) == base for d in same)
+        perm = torch.randperm(n, device='cuda')
+        bad = [(putin(coord=s['coord'][perm]), 'sorted'), (putin(coord=torch.cat([s['coord'][:1], s['coord'][:-1]])), 'unique'),
+               (putin(coord=s['coord'] - 5), 'non-negative'), (putin(scale_idx=fr['scale_num']), 'scale_idx'), (putin(scale_idx=-1), 'scale_idx'),
+               (putin(offset_tensor=s['offset_tensor'][:-1]), 'offset_tensor'), (putin(occ_lst=s['occ_lst'][:7]), 'occ_lst'),
+               (putin(occ_lst=[o[:-1] for o in s['occ_lst']]), 'occ_lst'), (putin(coord=s['coord'][:, :2]), 'coord')]
+        for d, word in bad:
+            with pytest.raises(ValueError, match=word):
+                model(d)
+        assert float(model(putin(coord=s['coord'][:0], offset_tensor=s['offset_tensor'][:0], occ_lst=[o[:0] for o in s['occ_lst']]))) == 0.0
+        enc = model.encode(putin())['enc_bytes']
+        dec = model.decode({'enc_bytes': enc, 'coord': s['coord'], 'offset_tensor': None, 'scale_idx': 0})
+        assert torch.equal(torch.cat(dec, dim=1), torch.cat([o.reshape(-1, 1) for o in s['occ_lst']], dim=1).float())
+        for blob in (b'', enc[:len(enc) // 2], bytes(np.random.default_rng(0).integers(0, 256, 500, dtype=np.uint8))):
+            with pytest.raises(ValueError, match='container'):
+                model.decode({'enc_bytes': blob, 'coord': s['coord'], 'offset_tensor': None, 'scale_idx': 0})
+
+
 def test_sequence_from_ply_files(pkg, tmp_path):
     """The driver on a real file sequence (main.py:69-119 with a dataset directory): five PLY frames (ascii and binary, shuffled
     vertex order, duplicated points - what read_ply_o3d + the voxel de-duplication of custom_dataset.py:259-270 accept), GOPs of
