@@ -113,13 +113,20 @@ def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None, keep='best'
         bits.zero_()
         for j, (f, pn) in enumerate(zip(gop.frames, gop.point_nums)):
             train_step(model, opt, f, pn, out=bits[j:j + 1])
-        loss_mean = float((bits / pns).sum()) / len(gop)     # the only host sync of the epoch
+        # the only host sync of the epoch.  Non-finite parameters make the epoch count as diverged (loss = inf): the loss itself
+        # would not show them - BCELoss's clamp at -100 (models/model_core.py:76-81) turns a NaN probability into 100 nats
+        val = (bits / pns).sum() / len(gop)
+        loss_mean = float(torch.where(torch.isfinite(model.flat_parameters()).all(), val, torch.full_like(val, float('inf'))))
         if best is not None:
             best.offer(epoch, loss_mean)
         opt.clamp_lr(min_lr)
         losses.append(loss_mean)
         if on_epoch is not None:
             on_epoch(epoch, loss_mean)
+    import math
+    if (best is not None and best.meta is None and losses) or (best is None and losses and not math.isfinite(losses[-1])):
+        raise FloatingPointError('the overfit diverged: epoch losses %s (no finite epoch to keep; learning rate %g)'
+                                 % (['%.4g' % x for x in losses], opt.lr))
     if best is not None:
         best.restore()          # also when the last epoch is the best: the checkpoint holds the lr from before the clamp
     if info is not None:

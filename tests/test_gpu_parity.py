@@ -1010,6 +1010,36 @@ def test_best_epoch_checkpoint_policy(pkg):
     assert enc_best['bpp']['point_bpp'] < enc_last['bpp']['point_bpp']
 
 
+def test_diverged_overfit_is_reported(pkg):
+    """A learning rate that sends the parameters to NaN.  The loss alone does not show it (BCELoss's clamp turns a NaN probability
+    into 100 nats, so the numbers stay finite): overfit_gop counts an epoch that ends with non-finite parameters as diverged
+    (loss = inf), keep='best' hands back the last sound epoch when there is one, and an overfit without one raises instead of
+    passing NaN parameters on to the model codec (where the reference's quantiser assertion, model_size_est.py:81, would be the
+    first thing to notice)."""
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    gop = overfit.Gop(None, [synthetic.sphere_shell(7, 40), synthetic.sphere_shell(7, 41)], None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    with pytest.raises(FloatingPointError, match='diverged'):
+        overfit.overfit_gop(model, FlatAdam(model, lr=1e8), gop, 3, keep='last')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    with pytest.raises(FloatingPointError, match='diverged'):
+        overfit.overfit_gop(model, FlatAdam(model, lr=1e8), gop, 3, keep='best')
+    # sound for two epochs, then the learning rate explodes: the second epoch is kept and can be coded
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    opt = FlatAdam(model, lr=0.01)
+    info = {}
+
+    def blow_up(epoch, loss):
+        if epoch == 1:
+            opt.lr = 1e8
+    losses = overfit.overfit_gop(model, opt, gop, 4, keep='best', info=info, on_epoch=blow_up)
+    assert math.isfinite(losses[0]) and math.isfinite(losses[1]) and losses[2] == float('inf') and losses[3] == float('inf')
+    assert info['coded_epoch'] == 1 and bool(torch.isfinite(model.flat_parameters()).all())
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    assert math.isfinite(enc['bpp']['bpp_all'])
+
+
 def test_threaded_gop_decode_equals_serial(pkg):
     """codec.decode_gop(workers=3): frames decoded concurrently on their own streams give the serial result."""
     from linr_pcgc_amd import codec, overfit, synthetic
