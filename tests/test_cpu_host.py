@@ -484,3 +484,34 @@ def test_host_code_under_sanitizers(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe, '400'], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and 'fuzz ok: 400 iterations' in run.stdout, (run.stdout[-500:], run.stderr[-3000:])
+
+
+def test_reference_checkpoint_optimizer_state_loads(golden_dir):
+    """GOPs >= 1 load GOP 0's `optimizer_state_dict` besides the weights (main.py:241-248).  The state inside the checkpoint the
+    reference ships - written by torch 1.13.1's Adam at epoch 70 (tests/golden/loot_optimizer_state.npz) - goes into FlatAdam
+    (learning rate as decayed, 7,223 steps on every tensor, both moments bit for bit) and comes back out in torch's format."""
+    from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model
+    g = np.load(os.path.join(golden_dir, 'loot_optimizer_state.npz'))
+    m = LINR_PCGC_Model({'scale_num': 7, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8, 'instage': 1})
+    sizes = [int(v) for v in g['sizes']]
+    assert sizes == [p.numel() for p in m.parameters()]          # 189 tensors in the reference's registration order
+    ea, es = torch.from_numpy(g['exp_avg']), torch.from_numpy(g['exp_avg_sq'])
+    state, off = {}, 0
+    for i, (p, n) in enumerate(zip(m.parameters(), sizes)):
+        state[i] = {'step': torch.tensor(float(g['step'][i])), 'exp_avg': ea[off:off + n].view(p.shape).clone(),
+                    'exp_avg_sq': es[off:off + n].view(p.shape).clone()}
+        off += n
+    sd = {'state': state, 'param_groups': [{'lr': float(g['lr']), 'betas': (float(g['beta1']), float(g['beta2'])), 'eps': float(g['eps']),
+                                            'weight_decay': float(g['weight_decay']), 'amsgrad': bool(g['amsgrad']), 'maximize': False,
+                                            'foreach': None, 'capturable': False, 'initial_lr': float(g['initial_lr']),
+                                            'params': list(range(len(sizes)))}]}
+    opt = FlatAdam(m)
+    opt.load_state_dict(sd)
+    assert opt.lr == float(g['lr']) and 0 < opt.lr < 0.01 and opt.t == 7223 and opt.t_scale.tolist() == [7223] * 7
+    assert opt.betas == (0.9, 0.999) and opt.eps == 1e-8 and opt.weight_decay == 1e-4
+    assert torch.equal(opt.exp_avg.cpu(), ea) and torch.equal(opt.exp_avg_sq.cpu(), es)
+    back = opt.state_dict()
+    assert all(torch.equal(back['state'][i]['exp_avg'].cpu(), state[i]['exp_avg']) and float(back['state'][i]['step']) == 7223.0 for i in range(len(sizes)))
+    ref = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4)
+    ref.load_state_dict(back)                                    # and torch takes it back
+    assert ref.param_groups[0]['lr'] == float(g['lr'])
