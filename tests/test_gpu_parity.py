@@ -1040,6 +1040,42 @@ def test_diverged_overfit_is_reported(pkg):
     assert math.isfinite(enc['bpp']['bpp_all'])
 
 
+def test_concurrent_training_in_threads_equals_serial(pkg):
+    """The training path is re-entrant too (include/linr_hip.h: no mutable global state on the data path): three GOPs overfitted
+    and encoded at the same time by three host threads on three streams end in the losses, parameters and stream bytes of the
+    same three jobs run one after the other.  (Models are built beforehand: torch's initialisation draws from a process-wide RNG.)"""
+    import threading
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+
+    def make(k):
+        gop = overfit.Gop(None, [synthetic.sphere_shell(7, 30 + 5 * k + t) for t in range(3)], None, 64, 'cuda')
+        return gop, overfit.gen_model(gop.scale_num, 'cuda', seed=100 + k), overfit.gen_model(gop.scale_num, 'cuda')
+
+    def job(gop, model, shell, out, stream):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(stream):
+            losses = overfit.overfit_gop(model, FlatAdam(model), gop, 4)
+            enc = codec.encode_gop(model, shell, gop, 8, n_threads=2)
+            stream.synchronize()
+        out.append((losses, [bytes(b) for f in enc['frames'] for b in f], enc['model_bin'], model.flat_parameters().clone()))
+    serial = []
+    for k in range(3):
+        job(*make(k), serial, torch.cuda.current_stream())
+    sets = [make(k) for k in range(3)]
+    torch.cuda.synchronize()
+    res = [[] for _ in range(3)]
+    threads = [threading.Thread(target=job, args=(*sets[k], res[k], torch.cuda.Stream())) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(3):
+        assert len(res[k]) == 1, 'thread %d died' % k
+        a, b = serial[k], res[k][0]
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and torch.equal(a[3], b[3]), k
+
+
 def test_threaded_gop_decode_equals_serial(pkg):
     """codec.decode_gop(workers=3): frames decoded concurrently on their own streams give the serial result."""
     from linr_pcgc_amd import codec, overfit, synthetic
