@@ -203,3 +203,87 @@ def test_reference_checkpoint_pins_network_semantics(golden_dir):
     assert assumed < 1.2, bpp
     others = [v for k, v in bpp.items() if k != ((0, 1, 2), False)]
     assert min(others) > 4.0 * assumed, bpp
+
+
+def test_reference_checkpoint_pins_wiring_and_channel_conventions(golden_dir, monkeypatch):
+    """The same behavioural pin for the conventions the tap-order sweep does not touch.  The network the REFERENCE trained is run
+    through the restatement as written and through eleven variants that each read one convention the other plausible way; every
+    variant predicts the unseen surface worse (bits/point, measured: assumed 0.963):
+      child index 4dz+2dy+dx instead of 4dx+2dy+dz (module_utils.py:93) 6.73 | child order reversed 10.89 | occupancy concat newest
+      first (upsample.py:206-209) 3.54 | Inception cat([out1, out0]) (resnet.py:55-60) 3.68 | prior_k on the previous prior instead of
+      the ORIGINAL x_glob (upsample.py:213) 5.74 | scale_idx counted from the coarsest 2.05 | scale_idx off by one 1.54 | scale
+      context [offsets | emb] instead of [emb | offsets] (model_core.py:48-53) 1.41 | 7-neighbour offsets x<->z 1.24, +<->- 1.13
+      (glob_params.py:3) | make_block without its ReLU (upsample.py:88-97) 1.16."""
+    import torch.nn.functional as F
+    from oracle import network as onet
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    scales = []
+    for s in range(int(g['scale_num'])):
+        c = g['s%d_coord' % s]
+        scales.append({'coord': c, 'occ': g['s%d_occ' % s], 'offset_tensor': g['s%d_offset' % s], 'scale_idx': s,
+                       'nbr': octree.neighbour_table(c)})
+    points, S = len(g['ori']), len(scales)
+    sd = _reference_state_dict(golden_dir, (0, 1, 2), False)
+
+    def bpp(sc):
+        with torch.no_grad():
+            return float(onet.frame_bits(sd, onet.to_torch_scales(sc))) / points
+    assumed = bpp(scales)
+    assert assumed < 1.2
+    # conventions of the inputs
+    dz_major = [((j >> 2) & 1) | (((j >> 1) & 1) << 1) | ((j & 1) << 2) for j in range(8)]
+    data_variants = {
+        'child index dz-major': ([dict(s, occ=s['occ'][:, dz_major]) for s in scales], 3.0),
+        'child order reversed': ([dict(s, occ=s['occ'][:, ::-1].copy()) for s in scales], 3.0),
+        'offsets x<->z': ([dict(s, offset_tensor=s['offset_tensor'][:, [0, 5, 6, 3, 4, 1, 2]]) for s in scales], 1.1),
+        'offsets +<->-': ([dict(s, offset_tensor=s['offset_tensor'][:, [0, 2, 1, 4, 3, 6, 5]]) for s in scales], 1.1),
+        'scale_idx from the coarsest': ([dict(s, scale_idx=S - 1 - s['scale_idx']) for s in scales], 1.5),
+        'scale_idx off by one': ([dict(s, scale_idx=min(s['scale_idx'] + 1, 6)) for s in scales], 1.3)}
+    for name, (sc, factor) in data_variants.items():
+        assert bpp(sc) > factor * assumed, name
+
+    # conventions of the wiring: one restated function replaced at a time
+    def inception_swapped(x, nbr, sdd, p):
+        out0 = onet.conv3(F.relu(onet.conv3(x, nbr, sdd[p + '.conv0_0.kernel'], sdd[p + '.conv0_0.bias'])), nbr,
+                          sdd[p + '.conv0_1.kernel'], sdd[p + '.conv0_1.bias'])
+        h = F.relu(onet.conv1(x, sdd[p + '.conv1_0.kernel'], sdd[p + '.conv1_0.bias']))
+        h = F.relu(onet.conv3(h, nbr, sdd[p + '.conv1_1.kernel'], sdd[p + '.conv1_1.bias']))
+        return torch.cat([onet.conv1(h, sdd[p + '.conv1_2.kernel'], sdd[p + '.conv1_2.bias']), out0], dim=1) + x
+
+    def cnp(cumulative, newest_first):
+        def forward(sdd, x_low, occ, nbr, stages=8):
+            u = 'upsampler.'
+            x_glob = onet.make_block(x_low, nbr, sdd, u + 'block_in')
+            logits, probs, prior = [], [], x_glob
+            for k in range(stages):
+                c = onet.conv3(prior, nbr, sdd[u + 'prune_blocks.%d.0.conv.kernel' % k], sdd[u + 'prune_blocks.%d.0.conv.bias' % k])
+                z = onet.mlp(c, sdd, u + 'inner_mlps.%d.0' % k)
+                logits.append(z)
+                probs.append(torch.sigmoid(z))
+                if k == stages - 1:
+                    break
+                seen = torch.flip(occ[:, :k + 1], dims=[1]) if newest_first else occ[:, :k + 1]
+                prior = (prior if cumulative else x_glob) + onet.make_block(seen, nbr, sdd, u + 'outter_blocks.%d' % k)
+            return logits, probs
+        return forward
+
+    def make_block_without_relu(x, nbr, sdd, p):
+        out, nl = onet.conv3(x, nbr, sdd[p + '.0.kernel'], sdd[p + '.0.bias']), 0
+        while (p + '.2.layers.%d.conv0_0.kernel' % nl) in sdd:
+            out = onet.inception(out, nbr, sdd, p + '.2.layers.%d' % nl)
+            nl += 1
+        return onet.conv3(out, nbr, sdd[p + '.3.kernel'], sdd[p + '.3.bias'])
+
+    def context_offsets_first(sdd, offset_tensor, scale_idx):
+        emb = sdd['scale_emb.weight'][scale_idx].unsqueeze(0).expand(offset_tensor.shape[0], -1)
+        return onet.mlp(torch.cat([offset_tensor, emb], dim=-1), sdd, 'scale_mlp.%d' % scale_idx)
+    wiring_variants = {'inception': (inception_swapped, 2.5), 'cnp_forward': (cnp(True, False), 3.0), 'make_block': (make_block_without_relu, 1.1),
+                       'scale_context': (context_offsets_first, 1.25)}
+    for attr, (fn, factor) in wiring_variants.items():
+        with monkeypatch.context() as mp:
+            mp.setattr(onet, attr, fn)
+            assert bpp(scales) > factor * assumed, attr
+    with monkeypatch.context() as mp:
+        mp.setattr(onet, 'cnp_forward', cnp(False, True))
+        assert bpp(scales) > 2.5 * assumed, 'occupancy concat newest first'
+    assert abs(bpp(scales) - assumed) < 1e-12          # the restatement is back as written
