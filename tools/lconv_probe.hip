@@ -1,0 +1,865 @@
+// Probe: 3x3x3 convolution 8->8 on Morton blocks staged in LDS, 64-row tiles sorted by their 27-bit neighbour mask inside the
+// block, absent taps skipped per tile (wave-uniform), against the lane = x-major row / 27 gathers through the L1 form of today's
+// cconv_mfma_k.  Host builds the geometry (loot10 stand-in: 10-bit sphere r = 250, all octree scales in one row space), the
+// neighbour table and the block plan.  build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/lconv_probe tools/lconv_probe.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#include <utility>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class F, int... Ks> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+#define TAPK(kk) (((kk) / 9) + 3 * (((kk) / 3) % 3) + 9 * ((kk) % 3))
+
+// ---------------------------------------------------------------- baseline: lane = row, 27 taps, full index table ----------
+template <int G>
+__global__ __launch_bounds__(256) void base_k(const float* __restrict__ in, const int* __restrict__ nbr, long ld, long n,
+                                              const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                              long gstride_in, long gstride_w) {
+    const int gi = blockIdx.y;
+    in += gi * gstride_in; out += gi * gstride_in; W += gi * gstride_w; bias += gi * 8;
+    const int lane = threadIdx.x & 63;
+    float wv[4][8];
+    {
+        const int blk = lane >> 2, j = lane & 3, kl = blk / 2, co = 4 * (blk % 2) + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = g * 8 + kl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[g][i] = k < 27 ? W[(k * 8 + i) * 8 + co] : 0.0f;
+        }
+    }
+    const long row_raw = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row_raw < n;
+    const long row = live ? row_raw : n - 1;
+    const char* pad = (const char*)(in - 8);
+    unsigned off[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) off[k] = (unsigned)(nbr[k * ld + row] + 1) << 5;
+    f32x4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = bias[4 * h + j];
+    constexpr int PF = 4;
+    f32x4 x[PF + 1][2];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { x[u][0] = *(const f32x4*)(pad + off[TAPK(u)]); x[u][1] = *(const f32x4*)(pad + off[TAPK(u)] + 16); }
+    __builtin_amdgcn_sched_barrier(0);
+    sfor<27>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int k = TAPK(kk), g = k / 8, ab = (k % 8) * 2;
+        if constexpr (kk + PF < 27) {
+            x[(kk + PF) % (PF + 1)][0] = *(const f32x4*)(pad + off[TAPK(kk + PF)]);
+            x[(kk + PF) % (PF + 1)][1] = *(const f32x4*)(pad + off[TAPK(kk + PF)] + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i / 4][i % 4], acc[0], 4, ab, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i / 4][i % 4], acc[1], 4, ab + 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (live) { *(f32x4*)(out + row * 8) = acc[0]; *(f32x4*)(out + row * 8 + 4) = acc[1]; }
+}
+
+// ---------------------------------------------------------------- block-local form -----------------------------------------
+struct Plan {
+    const int* blk_src_off;      // [nblk + 1]  range of the block's source rows (own rows + halo, ascending) in src[]
+    const int* src;              // global row ids
+    const int* blk_tile_off;     // [nblk + 1]
+    const unsigned* tile_mask;   // [ntiles]    bit kk = step kk (LINR_TAP order) is live
+    const int* tile_tap_off;     // [ntiles]    first 64-entry line of the tile in idx16
+    const int* tile_rows;        // [ntiles][64] global row of each lane, -1 = none
+    const unsigned short* idx16; // [lines][64] local slot of the neighbour (0 = absent: the zero slot)
+};
+#ifndef LC_MAXSRC
+#define LC_MAXSRC 1279            // slots 1 .. LC_MAXSRC; slot 0 = zeros
+#endif
+#define LC_ROWB 32
+
+template <int PIPE>
+__global__ __launch_bounds__(256) void lconv_k(const float* __restrict__ in, Plan P, const float* __restrict__ W,
+                                               const float* __restrict__ bias, float* __restrict__ out, long gstride_in,
+                                               long gstride_w) {
+    __shared__ f32x4 rows[(LC_MAXSRC + 1) * 2];
+    __shared__ f32x4 wl[27 * 16];                 // [k][hb][j][i/4] -> 32 B per (k, hb, j)
+    const int gi = blockIdx.y, b = blockIdx.x;
+    in += gi * gstride_in; out += gi * gstride_in; W += gi * gstride_w; bias += gi * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = P.blk_src_off[b], ns = P.blk_src_off[b + 1] - s0;
+    if (tid < 2) rows[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < 2 * ns; e += 256) {
+        const int r = P.src[s0 + (e >> 1)];
+        rows[2 + e] = *(const f32x4*)(in + (long)r * 8 + 4 * (e & 1));
+    }
+    for (int e = tid; e < 27 * 64; e += 256) {     // e = ((k * 2 + hb) * 4 + j) * 8 + i
+        const int i = e & 7, j = (e >> 3) & 3, hb = (e >> 5) & 1, k = e >> 6;
+        ((float*)wl)[e] = W[(k * 8 + i) * 8 + 4 * hb + j];
+    }
+    __syncthreads();
+    const int t0 = P.blk_tile_off[b], nt = P.blk_tile_off[b + 1] - t0;
+    const char* rb = (const char*)rows;
+    const char* wb = (const char*)wl + (((lane >> 2) & 1) * 4 + (lane & 3)) * 32;
+    for (int t = wave; t < nt; t += 4) {
+        const int T = t0 + t;
+        unsigned m = __builtin_amdgcn_readfirstlane(P.tile_mask[T]);
+        const unsigned short* ip = P.idx16 + (long)P.tile_tap_off[T] * 64 + lane;
+        const int row = P.tile_rows[(long)T * 64 + lane];
+        f32x4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][j] = bias[4 * h + j];
+        if (PIPE == 0) {
+            while (m) {
+                const int kk = __builtin_ctz(m); m &= m - 1;
+                const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+                const unsigned slot = *ip; ip += 64;
+                const f32x4 x0 = *(const f32x4*)(rb + slot * 32), x1 = *(const f32x4*)(rb + slot * 32 + 16);
+                const f32x4 w0 = *(const f32x4*)(wb + k * 256), w1 = *(const f32x4*)(wb + k * 256 + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[i], x0[i], acc[0], 4, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[i], x0[i], acc[1], 4, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[i], x1[i], acc[0], 4, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[i], x1[i], acc[1], 4, 1, 0);
+                }
+            }
+        } else {
+            // one tap ahead: slot, rows and weights of the next live tap are requested before the MFMAs of this one
+            int kk = __builtin_ctz(m | 0x80000000u); m &= m - 1;
+            unsigned slot = *ip; ip += 64;
+            unsigned slotn = *ip;                                     // the table has a spare line at the end
+            int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+            f32x4 x0 = *(const f32x4*)(rb + slot * 32), x1 = *(const f32x4*)(rb + slot * 32 + 16);
+            f32x4 w0 = *(const f32x4*)(wb + k * 256), w1 = *(const f32x4*)(wb + k * 256 + 16);
+            while (true) {
+                const bool more = m != 0;
+                const int kkn = __builtin_ctz(m | 0x80000000u); m &= m - 1;
+                const int kn = kkn == 31 ? 0 : kkn / 9 + 3 * ((kkn / 3) % 3) + 9 * (kkn % 3);
+                ip += 64;
+                const unsigned slotnn = *ip;
+                const f32x4 y0 = *(const f32x4*)(rb + slotn * 32), y1 = *(const f32x4*)(rb + slotn * 32 + 16);
+                const f32x4 v0 = *(const f32x4*)(wb + kn * 256), v1 = *(const f32x4*)(wb + kn * 256 + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[i], x0[i], acc[0], 4, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w0[i], x0[i], acc[1], 4, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[i], x1[i], acc[0], 4, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[i], x1[i], acc[1], 4, 1, 0);
+                }
+                if (!more) break;
+                x0 = y0; x1 = y1; w0 = v0; w1 = v1; slotn = slotnn;
+            }
+        }
+        if (row >= 0) { *(f32x4*)(out + (long)row * 8) = acc[0]; *(f32x4*)(out + (long)row * 8 + 4) = acc[1]; }
+    }
+}
+
+
+// Variant 2: weights register-resident as in cconv_mfma_k (static ABID), the dynamic tap selects its 16 MFMAs through a switch
+// (wave-uniform jump); slots prefetched three live taps ahead, rows one ahead.  LAB: 1 = no staging, 2 = no tap loop, 4 = no MFMAs
+template <int LAB>
+__global__ __launch_bounds__(256) void lconv2_k(const float* __restrict__ in, Plan P, const float* __restrict__ W,
+                                                const float* __restrict__ bias, float* __restrict__ out, long gstride_in,
+                                                long gstride_w) {
+    __shared__ f32x4 rows[(LC_MAXSRC + 1) * 2];
+    const int gi = blockIdx.y, b = blockIdx.x;
+    in += gi * gstride_in; out += gi * gstride_in; W += gi * gstride_w; bias += gi * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = P.blk_src_off[b], ns = P.blk_src_off[b + 1] - s0;
+    if (tid < 2) rows[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(LAB & 1)) {
+        for (int e = tid; e < 2 * ns; e += 256) {
+            const int r = P.src[s0 + (e >> 1)];
+            rows[2 + e] = *(const f32x4*)(in + (long)r * 8 + 4 * (e & 1));
+        }
+    }
+    float wv[4][8];
+    {
+        const int blk = lane >> 2, j = lane & 3, kl = blk / 2, co = 4 * (blk % 2) + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = g * 8 + kl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[g][i] = k < 27 ? W[(k * 8 + i) * 8 + co] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int t0 = P.blk_tile_off[b], nt = P.blk_tile_off[b + 1] - t0;
+    const char* rb = (const char*)rows;
+    for (int t = wave; t < nt; t += 4) {
+        const int T = t0 + t;
+        unsigned m = __builtin_amdgcn_readfirstlane(P.tile_mask[T]);
+        const unsigned short* ip = P.idx16 + (long)P.tile_tap_off[T] * 64 + lane;
+        const int row = P.tile_rows[(long)T * 64 + lane];
+        f32x4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][j] = bias[4 * h + j];
+        if (!(LAB & 2)) {
+            unsigned s1 = ip[0], s2 = ip[64], s3 = ip[128];          // spare lines at the end of the table
+            ip += 192;
+            f32x4 x0 = *(const f32x4*)(rb + s1 * 32), x1 = *(const f32x4*)(rb + s1 * 32 + 16);
+            while (m) {
+                const int kk = __builtin_ctz(m); m &= m - 1;
+                const unsigned s4 = *ip; ip += 64;
+                const f32x4 y0 = *(const f32x4*)(rb + s2 * 32), y1 = *(const f32x4*)(rb + s2 * 32 + 16);
+                if (!(LAB & 4)) {
+                    switch (kk) {
+#define CASE(KK) case KK: { constexpr int k = TAPK(KK), g = k / 8, ab = (k % 8) * 2; \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+                            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x0[i], acc[0], 4, ab, 0); \
+                            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x0[i], acc[1], 4, ab + 1, 0); } \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) { \
+                            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][4 + i], x1[i], acc[0], 4, ab, 0); \
+                            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][4 + i], x1[i], acc[1], 4, ab + 1, 0); } } break;
+                        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+                        CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20) CASE(21) CASE(22) CASE(23) CASE(24) CASE(25) CASE(26)
+                        default: break;
+                    }
+                } else { acc[0] += x0; acc[1] += x1; }
+                x0 = y0; x1 = y1; s2 = s3; s3 = s4;
+            }
+        }
+        if (row >= 0) { *(f32x4*)(out + (long)row * 8) = acc[0]; *(f32x4*)(out + (long)row * 8 + 4) = acc[1]; }
+    }
+}
+
+
+// Variant 3: every tile's tap list is padded to a multiple of 3 (zero-slot lines) and runs as a fully unrolled static loop of N
+// steps: all N slot loads up front, rows PF steps ahead, weights of the (dynamic, wave-uniform) tap from an LDS image in step order.
+template <int N, int LAB>
+__device__ __forceinline__ void lc3_tile(const char* rb, const char* wb, unsigned m, const unsigned short* ip, f32x4 (&acc)[2]) {
+    unsigned sl[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) sl[j] = ip[j * 64];
+    constexpr int PF = 2;
+    f32x4 x[PF + 1][2], w[PF + 1][2];
+    int kq[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { kq[j] = m ? __builtin_ctz(m) : 0; m &= m - 1; }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        x[u][0] = *(const f32x4*)(rb + sl[u] * 32); x[u][1] = *(const f32x4*)(rb + sl[u] * 32 + 16);
+        w[u][0] = *(const f32x4*)(wb + kq[u] * 256); w[u][1] = *(const f32x4*)(wb + kq[u] * 256 + 16);
+    }
+    sfor<N>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j + PF < N) {
+            constexpr int u = (j + PF) % (PF + 1);
+            x[u][0] = *(const f32x4*)(rb + sl[j + PF] * 32); x[u][1] = *(const f32x4*)(rb + sl[j + PF] * 32 + 16);
+            w[u][0] = *(const f32x4*)(wb + kq[j + PF] * 256); w[u][1] = *(const f32x4*)(wb + kq[j + PF] * 256 + 16);
+        }
+        constexpr int c = j % (PF + 1);
+        if constexpr (!(LAB & 4)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[0], 4, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[1], 4, 1, 0);
+            }
+        } else { acc[0] += x[c][0] * w[c][0]; acc[1] += x[c][1] * w[c][1]; }
+    });
+}
+
+template <int LAB>
+__global__ __launch_bounds__(256) void lconv3_k(const float* __restrict__ in, Plan P, const float* __restrict__ W,
+                                                const float* __restrict__ bias, float* __restrict__ out, long gstride_in,
+                                                long gstride_w) {
+    __shared__ f32x4 rows[(LC_MAXSRC + 1) * 2];
+    __shared__ f32x4 wl[27 * 16];                 // [kk][hb][j][i/4]: step order
+    const int gi = blockIdx.y, b = blockIdx.x;
+    in += gi * gstride_in; out += gi * gstride_in; W += gi * gstride_w; bias += gi * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = P.blk_src_off[b], ns = P.blk_src_off[b + 1] - s0;
+    if (tid < 2) rows[tid] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(LAB & 1)) {
+        // 2 ns sixteen-byte pieces, up to 10 per thread (LC_MAXSRC 1279): all index loads, then all row loads, then the writes
+        constexpr int SU = (2 * LC_MAXSRC + 255) / 256;
+        int r[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u; r[u] = e < 2 * ns ? P.src[s0 + (e >> 1)] : -1; }
+        f32x4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u; if (r[u] >= 0) v[u] = *(const f32x4*)(in + (long)r[u] * 8 + 4 * (e & 1)); }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u; if (r[u] >= 0) rows[2 + e] = v[u]; }
+    }
+    for (int e = tid; e < 27 * 64; e += 256) {     // e = ((kk * 2 + hb) * 4 + j) * 8 + i
+        const int i = e & 7, j = (e >> 3) & 3, hb = (e >> 5) & 1, kk = e >> 6;
+        const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+        ((float*)wl)[e] = W[(k * 8 + i) * 8 + 4 * hb + j];
+    }
+    __syncthreads();
+    const int t0 = P.blk_tile_off[b], nt = P.blk_tile_off[b + 1] - t0;
+    const char* rb = (const char*)rows;
+    const char* wb = (const char*)wl + (((lane >> 2) & 1) * 4 + (lane & 3)) * 32;
+    for (int t = wave; t < nt; t += 4) {
+        const int T = t0 + t;
+        const unsigned m = __builtin_amdgcn_readfirstlane(P.tile_mask[T]);
+        const unsigned short* ip = P.idx16 + (long)P.tile_tap_off[T] * 64 + lane;
+        const int row = P.tile_rows[(long)T * 64 + lane];
+        f32x4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][j] = bias[4 * h + j];
+        if (!(LAB & 2)) {
+            const int cls = (__builtin_popcount(m) + 2) / 3;
+            switch (cls) {
+                case 0: case 1: case 2: case 3: lc3_tile<9, LAB>(rb, wb, m, ip, acc); break;
+                case 4: lc3_tile<12, LAB>(rb, wb, m, ip, acc); break;
+                case 5: lc3_tile<15, LAB>(rb, wb, m, ip, acc); break;
+                case 6: lc3_tile<18, LAB>(rb, wb, m, ip, acc); break;
+                case 7: lc3_tile<21, LAB>(rb, wb, m, ip, acc); break;
+                case 8: lc3_tile<24, LAB>(rb, wb, m, ip, acc); break;
+                default: lc3_tile<27, LAB>(rb, wb, m, ip, acc); break;
+            }
+        }
+        if (row >= 0) { *(f32x4*)(out + (long)row * 8) = acc[0]; *(f32x4*)(out + (long)row * 8 + 4) = acc[1]; }
+    }
+}
+
+
+// Variant 4: one workgroup per block of 256 rows (4 tiles = 4 waves), persistent over the G groups: the tile's slots stay in
+// registers, the rows / weights of group g + 1 are requested before the taps of group g and parked in the other LDS buffer after
+// them; one barrier per group.  Fixed-stride plan: src4[b][LC4_MAXSRC], nsrc4[b], tile 4 b + wave, idx4[tile][27][64].
+#ifndef LC4_MAXSRC
+#define LC4_MAXSRC 615
+#endif
+struct Plan4 { const int* nsrc; const int* src; const unsigned* tile_mask; const int* tile_rows; const unsigned short* idx; };
+
+template <int N, int LAB>
+__device__ __forceinline__ void lc4_body(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
+                                         float* __restrict__ out, long gstride_in, long gstride_w, int G, f32x4* rows, f32x4* wl,
+                                         const int (&r)[(2 * LC4_MAXSRC + 255) / 256], int ns2, unsigned m, const unsigned short* ip,
+                                         int row, int tid, int lane) {
+    constexpr int SU = (2 * LC4_MAXSRC + 255) / 256;
+    constexpr int RB = (LC4_MAXSRC + 1) * 2;          // f32x4 per rows buffer
+    unsigned sl[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) sl[j] = ip[j * 64];
+    int kq[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { kq[j] = m ? __builtin_ctz(m) : 0; m &= m - 1; }
+    const char* wsel = (const char*)wl + (((lane >> 2) & 1) * 4 + (lane & 3)) * 32;
+    // the slots must have arrived before the loop: left pending, the first use inside it is guarded by a vmcnt(0) that also waits
+    // for the loads of the next group issued just before (the loop header merges both states)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int g = 0; g < G; ++g) {
+        f32x4 v[SU];
+        float wr[7];
+        const bool nxt = g + 1 < G;
+        if (nxt && !(LAB & 1)) {
+            const float* inn = in + (long)(g + 1) * gstride_in;
+            const float* Wn = W + (long)(g + 1) * gstride_w;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u; if (e < ns2) v[u] = *(const f32x4*)(inn + (long)r[u] * 8 + 4 * (e & 1)); }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int e = tid + 256 * u;
+                if (e < 1728) { const int i = e & 7, j = (e >> 3) & 3, hb = (e >> 5) & 1, kk = e >> 6; wr[u] = Wn[(TAPK(kk) * 8 + i) * 8 + 4 * hb + j]; }
+            }
+        }
+        const char* rb = (const char*)(rows + (g & 1) * RB);
+        const char* wb = wsel + (g & 1) * (27 * 256);
+        f32x4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][j] = bias[g * 8 + 4 * h + j];
+        if (!(LAB & 2)) {
+            constexpr int PF = 2;
+            f32x4 x[PF + 1][2], w[PF + 1][2];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                x[u][0] = *(const f32x4*)(rb + sl[u]); x[u][1] = *(const f32x4*)(rb + (sl[u] ^ 16));
+                w[u][0] = *(const f32x4*)(wb + kq[u] * 256); w[u][1] = *(const f32x4*)(wb + kq[u] * 256 + 16);
+            }
+            sfor<N>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (j + PF < N) {
+                    constexpr int u = (j + PF) % (PF + 1);
+                    x[u][0] = *(const f32x4*)(rb + sl[j + PF]); x[u][1] = *(const f32x4*)(rb + (sl[j + PF] ^ 16));
+                    w[u][0] = *(const f32x4*)(wb + kq[j + PF] * 256); w[u][1] = *(const f32x4*)(wb + kq[j + PF] * 256 + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int c = j % (PF + 1);
+                if constexpr (!(LAB & 4)) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[0], 4, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[1], 4, 1, 0);
+                    }
+                } else { acc[0] += x[c][0] * w[c][0]; acc[1] += x[c][1] * w[c][1]; }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if (nxt && !(LAB & 1)) {
+            f32x4* rn = rows + ((g + 1) & 1) * RB;
+            float* wn = (float*)wl + ((g + 1) & 1) * (27 * 64);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u, sl_ = (e >> 1) + 1; if (e < ns2) rn[2 * sl_ + ((e & 1) ^ ((sl_ >> 3) & 1))] = v[u]; }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) { const int e = tid + 256 * u; if (e < 1728) wn[e] = wr[u]; }
+        }
+        __syncthreads();
+        // the output rows leave after the barrier: a store issued before the wait for the staged loads would be waited for too
+        if (row >= 0) {
+            float* op = out + (long)g * gstride_in + (long)row * 8;
+            *(f32x4*)op = acc[0]; *(f32x4*)(op + 4) = acc[1];
+        }
+    }
+}
+
+template <int LAB>
+__global__ __launch_bounds__(256) void lconv4_k(const float* __restrict__ in, Plan4 P, const float* __restrict__ W,
+                                                const float* __restrict__ bias, float* __restrict__ out, long gstride_in,
+                                                long gstride_w, int G) {
+    constexpr int SU = (2 * LC4_MAXSRC + 255) / 256;
+    constexpr int RB = (LC4_MAXSRC + 1) * 2;
+    __shared__ f32x4 rows[2 * RB];
+    __shared__ f32x4 wl[2 * 27 * 16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ns2 = 2 * P.nsrc[b];
+    int r[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u; r[u] = e < ns2 ? P.src[(long)b * LC4_MAXSRC + (e >> 1)] : 0; }
+    const int T = 4 * b + wave;
+    const unsigned m = __builtin_amdgcn_readfirstlane(P.tile_mask[T]);
+    const unsigned short* ip = P.idx + (long)T * (27 * 64) + lane;
+    const int row = P.tile_rows[(long)T * 64 + lane];
+    if (tid < 2) { rows[tid] = (f32x4){0.f, 0.f, 0.f, 0.f}; rows[RB + tid] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { const int e = tid + 256 * u, sl_ = (e >> 1) + 1; if (e < ns2) rows[2 * sl_ + ((e & 1) ^ ((sl_ >> 3) & 1))] = *(const f32x4*)(in + (long)r[u] * 8 + 4 * (e & 1)); }
+        for (int e = tid; e < 1728; e += 256) {
+            const int i = e & 7, j = (e >> 3) & 3, hb = (e >> 5) & 1, kk = e >> 6;
+            ((float*)wl)[e] = W[(TAPK(kk) * 8 + i) * 8 + 4 * hb + j];
+        }
+    }
+    __syncthreads();
+    const int cls = (__builtin_popcount(m) + 2) / 3;
+#define LC4_CASE(N) lc4_body<N, LAB>(in, W, bias, out, gstride_in, gstride_w, G, rows, wl, r, ns2, m, ip, row, tid, lane)
+    switch (cls) {
+        case 0: case 1: case 2: case 3: LC4_CASE(9); break;
+        case 4: LC4_CASE(12); break;
+        case 5: LC4_CASE(15); break;
+        case 6: LC4_CASE(18); break;
+        case 7: LC4_CASE(21); break;
+        case 8: LC4_CASE(24); break;
+        default: LC4_CASE(27); break;
+    }
+}
+
+
+// Variant 5 = variant 4 with the per-step instruction overhead removed: everything a step needs beside its 4 LDS reads and
+// 16 MFMAs is loop-invariant over the groups and sits in registers (row slot byte offsets, weight-tap LDS addresses), the two
+// LDS buffers are compile-time immediates (group loop unrolled by two), global addresses are uniform base + 32-bit lane offset.
+struct Lc5Regs { unsigned roff[(2 * LC4_MAXSRC + 255) / 256]; unsigned woff[7]; unsigned lrow[(2 * LC4_MAXSRC + 255) / 256]; };
+
+template <int N, int BUF, int LAB>
+__device__ __forceinline__ void lc5_iter(int g, int G, const char* __restrict__ in, const char* __restrict__ W, const float* __restrict__ bias,
+                                         char* __restrict__ out, long gstride_b, long wstride_b, char* lds, const Lc5Regs& rg, int ns2,
+                                         const unsigned (&sl)[N], const unsigned (&wa)[N], int orow, int tid) {
+    constexpr int SU = (2 * LC4_MAXSRC + 255) / 256;
+    constexpr int RBB = (LC4_MAXSRC + 1) * 32;         // bytes per rows buffer
+    constexpr int WLB = 27 * 256;                      // bytes per weights image
+    constexpr int ROWS0 = 0, WL0 = 2 * RBB;            // LDS map: rows[0] rows[1] wl[0] wl[1]
+    f32x4 v[SU];
+    float wr[7];
+    const bool nxt = g + 1 < G;
+    if (nxt && !(LAB & 1)) {
+        const char* inn = in + (long)(g + 1) * gstride_b;
+        const char* Wn = W + (long)(g + 1) * wstride_b;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) if (tid + 256 * u < ns2) v[u] = *(const f32x4*)(inn + rg.roff[u]);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) if (tid + 256 * u < 1728) wr[u] = *(const float*)(Wn + rg.woff[u]);
+    }
+    const char* rb = lds + ROWS0 + BUF * RBB;
+    const char* wb = lds + WL0 + BUF * WLB;
+    f32x4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = bias[g * 8 + 4 * h + j];
+    if (!(LAB & 2)) {
+        constexpr int PF = 2;
+        f32x4 x[PF + 1][2], w[PF + 1][2];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            x[u][0] = *(const f32x4*)(rb + sl[u]); x[u][1] = *(const f32x4*)(rb + sl[u] + 16);
+            w[u][0] = *(const f32x4*)(wb + wa[u]); w[u][1] = *(const f32x4*)(wb + wa[u] + 16);
+        }
+        sfor<N>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + PF < N) {
+                constexpr int u = (j + PF) % (PF + 1);
+                x[u][0] = *(const f32x4*)(rb + sl[j + PF]); x[u][1] = *(const f32x4*)(rb + sl[j + PF] + 16);
+                w[u][0] = *(const f32x4*)(wb + wa[j + PF]); w[u][1] = *(const f32x4*)(wb + wa[j + PF] + 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int c = j % (PF + 1);
+            if constexpr (!(LAB & 4)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[0], 4, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[c][i / 4][i % 4], x[c][i / 4][i % 4], acc[1], 4, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    if (nxt && !(LAB & 1)) {
+        char* rn = lds + ROWS0 + (BUF ^ 1) * RBB;
+        char* wn = lds + WL0 + (BUF ^ 1) * WLB;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) if (tid + 256 * u < ns2) *(f32x4*)(rn + rg.lrow[u]) = v[u];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) if (tid + 256 * u < 1728) *(float*)(wn + 4 * (tid + 256 * u)) = wr[u];
+    }
+    __syncthreads();
+    if (orow >= 0) {
+        char* op = out + (long)g * gstride_b + (unsigned)orow;
+        *(f32x4*)op = acc[0]; *(f32x4*)(op + 16) = acc[1];
+    }
+}
+
+template <int N, int LAB>
+__device__ __forceinline__ void lc5_body(int G, const char* in, const char* W, const float* bias, char* out, long gstride_b, long wstride_b,
+                                         char* lds, const Lc5Regs& rg, int ns2, unsigned m, const unsigned short* ip, int orow, int tid, int lane) {
+    unsigned sl[N], wa[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) sl[j] = ip[j * 64];
+    const unsigned lanepart = (((lane >> 2) & 1) * 4 + (lane & 3)) * 32;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { const int kk = m ? __builtin_ctz(m) : 0; m &= m - 1; wa[j] = lanepart + kk * 256; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int g = 0; g < G; g += 2) {
+        lc5_iter<N, 0, LAB>(g, G, in, W, bias, out, gstride_b, wstride_b, lds, rg, ns2, sl, wa, orow, tid);
+        if (g + 1 < G) lc5_iter<N, 1, LAB>(g + 1, G, in, W, bias, out, gstride_b, wstride_b, lds, rg, ns2, sl, wa, orow, tid);
+    }
+}
+
+template <int LAB>
+__global__ __launch_bounds__(256) void lconv5_k(const float* __restrict__ in_, Plan4 P, const float* __restrict__ W_,
+                                                const float* __restrict__ bias, float* __restrict__ out_, long gstride_in,
+                                                long gstride_w, int G) {
+    constexpr int SU = (2 * LC4_MAXSRC + 255) / 256;
+    constexpr int RBB = (LC4_MAXSRC + 1) * 32, WLB = 27 * 256;
+    __shared__ __attribute__((aligned(16))) char lds[2 * RBB + 2 * WLB];
+    const char* in = (const char*)in_; const char* W = (const char*)W_; char* out = (char*)out_;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ns2 = 2 * P.nsrc[b];
+    Lc5Regs rg;
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        const int e = tid + 256 * u;
+        const int r = e < ns2 ? P.src[(long)b * LC4_MAXSRC + (e >> 1)] : 0;
+        rg.roff[u] = (unsigned)r * 32u + 16u * (e & 1);
+        rg.lrow[u] = 32u + 16u * e;                   // slot e / 2 + 1, half e & 1
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int e = tid + 256 * u, i = e & 7, j = (e >> 3) & 3, hb = (e >> 5) & 1, kk = (e >> 6) % 27;
+        rg.woff[u] = 4u * ((TAPK(kk) * 8 + i) * 8 + 4 * hb + j);
+    }
+    const int T = 4 * b + wave;
+    const unsigned m = __builtin_amdgcn_readfirstlane(P.tile_mask[T]);
+    const unsigned short* ip = P.idx + (long)T * (27 * 64) + lane;
+    const int row = P.tile_rows[(long)T * 64 + lane];
+    const int orow = row >= 0 ? row * 32 : -1;
+    if (tid < 2) { *(f32x4*)(lds + 16 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f}; *(f32x4*)(lds + RBB + 16 * tid) = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) if (tid + 256 * u < ns2) *(f32x4*)(lds + rg.lrow[u]) = *(const f32x4*)(in + rg.roff[u]);
+#pragma unroll
+    for (int u = 0; u < 7; ++u) if (tid + 256 * u < 1728) *(float*)(lds + 2 * RBB + 4 * (tid + 256 * u)) = *(const float*)(W + rg.woff[u]);
+    __syncthreads();
+    const int cls = (__builtin_popcount(m) + 2) / 3;
+#define LC5_CASE(N) lc5_body<N, LAB>(G, in, W, bias, out, gstride_in * 4, gstride_w * 4, lds, rg, ns2, m, ip, orow, tid, lane)
+    switch (cls) {
+        case 0: case 1: case 2: case 3: LC5_CASE(9); break;
+        case 4: LC5_CASE(12); break;
+        case 5: LC5_CASE(15); break;
+        case 6: LC5_CASE(18); break;
+        case 7: LC5_CASE(21); break;
+        case 8: LC5_CASE(24); break;
+        default: LC5_CASE(27); break;
+    }
+}
+
+// ---------------------------------------------------------------- host ------------------------------------------------------
+static inline uint64_t key3(int x, int y, int z) { return ((uint64_t)(x + 1) << 42) | ((uint64_t)(y + 1) << 21) | (uint64_t)(z + 1); }
+static inline uint64_t spread3(uint64_t v) { uint64_t o = 0; for (int b = 0; b < 12; ++b) o |= ((v >> b) & 1) << (3 * b); return o; }
+
+int main(int argc, char** argv) {
+    const int W = argc > 1 ? atoi(argv[1]) : 512;          // rows per Morton block
+    const int G = 8;
+    // geometry: 10-bit shell, then octree levels
+    std::vector<std::vector<int>> scales;                  // coords x,y,z per scale (x-major sorted)
+    {
+        std::vector<int> c;
+        const double rin = 249.5 * 249.5, rout = 250.5 * 250.5;
+        for (int x = 255; x <= 769; ++x) for (int y = 255; y <= 769; ++y) for (int z = 255; z <= 769; ++z) {
+            const double d = (double)(x - 512) * (x - 512) + (double)(y - 512) * (y - 512) + (double)(z - 512) * (z - 512);
+            if (d > rin && d < rout) { c.push_back(x); c.push_back(y); c.push_back(z); }
+        }
+        printf("points %zu\n", c.size() / 3);
+        std::vector<int> cur = c;
+        for (int s = 0; s < 16; ++s) {
+            std::vector<uint64_t> ks(cur.size() / 3);
+            for (size_t i = 0; i < ks.size(); ++i) ks[i] = key3(cur[3 * i] >> 1, cur[3 * i + 1] >> 1, cur[3 * i + 2] >> 1);
+            std::sort(ks.begin(), ks.end());
+            ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+            std::vector<int> p(ks.size() * 3);
+            for (size_t i = 0; i < ks.size(); ++i) { p[3 * i] = (int)(ks[i] >> 42) - 1; p[3 * i + 1] = (int)((ks[i] >> 21) & 0x1FFFFF) - 1; p[3 * i + 2] = (int)(ks[i] & 0x1FFFFF) - 1; }
+            scales.push_back(p);
+            if (ks.size() < 64) break;
+            cur = p;
+        }
+    }
+    long R = 0;
+    for (auto& s : scales) R += s.size() / 3;
+    printf("scales %zu rows %ld\n", scales.size(), R);
+    const long ld = (R + 63) & ~63L;
+    std::vector<int> nbr(27 * ld, -1);
+    std::vector<uint64_t> mort(R);
+    {
+        long base = 0;
+        for (size_t si = 0; si < scales.size(); ++si) {
+            auto& s = scales[si];
+            const long n = s.size() / 3;
+            std::vector<uint64_t> ks(n);
+            for (long i = 0; i < n; ++i) ks[i] = key3(s[3 * i], s[3 * i + 1], s[3 * i + 2]);
+            for (long i = 0; i < n; ++i) {
+                mort[base + i] = ((uint64_t)si << 58) | (spread3(s[3 * i]) << 2) | (spread3(s[3 * i + 1]) << 1) | spread3(s[3 * i + 2]);
+                for (int k = 0; k < 27; ++k) {
+                    const uint64_t q = key3(s[3 * i] + k % 3 - 1, s[3 * i + 1] + (k / 3) % 3 - 1, s[3 * i + 2] + k / 9 - 1);
+                    auto it = std::lower_bound(ks.begin(), ks.end(), q);
+                    if (it != ks.end() && *it == q) nbr[k * ld + base + i] = (int)(base + (it - ks.begin()));
+                }
+            }
+            base += n;
+        }
+    }
+    // masks in LINR_TAP step order
+    std::vector<unsigned> mask(R);
+    double keff = 0;
+    for (long r = 0; r < R; ++r) {
+        unsigned m = 0;
+        for (int kk = 0; kk < 27; ++kk) if (nbr[TAPK(kk) * ld + r] >= 0) m |= 1u << kk;
+        mask[r] = m; keff += __builtin_popcount(m);
+    }
+    printf("K_eff %.2f\n", keff / R);
+    // plan
+    std::vector<int> order(R);
+    for (long r = 0; r < R; ++r) order[r] = (int)r;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return mort[a] < mort[b]; });
+    std::vector<int> blk_src_off{0}, src, blk_tile_off{0}, tile_tap_off, tile_rows;
+    std::vector<unsigned> tile_mask;
+    std::vector<unsigned short> idx16;
+    long live_sum = 0, padded_sum = 0; int max_src = 0;
+    std::vector<int> slot_of(R, 0);
+    for (long b0 = 0; b0 < R; b0 += W) {
+        const long b1 = std::min(R, b0 + W);
+        std::vector<int> own(order.begin() + b0, order.begin() + b1);
+        std::vector<int> all = own;
+        for (int r : own) for (int k = 0; k < 27; ++k) if (nbr[k * ld + r] >= 0) all.push_back(nbr[k * ld + r]);
+        std::sort(all.begin(), all.end());
+        all.erase(std::unique(all.begin(), all.end()), all.end());
+        if ((int)all.size() > LC_MAXSRC) { printf("block too large: %zu sources\n", all.size()); return 1; }
+        max_src = std::max(max_src, (int)all.size());
+        for (size_t i = 0; i < all.size(); ++i) slot_of[all[i]] = (int)i + 1;
+        src.insert(src.end(), all.begin(), all.end());
+        blk_src_off.push_back((int)src.size());
+        std::stable_sort(own.begin(), own.end(), [&](int a, int b) { return mask[a] < mask[b]; });
+        for (size_t t = 0; t < own.size(); t += 64) {
+            unsigned m = 0;
+            for (size_t l = t; l < std::min(own.size(), t + 64); ++l) m |= mask[own[l]];
+            tile_mask.push_back(m);
+            tile_tap_off.push_back((int)(idx16.size() / 64));
+            live_sum += __builtin_popcount(m);
+            for (int l = 0; l < 64; ++l) tile_rows.push_back(t + l < own.size() ? own[t + l] : -1);
+            for (int kk = 0; kk < 27; ++kk) if (m >> kk & 1)
+                for (int l = 0; l < 64; ++l) {
+                    int s = 0;
+                    if (t + l < own.size()) { const int nb = nbr[TAPK(kk) * ld + own[t + l]]; if (nb >= 0) s = slot_of[nb]; }
+                    idx16.push_back((unsigned short)s);
+                }
+            {   // pad to the tile's class (lconv3_k): a multiple of 3, at least 9 lines
+                const int live = __builtin_popcount(m), cls = std::max(9, (live + 2) / 3 * 3);
+                padded_sum += cls;
+                for (int j = live; j < cls; ++j) for (int l = 0; l < 64; ++l) idx16.push_back(0);
+            }
+        }
+        blk_tile_off.push_back((int)tile_mask.size());
+    }
+    for (int l = 0; l < 256; ++l) idx16.push_back(0);      // spare lines for the one-ahead reads
+    const int nblk = (int)blk_src_off.size() - 1, ntiles = (int)tile_mask.size();
+    printf("padded steps per tile %.2f\n", (double)padded_sum / tile_mask.size());
+    printf("W %d: blocks %d tiles %d (x-major tiles %ld) live taps per tile %.2f  max sources %d  idx16 %.1f B/row  src/row %.2f\n", W, nblk, ntiles,
+           (R + 63) / 64, (double)live_sum / ntiles, max_src, idx16.size() * 2.0 / R, (double)src.size() / R);
+    // device data
+    std::vector<float> hin((size_t)G * (R + 1) * 8), hW((size_t)G * 27 * 64), hb(G * 8);
+    srand(1);
+    for (auto& v : hin) v = (float)(rand() / (double)RAND_MAX) - 0.5f;
+    for (int g = 0; g < G; ++g) for (int j = 0; j < 8; ++j) hin[(size_t)g * (R + 1) * 8 + j] = 0.0f;      // pad rows
+    for (auto& v : hW) v = ((float)(rand() / (double)RAND_MAX) - 0.5f) * 0.2f;
+    for (auto& v : hb) v = (float)(rand() / (double)RAND_MAX) - 0.5f;
+    float *din, *dW, *db, *dout0, *dout1;
+    int *dnbr, *dso, *dsrc, *dto, *dtt, *dtr; unsigned* dtm; unsigned short* didx;
+    CK(hipMalloc(&din, hin.size() * 4)); CK(hipMalloc(&dW, hW.size() * 4)); CK(hipMalloc(&db, hb.size() * 4));
+    CK(hipMalloc(&dout0, hin.size() * 4)); CK(hipMalloc(&dout1, hin.size() * 4));
+    CK(hipMalloc(&dnbr, nbr.size() * 4)); CK(hipMalloc(&dso, blk_src_off.size() * 4)); CK(hipMalloc(&dsrc, src.size() * 4));
+    CK(hipMalloc(&dto, blk_tile_off.size() * 4)); CK(hipMalloc(&dtt, tile_tap_off.size() * 4)); CK(hipMalloc(&dtr, tile_rows.size() * 4));
+    CK(hipMalloc(&dtm, tile_mask.size() * 4)); CK(hipMalloc(&didx, idx16.size() * 2));
+    CK(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dnbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dso, blk_src_off.data(), blk_src_off.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dsrc, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dto, blk_tile_off.data(), blk_tile_off.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dtt, tile_tap_off.data(), tile_tap_off.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtr, tile_rows.data(), tile_rows.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dtm, tile_mask.data(), tile_mask.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(didx, idx16.data(), idx16.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(dout0, 0, hin.size() * 4)); CK(hipMemset(dout1, 0, hin.size() * 4));
+    Plan P = {dso, dsrc, dto, dtm, dtt, dtr, didx};
+    const long gs = (R + 1) * 8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time_it = [&](auto&& fn, const char* name) {
+        for (int i = 0; i < 3; ++i) fn();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 30; ++i) fn();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s %8.1f us per 8-group launch  = %.2f us per row pass\n", name, ms / 30 * 1e3, ms / 30 * 1e3 / G);
+    };
+    time_it([&] { base_k<8><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout0 + 8, gs, 27 * 64); }, "baseline (lane = row, 27 taps via L1)");
+    time_it([&] { lconv_k<0><<<dim3(nblk, G), 256>>>(din + 8, P, dW, db, dout1 + 8, gs, 27 * 64); }, "block-local, LDS rows, live taps (plain loop)");
+    std::vector<float> o0(hin.size()), o1(hin.size());
+    CK(hipMemcpy(o0.data(), dout0, o0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), dout1, o1.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < o0.size(); ++i) if (o0[i] != o1[i]) ++bad;
+    printf("plain loop vs baseline: %zu of %zu values differ\n", bad, o0.size());
+    CK(hipMemset(dout1, 0, hin.size() * 4));
+    time_it([&] { lconv_k<1><<<dim3(nblk, G), 256>>>(din + 8, P, dW, db, dout1 + 8, gs, 27 * 64); }, "block-local, one tap ahead");
+    CK(hipMemcpy(o1.data(), dout1, o1.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < o0.size(); ++i) if (o0[i] != o1[i]) ++bad;
+    printf("one-ahead vs baseline: %zu of %zu values differ\n", bad, o0.size());
+    auto run2 = [&](auto kern, const char* name, bool check) {
+        CK(hipMemset(dout1, 0, hin.size() * 4));
+        time_it([&] { kern<<<dim3(nblk, G), 256>>>(din + 8, P, dW, db, dout1 + 8, gs, 27 * 64); }, name);
+        if (check) {
+            CK(hipMemcpy(o1.data(), dout1, o1.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad2 = 0;
+            for (size_t i = 0; i < o0.size(); ++i) if (o0[i] != o1[i]) ++bad2;
+            printf("    vs baseline: %zu of %zu values differ\n", bad2, o0.size());
+        }
+    };
+
+    // ---- fixed-stride plan of 256-row blocks (variant 4) ----
+    {
+        const int W4 = 256;
+        const int nb4 = (int)((R + W4 - 1) / W4);
+        std::vector<int> nsrc4(nb4), src4((size_t)nb4 * LC4_MAXSRC, 0), trow4((size_t)nb4 * 256, -1);
+        std::vector<unsigned> tmask4((size_t)nb4 * 4, 0);
+        std::vector<unsigned short> idx4((size_t)nb4 * 4 * 27 * 64 + 64, 0), idx5((size_t)nb4 * 4 * 27 * 64 + 64, 0);
+        long live4 = 0, pad4 = 0, maxcls_sum = 0; int maxsrc4 = 0;
+        for (int b = 0; b < nb4; ++b) {
+            const long b0 = (long)b * W4, b1 = std::min(R, b0 + W4);
+            std::vector<int> own(order.begin() + b0, order.begin() + b1);
+            std::vector<int> all = own;
+            for (int r : own) for (int k = 0; k < 27; ++k) if (nbr[k * ld + r] >= 0) all.push_back(nbr[k * ld + r]);
+            std::sort(all.begin(), all.end());
+            all.erase(std::unique(all.begin(), all.end()), all.end());
+            maxsrc4 = std::max(maxsrc4, (int)all.size());
+            if ((int)all.size() > LC4_MAXSRC) { printf("W 256 block too large: %zu sources\n", all.size()); return 1; }
+            nsrc4[b] = (int)all.size();
+            for (size_t i = 0; i < all.size(); ++i) { slot_of[all[i]] = (int)i + 1; src4[(size_t)b * LC4_MAXSRC + i] = all[i]; }
+            std::stable_sort(own.begin(), own.end(), [&](int a, int c) { return mask[a] < mask[c]; });
+            int mc = 0;
+            for (int t = 0; t < 4; ++t) {
+                unsigned m = 0;
+                for (int l = 0; l < 64; ++l) if ((size_t)(64 * t + l) < own.size()) m |= mask[own[64 * t + l]];
+                tmask4[4 * b + t] = m;
+                const int live = __builtin_popcount(m), cls = std::max(9, (live + 2) / 3 * 3);
+                live4 += live; pad4 += cls; mc = std::max(mc, cls);
+                int line = 0;
+                for (int kk = 0; kk < 27; ++kk) if (m >> kk & 1) {
+                    for (int l = 0; l < 64; ++l) {
+                        int sslot = 0;
+                        if ((size_t)(64 * t + l) < own.size()) { const int nb = nbr[TAPK(kk) * ld + own[64 * t + l]]; if (nb >= 0) sslot = slot_of[nb]; }
+                        idx4[((size_t)(4 * b + t) * 27 + line) * 64 + l] = (unsigned short)(sslot * 32 + 16 * ((sslot >> 3) & 1));
+                        idx5[((size_t)(4 * b + t) * 27 + line) * 64 + l] = (unsigned short)(sslot * 32);
+                    }
+                    ++line;
+                }
+                for (int l = 0; l < 64; ++l) if ((size_t)(64 * t + l) < own.size()) trow4[(size_t)(4 * b + t) * 64 + l] = own[64 * t + l];
+            }
+            maxcls_sum += mc;
+        }
+        printf("W 256: blocks %d  live taps per tile %.2f  padded %.2f  slowest tile of a block %.2f  max sources %d\n", nb4, (double)live4 / (4.0 * nb4),
+               (double)pad4 / (4.0 * nb4), (double)maxcls_sum / nb4, maxsrc4);
+        int *dn4, *ds4, *dr4; unsigned* dm4; unsigned short* di4;
+        CK(hipMalloc(&dn4, nsrc4.size() * 4)); CK(hipMalloc(&ds4, src4.size() * 4)); CK(hipMalloc(&dr4, trow4.size() * 4));
+        CK(hipMalloc(&dm4, tmask4.size() * 4)); CK(hipMalloc(&di4, idx4.size() * 2));
+        CK(hipMemcpy(dn4, nsrc4.data(), nsrc4.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ds4, src4.data(), src4.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dr4, trow4.data(), trow4.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dm4, tmask4.data(), tmask4.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(di4, idx4.data(), idx4.size() * 2, hipMemcpyHostToDevice));
+        Plan4 P4 = {dn4, ds4, dm4, dr4, di4};
+        auto run4 = [&](auto kern, const char* name, bool check) {
+            CK(hipMemset(dout1, 0, hin.size() * 4));
+            time_it([&] { kern<<<nb4, 256>>>(din + 8, P4, dW, db, dout1 + 8, gs, 27 * 64, G); }, name);
+            if (check) {
+                CK(hipMemcpy(o1.data(), dout1, o1.size() * 4, hipMemcpyDeviceToHost));
+                size_t bad2 = 0;
+                for (size_t i = 0; i < o0.size(); ++i) if (o0[i] != o1[i]) ++bad2;
+                printf("    vs baseline: %zu of %zu values differ\n", bad2, o0.size());
+            }
+        };
+        unsigned short* di5;
+        CK(hipMalloc(&di5, idx5.size() * 2)); CK(hipMemcpy(di5, idx5.data(), idx5.size() * 2, hipMemcpyHostToDevice));
+        Plan4 P5 = {dn4, ds4, dm4, dr4, di5};
+        auto run5 = [&](auto kern, const char* name, bool check) {
+            CK(hipMemset(dout1, 0, hin.size() * 4));
+            time_it([&] { kern<<<nb4, 256>>>(din + 8, P5, dW, db, dout1 + 8, gs, 27 * 64, G); }, name);
+            if (check) {
+                CK(hipMemcpy(o1.data(), dout1, o1.size() * 4, hipMemcpyDeviceToHost));
+                size_t bad2 = 0;
+                for (size_t i = 0; i < o0.size(); ++i) if (o0[i] != o1[i]) ++bad2;
+                printf("    vs baseline: %zu of %zu values differ\n", bad2, o0.size());
+            }
+        };
+        run5(lconv5_k<0>, "v5 lean steps, W 256", true);
+        run5(lconv5_k<1>, "v5 without the staging of groups 1..7", false);
+        run5(lconv5_k<2>, "v5 without the tap loop", false);
+        run4(lconv4_k<0>, "v4 persistent over groups, W 256", true);
+        run4(lconv4_k<1>, "v4 without the staging of groups 1..7", false);
+        run4(lconv4_k<2>, "v4 without the tap loop", false);
+        run4(lconv4_k<4>, "v4 without MFMAs", false);
+    }
+    run2(lconv3_k<0>, "v3 static classes, LDS weights, rows 2 ahead", true);
+    run2(lconv3_k<1>, "v3 without staging", false);
+    run2(lconv3_k<2>, "v3 without the tap loop", false);
+    run2(lconv3_k<4>, "v3 without MFMAs", false);
+    run2(lconv2_k<0>, "v2 register weights + switch, slots 3 ahead", true);
+    run2(lconv2_k<1>, "v2 without staging", false);
+    run2(lconv2_k<2>, "v2 without the tap loop (prologue + epilogue)", false);
+    run2(lconv2_k<3>, "v2 neither (weights, sync, epilogue)", false);
+    run2(lconv2_k<4>, "v2 without MFMAs", false);
+    return 0;
+}
