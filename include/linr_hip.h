@@ -8,8 +8,8 @@
  *   - every pointer is a DEVICE pointer unless its name ends in _h (host); the caller (PyTorch's caching
  *     allocator) owns all memory; nothing is allocated, freed or retained across calls.  The library keeps no mutable
  *     global state on the data path: calls on different streams may run from different host threads (the GOP decoder
- *     does).  The two optional process-wide aids - the live kernel timing of linr_prof_* and the auxiliary
- *     weight-gradient stream of LINR_WGRAD_STREAM=1 - are mutex-guarded.
+ *     does).  The two optional process-wide aids - the live kernel timing of linr_prof_* (mutex-guarded) and the
+ *     on-chip poison test hook of linr_debug_poison (an atomic mask) - are off by default.
  *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no host synchronisation.
  *   - return value: 0 on success, >0 = hipError_t, <0 = argument error (LINR_E*).  No exceptions cross.
  *   - feature matrices are row-major float32 [rows, ld] with an explicit leading dimension `*_ld` so that a
@@ -46,8 +46,10 @@ LINR_API int linr_abi_version(void);
 /* number of float parameters of LINR_PCGC_Model(scale_num, hidden=8, block_layers, outstage=8, instage=1)
  * in parameters() order (models/model_core.py:31-35, models/upsample.py:43-76; block_layers = main.py:521, the
  * Inception layers of block_in's ResNetBlock, 1..4 - the outter blocks always have one, upsample.py:72-76).
- * 54,712 for scale_num = 7, block_layers = 1.  hidden_channel_conv (main.py:520) is fixed at 8: the kernels are
- * specialised for 8-wide rows. */
+ * 54,712 for scale_num = 7, block_layers = 1.  This count and the whole-network entry points (linr_net_*) are the
+ * hidden_channel_conv = 8 model (main.py:520 default): their kernels are specialised for 8-wide rows.  Widths 16 / 32 run on
+ * the channel-blocked executor of the host mirror (linr_pcgc_amd/wide_net.py), which drives the op-level entries below on
+ * 8-wide channel blocks and keeps its own parameter count. */
 LINR_API int64_t linr_param_count(int32_t scale_num, int32_t block_layers);
 
 /* ---- kernel map -------------------------------------------------------------------------------------------

@@ -132,7 +132,8 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
     occ_bits = 8 * sum(len(b) for fb in frames_bytes for b in fb)
     return {'frames': frames_bytes, 'model_bin': comp['final_bytes'], 'side_info': side_info, 'low_enc_bytes': low,
             'point_num': points, 'bits_est': bits_est,
-            # the two side-info fields this codec adds (arithmetic version, precision: one byte each) are counted with the model
+            # the five one-byte side-info fields this codec adds (arith_version, precision, scale_num, block_layers,
+            # hidden_channel_conv: EXTRA_SIDE_BITS = 40) are counted with the model
             'bpp': {'point_bpp': occ_bits / points, 'model_bpp': (comp['bit_real'] + EXTRA_SIDE_BITS) / points,
                     'xyzlow_bpp': len(low) * 8 / points,
                     'bpp_all': (occ_bits + comp['bit_real'] + EXTRA_SIDE_BITS + len(low) * 8) / points}}       # test_utils.py:146-157

@@ -19,7 +19,8 @@ struct DecodeWs {              // byte offsets into the caller's workspace
 
 size_t cub_bytes_for(int64_t n) {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (int)(n > 0 ? n : 1));
+    // the scan runs over n + 1 items (linr_decode_scale), the sort over at most 8 n keys: reserve for exactly those calls
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, (int)((n > 0 ? n : 1) + 1));
     (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(8 * (n > 0 ? n : 1)), 0, 63);
     return a > b ? a : b;
 }

@@ -97,7 +97,7 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
             # without a barrier between them cannot clean up safely: such callers pass a fresh directory.)
             if os.path.isdir(work_dir):
                 for f in os.listdir(work_dir):
-                    if f.endswith('_failed'):
+                    if f.endswith('_failed') or f.endswith('_done'):
                         os.remove(os.path.join(work_dir, f))
             if os.path.exists(ck_path):
                 os.remove(ck_path)
@@ -148,8 +148,9 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     try:
         _phase_b(schedule, static_mine, first_claim, order, claim_dir, rank, groups, results, load, call, other_fn)
     except BaseException:
-        open(os.path.join(work_dir, 'rank%d_failed' % rank), 'w').close()       # check_failures() lets the others skip the final reduce
+        open(os.path.join(work_dir, 'rank%d_failed' % rank), 'w').close()       # wait_all_done() lets the others skip the final reduce
         raise
+    open(os.path.join(work_dir, 'rank%d_done' % rank), 'w').close()
     return results
 
 
@@ -159,6 +160,22 @@ def check_failures(work_dir):
     bad = sorted(f for f in os.listdir(work_dir) if f.endswith('_failed')) if os.path.isdir(work_dir) else []
     if bad:
         raise RuntimeError('ranks failed: %s' % ', '.join(bad))
+
+
+def wait_all_done(work_dir, world, poll_s=0.05, timeout_s=None):
+    """File rendezvous in front of the final reductions: returns once every rank of the job has left its rank<N>_done marker
+    (run_sequence writes it on success), raises as soon as ANY rank<N>_failed marker exists.  check_failures() alone only covers
+    'fail first, check later': a rank that finishes before another one fails would see no marker and wait in the collective for
+    a rank that is gone.  Nothing is pending in a collective while this polls."""
+    t0 = time.time()
+    while True:
+        check_failures(work_dir)
+        if all(os.path.exists(os.path.join(work_dir, 'rank%d_done' % r)) for r in range(world)):
+            return
+        if timeout_s is not None and time.time() - t0 > timeout_s:
+            raise RuntimeError('ranks still running after %.0f s: %s' % (timeout_s, ', '.join(
+                str(r) for r in range(world) if not os.path.exists(os.path.join(work_dir, 'rank%d_done' % r)))))
+        time.sleep(poll_s)
 
 
 def _phase_b(schedule, static_mine, first_claim, order, claim_dir, rank, groups, results, load, call, other_fn):

@@ -169,7 +169,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
                                     'low_enc_ret': codec.enc_all_frame_low_xyz(gop)})
                 entry.update({'real_bpp_all': out['bpp_all'], 'real_point_bpp': out['point_bpp'], 'point_bpp_val': out['point_bpp_val'],
                               'model_bpp': out['model_bpp'], 'xyzlow_bpp': out['xyzlow_bpp'], 'enc_time': out['enc_time'],
-                              'dec_time': out['dec_time'], 'enc_mode': out['enc_mode'], 'model_bitdepth_final': 8})
+                              'dec_time': out['dec_time'], 'enc_mode': out['enc_mode'],
+                              'model_bitdepth_final': getattr(args, 'model_bitdepth', 8)})     # main.py:411 writes the depth in use
                 for key in ('real_bpp_all', 'real_point_bpp', 'point_bpp_val', 'model_bpp', 'xyzlow_bpp', 'enc_time', 'dec_time', 'enc_mode'):
                     log.write('%s: %r\n' % (key, entry[key]))
             log.write('\n')
@@ -238,7 +239,8 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
             ahead['pool'].shutdown(wait=True)
     torch.cuda.synchronize()
     my_wall = time.time() - t0
-    gop_parallel.check_failures(os.path.join(args.out, 'output'))          # a failed rank left a marker: do not wait for it below
+    # every rank has finished (its done marker) or one has failed (its marker: raise here, outside any collective)
+    gop_parallel.wait_all_done(os.path.join(args.out, 'output'), world)
     wall = gop_parallel.max_over_ranks(my_wall, dist, 'cuda')
     # phase A = rank 0's GOP 0; phase B = the rest of the wall.  Phase-B efficiency = busy GPU-seconds of the GOPs >= 1
     # over (ranks x phase-B wall): what SURVEY.md section 8e asks to be reported next to the whole-sequence wall.

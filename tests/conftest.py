@@ -24,3 +24,26 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    """The package with its HIP library loaded (GPU tests): raises if liblinr_hip.so is missing - there is no fallback."""
+    import linr_pcgc_amd  # noqa: F401
+    from linr_pcgc_amd import _lib
+    _lib.lib()
+    return linr_pcgc_amd
+
+
+@pytest.fixture(scope='module')
+def shell(golden_dir):
+    """The golden 128-cube shell (reference-generated octree fixture) with the oracle's neighbour tables."""
+    import numpy as np
+    from oracle import octree as ooct
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    scales = []
+    for s in range(int(g['scale_num'])):
+        c = g['s%d_coord' % s]
+        scales.append({'coord': c, 'occ': g['s%d_occ' % s], 'offset_tensor': g['s%d_offset' % s], 'scale_idx': s,
+                       'nbr': ooct.neighbour_table(c)})
+    return {'scales': scales, 'point_num': int(len(g['ori']))}

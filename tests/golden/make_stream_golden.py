@@ -1,7 +1,7 @@
 """Writes tests/golden/stream_v<ARITH_VERSION>.npz: the coded streams of a tiny fixed cloud under a fixed-seed (untrained) model,
 fp32 and bf16, with the coordinates they must decode to.  Run on a GPU box whenever codec.ARITH_VERSION is bumped on purpose:
     gpurun -- 'python tests/golden/make_stream_golden.py gpurun_out/stream_golden.npz'   then copy it to tests/golden/.
-tests/test_gpu_parity.py::test_committed_stream_still_decodes decodes the committed file: a change of the forward's fp32
+tests/test_gpu_drivers.py::test_committed_stream_still_decodes decodes the committed file: a change of the forward's fp32
 evaluation order WITHOUT a version bump turns the decoded geometry into garbage there."""
 import os
 import sys

@@ -1,5 +1,6 @@
 """CPU, world_size 2 and 8 over gloo: GOP sharding, the GOP-0 checkpoint hand-off and the MAX-over-ranks timing."""
 import os
+import pytest
 import tempfile
 
 import torch
@@ -194,3 +195,19 @@ def test_stale_failure_markers_of_an_earlier_run_are_cleared():
         # and again in the same directory: the claim files of the first run must not make the second one stop after GOP 0
         res = gp.run_sequence(groups, work, lambda g: {'result': ('first', g[0])}, lambda g, ck: ('other', g[0]), schedule='pull')
         assert sorted(res) == [0, 1, 2]
+
+
+def test_wait_all_done_rendezvous(tmp_path):
+    """a rank that finishes BEFORE another one fails must not walk into the final collective.  wait_all_done returns
+    only when every rank left its done marker and raises as soon as a failure marker appears, also one written later."""
+    import threading
+    work = str(tmp_path / 'work')
+    os.makedirs(work)
+    for r in range(3):
+        open(os.path.join(work, 'rank%d_done' % r), 'w').close()
+    gp.wait_all_done(work, 3, timeout_s=5)                       # all there: returns
+    with pytest.raises(RuntimeError, match='still running'):
+        gp.wait_all_done(work, 4, poll_s=0.01, timeout_s=0.2)    # rank 3 never finishes: the optional timeout says who
+    threading.Timer(0.2, lambda: open(os.path.join(work, 'rank3_failed'), 'w').close()).start()
+    with pytest.raises(RuntimeError, match='rank3_failed'):
+        gp.wait_all_done(work, 4, poll_s=0.01, timeout_s=10)     # ... and fails late: the waiting ranks raise, nobody hangs

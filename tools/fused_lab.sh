@@ -6,8 +6,9 @@ cd $R/linr_pcgc_amd/csrc
 if [ "$1" = build ]; then
   mkdir -p $R/tools/_lab
   for m in $2; do
-    hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -DFB_LAB=$m -c fused_bwd.hip -o $R/tools/_lab/fused_bwd_$m.o
-    hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/liblinr_fb_$m.so _obj/kmap.o _obj/spconv.o _obj/linear.o _obj/loss_optim.o _obj/net.o _obj/fused.o $R/tools/_lab/fused_bwd_$m.o _obj/occ_wgrad.o _obj/net_bf16.o _obj/decode.o _obj/ac.o -lpthread
+    # the product's flags for this file (csrc/build.sh) and EVERY other object of the library, whatever build.sh links today
+    hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fvisibility=hidden -mllvm -amdgpu-mfma-vgpr-form -DFB_LAB=$m -c fused_bwd.hip -o $R/tools/_lab/fused_bwd_$m.o
+    hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_lab/liblinr_fb_$m.so $(ls _obj/*.o | grep -v '/fused_bwd.o$') $R/tools/_lab/fused_bwd_$m.o -lpthread
   done
   ls $R/tools/_lab/*.so
 else

@@ -10,7 +10,7 @@ for grp in \
   "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf /tmp/pmcf_$i
-  timeout -k 10 200 rocprofv3 --kernel-trace --kernel-include-regex "conv88_bwd_wgrad|cconv_mfma" --pmc $grp --output-format csv -d /tmp/pmcf_$i -- python3 $R/tools/fused_probe.py 3 > /tmp/pmcf_$i.log 2>&1 || { tail -5 /tmp/pmcf_$i.log; exit 1; }
-  python3 $R/tools/pmc_summary.py /tmp/pmcf_$i "conv88_bwd_wgrad,cconv_mfma" >> $OUT
+  timeout -k 10 200 rocprofv3 --kernel-trace --kernel-include-regex "conv_bwd_wgrad_k|cconv_mfma_k" --pmc $grp --output-format csv -d /tmp/pmcf_$i -- python3 $R/tools/fused_probe.py 3 > /tmp/pmcf_$i.log 2>&1 || { tail -5 /tmp/pmcf_$i.log; exit 1; }
+  python3 $R/tools/pmc_summary.py /tmp/pmcf_$i "conv_bwd_wgrad_k,cconv_mfma_k" >> $OUT
 done
 cat $OUT
