@@ -66,6 +66,37 @@ class Gop:
         return g
 
 
+def staging_split(config, frame_ids, device='cuda', scale_num=None, min_point_num=64):
+    """Milliseconds per frame of the three staging steps, each timed synchronously on the given synthetic frames: the generator
+    (stands in for file input), the octree levels (parents, child occupancy: module_utils.prepare_frame) and the kernel maps
+    (engine.Frame: neighbour search, compressed map, tiled copy, 7-neighbour features).  Measurement aid of bench.py / tools."""
+    import time
+    from . import engine, synthetic
+    t = {'generator': 0.0, 'octree': 0.0, 'kernel_map': 0.0}
+    n = 0
+    for i in frame_ids:
+        torch.cuda.synchronize()
+        t0 = time.time()
+        pts = synthetic.sequence_frame_device(config, i, device)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        fr = prepare_frame(pts, scale_num, min_point_num, device=device, with_offsets=False)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        f = engine.Frame(fr['all_input_info'], fr['scale_num'], device, validate=True, with_arena=False)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        t['generator'] += t1 - t0
+        t['octree'] += t2 - t1
+        t['kernel_map'] += t3 - t2
+        n += 1
+        del f, fr, pts
+    out = {k: round(v * 1e3 / max(n, 1), 3) for k, v in t.items()}
+    out['total_without_generator'] = round(out['octree'] + out['kernel_map'], 3)
+    out['frames'] = n
+    return out
+
+
 class BestState:
     """Device-side snapshot of (parameters, Adam moments, counters, lr) of the best epoch so far - what the reference keeps in
     model.pth: it saves the checkpoint only when the epoch's mean loss improves (main.py:413-426,440-451), so the encoder codes

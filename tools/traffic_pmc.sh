@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the kernels of a training step, executor configuration (grouped launches): separate --pmc passes for FETCH_SIZE and
+# HBM traffic of EVERY kernel of a training step (all of the library's kernels are named *_k), executor configuration (grouped launches): separate --pmc passes for FETCH_SIZE and
 # WRITE_SIZE (KB per dispatch; FETCH_SIZE is doubled for gfx950 as MI355X_MICROARCH.md prescribes), averaged per kernel name.
 #   gpurun -- 'bash tools/traffic_pmc.sh'   ->  gpurun_out/pmc_traffic.txt, gpurun_out/traffic.json  (copy the latter to profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/pmc_traffic.txt
 : > $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/tr_$c
-  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "conv_bwd_wgrad_k|cconv_mfma_k|cconv_dual44_k|spconv_wgrad_t_k|occ_conv7_k|occ_wgrad7_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
   echo "pass $c done"
 done
-python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic.json | tee -a $OUT
+python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic.json 3 "$(grep -h "^rows" /tmp/tr_FETCH_SIZE.log | tail -1)" | tee -a $OUT

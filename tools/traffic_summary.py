@@ -12,12 +12,16 @@ def load(d, counter):
 
 
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
-out = {'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/traffic_probe.py: 3 training steps of the '
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+rows = int(sys.argv[5].split()[1]) if len(sys.argv) > 5 and sys.argv[5].split()[:1] == ['rows'] else None
+out = {'steps': steps, 'rows': rows, 'method': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/traffic_probe.py: 3 training steps of the '
                  'executor on frame 0 of loot10, every dispatch of a step; bytes = 2 x FETCH_SIZE (gfx950: the counter tallies '
                  '128-B requests as 64 B) + WRITE_SIZE, mean per dispatch of that kernel name', 'kernels': {}}
 for name in sorted(fetch):
     f, w = fetch[name], write.get(name, [0.0])
     fb, wb = 2.0 * 1024.0 * sum(f) / len(f), 1024.0 * sum(w) / len(w)
-    out['kernels'][name] = {'dispatches': len(f), 'fetch_bytes_x2': int(fb), 'write_bytes': int(wb), 'bytes_per_dispatch': int(fb + wb)}
+    out['kernels'][name] = {'dispatches': len(f), 'dispatches_per_step': round(len(f) / steps, 3), 'bytes_per_step': int((fb + wb) * len(f) / steps), 'fetch_bytes_x2': int(fb), 'write_bytes': int(wb), 'bytes_per_dispatch': int(fb + wb)}
     print('%-60s n=%3d  2xFETCH %8.1f MB  WRITE %7.1f MB' % (name[:60], len(f), fb / 1e6, wb / 1e6))
+out['bytes_per_step_all_kernels'] = int(sum(k['bytes_per_step'] for k in out['kernels'].values()))
+print('all kernels: %.3f GB per training step' % (out['bytes_per_step_all_kernels'] / 1e9))
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
