@@ -352,7 +352,7 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def sequence_leg(args, rank, world, dist):
+def sequence_leg(args, rank, world, dist, stage_all=True):
     """BASELINE config[2] for real: seq_frames frames in GOPs of args.gop, GOP 0 from scratch on rank 0, the other GOPs
     warm-started from its checkpoint and dealt over the ranks (static longest-first deal so that every input is staged in
     HBM before the timed region starts), each GOP overfitted, encoded to files and spot-decoded.  Strong scaling: the
@@ -371,7 +371,7 @@ def sequence_leg(args, rank, world, dist):
                            '--first-epoch', str(args.seq_epochs), '--others-epoch', str(args.seq_epochs), '--out', out_dir,
                            '--decode'])
     try:
-        summary, _ = seq_run.run_sequence_job(sargs, rank, world, dist, stage_all=True, decode_frames=args.seq_decode_frames)
+        summary, _ = seq_run.run_sequence_job(sargs, rank, world, dist, stage_all=stage_all, decode_frames=args.seq_decode_frames)
     finally:
         if dist is not None:
             dist.barrier()
@@ -785,8 +785,31 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # the same flow END TO END: nothing resident before t0 - every GOP is generated, its octrees and kernel maps built (the next GOP's in
+    # a background thread while the current one trains), overfitted, encoded, spot-decoded.  One GPU only (with N > 1 the headline
+    # numbers above already came from N ranks; the cold flow is a per-rank property).
+    seq_cold, stage_split = None, None
+    if world == 1 and not args.no_sequence and not os.environ.get('LINR_SKIP_COLD'):
+        try:
+            seq_cold = sequence_leg(args, rank, world, dist, stage_all=False)
+            log('cold sequence leg: %s' % seq_cold)
+            from linr_pcgc_amd import overfit as _ov
+            _ov.staging_split(args.config, range(2), 'cuda')                    # first calls pay for lazy loads
+            stage_split = _ov.staging_split(args.config, range(8), 'cuda')
+            stage_split['note'] = ('ms per frame, each step timed synchronously on frames 0..7: the synthetic generator stands in for file '
+                                   'input; octree = minimum / sort + unique / child occupancy of every level (linr_coords_minmax, '
+                                   'linr_coords_sort_unique, linr_octree_level); kernel_map = neighbour search, compressed map, tiled copy, '
+                                   '7-neighbour features')
+            log('staging split: %s' % stage_split)
+        except Exception as e:
+            seq_cold = {'error': repr(e)}
+            log('cold sequence leg failed: %r' % (e,))
     if rank == 0:
         out['sequence'] = seq
+        out['sequence_cold'] = seq_cold
+        out['staging_ms_per_frame'] = stage_split
+        if isinstance(seq_cold, dict) and 'sec_per_frame' in seq_cold:
+            out['sequence_cold_sec_per_frame'] = seq_cold['sec_per_frame']
         if isinstance(seq, dict) and 'sec_per_frame' in seq:
             # strong-scaling numbers of the BASELINE config[2] flow at the TOP level, beside the weak-scaling `value`
             out['sequence_sec_per_frame'] = seq['sec_per_frame']

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 5
+#define LINR_ABI_VERSION 6
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -77,6 +77,24 @@ LINR_API int linr_kmap_offset_feat(const int32_t* nbr, int64_t ld, int64_t row_b
  * search as the kernel map; ws: linr_kmap_workspace_bytes(m) bytes, 8-byte aligned. */
 LINR_API int linr_octree_occupancy(const int32_t* child, int64_t m, const int32_t* parent, int64_t n, float* occ, void* ws,
                           size_t ws_bytes, void* stream);
+/* Sorted unique coordinate list, optionally of the parents: the torch.unique(dim=0) of datautils/custom_dataset.py:271-282 (the
+ * input cloud: shift 0) and of octree_level.forward (models/module_utils.py:92,103: parent = unique(floor(child / 2)): shift 1) as one
+ * call - compact x-major keys of ((coords - origin) >> shift), radix sort over 3 (coord_bits - shift) bits, unique, decode.  coords:
+ * int32 [n,3] with (coords - origin) in [0, 2^coord_bits), coord_bits <= 20, any order, duplicates allowed; origin: DEVICE int32 [3]
+ * or NULL (zero); out: int32 [n,3] (room for n rows); *count: DEVICE int64 =
+ * number of distinct rows written.  ws: at least linr_sort_unique_workspace_bytes(n) bytes, 256-byte aligned. */
+LINR_API size_t linr_sort_unique_workspace_bytes(int64_t n);
+LINR_API int linr_coords_sort_unique(const int32_t* coords, int64_t n, const int32_t* origin, int32_t shift, int32_t coord_bits, int32_t* out,
+                                     int64_t* count, void* ws, size_t ws_bytes, void* stream);
+/* Per-axis minimum / maximum of a coordinate list (the coord_data_min of custom_dataset.py:276-279 and the span that fixes the
+ * octree depth): coords int32 [n,3], n >= 1; out: DEVICE int32 [6] = min x, y, z, max x, y, z. */
+LINR_API int linr_coords_minmax(const int32_t* coords, int64_t n, int32_t* out, void* stream);
+/* One octree level as one call (octree_level.forward, models/module_utils.py:86-110: parents AND their child occupancy; the dataset
+ * calls it once per scale, datautils/custom_dataset.py:289-344): child int32 [m,3] sorted x-major and unique, coordinates in
+ * [0, 2^coord_bits); parent [m,3] and occ [m,8] have room for m rows, *count (DEVICE int64) = the number of parents written.
+ * ws: linr_sort_unique_workspace_bytes(m) bytes, 256-byte aligned. */
+LINR_API int linr_octree_level(const int32_t* child, int64_t m, int32_t coord_bits, int32_t* parent, float* occ, int64_t* count, void* ws,
+                               size_t ws_bytes, void* stream);
 /* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
 LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
 

@@ -167,3 +167,180 @@ extern "C" int linr_decode_scale(const int32_t* coord, int64_t n, int32_t scale_
     *child_n_h = total;
     return linr_launch_rc();
 }
+
+// ---- sorted unique coordinate list, optionally of the parents (coords >> shift); one octree level as one call ------------------------
+// torch.unique(dim=0) of custom_dataset.py:271-282 (the input cloud, shift 0) and of octree_level.forward (models/module_utils.py:
+// 92,103: parent = unique(floor(child / 2)), shift 1): compact x-major keys (x << 2b | y << b | z with b = the bits a coordinate
+// needs, so the radix sort runs over 3 b bits, not 63), radix sort, unique, decode.  Before these entries the host mirror spent ~30
+// small torch launches per octree level on it (tools/stage_split.py: 2.5 ms per loot10 frame).
+namespace {
+// K = uint32_t when the compact key fits (3 b <= 32: every level of a 10-bit cloud, the parent levels of an 11-bit one), else uint64_t
+template <typename K>
+__global__ __launch_bounds__(LINR_BLOCK) void su_keys_k(const int32_t* __restrict__ c, int64_t n, const int32_t* __restrict__ origin, int shift,
+                                                        int b, K* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int ox = origin ? origin[0] : 0, oy = origin ? origin[1] : 0, oz = origin ? origin[2] : 0;
+    const uint64_t x = (uint64_t)((c[3 * i] - ox) >> shift), y = (uint64_t)((c[3 * i + 1] - oy) >> shift), z = (uint64_t)((c[3 * i + 2] - oz) >> shift);
+    keys[i] = (K)((x << (2 * b)) | (y << b) | z);
+}
+template <typename K>
+__global__ __launch_bounds__(LINR_BLOCK) void su_decode_k(const K* __restrict__ keys, const int* __restrict__ num, int64_t cap, int b,
+                                                          int32_t* __restrict__ out, int64_t* __restrict__ count) {
+    const int64_t m = *num < cap ? *num : cap;
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i == 0) *count = m;
+    if (i >= m) return;
+    const uint64_t k = keys[i], mk = ((uint64_t)1 << b) - 1;
+    out[3 * i] = (int32_t)(k >> (2 * b));
+    out[3 * i + 1] = (int32_t)((k >> b) & mk);
+    out[3 * i + 2] = (int32_t)(k & mk);
+}
+// child occupancy from the sorted compact CHILD keys (b bits per coordinate) and the sorted unique compact PARENT keys (b - 1 bits):
+// octree_occ_k of kmap.hip with the parent count read on the device
+template <typename KC, typename KP>
+__global__ __launch_bounds__(LINR_BLOCK) void su_occ_k(const KC* __restrict__ ck, int64_t m, const KP* __restrict__ pk,
+                                                       const int* __restrict__ num, int b, float* __restrict__ occ) {
+    const int64_t n = *num;
+    const int64_t idx = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (idx >= 4 * n) return;
+    const int q = (int)(idx & 3);
+    const int64_t j = idx >> 2;
+    const int dx = q >> 1, dy = q & 1, pb = b - 1;
+    const uint64_t k = pk[j], mk = ((uint64_t)1 << pb) - 1;
+    const uint64_t px = k >> (2 * pb), py = (k >> pb) & mk, pz = k & mk;
+    const uint64_t key0 = ((2 * px + dx) << (2 * b)) | ((2 * py + dy) << b) | (2 * pz);
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)ck[mid] < key0) lo = mid + 1; else hi = mid;
+    }
+    const bool h0 = lo < m && (uint64_t)ck[lo] == key0;
+    if (h0) ++lo;
+    const bool h1 = lo < m && (uint64_t)ck[lo] == key0 + 1;
+    occ[j * 8 + 4 * dx + 2 * dy] = h0 ? 1.0f : 0.0f;
+    occ[j * 8 + 4 * dx + 2 * dy + 1] = h1 ? 1.0f : 0.0f;
+}
+size_t su_cub_bytes(int64_t n) {
+    size_t a = 0, b = 0, c = 0, d = 0;
+    const int m = (int)(n > 0 ? n : 1);
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, m, 0, 60);
+    (void)hipcub::DeviceSelect::Unique(nullptr, b, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr, m);
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, c, (const uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 32);
+    (void)hipcub::DeviceSelect::Unique(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr, m);
+    a = a > b ? a : b;
+    c = c > d ? c : d;
+    return a > c ? a : c;
+}
+// keys of (coords >> shift) into k0, sorted into k1, unique back into k0, *num = how many
+template <typename K>
+int su_sort_unique(const int32_t* coords, int64_t n, const int32_t* origin, int shift, int b, K* k0, K* k1, int* num, void* cub, size_t cb,
+                   hipStream_t s) {
+    su_keys_k<K><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(coords, n, origin, shift, b, k0);
+    int rc = linr_hip_rc(hipcub::DeviceRadixSort::SortKeys(cub, cb, k0, k1, (int)n, 0, 3 * b, s));
+    if (rc) return rc;
+    return linr_hip_rc(hipcub::DeviceSelect::Unique(cub, cb, k1, k0, num, (int)n, s));
+}
+template <typename K>
+int su_unique_coords(const int32_t* coords, int64_t n, const int32_t* origin, int shift, int b, char* base, size_t kb, int32_t* out,
+                     int64_t* count, hipStream_t s) {
+    K* k0 = (K*)base;
+    K* k1 = (K*)(base + kb);
+    int* num = (int*)(base + 3 * kb);
+    int rc = su_sort_unique<K>(coords, n, origin, shift, b, k0, k1, num, base + 3 * kb + 256, su_cub_bytes(n), s);
+    if (rc) return rc;
+    su_decode_k<K><<<linr_grid(n, LINR_BLOCK), LINR_BLOCK, 0, s>>>(k0, num, n, b, out, count);
+    return linr_launch_rc();
+}
+template <typename KC, typename KP>
+int su_level(const int32_t* child, int64_t m, int b, char* base, size_t kb, int32_t* parent, float* occ, int64_t* count, hipStream_t s) {
+    KP* k0 = (KP*)base;
+    KP* k1 = (KP*)(base + kb);
+    KC* ck = (KC*)(base + 2 * kb);
+    int* num = (int*)(base + 3 * kb);
+    su_keys_k<KC><<<linr_grid(m, LINR_BLOCK), LINR_BLOCK, 0, s>>>(child, m, nullptr, 0, b, ck);
+    int rc = su_sort_unique<KP>(child, m, nullptr, 1, b - 1, k0, k1, num, base + 3 * kb + 256, su_cub_bytes(m), s);
+    if (rc) return rc;
+    su_decode_k<KP><<<linr_grid(m, LINR_BLOCK), LINR_BLOCK, 0, s>>>(k0, num, m, b - 1, parent, count);
+    su_occ_k<KC, KP><<<linr_grid(4 * m, LINR_BLOCK), LINR_BLOCK, 0, s>>>(ck, m, k0, num, b, occ);
+    return linr_launch_rc();
+}
+}  // namespace
+
+extern "C" size_t linr_sort_unique_workspace_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    return 3 * up256((size_t)n * 8) + 256 + up256(su_cub_bytes(n));
+}
+
+// coords: int32 [n,3], every (coordinate - origin) in [0, 2^coord_bits), coord_bits <= 20, any order, duplicates allowed; origin:
+// device int32 [3] subtracted from every row first (the frame's coord_data_min, custom_dataset.py:276-279) or nullptr.  out: int32 [n,3]
+// (room for n rows); *count (device int64) = number of distinct rows of (coords >> shift), written to out in x-major order.
+extern "C" int linr_coords_sort_unique(const int32_t* coords, int64_t n, const int32_t* origin, int32_t shift, int32_t coord_bits, int32_t* out,
+                                       int64_t* count, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || shift < 0 || shift > 19 || coord_bits < 1 || coord_bits > 20 || n > INT32_MAX) return LINR_EINVAL;
+    if (!count) return LINR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return linr_hip_rc(hipMemsetAsync(count, 0, sizeof(int64_t), s));
+    if (!coords || !out || !ws) return LINR_EINVAL;
+    if (ws_bytes < linr_sort_unique_workspace_bytes(n)) return LINR_ENOSPC;
+    if (((uintptr_t)ws) & 255u) return LINR_EALIGN;
+    const int b = coord_bits - shift > 1 ? coord_bits - shift : 1;
+    const size_t kb = up256((size_t)n * 8);
+    if (3 * b <= 32) return su_unique_coords<uint32_t>(coords, n, origin, shift, b, (char*)ws, kb, out, count, s);
+    return su_unique_coords<uint64_t>(coords, n, origin, shift, b, (char*)ws, kb, out, count, s);
+}
+
+// One octree level (octree_level.forward, models/module_utils.py:86-110) as one call: child int32 [m,3] sorted x-major and unique,
+// coordinates in [0, 2^coord_bits); parent [m,3] / occ [m,8] have room for m rows; *count (device int64) = the number of parents.
+extern "C" int linr_octree_level(const int32_t* child, int64_t m, int32_t coord_bits, int32_t* parent, float* occ, int64_t* count, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (m < 0 || coord_bits < 1 || coord_bits > 20 || m > INT32_MAX) return LINR_EINVAL;
+    if (!count) return LINR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) return linr_hip_rc(hipMemsetAsync(count, 0, sizeof(int64_t), s));
+    if (!child || !parent || !occ || !ws) return LINR_EINVAL;
+    if (ws_bytes < linr_sort_unique_workspace_bytes(m)) return LINR_ENOSPC;
+    if (((uintptr_t)ws) & 255u) return LINR_EALIGN;
+    const int b = coord_bits > 1 ? coord_bits : 2;
+    const size_t kb = up256((size_t)m * 8);
+    if (3 * b <= 32) return su_level<uint32_t, uint32_t>(child, m, b, (char*)ws, kb, parent, occ, count, s);
+    if (3 * (b - 1) <= 32) return su_level<uint64_t, uint32_t>(child, m, b, (char*)ws, kb, parent, occ, count, s);
+    return su_level<uint64_t, uint64_t>(child, m, b, (char*)ws, kb, parent, occ, count, s);
+}
+
+// Per-axis minimum and maximum of a coordinate list: out[0..2] = min, out[3..5] = max (device int32 [6]); what custom_dataset.py:
+// 276-279 computes with tensor reductions (torch's int64 column reductions cost 0.32 ms each on a 784 k-point frame).
+namespace {
+__global__ __launch_bounds__(LINR_BLOCK) void minmax_init_k(int32_t* out) {
+    if (threadIdx.x < 3) out[threadIdx.x] = INT32_MAX;
+    else if (threadIdx.x < 6) out[threadIdx.x] = INT32_MIN;
+}
+__global__ __launch_bounds__(LINR_BLOCK) void minmax_k(const int32_t* __restrict__ c, int64_t n, int32_t* __restrict__ out) {
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LINR_BLOCK) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const int v = c[3 * i + a]; lo[a] = v < lo[a] ? v : lo[a]; hi[a] = v > hi[a] ? v : hi[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int l = __shfl_xor(lo[a], d, 64), h = __shfl_xor(hi[a], d, 64);
+            lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {          // integer min / max: the order of the atomics does not matter
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(out + a, lo[a]); atomicMax(out + 3 + a, hi[a]); }
+    }
+}
+}  // namespace
+
+extern "C" int linr_coords_minmax(const int32_t* coords, int64_t n, int32_t* out, void* stream) {
+    if (n < 1 || !coords || !out) return LINR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    minmax_init_k<<<1, LINR_BLOCK, 0, s>>>(out);
+    const int64_t blocks = (n + LINR_BLOCK * 8 - 1) / (LINR_BLOCK * 8);
+    minmax_k<<<(unsigned)(blocks < 1024 ? blocks : 1024), LINR_BLOCK, 0, s>>>(coords, n, out);
+    return linr_launch_rc();
+}

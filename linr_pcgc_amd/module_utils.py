@@ -75,8 +75,17 @@ def ravel_key(coord):
     return (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
 
 
-def unique_sorted(coord):
-    """torch.unique(dim=0): de-duplicated rows in x-major order, int32."""
+def unique_sorted(coord, coord_bits=None):
+    """torch.unique(dim=0): de-duplicated rows in x-major order, int32.  On the GPU one library call (key sort + unique:
+    linr_coords_sort_unique) for coordinates in [0, 2^20); torch.unique otherwise.  coord_bits: the caller vouches that every
+    coordinate is in [0, 2^coord_bits) (no range check, fewer radix passes)."""
+    if coord.is_cuda and coord.shape[0] > 0 and coord.dtype in (torch.int32, torch.int64):
+        from . import ops
+        if coord_bits is not None:
+            return ops.coords_sort_unique(coord.to(torch.int32).contiguous(), 0, coord_bits)
+        lo, hi = torch.aminmax(coord)
+        if int(lo) >= 0 and int(hi) < (1 << 20):
+            return ops.coords_sort_unique(coord.to(torch.int32).contiguous(), 0)
     key = torch.unique(ravel_key(coord))
     mask = (1 << 21) - 1
     return torch.stack([(key >> 42) - 1, ((key >> 21) & mask) - 1, (key & mask) - 1], dim=1).to(torch.int32)
@@ -107,11 +116,11 @@ class octree_level(nn.Module):
         super().__init__()
         self.offsets = torch.tensor([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], dtype=torch.int64)
 
-    def forward(self, leaf, qsc=None):
+    def forward(self, leaf, qsc=None, coord_bits=20):
+        if leaf.is_cuda and leaf.dtype == torch.int32:        # GPU: parents (key sort + unique of leaf >> 1) and their child occupancy
+            from . import ops                                  # (sorted-key search) in ONE library call; leaf coordinates are >= 0
+            return ops.octree_level(leaf.contiguous(), coord_bits)
         parent = unique_sorted(torch.div(leaf.to(torch.int64), 2, rounding_mode='floor'))
-        if leaf.is_cuda and leaf.dtype == torch.int32:        # GPU: the kernel map's sorted-key search (linr_octree_occupancy)
-            from . import ops
-            return parent, ops.octree_occupancy(leaf.contiguous(), parent.contiguous())
         off = self.offsets.to(leaf.device)
         # all 8 child lookups of every parent as ONE batched search over the sorted leaf keys
         q = (parent.to(torch.int64)[:, None, :] * 2 + off[None, :, :]).reshape(-1, 3)
@@ -131,8 +140,9 @@ octree_level_obj = octree_level()
 class qscTensor:
     """module_utils.py:155-224 (the members the drivers use): sorted unique coords + 7-neighbour occupancy."""
 
-    def __init__(self, coord, feat=None, presorted=False):
-        self.coord = coord if presorted else unique_sorted(coord)
+    def __init__(self, coord, feat=None, presorted=False, coord_bits=None):
+        self.coord_bits = coord_bits                  # set by prepare_frame: every coordinate is in [0, 2^coord_bits)
+        self.coord = coord if presorted else unique_sorted(coord, coord_bits)
         self.feat = feat
         self.parent_C = self.occupancy = self.offset_tensor = None
 
@@ -143,7 +153,10 @@ class qscTensor:
         return contains(self.coord, coord_in).reshape(-1, 1)
 
     def set_oct_level(self):
-        self.parent_C, self.occupancy = octree_level_obj(self.coord)
+        if self.coord_bits is not None:
+            self.parent_C, self.occupancy = octree_level_obj(self.coord, coord_bits=self.coord_bits)
+        else:
+            self.parent_C, self.occupancy = octree_level_obj(self.coord)
 
     def get_oct_level(self):
         return self.parent_C, self.occupancy
@@ -165,25 +178,44 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
     """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3].
     with_offsets=False leaves 'offset_tensor' None: engine.Frame then reads the 7-neighbour occupancy off the kernel map
     it builds anyway (linr_kmap_offset_feat) and overfit.Gop stores those rows back into the dicts."""
+    dev = torch.device(device)
     if torch.is_tensor(points):                    # device-resident input (synthetic.sequence_frame_device): no host round trip
-        pts = points[:, :3].to(device=device, dtype=torch.int64)
+        pts = points[:, :3].to(device=dev)
     else:
-        pts = torch.as_tensor(np.asarray(points)[:, :3].astype(np.int64), device=device)
+        pts = torch.as_tensor(np.asarray(points)[:, :3], device=dev)
     if pts.shape[0] == 0:
         raise ValueError('the frame has no points')
-    cmin = pts.min(dim=0).values
-    span = int((pts.max(dim=0).values - cmin).max())
-    if span >= (1 << 20):
-        raise ValueError('the cloud spans %d voxels along an axis; the kernel map holds 20-bit coordinates (the data sets of the '
-                         'reference are 10 to 12 bit)' % (span + 1))
-    cur = qscTensor(pts - cmin)
+    if dev.type == 'cuda' and not pts.dtype.is_floating_point and (pts.dtype == torch.int32 or int(pts.abs().max()) < (1 << 30)):
+        # GPU: minimum / span by one kernel, the shift by coord_data_min inside the key kernel of the sort (torch's int64 column
+        # reductions alone cost 0.64 ms per 784 k-point frame)
+        from . import ops
+        p32 = pts.to(torch.int32).contiguous()
+        mm = ops.coords_minmax(p32)
+        mmh = mm.tolist()
+        cmin = torch.tensor(mmh[:3], dtype=torch.int64)
+        span = max(mmh[3 + a] - mmh[a] for a in range(3))
+        if span >= (1 << 20):
+            raise ValueError('the cloud spans %d voxels along an axis; the kernel map holds 20-bit coordinates (the data sets of the '
+                             'reference are 10 to 12 bit)' % (span + 1))
+        bits = max(1, int(span).bit_length())
+        cur = qscTensor(ops.coords_sort_unique(p32, 0, bits, origin=mm[:3]), presorted=True, coord_bits=bits)
+    else:
+        pts = pts.to(torch.int64)
+        cmin = pts.min(dim=0).values
+        span = int((pts.max(dim=0).values - cmin).max())
+        if span >= (1 << 20):
+            raise ValueError('the cloud spans %d voxels along an axis; the kernel map holds 20-bit coordinates (the data sets of the '
+                             'reference are 10 to 12 bit)' % (span + 1))
+        bits = max(1, int(span).bit_length())             # every shifted coordinate is in [0, 2^bits); one bit less per level
+        cur = qscTensor(pts - cmin, coord_bits=bits)
     ori = cur.get_coord()
     info = []
     limit = 100000 if scale_num is None else scale_num
     for s in range(limit):
         cur.set_oct_level()
         parent, occ = cur.get_oct_level()
-        low = qscTensor(parent, presorted=True)
+        bits = max(1, bits - 1)
+        low = qscTensor(parent, presorted=True, coord_bits=bits)
         if with_offsets:
             low.set_offset_tensor()
         info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),

@@ -248,6 +248,56 @@ def occ_wgrad7(occ, gouts, lo, mask, n, nblocks=256):
     return gw, gb
 
 
+def _aligned_ws(nbytes, device):
+    ws = _lib.scratch(nbytes + 256, device)
+    base = (ws.data_ptr() + 255) & ~255
+    return ws, base, ws.numel() - (base - ws.data_ptr())
+
+
+def coords_minmax(coords):
+    """Per-axis (min x, y, z, max x, y, z) of an int32 [n,3] GPU coordinate list as a Python list (one kernel + one host read)."""
+    _dev(coords, torch.int32, 'coords')
+    out = torch.empty(6, dtype=torch.int32, device=coords.device)
+    check(_lib.lib().linr_coords_minmax(coords.data_ptr(), coords.shape[0], out.data_ptr(), _stream()), 'linr_coords_minmax')
+    return out
+
+
+def coords_sort_unique(coords, shift=0, coord_bits=20, origin=None):
+    """Sorted (x-major) unique rows of ((coords - origin) >> shift): int32 [n,3] on the GPU in, int32 [m,3] out; shifted coordinates
+    in [0, 2^coord_bits); origin: int32 [3] GPU tensor or None.  One library call (linr_coords_sort_unique) + one host read of the
+    count - torch.unique(dim=0) of the reference's dataset code (custom_dataset.py:271-282, shift 0)."""
+    _dev(coords, torch.int32, 'coords')
+    L = _lib.lib()
+    n = coords.shape[0]
+    out = torch.empty((n, 3), dtype=torch.int32, device=coords.device)
+    if n == 0:
+        return out
+    count = torch.empty(1, dtype=torch.int64, device=coords.device)
+    ws, base, nbytes = _aligned_ws(L.linr_sort_unique_workspace_bytes(n), coords.device)
+    check(L.linr_coords_sort_unique(coords.data_ptr(), n, None if origin is None else origin.data_ptr(), int(shift), int(coord_bits),
+                                    out.data_ptr(), count.data_ptr(), base, nbytes, _stream()), 'linr_coords_sort_unique')
+    m = int(count)
+    return out if m == n else out[:m].clone()
+
+
+def octree_level(child, coord_bits=20):
+    """One octree level (octree_level.forward, models/module_utils.py:86-110) in one library call: child int32 [m,3] sorted x-major
+    and unique -> (parent int32 [n,3] = sorted unique child >> 1, occ float32 [n,8])."""
+    _dev(child, torch.int32, 'child')
+    L = _lib.lib()
+    m = child.shape[0]
+    parent = torch.empty((m, 3), dtype=torch.int32, device=child.device)
+    occ = torch.empty((m, 8), dtype=torch.float32, device=child.device)
+    if m == 0:
+        return parent, occ
+    count = torch.empty(1, dtype=torch.int64, device=child.device)
+    ws, base, nbytes = _aligned_ws(L.linr_sort_unique_workspace_bytes(m), child.device)
+    check(L.linr_octree_level(child.data_ptr(), m, int(coord_bits), parent.data_ptr(), occ.data_ptr(), count.data_ptr(), base, nbytes,
+                              _stream()), 'linr_octree_level')
+    n = int(count)
+    return parent[:n].clone(), occ[:n].clone()          # exact-size copies: the m-row buffers go back to the allocator
+
+
 def octree_occupancy(child, parent):
     """occ float32 [N,8] of the parents (sorted unique floor(child/2)) of a sorted unique child list (int32 [M,3])."""
     _dev(child, torch.int32, 'child')

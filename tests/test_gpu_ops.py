@@ -281,3 +281,40 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     assert torch.equal(slab_t, slab_tt), 'coalesced-gather + LDS-transpose weight gradients must equal the table kernel bit for bit'
     slab2 = ops.spconv_wgrad_cmap(xb[1:], go.to(dev), nbr, n, cin, cout, reduce=False)
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
+
+
+@pytest.mark.parametrize('n,span,shift', [(1, 4, 0), (5000, 40, 0), (5000, 40, 1), (200000, 1000, 1), (70000, (1 << 20) - 1, 0), (0, 4, 1)])
+def test_coords_sort_unique_matches_torch_unique(pkg, n, span, shift):
+    """linr_coords_sort_unique (input de-dup and the parent step of every octree level as one call) against torch.unique(dim=0)
+    of (coords >> shift): same rows, same x-major order, bit-exact (custom_dataset.py:271-282, module_utils.py:92,103)."""
+    from linr_pcgc_amd import ops
+    g = torch.Generator().manual_seed(n + span + shift)
+    c = torch.randint(0, span + 1, (n, 3), generator=g, dtype=torch.int64)
+    if n > 10:
+        c[: n // 3] = c[n // 3: 2 * (n // 3)]                  # plenty of duplicates
+    got = ops.coords_sort_unique(c.to(torch.int32).cuda().contiguous(), shift, max(1, int(span).bit_length())).cpu()
+    if n:
+        assert torch.equal(ops.coords_sort_unique(c.to(torch.int32).cuda().contiguous(), shift).cpu(), got)      # default: 20-bit keys
+    want = torch.unique(c >> shift, dim=0).to(torch.int32) if n else torch.zeros((0, 3), dtype=torch.int32)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
+def test_octree_levels_through_the_library_match_the_oracle(pkg):
+    """prepare_frame on the GPU (sort + unique + occupancy in the library) against the numpy oracle, every scale of a sphere shell:
+    coordinates, child occupancy and the point count bit-exact."""
+    from linr_pcgc_amd import synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    pts = synthetic.sphere_shell(7, 50.0)
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([pts, pts[rng.integers(0, len(pts), 500)]])[rng.permutation(len(pts) + 500)]      # shuffled, with duplicates
+    pts = pts + np.array([5, -70, 1000], dtype=pts.dtype)                      # a frame minimum that is not the origin (coord_data_min)
+    fr = prepare_frame(torch.as_tensor(pts).cuda(), None, 64, device='cuda', with_offsets=False)
+    ref = ooct.prepare_frame(pts, None, 64)
+    assert fr['coord_data_min'] == [int(v) for v in ref['coord_data_min']]
+    assert np.array_equal(fr['ori'].cpu().numpy(), ref['ori'])
+    fr64 = prepare_frame(torch.as_tensor(pts.astype(np.int64)).cuda(), None, 64, device='cuda', with_offsets=False)      # int64 input: same result
+    assert torch.equal(fr64['ori'], fr['ori']) and fr64['coord_data_min'] == fr['coord_data_min']
+    assert fr['point_num'] == ref['point_num'] and fr['scale_num'] == ref['scale_num']
+    for a, b in zip(fr['all_input_info'], ref['scales']):
+        assert np.array_equal(a['coord'].cpu().numpy(), b['coord'])
+        assert np.array_equal(a['occ'].cpu().numpy(), b['occ'])

@@ -69,6 +69,60 @@ __global__ __launch_bounds__(256) void base_k(const float* __restrict__ in, cons
     if (live) { *(f32x4*)(out + row * 8) = acc[0]; *(f32x4*)(out + row * 8 + 4) = acc[1]; }
 }
 
+// the baseline with another gather prefetch depth
+template <int PFD>
+__global__ __launch_bounds__(256) void base_pf_k(const float* __restrict__ in, const int* __restrict__ nbr, long ld, long n,
+                                              const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ out,
+                                              long gstride_in, long gstride_w) {
+    const int gi = blockIdx.y;
+    in += gi * gstride_in; out += gi * gstride_in; W += gi * gstride_w; bias += gi * 8;
+    const int lane = threadIdx.x & 63;
+    float wv[4][8];
+    {
+        const int blk = lane >> 2, j = lane & 3, kl = blk / 2, co = 4 * (blk % 2) + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = g * 8 + kl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[g][i] = k < 27 ? W[(k * 8 + i) * 8 + co] : 0.0f;
+        }
+    }
+    const long row_raw = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = row_raw < n;
+    const long row = live ? row_raw : n - 1;
+    const char* pad = (const char*)(in - 8);
+    unsigned off[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) off[k] = (unsigned)(nbr[k * ld + row] + 1) << 5;
+    f32x4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = bias[4 * h + j];
+    constexpr int PF = PFD;
+    f32x4 x[PF + 1][2];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { x[u][0] = *(const f32x4*)(pad + off[TAPK(u)]); x[u][1] = *(const f32x4*)(pad + off[TAPK(u)] + 16); }
+    __builtin_amdgcn_sched_barrier(0);
+    sfor<27>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int k = TAPK(kk), g = k / 8, ab = (k % 8) * 2;
+        if constexpr (kk + PF < 27) {
+            x[(kk + PF) % (PF + 1)][0] = *(const f32x4*)(pad + off[TAPK(kk + PF)]);
+            x[(kk + PF) % (PF + 1)][1] = *(const f32x4*)(pad + off[TAPK(kk + PF)] + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i / 4][i % 4], acc[0], 4, ab, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[g][i], x[kk % (PF + 1)][i / 4][i % 4], acc[1], 4, ab + 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (live) { *(f32x4*)(out + row * 8) = acc[0]; *(f32x4*)(out + row * 8 + 4) = acc[1]; }
+}
+
+
 // the same with TPW tiles per wave: the 32 per-lane weight loads and their address arithmetic once per wave instead of once per tile
 template <int TPW>
 __global__ __launch_bounds__(256) void base_multi_k(const float* __restrict__ in, const int* __restrict__ nbr, long ld, long n,
@@ -812,6 +866,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 8000; ++i) base_k<8><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout0 + 8, gs, 27 * 64);
     CK(hipDeviceSynchronize());
     time_it([&] { base_k<8><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout0 + 8, gs, 27 * 64); }, "baseline (lane = row, 27 taps via L1)");
+    time_it([&] { base_pf_k<2><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, gathers 2 taps ahead");
+    time_it([&] { base_pf_k<6><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, gathers 6 taps ahead");
+    time_it([&] { base_pf_k<8><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, gathers 8 taps ahead");
+    time_it([&] { base_pf_k<12><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, gathers 12 taps ahead");
     time_it([&] { base_multi_k<2><<<dim3((unsigned)((R + 511) / 512), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, 2 tiles per wave");
     time_it([&] { base_multi_k<4><<<dim3((unsigned)((R + 1023) / 1024), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout1 + 8, gs, 27 * 64); }, "baseline, 4 tiles per wave");
     time_it([&] { base_k<8><<<dim3((unsigned)((R + 255) / 256), G), 256>>>(din + 8, dnbr, ld, R, dW, db, dout0 + 8, gs, 27 * 64); }, "baseline again");
