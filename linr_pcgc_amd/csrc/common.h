@@ -55,6 +55,20 @@ struct LinrAdamRanges {
     int active[16];
     float step_size[16], bc2_sqrt[16];
 };
+// torch.optim.Adam's single-tensor update, the ONE definition every kernel that applies it uses (adam_k, step_tail_k): the operations
+// are pinned - separate multiplies and adds for the moments, one fused multiply-add for the step (what adam_k has compiled to since
+// round 1) - so that the fused and the stand-alone path update parameters bit-identically whatever the surrounding code looks like.
+__device__ __forceinline__ float linr_adam_update(float p, float grad, float& m, float& v, float step_size, float bc2_sqrt, float beta1,
+                                                  float omb1, float beta2, float omb2, float eps, float wd) {
+#pragma clang fp contract(off)
+    const float g = fmaf(wd, p, grad);
+    const float mi = m * beta1 + omb1 * g;           // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
+    const float vi = v * beta2 + (omb2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    m = mi;
+    v = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    return fmaf(-step_size, mi / denom, p);
+}
 __attribute__((visibility("hidden")))
 int linr_adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double step_size,
                      double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,

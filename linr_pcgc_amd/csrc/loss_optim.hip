@@ -117,14 +117,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void adam_k(float* __restrict__ params,
         step_size = rg.step_size[r];
         bc2_sqrt = rg.bc2_sqrt[r];
     }
-    const float p = params[i];
-    const float g = fmaf(wd, p, grads[i]);
-    const float mi = m[i] * beta1 + omb1 * g;           // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
-    const float vi = v[i] * beta2 + (omb2 * g) * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    float mi = m[i], vi = v[i];
+    params[i] = linr_adam_update(params[i], grads[i], mi, vi, step_size, bc2_sqrt, beta1, omb1, beta2, omb2, eps, wd);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    params[i] = p - step_size * (mi / denom);
 }
 
 int linr_adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double step_size,

@@ -454,9 +454,12 @@ def test_adam_skips_a_scale_until_its_first_gradient(pkg, shell):
     opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     for it in range(7):
         j = it % 4
-        train_step(model, opt, frames[j], shell['point_num'])
+        bits_fused = train_step(model, opt, frames[j], shell['point_num'])
         bits = torch.zeros(1, dtype=torch.float64, device='cuda')
         engine.net_forward(frames2[j], model2.flat_parameters(), 0, 8, None, bits)
+        # the two-launch tail of the fused step (embedding gradients + bits finish: step_pre_k; slab reduction + Adam: step_tail_k) against the
+        # four-launch form of the unfused path: the bits of every step bitwise
+        assert float(bits_fused) == float(bits), 'bits of the fused step differ from linr_net_forward at step %d' % it
         opt2.zero_grad()
         engine.net_backward(frames2[j], model2.flat_parameters(), opt2.grad, 1.0 / shell['point_num'])
         opt2.step(frames2[j])
@@ -470,6 +473,7 @@ def test_adam_skips_a_scale_until_its_first_gradient(pkg, shell):
     assert float(st[names.index('scale_mlp.4.0.weight')]['step']) == 5.0 and float(st[names.index('scale_mlp.0.0.weight')]['step']) == 7.0
     # the package's two training paths apply the same update
     assert torch.equal(model.flat_parameters(), model2.flat_parameters()), 'fused train_step and net_backward + FlatAdam.step differ'
+    assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq), 'Adam moments of the two paths differ'
     flat_o = torch.cat([v.detach().reshape(-1) for v in sdo.values()])
     _close(model.flat_parameters(), flat_o, 0, 3e-3, 'parameters after 7 Adam steps over frames with 4 / 5 scales')
     off = 0
