@@ -457,8 +457,8 @@ def test_adam_skips_a_scale_until_its_first_gradient(pkg, shell):
         bits_fused = train_step(model, opt, frames[j], shell['point_num'])
         bits = torch.zeros(1, dtype=torch.float64, device='cuda')
         engine.net_forward(frames2[j], model2.flat_parameters(), 0, 8, None, bits)
-        # the two-launch tail of the fused step (embedding gradients + bits finish: step_pre_k; slab reduction + Adam: step_tail_k) against the
-        # four-launch form of the unfused path: the bits of every step bitwise
+        # the fused step (linr_net_train_step: forward, backward, reduction, Adam in one call) against the unfused entries: the bits of
+        # every step bitwise
         assert float(bits_fused) == float(bits), 'bits of the fused step differ from linr_net_forward at step %d' % it
         opt2.zero_grad()
         engine.net_backward(frames2[j], model2.flat_parameters(), opt2.grad, 1.0 / shell['point_num'])
