@@ -129,6 +129,22 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
                      int64_t ld, int64_t n, const float* W, const float* bias, int32_t cin, int32_t cout,
                      const float* res, int32_t res_ld, const float* act, int32_t act_ld, float* out, int32_t out_ld,
                      uint32_t flags, void* stream);
+/* The same convolution for channel-BLOCKED activations wider than 8 (--hidden_channel_conv 16 / 32, main.py:520; models/upsample.py:
+ * 38-76, models/resnet.py:12-51): a C-wide matrix is C / 8 blocks [rows][8], each with its zero row in front.  ONE gather of all
+ * input blocks per tap feeds every output channel (csrc/wide.hip).  in_h / out_h / res_h / act_h: HOST arrays of device pointers to
+ * the blocks.  fwd: gathers ceil(cin / 8) blocks (cin < 8: channels >= cin of the one block are ignored), produces cout / 8 blocks;
+ * bwd: gathers the output gradient's cout / 8 blocks at the mirrored taps, produces cin / 8 blocks.  cin, cout <= 32 (8, 16, 32;
+ * cin < 8 forward only).  W [27][cin][cout], bias [cout] or NULL; flags: LINR_RELU, LINR_ACCUM, LINR_RELU_MASK. */
+LINR_API int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                              const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
+                              const float* const* act_h, float* const* out_h, uint32_t flags, void* stream);
+/* Weight gradient of that convolution: gW [27][cin][cout], gb [cout] (may be NULL) from the ceil(cin / 8) input blocks in_h (zero row in
+ * front) and the cout / 8 output-gradient blocks g_h; all block pairs as the groups of grouped launches of the 8-wide transposing
+ * kernel into `slab` (linr_spconv_wgrad_wide_slab_bytes(cin, cout) bytes), then ONE fixed-order reduction into the dense tensors.
+ * nbr / tile8t: the frame's kernel map [27][ld] and its tiled copy (linr_kmap_tile8t). */
+LINR_API size_t linr_spconv_wgrad_wide_slab_bytes(int32_t cin, int32_t cout);
+LINR_API int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, const float* const* g_h, int32_t cout, const int32_t* nbr,
+                                    const int32_t* tile8t, int64_t ld, int64_t n, float* slab, float* gW, float* gb, void* stream);
 
 /* Backward-weight of the same convolution as a stand-alone kernel (the executor uses it for the first convolutions of the outter
  * blocks, whose inputs need no gradient, and for the schedules without the fused backward below): lane = (offset, channel quad),

@@ -62,6 +62,9 @@ _PROTOS = {
                                        c_ptr, c_i32, c_u32, c_ptr]),
     'linr_spconv_bwd_data': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_i32,
                                             c_ptr, c_i32, c_u32, c_ptr]),
+    'linr_spconv_wide': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, ctypes.c_uint32, c_ptr]),
+    'linr_spconv_wgrad_wide_slab_bytes': (ctypes.c_size_t, [c_i32, c_i32]),
+    'linr_spconv_wgrad_wide': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_spconv_cmap': (ctypes.c_int, [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr,
                                         c_i32, c_ptr, c_i32, c_ptr, c_i32, c_u32, c_ptr]),
     'linr_spconv_bwd_weight_workspace_bytes': (c_size, [c_i64, c_i32, c_i32]),

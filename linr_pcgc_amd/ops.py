@@ -185,6 +185,42 @@ def spconv_cmap(x, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None
     return out
 
 
+def _ptr_array(blocks):
+    import ctypes
+    return (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+
+
+def spconv_wide(xs, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None, relu=False, outs=None, accumulate=False):
+    """linr_spconv_wide: a 3x3x3 convolution on channel-blocked activations, one gather of all input blocks per tap.
+    xs: the gathered blocks (views buf[1:] of [n+1, 8] buffers whose row 0 is zero); kernel [27, cin, cout]; outs / res / act: lists
+    of [n, 8] blocks of the produced side (cout / 8 forward, cin / 8 backward)."""
+    cin, cout = kernel.shape[1], kernel.shape[2]
+    npb = (cin if bwd else cout) // 8
+    if outs is None:
+        outs = [torch.empty((n, 8), dtype=torch.float32, device=xs[0].device) for _ in range(npb)]
+    flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0)
+    check(_lib.lib().linr_spconv_wide(1 if bwd else 0, _ptr_array(xs), lo.data_ptr(), mask.data_ptr(), lo.stride(0), n, kernel.data_ptr(),
+                                      _ptr(bias), cin, cout, None if res is None else _ptr_array(res), None if act is None else _ptr_array(act),
+                                      _ptr_array(outs), flags, _stream()), 'linr_spconv_wide')
+    return outs
+
+
+def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None):
+    """linr_spconv_wgrad_wide: kernel / bias gradient of a convolution on channel-blocked activations (all block pairs in grouped
+    launches, one reduction).  gw [27, cin, cout] / gb [cout]: contiguous destinations (e.g. views of the flat gradient) or None."""
+    L = _lib.lib()
+    dev = xs[0].device
+    if gw is None:
+        gw = torch.empty((27, cin, cout), dtype=torch.float32, device=dev)
+    if gb is None:
+        gb = torch.empty((cout,), dtype=torch.float32, device=dev)
+    assert gw.is_contiguous() and gb.is_contiguous()
+    slab = _lib.scratch(L.linr_spconv_wgrad_wide_slab_bytes(cin, cout), dev)
+    check(L.linr_spconv_wgrad_wide(_ptr_array(xs), cin, _ptr_array(gouts), cout, nbr.data_ptr(), _ptr(tile8t), nbr.stride(0), n,
+                                   slab.data_ptr(), gw.data_ptr(), gb.data_ptr(), _stream()), 'linr_spconv_wgrad_wide')
+    return gw, gb
+
+
 def kmap_tile8t(nbr, n=None):
     """linr_kmap_tile8t: the tiled copy of the kernel map in the lane order of the transposing weight-gradient kernel."""
     L = _lib.lib()

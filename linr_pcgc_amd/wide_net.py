@@ -2,15 +2,16 @@
 ``channels // 2``): the same network with wider feature rows, run on the library's 8-wide kernels by CHANNEL BLOCKING.
 
 Every C-wide activation is kept as C / 8 separate [rows + 1][8] matrices (zero row in front, what the kernels gather from), so
-a convolution Ci -> Co is (Ci / 8) x (Co / 8) launches of the tuned 8 -> 8 compressed-map MFMA kernel (``linr_spconv_cmap``) that
-accumulate into the output block (``LINR_ACCUM``; bias with the first, residual / ReLU with the last), a pointwise layer the same
-with ``linr_linear_fwd`` on sub-blocks of its weight matrix (addressed through the kernel's weight strides, no copies), weight
+a convolution Ci -> Co is ONE launch of ``linr_spconv_wide`` (csrc/wide.hip: every input block of a row gathered once per tap, the
+weights of a tap as an A-operand image in LDS, all output channels from that one gather; the same for backward-data at the mirrored
+taps), a pointwise layer is (Ci / 8) x (Co / 8) launches of ``linr_linear_fwd`` on sub-blocks of its weight matrix (addressed through the kernel's weight strides, no copies), weight
 gradients block by block with ``linr_spconv_bwd_weight`` / ``linr_linear_bwd_weight``; concatenations are free.  Only data
 movement is left to torch (slices of the 3x3x3 kernels, the [emb | offsets] input of the scale MLP); every arithmetic
 instruction runs in liblinr_hip.so.  Deterministic (fixed launch order, no atomics); the forward is the same launches in
 training, encoding and stage-by-stage decoding, so streams decode losslessly.
 
-Not tuned: ~3.5x the convolution work of the 8-wide network in ~10x as many launches, unfused backward.  The 8-wide model
+Partly tuned: ~3.7x the convolution work of the 8-wide network; forward and backward-data convolutions run at ~65 % of the matrix
+cores' rate, the weight gradients block pair by block pair, unfused backward, schedule in Python (profiles/r04_wide.txt).  The 8-wide model
 (every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
 """
 import torch
@@ -71,53 +72,34 @@ class _Conv:
         self.ci, self.co = mod.kernel.shape[1], mod.kernel.shape[2]
         self.nbi, self.nbo = (self.ci + B - 1) // B, self.co // B
 
-    def sub(self, net, bi, bo):
-        """Dense [27][<=8][8] copy of a block of the kernel, made once per step (forward and backward-data share it)."""
-        key = (id(self), bi, bo)
-        w = net.subs.get(key)
-        if w is None:
-            w = self.mod.kernel[:, B * bi:min(B * bi + B, self.ci), B * bo:B * bo + B].contiguous()
-            net.subs[key] = w
-        return w
-
     def fwd(self, net, xs, relu=False, res=None):
+        """ONE launch (linr_spconv_wide): every input block of a row is gathered once per tap and feeds all output channels."""
         n = xs[0].shape[0]
         outs = _blocks(n, self.nbo, xs[0].device)
-        bias = self.mod.bias
-        for bo in range(self.nbo):
-            for bi in range(self.nbi):
-                last = bi == self.nbi - 1
-                ops.spconv_cmap(xs[bi], net.lo, net.mask, n, self.sub(net, bi, bo), bias[0, B * bo:B * bo + B] if bi == 0 else None,
-                                res=res[bo] if (res is not None and last) else None, relu=relu and last, out=outs[bo],
-                                accumulate=bi > 0)
+        ops.spconv_wide(xs[:self.nbi], net.lo, net.mask, n, self.mod.kernel, self.mod.bias.reshape(-1), res=res, relu=relu, outs=outs)
         return outs
 
     def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True):
         """Parameter gradients into .grad; input gradient (masked by act > 0: the ReLU that produced xs) accumulated into
         gins (list of (buffer, has_content)) or returned as fresh blocks."""
         n = gouts[0].shape[0]
-        gk, gbias = self.mod.kernel.grad, self.mod.bias.grad
-        for bi in range(self.nbi):
-            cw = min(B, self.ci - B * bi)
-            for bo in range(self.nbo):
-                # the transposing weight-gradient kernel (coalesced gathers through the frame's tiled index table) + the fixed-order
-                # slab reduction
-                gw, gb = ops.spconv_wgrad_cmap(xs[bi], gouts[bo], net.nbr_full, n, cw, B, tile8t=net.tile8t)
-                gk[:, B * bi:B * bi + cw, B * bo:B * bo + B].copy_(gw)
-                if bi == 0:
-                    gbias[0, B * bo:B * bo + B].copy_(gb)
+        # weight gradients: all (input block, gradient block) pairs as groups of grouped launches of the transposing 8-wide kernel, ONE
+        # fixed-order reduction straight into the parameter gradients (views of the flat gradient)
+        ops.spconv_wgrad_wide(xs[:self.nbi], gouts[:self.nbo], net.nbr_full, net.tile8t, n, self.ci, self.co,
+                              gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1))
         if not need_input_grad:
             return None
         fresh = gins is None
         if fresh:
             gins = [[g, False] for g in _blocks(n, self.nbi, gouts[0].device)]
-        for bi in range(self.nbi):
-            for bo in range(self.nbo):
-                last = bo == self.nbo - 1
-                ops.spconv_cmap(gouts[bo], net.lo, net.mask, n, self.sub(net, bi, bo), None, bwd=True,
-                                act=act[bi] if (act is not None and last) else None, out=gins[bi][0],
-                                accumulate=gins[bi][1] or bo > 0)
-            gins[bi][1] = True
+        # backward-data in one launch: the output gradient's blocks gathered once per (mirrored) tap for all input channels; blocks that
+        # already hold a gradient are accumulated into (all of them or none: the callers fill a list uniformly)
+        acc = gins[0][1]
+        assert all(g[1] == acc for g in gins)
+        ops.spconv_wide(gouts[:self.nbo], net.lo, net.mask, n, self.mod.kernel, None, bwd=True, act=act, outs=[g[0] for g in gins],
+                        accumulate=acc)
+        for g in gins:
+            g[1] = True
         return [g for g, _ in gins] if fresh else None
 
 
@@ -261,7 +243,6 @@ class WideNet:
             raise ValueError('hidden_channel_conv must be 8 (the tuned kernels) or 16 / 32 (channel-blocked executor), got %d' % hidden)
         self.model, self.C = model, hidden
         self._built = False
-        self.subs = {}
 
     def _build(self):
         up = self.model.upsampler
@@ -318,7 +299,6 @@ class WideNet:
         """Stages [k0, k1) teacher-forced on frame.occ (decoder: the columns decoded so far): probs [8, rows] rows k0..k1-1, bits
         (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8)."""
         self._bind(frame)
-        self.subs = {}                          # kernel blocks of this step (the parameters change between steps)
         if frame.rows == 0:
             return None
         x0, sce_tape = self._scale_context(frame, keep)
