@@ -659,7 +659,8 @@ def main():
                 train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
             torch.cuda.synchronize()
             wide_leg = {'hidden_channel_conv': 16, 'ms_per_step': round((time.time() - t0) * 1e3 / 5, 2), 'parameters': int(mw.flat_parameters().numel()),
-                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py): the 8-wide kernels on 8-channel blocks, not tuned'}
+                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py): convolutions as single launches of csrc/wide.hip (one gather per tap for all '
+                                    'output channels), weight gradients in grouped launches, pointwise layers block pair by block pair, Python schedule'}
             del mw, ow
         except Exception as e:
             wide_leg = {'error': repr(e)}
