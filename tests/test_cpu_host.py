@@ -67,6 +67,28 @@ def test_c_abi_argument_checks(lib):
     g7[3] = None
     assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 16, p16, 8, ctypes.byref(rows), None) == -1 and rows.value == 0
     assert lib.linr_occ_wgrad7(p16, g7, p16, p16, 16, 0, p16, 8, ctypes.byref(rows), None) == 0               # empty input is fine
+    # round-4 entries: octree levels without torch.unique, convolutions on channel-blocked activations (widths 16 / 32)
+    assert lib.linr_coords_sort_unique(p16, -1, None, 0, 20, p16, p16, p16, 1024, None) == -1               # n < 0
+    assert lib.linr_coords_sort_unique(p16, 8, None, 0, 21, p16, p16, p16, 1024, None) == -1                # more than 20 bits
+    assert lib.linr_coords_sort_unique(p16, 8, None, 20, 20, p16, p16, p16, 1024, None) == -1               # shift out of range
+    assert lib.linr_coords_sort_unique(p16, 8, None, 0, 10, p16, None, p16, 1024, None) == -1               # no count
+    assert lib.linr_octree_level(p16, -1, 10, p16, p16, p16, p16, 1024, None) == -1
+    assert lib.linr_octree_level(p16, 8, 0, p16, p16, p16, p16, 1024, None) == -1                           # coord_bits < 1
+    assert lib.linr_octree_level(p16, 8, 10, p16, p16, None, p16, 1024, None) == -1                         # no count
+    assert lib.linr_coords_minmax(p16, 0, p16, None) == -1 and lib.linr_coords_minmax(p16, 8, None, None) == -1
+    b2 = (ctypes.c_void_p * 2)(p16, p16)
+    assert lib.linr_spconv_wide(0, b2, p16, p16, 16, 16, p16, p16, 16, 12, None, None, b2, 0, None) == -1   # cout not a multiple of 8
+    assert lib.linr_spconv_wide(0, b2, p16, p16, 16, 16, p16, p16, 40, 16, None, None, b2, 0, None) == -1   # cin > 32
+    assert lib.linr_spconv_wide(0, None, p16, p16, 16, 16, p16, p16, 16, 16, None, None, b2, 0, None) == -1
+    assert lib.linr_spconv_wide(0, b2, p16, p16, 16, 16, p16, p16, 16, 16, None, None, b2, 64, None) == -1  # unknown flag
+    assert lib.linr_spconv_wide(1, b2, p16, p16, 16, 16, p16, p16, 4, 16, None, None, b2, 0, None) == -1    # backward needs cin % 8 == 0
+    assert lib.linr_spconv_wide(0, b2, p16, p16, 16, 16, p16, p16, 16, 16, None, None, b2, 4, None) == -1   # LINR_RELU_MASK without act blocks
+    b2m = (ctypes.c_void_p * 2)(p16, p16 + 4)
+    assert lib.linr_spconv_wide(0, b2m, p16, p16, 16, 16, p16, p16, 16, 16, None, None, b2, 0, None) == -3  # a gathered block misaligned
+    assert lib.linr_spconv_wide(0, b2, p16, p16, 16, 0, p16, p16, 16, 16, None, None, b2, 0, None) == 0     # empty input is fine
+    assert lib.linr_spconv_wgrad_wide(b2, 16, b2, 5, p16, None, 16, 16, p16, p16, p16, None) == -1          # cout 5
+    assert lib.linr_spconv_wgrad_wide(b2, 16, b2, 16, p16, None, 16, 16, None, p16, p16, None) == -1        # no slab
+    assert lib.linr_spconv_wgrad_wide_slab_bytes(16, 16) == 512 * 4 * 1736 * 4 and lib.linr_spconv_wgrad_wide_slab_bytes(0, 16) == 0
     # whole network: NULL frame / parameters, stage range
     assert lib.linr_net_forward(None, p16, p16, 4096, 0, 8, None, None, None) == -1
     assert lib.linr_net_train_step(None, p16, p16, 4096, 1.0, None, None, 0.01, 1, None, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
