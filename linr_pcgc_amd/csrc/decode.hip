@@ -315,24 +315,20 @@ __global__ __launch_bounds__(LINR_BLOCK) void minmax_init_k(int32_t* out) {
     if (threadIdx.x < 3) out[threadIdx.x] = INT32_MAX;
     else if (threadIdx.x < 6) out[threadIdx.x] = INT32_MIN;
 }
-__global__ __launch_bounds__(LINR_BLOCK) void minmax_k(const int32_t* __restrict__ c, int64_t n, int32_t* __restrict__ out) {
-    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-    for (int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LINR_BLOCK) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { const int v = c[3 * i + a]; lo[a] = v < lo[a] ? v : lo[a]; hi[a] = v > hi[a] ? v : hi[a]; }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const int l = __shfl_xor(lo[a], d, 64), h = __shfl_xor(hi[a], d, 64);
-            lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a];
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {          // integer min / max: the order of the atomics does not matter
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(out + a, lo[a]); atomicMax(out + 3 + a, hi[a]); }
-    }
+// The flat int32 stream read coalesced: with a grid whose thread count is a multiple of 3 every thread stays on one axis.  Per block
+// one LDS reduction, then 6 global atomics (integer min / max: the order of the atomics does not matter).
+__global__ __launch_bounds__(LINR_BLOCK) void minmax_k(const int32_t* __restrict__ c, int64_t n3, int32_t* __restrict__ out) {
+    __shared__ int s_lo[3], s_hi[3];
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = INT32_MAX; s_hi[threadIdx.x] = INT32_MIN; }
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x, stride = (int64_t)gridDim.x * LINR_BLOCK;      // stride % 3 == 0
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int64_t i = t0; i < n3; i += stride) { const int v = c[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    const int a = (int)(t0 % 3);
+    if (lo <= hi) { atomicMin(&s_lo[a], lo); atomicMax(&s_hi[a], hi); }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(out + threadIdx.x, s_lo[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(out + threadIdx.x, s_hi[threadIdx.x - 3]);
 }
 }  // namespace
 
@@ -340,7 +336,9 @@ extern "C" int linr_coords_minmax(const int32_t* coords, int64_t n, int32_t* out
     if (n < 1 || !coords || !out) return LINR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     minmax_init_k<<<1, LINR_BLOCK, 0, s>>>(out);
-    const int64_t blocks = (n + LINR_BLOCK * 8 - 1) / (LINR_BLOCK * 8);
-    minmax_k<<<(unsigned)(blocks < 1024 ? blocks : 1024), LINR_BLOCK, 0, s>>>(coords, n, out);
+    int64_t blocks = (3 * n + LINR_BLOCK * 16 - 1) / (LINR_BLOCK * 16);
+    blocks = (blocks < 768 ? blocks : 768);
+    blocks = (blocks + 2) / 3 * 3;          // thread count a multiple of 3: one axis per thread
+    minmax_k<<<(unsigned)blocks, LINR_BLOCK, 0, s>>>(coords, 3 * n, out);
     return linr_launch_rc();
 }

@@ -291,7 +291,7 @@ def _aligned_ws(nbytes, device):
 
 
 def coords_minmax(coords):
-    """Per-axis (min x, y, z, max x, y, z) of an int32 [n,3] GPU coordinate list as a Python list (one kernel + one host read)."""
+    """Per-axis (min x, y, z, max x, y, z) of an int32 [n,3] GPU coordinate list as a device int32 [6] tensor (two launches, no host read)."""
     _dev(coords, torch.int32, 'coords')
     out = torch.empty(6, dtype=torch.int32, device=coords.device)
     check(_lib.lib().linr_coords_minmax(coords.data_ptr(), coords.shape[0], out.data_ptr(), _stream()), 'linr_coords_minmax')

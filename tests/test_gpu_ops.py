@@ -283,6 +283,17 @@ def test_wgrad_cmap_entry_matches_oracle(pkg, shell, cin, cout):
     assert torch.equal(slab1, slab2), 'partials must be bit-reproducible'
 
 
+@pytest.mark.parametrize('n', [1, 2, 85, 256, 4099, 800001])
+def test_coords_minmax_matches_torch(pkg, n):
+    """linr_coords_minmax against the column reductions of custom_dataset.py:276-279 (negative coordinates included), bit-exact."""
+    from linr_pcgc_amd import ops
+    g = torch.Generator().manual_seed(n)
+    c = torch.randint(-1000, 1 << 20, (n, 3), generator=g, dtype=torch.int32)
+    c[:, 1] += 77
+    got = ops.coords_minmax(c.to(_dev())).cpu()
+    assert got[:3].tolist() == c.min(dim=0).values.tolist() and got[3:].tolist() == c.max(dim=0).values.tolist()
+
+
 @pytest.mark.parametrize('n,span,shift', [(1, 4, 0), (5000, 40, 0), (5000, 40, 1), (200000, 1000, 1), (70000, (1 << 20) - 1, 0), (0, 4, 1)])
 def test_coords_sort_unique_matches_torch_unique(pkg, n, span, shift):
     """linr_coords_sort_unique (input de-dup and the parent step of every octree level as one call) against torch.unique(dim=0)

@@ -176,3 +176,57 @@ def test_wide_gop_encode_decode_roundtrip(pkg):
     for i in range(2):
         ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
         assert torch.equal(dec[i], ref)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 16), (8, 16), (16, 8), (32, 32), (3, 16), (16, 32)])
+def test_wide_conv_entries_match_the_oracle_conv(pkg, shell, cin, cout):
+    """linr_spconv_wide (forward with bias / residual / ReLU, backward-data with the ReLU mask) and linr_spconv_wgrad_wide against
+    oracle.network.conv3 (MinkowskiConvolution kernel_size 3) and its autograd on the finest scale of the
+    shell.  Tolerance: fp32 sums of up to 27 x 32 products in a different order (1e-5 relative to the largest entry)."""
+    from linr_pcgc_amd import ops
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    nbr_o = torch.from_numpy(sc['nbr']).long().cuda()                          # oracle layout [n, 27]
+    ld = (n + 63) // 64 * 64
+    nbr = torch.full((27, ld), -1, dtype=torch.int32, device='cuda')           # library layout [27, ld]
+    nbr[:, :n] = ops.kmap_build(torch.from_numpy(sc['coord']).cuda())
+    lo, mask = ops.kmap_compress(nbr, n)
+    tile8t = ops.kmap_tile8t(nbr, n)
+    torch.manual_seed(cin * 100 + cout)
+    W = (torch.randn(27, cin, cout, device='cuda') * 0.1).requires_grad_()
+    b = torch.randn(1, cout, device='cuda', requires_grad=True)
+    nbi, nbo = (cin + 7) // 8, cout // 8
+
+    def blocks(t, nb):
+        """[n, 8 nb] (zero-padded channels) -> blocks: views buf[i, 1:] of [n + 1, 8] buffers whose row 0 is zero."""
+        buf = torch.zeros((nb, n + 1, 8), device='cuda')
+        for i in range(nb):
+            w = min(8, t.shape[1] - 8 * i)
+            buf[i, 1:, :w] = t[:, 8 * i:8 * i + w]
+        return buf, [buf[i, 1:] for i in range(nb)]
+
+    x = torch.randn(n, cin, device='cuda', requires_grad=True)
+    res = torch.randn(n, cout, device='cuda')
+    xbuf, xs = blocks(x.detach(), nbi)
+    if cin % 8:
+        xbuf[-1, 1:, cin % 8:] = 7.0                                           # channels past cin must be ignored
+    _, rs = blocks(res, nbo)
+    outs = ops.spconv_wide(xs, lo, mask, n, W.detach(), b.detach().reshape(-1), res=rs, relu=True)
+    pre = onet.conv3(x, nbr_o, W, b) + res
+    ref = torch.relu(pre)
+    got = torch.cat(outs, dim=1)
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+    g = torch.randn(n, cout, device='cuda')
+    _, gs = blocks(g, nbo)
+    y = onet.conv3(x, nbr_o, W, b)
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y, [x, W, b], g)
+    gw, gb = ops.spconv_wgrad_wide(xs, gs, nbr, tile8t, n, cin, cout)
+    assert float((gw - gw_ref).abs().max()) <= 1e-5 * float(gw_ref.abs().max())
+    assert float((gb - gb_ref.reshape(-1)).abs().max()) <= 1e-5 * float(gb_ref.abs().max())
+    if cin % 8 == 0:
+        act = torch.randn(n, cin, device='cuda')
+        _, acts = blocks(act, nbi)
+        gi = ops.spconv_wide(gs, lo, mask, n, W.detach(), None, bwd=True, act=acts)
+        want = gx_ref * (act > 0)
+        assert float((torch.cat(gi, dim=1) - want).abs().max()) <= 1e-5 * float(want.abs().max())
