@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 6
+#define LINR_ABI_VERSION 7
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -139,12 +139,31 @@ LINR_API int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int32
                               const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
                               const float* const* act_h, float* const* out_h, uint32_t flags, void* stream);
 /* Weight gradient of that convolution: gW [27][cin][cout], gb [cout] (may be NULL) from the ceil(cin / 8) input blocks in_h (zero row in
- * front) and the cout / 8 output-gradient blocks g_h; all block pairs as the groups of grouped launches of the 8-wide transposing
- * kernel into `slab` (linr_spconv_wgrad_wide_slab_bytes(cin, cout) bytes), then ONE fixed-order reduction into the dense tensors.
+ * front) and the cout / 8 output-gradient blocks g_h: one launch whose groups are the input blocks - the gathered, LDS-transposed rows
+ * of a block multiply the tiles of ALL gradient blocks (cout 8 / 16 / 32 with the tiled table; else block pair by block pair) - into
+ * `slab` (linr_spconv_wgrad_wide_slab_bytes(cin, cout) bytes), then ONE fixed-order reduction into the dense tensors.
  * nbr / tile8t: the frame's kernel map [27][ld] and its tiled copy (linr_kmap_tile8t). */
 LINR_API size_t linr_spconv_wgrad_wide_slab_bytes(int32_t cin, int32_t cout);
 LINR_API int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, const float* const* g_h, int32_t cout, const int32_t* nbr,
                                     const int32_t* tile8t, int64_t ld, int64_t n, float* slab, float* gW, float* gb, void* stream);
+
+/* Pointwise layers of the wide network on blocked activations (MinkowskiConvolution kernel_size 1: models/resnet.py:25-46 conv1_0,
+ * conv1_2; the head's nn.Linear(C, 24): models/upsample.py:73-76) as ONE launch: out = [ReLU]([mask]((bias + in @ W) + res + old)).
+ * in_h / out_h / res_h / act_h: HOST arrays of device pointers - blocked (channels / 8 matrices [n][8]) or, with *_blocked = 0, ONE
+ * dense [n][channels] matrix (the head's 24 hidden units); res / act are laid out like out.  Weight element (ci, co) at
+ * W[ci * ws_ci + co * ws_co]: ME layout (cout, 1), torch layout (1, cin); backward-data = the same call with the roles of cin / cout
+ * and the two strides swapped (as linr_linear_bwd_data).  Shapes: blocked -> blocked with cin, cout in {8, 16, 32}; blocked (16, 32)
+ * -> dense 24 and dense 24 -> blocked (16, 32).  flags: LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS. */
+LINR_API int linr_linear_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* W, int32_t ws_ci, int32_t ws_co,
+                              const float* bias, int32_t cout, int32_t out_blocked, const float* const* res_h, const float* const* act_h,
+                              float* const* out_h, int64_t n, uint32_t flags, void* stream);
+/* Their weight gradient: gW(ci, co) = sum_r x[r][ci] g[r][co] written at gW[ci * ws_ci + co * ws_co], gb[co] = sum_r g[r][co] (NULL:
+ * skipped); LINR_ACCUM adds to the destinations.  All (input piece, gradient piece) pairs in one grouped launch + one fixed-order
+ * reduction; ws: linr_linear_wgrad_wide_workspace_bytes(n, cin, cout) bytes.  Dense sides: up to 31 channels. */
+LINR_API size_t linr_linear_wgrad_wide_workspace_bytes(int64_t n, int32_t cin, int32_t cout);
+LINR_API int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* const* g_h, int32_t cout,
+                                    int32_t g_blocked, int64_t n, float* gW, int32_t ws_ci, int32_t ws_co, float* gb, uint32_t flags,
+                                    void* ws, size_t ws_bytes, void* stream);
 
 /* Backward-weight of the same convolution as a stand-alone kernel (the executor uses it for the first convolutions of the outter
  * blocks, whose inputs need no gradient, and for the schedules without the fused backward below): lane = (offset, channel quad),

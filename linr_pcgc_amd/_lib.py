@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -65,6 +65,11 @@ _PROTOS = {
     'linr_spconv_wide': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, ctypes.c_uint32, c_ptr]),
     'linr_spconv_wgrad_wide_slab_bytes': (ctypes.c_size_t, [c_i32, c_i32]),
     'linr_spconv_wgrad_wide': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_linear_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32,
+                                        ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_uint32, c_ptr]),
+    'linr_linear_wgrad_wide_workspace_bytes': (ctypes.c_size_t, [c_i64, ctypes.c_int32, ctypes.c_int32]),
+    'linr_linear_wgrad_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_i64, c_ptr,
+                                              ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_uint32, c_ptr, ctypes.c_size_t, c_ptr]),
     'linr_spconv_cmap': (ctypes.c_int, [c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr,
                                         c_i32, c_ptr, c_i32, c_ptr, c_i32, c_u32, c_ptr]),
     'linr_spconv_bwd_weight_workspace_bytes': (c_size, [c_i64, c_i32, c_i32]),

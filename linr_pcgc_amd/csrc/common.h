@@ -104,6 +104,10 @@ int linr_conv3_wgrad_partial(const float* in, int in_ld, const float* gout, int 
 __attribute__((visibility("hidden")))
 int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int gout_ld, int64_t n, int cin, int cout,
                               LinrLinDst d, int nblocks, hipStream_t s, const Grp* gp = nullptr, int ngroups = 1);
+__attribute__((visibility("hidden"))) int linr_lin_blocks(int64_t n);
+__attribute__((visibility("hidden")))
+int linr_linear_slab_reduce_launch(const float* slab, int nblocks, int64_t stride, int cin, int cout, float* gW, int ws_ci, int ws_co,
+                                   float* gb, unsigned flags, hipStream_t s);
 __attribute__((visibility("hidden")))
 int linr_cconv_launch(bool bwd, const float* in, int in_ld, const int32_t* lo, const uint32_t* mask, int64_t ld,
                       int64_t n, const float* W, const float* bias, int cin, int cout, const float* res, int res_ld,

@@ -221,7 +221,7 @@ int linr_linear_wgrad_partial(const float* in, int in_ld, const float* gout, int
 // 16 threads per element (block slices in four interleaved chains, slices added in order): as slab_reduce_k of spconv.hip
 __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* __restrict__ slab, int nblocks, int cin,
                                                                    int cout, float* __restrict__ gW, int ws_ci,
-                                                                   int ws_co, float* __restrict__ gb, unsigned flags) {
+                                                                   int ws_co, float* __restrict__ gb, unsigned flags, int64_t stride) {
     __shared__ float part[LR_SLICES][LR_ELEMS + 1];
     const int el = threadIdx.x % LR_ELEMS, sl = threadIdx.x / LR_ELEMS;
     const int e = blockIdx.x * LR_ELEMS + el;
@@ -230,12 +230,12 @@ __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* 
     if (e < elems) {
         int b = sl;
         for (; b + 3 * LR_SLICES < nblocks; b += 4 * LR_SLICES) {
-            s0 += slab[(int64_t)(b + 0 * LR_SLICES) * elems + e];
-            s1 += slab[(int64_t)(b + 1 * LR_SLICES) * elems + e];
-            s2 += slab[(int64_t)(b + 2 * LR_SLICES) * elems + e];
-            s3 += slab[(int64_t)(b + 3 * LR_SLICES) * elems + e];
+            s0 += slab[(int64_t)(b + 0 * LR_SLICES) * stride + e];
+            s1 += slab[(int64_t)(b + 1 * LR_SLICES) * stride + e];
+            s2 += slab[(int64_t)(b + 2 * LR_SLICES) * stride + e];
+            s3 += slab[(int64_t)(b + 3 * LR_SLICES) * stride + e];
         }
-        for (; b < nblocks; b += LR_SLICES) s0 += slab[(int64_t)b * elems + e];
+        for (; b < nblocks; b += LR_SLICES) s0 += slab[(int64_t)b * stride + e];
     }
     part[sl][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -249,10 +249,19 @@ __global__ __launch_bounds__(LINR_BLOCK) void linear_slab_reduce_k(const float* 
     *d = (flags & LINR_ACCUM) ? *d + s : s;
 }
 
-static int lin_blocks(int64_t n) {
+int linr_lin_blocks(int64_t n) {
     int64_t nb = (n + 255) / 256;
     if (nb > LINR_WG_BLOCKS) nb = LINR_WG_BLOCKS;
     return (int)(nb < 1 ? 1 : nb);
+}
+static int lin_blocks(int64_t n) { return linr_lin_blocks(n); }
+
+// slab rows of `stride` floats, each a dense [cin + 1][cout] partial (bias = row cin) in front: fixed-order sum, scattered to the strides
+int linr_linear_slab_reduce_launch(const float* slab, int nblocks, int64_t stride, int cin, int cout, float* gW, int ws_ci, int ws_co,
+                                   float* gb, unsigned flags, hipStream_t s) {
+    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LR_ELEMS), LINR_BLOCK, 0, s>>>(slab, nblocks, cin, cout, gW, ws_ci, ws_co, gb, flags,
+                                                                                       stride);
+    return linr_launch_rc();
 }
 
 extern "C" size_t linr_linear_bwd_weight_workspace_bytes(int64_t n, int32_t cin, int32_t cout) {
@@ -273,7 +282,5 @@ extern "C" int linr_linear_bwd_weight(const float* in, int32_t in_ld, const floa
     LinrLinDst d = {(float*)ws, (int64_t)(cin + 1) * cout, 0, cout, 1, (int64_t)cin * cout};
     int rc = linr_linear_wgrad_partial(in, in_ld, gout, gout_ld, n, cin, cout, d, nb, s);
     if (rc) return rc;
-    linear_slab_reduce_k<<<linr_grid((cin + 1) * cout, LR_ELEMS), LINR_BLOCK, 0, s>>>((const float*)ws, nb, cin, cout, gW,
-                                                                                       ws_ci, ws_co, gb, flags);
-    return linr_launch_rc();
+    return linr_linear_slab_reduce_launch((const float*)ws, nb, (int64_t)(cin + 1) * cout, cin, cout, gW, ws_ci, ws_co, gb, flags, s);
 }

@@ -245,6 +245,166 @@ __global__ __launch_bounds__(LINR_BLOCK) void wide_slab_reduce_k(const float* __
     else if (gb) gb[e - 27 * cin * cout] = s;
 }
 
+
+// One gather for ALL gradient blocks: spconv_wgrad_t_k<8, false> (csrc/fused.hip) with the transposed image of an input block's
+// gathered rows multiplied with the 8-row tiles of NGB gradient blocks (group = input block, blockIdx.y) - the gathers, index loads
+// and LDS transposes of a pair launch are paid once per input block instead of once per (input, gradient) pair; per accumulator the
+// same v_mfma_f32_4x4x1 sequence in the same row order and the same wave fold as the pair kernel, so the slab holds the same bits.
+#define WW_WAVES 4
+#define WW_PITCH 288                  // bytes per tap in the LDS image: 8 rows x 32 B + 32 B
+#define WW_TAPS 28                    // 27 taps + the dump slot of the 7th gather's unused lane group
+struct WwArgs {
+    const float* in[WC_MAXB];         // input blocks (zero row at [-8, 0))
+    const float* g[WC_MAXB];          // gradient blocks [n][8]
+    int cw[WC_MAXB];                  // live channels of an input block
+    int nbo;                          // gradient blocks of the convolution (pair p = bi * nbo + bo)
+    float* slab; int64_t block_stride;
+};
+
+template <int NGB>
+__global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_t* __restrict__ tile8t, int64_t n) {
+    constexpr int NA = 32;                                  // accumulator floats per lane and gradient block
+    constexpr int IMG_F4 = WW_TAPS * WW_PITCH / 16;
+    constexpr int FOLD_F4 = 16 * (NA + 1);
+    constexpr int SMEM_F4 = WW_WAVES * (IMG_F4 > FOLD_F4 ? IMG_F4 : FOLD_F4);
+    __shared__ float4 smem[SMEM_F4];
+    __shared__ float sbias[NGB][WW_WAVES][8];
+    float* sacc = reinterpret_cast<float*>(smem);
+    const int bi = blockIdx.y;
+    const float* in = a.in[bi];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 1, kk = lane >> 1, k = kk < 27 ? kk : 26;              // MFMA-side role: (tap, quad)
+    const int gq = lane & 1, gu8 = (lane >> 1) & 7, gt = lane >> 4;             // gather-side role: (tap of 4, row of 8, quad)
+    f32x4 acc[NGB][4][2];
+#pragma unroll
+    for (int b = 0; b < NGB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[b][c][h] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + 7) & ~(int64_t)7;
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t b1 = (b0 + per < n) ? b0 + per : n;
+    const char* ubase = reinterpret_cast<const char*>(in - 8);
+    const uint32_t uoff = 32u + 16u * gq;
+    const int gu = (lane >> 3) & 7, gc = lane & 7;           // the lane's element of an 8-row gradient tile
+    const int32_t* tk = tile8t + (gt * 8 + gu8) * 8;
+    char* img = reinterpret_cast<char*>(smem + wave * IMG_F4);
+    uint32_t wofs[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int p = 4 * j + gt;
+        wofs[j] = (uint32_t)((p < 27 ? LINR_TAP(p) : 27) * WW_PITCH + gu8 * 32 + gq * 16);
+    }
+    const uint32_t rd0 = (uint32_t)(k * WW_PITCH + q * 16);
+    float bsum[NGB], gvn[NGB], gvc[NGB];
+#pragma unroll
+    for (int b = 0; b < NGB; ++b) bsum[b] = gvn[b] = gvc[b] = 0.0f;
+    const int64_t g00 = b0 + 8 * wave;
+    int4 ia = make_int4(-1, -1, -1, -1), ib = ia;
+    float4 xg[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) xg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g00 < b1) {                        // wave-uniform; blocks behind the last row must not touch the tables at all
+        const int4 a0 = *reinterpret_cast<const int4*>(tk + g00 * 32);
+        const int4 c0 = *reinterpret_cast<const int4*>(tk + g00 * 32 + 4);
+#pragma unroll
+        for (int b = 0; b < NGB; ++b) gvc[b] = (g00 + gu < n) ? a.g[b][(g00 + gu) * 8 + gc] : 0.0f;
+        const int32_t i0[8] = {a0.x, a0.y, a0.z, a0.w, c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)i0[j] << 5) + uoff));
+        const int64_t g1r = g00 + 8 * WW_WAVES;           // spare all -1 groups behind the last row group: no bounds check
+        ia = *reinterpret_cast<const int4*>(tk + g1r * 32);
+        ib = *reinterpret_cast<const int4*>(tk + g1r * 32 + 4);
+#pragma unroll
+        for (int b = 0; b < NGB; ++b) gvn[b] = (g1r + gu < n) ? a.g[b][(g1r + gu) * 8 + gc] : 0.0f;
+    }
+    for (int64_t g0r = g00; g0r < b1; g0r += 8 * WW_WAVES) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wofs[j]) = xg[j];
+        __builtin_amdgcn_sched_barrier(0);
+        float gv[NGB];
+#pragma unroll
+        for (int b = 0; b < NGB; ++b) gv[b] = gvc[b];
+        {
+            const int32_t idn[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)idn[j] << 5) + uoff));
+            const int64_t g2r = g0r + 16 * WW_WAVES;
+            ia = *reinterpret_cast<const int4*>(tk + g2r * 32);
+            ib = *reinterpret_cast<const int4*>(tk + g2r * 32 + 4);
+#pragma unroll
+            for (int b = 0; b < NGB; ++b) {
+                gvc[b] = gvn[b];
+                gvn[b] = (g2r + gu < n) ? a.g[b][(g2r + gu) * 8 + gc] : 0.0f;
+            }
+        }
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(img + rd0 + (uint32_t)(u * 32));
+#pragma unroll
+        for (int b = 0; b < NGB; ++b) bsum[b] += gv[b];
+        static_for<NGB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            static_for<8>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                static_for<2>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    constexpr int ab = u * 2 + h;           // the block holding g[row u][4h .. 4h+3]
+                    acc[b][0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].x, acc[b][0][h], 4, ab, 0);
+                    acc[b][1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].y, acc[b][1][h], 4, ab, 0);
+                    acc[b][2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].z, acc[b][2][h], 4, ab, 0);
+                    acc[b][3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].w, acc[b][3][h], 4, ab, 0);
+                });
+            });
+        });
+    }
+    // bias sums: lane l holds the partial column sum of channel gc over rows gu, gu + 8, ...: the 8 row phases by a fixed xor tree
+#pragma unroll
+    for (int b = 0; b < NGB; ++b) {
+        float t = bsum[b];
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) t += __shfl_xor(t, m, 64);
+        if (lane < 8) sbias[b][wave][lane] = t;
+    }
+    const int cinv = a.cw[bi];
+    const int per_k = cinv * 8, total = 27 * per_k;
+    float* dst0 = a.slab + (int64_t)blockIdx.x * a.block_stride + (int64_t)bi * a.nbo * WW_PAIR;
+    static_for<NGB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        __syncthreads();                       // the images (b = 0) or the previous block's fold are done with
+        {
+            float* mine = sacc + (wave * 64 + lane) * (NA + 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mine[(c * 2 + h) * 4 + i] = acc[b][c][h][i];
+        }
+        __syncthreads();
+        float* dst = dst0 + (int64_t)b * WW_PAIR;
+        const int tid = threadIdx.x;
+        if (tid < 8) {
+            float t = sbias[b][0][tid];
+            for (int w = 1; w < WW_WAVES; ++w) t += sbias[b][w][tid];
+            dst[1728 + tid] = t;
+        }
+        for (int e = tid; e < total; e += WW_WAVES * 64) {
+            const int kq = e / per_k, r = e - kq * per_k;
+            const int ci = r >> 3, co = r & 7;
+            const int idx = (2 * kq + (ci >> 2)) * (NA + 1) + ((ci & 3) * 2 + (co >> 2)) * 4 + (co & 3);
+            constexpr int W = 64 * (NA + 1);
+            float t = sacc[idx];
+#pragma unroll
+            for (int w = 1; w < WW_WAVES; ++w) t += sacc[w * W + idx];
+            dst[e] = t;
+        }
+    });
+}
+
 extern "C" size_t linr_spconv_wgrad_wide_slab_bytes(int32_t cin, int32_t cout) {
     if (cin < 1 || cout < 8) return 0;
     return (size_t)LINR_WG_BLOCKS * ((cin + 7) / 8) * (cout / 8) * WW_PAIR * sizeof(float);
@@ -266,6 +426,22 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
     }
     for (int i = 0; i < nbi; ++i) if (!in_h[i] || !linr_aligned16(in_h[i])) return in_h[i] ? LINR_EALIGN : LINR_EINVAL;
     for (int i = 0; i < nbo; ++i) if (!g_h[i]) return LINR_EINVAL;
+    int nblk = LINR_WG_BLOCKS;
+    if (tile8t && linr_aligned16(tile8t) && (nbo == 1 || nbo == 2 || nbo == 4)) {
+        // one launch: group = input block, all gradient blocks from its one gather
+        WwArgs a;
+        for (int i = 0; i < WC_MAXB; ++i) { a.in[i] = in_h[i < nbi ? i : 0]; a.g[i] = g_h[i < nbo ? i : 0]; a.cw[i] = 8; }
+        for (int i = 0; i < nbi; ++i) a.cw[i] = cin - 8 * i < 8 ? cin - 8 * i : 8;
+        a.nbo = nbo; a.slab = slab; a.block_stride = (int64_t)npairs * WW_PAIR;
+        // 256 persistent blocks per input block (sweep 128 .. 512 on loot10, profiles/r04_wide.txt: 16 -> 16 86 us at 256, 96 at 384, 108 at 512)
+        nblk = 256;
+        const dim3 grid(nblk, nbi);
+        if (nbo == 1) wwgrad_k<1><<<grid, WW_WAVES * 64, 0, s>>>(a, tile8t, n);
+        else if (nbo == 2) wwgrad_k<2><<<grid, WW_WAVES * 64, 0, s>>>(a, tile8t, n);
+        else wwgrad_k<4><<<grid, WW_WAVES * 64, 0, s>>>(a, tile8t, n);
+        const int rc = linr_launch_rc();
+        if (rc) return rc;
+    } else
     for (int p0 = 0; p0 < npairs; p0 += LINR_MAXG) {
         const int ng = npairs - p0 < LINR_MAXG ? npairs - p0 : LINR_MAXG;
         Grp gp = Grp();
@@ -282,6 +458,171 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
         if (rc) return rc;
     }
     const int total = 27 * cin * cout + cout;
-    wide_slab_reduce_k<<<linr_grid(total, 16), LINR_BLOCK, 0, s>>>(slab, LINR_WG_BLOCKS, npairs, cin, cout, gW, gb);
+    wide_slab_reduce_k<<<linr_grid(total, 16), LINR_BLOCK, 0, s>>>(slab, nblk, npairs, cin, cout, gW, gb);
     return linr_launch_rc();
+}
+
+// ---- pointwise layers on channel-blocked activations ---------------------------------------------------------------------------------
+// MinkowskiConvolution(kernel_size=1) / nn.Linear of the wide network (conv1_0 C -> C/2, conv1_2 C/2 -> C/2: models/resnet.py:25-46;
+// the head's Linear(C, 24): models/upsample.py:73-76) as ONE launch: a lane owns a row, reads every input block once, and writes every
+// output block - the blocked form ran (Ci / 8)(Co / 8) launches of linear_k<8, 8> accumulating through memory.  The weight element
+// (ci, co) lives at W[ci * ws_ci + co * ws_co] (wave-uniform: scalar loads), so ME's [cin][cout], torch's [cout][cin] and the
+// backward-data pass (strides swapped) are the same kernel.  Per output: bias, then the inputs ascending (one fmaf chain), then
+// + res, + old (LINR_ACCUM), * (act > 0) (LINR_RELU_MASK), ReLU - the epilogue order of linear_k (csrc/linear.hip).
+struct WlArgs {
+    const float* in[WC_MAXB];      // INB: cin / 8 blocks [n][8]; else in[0] = one [n][cin] matrix
+    float* out[WC_MAXB];           // OUTB: cout / 8 blocks [n][8]; else out[0] = one [n][cout] matrix
+    const float* res[WC_MAXB];     // laid out like out, or all nullptr
+    const float* act[WC_MAXB];     // laid out like out (LINR_RELU_MASK)
+    const float* W; int ws_ci, ws_co;
+    const float* bias;             // [cout] or nullptr
+    unsigned flags;
+};
+
+template <int CIN, int COUT, bool INB, bool OUTB>
+__global__ __launch_bounds__(LINR_BLOCK) void wlin_k(WlArgs a, int64_t n) {
+    const int64_t row = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (row >= n) return;
+    float x[CIN];
+    if constexpr (INB) {
+#pragma unroll
+        for (int b = 0; b < CIN / 8; ++b) {
+            const float4 t0 = *reinterpret_cast<const float4*>(a.in[b] + row * 8), t1 = *reinterpret_cast<const float4*>(a.in[b] + row * 8 + 4);
+            x[8 * b] = t0.x; x[8 * b + 1] = t0.y; x[8 * b + 2] = t0.z; x[8 * b + 3] = t0.w;
+            x[8 * b + 4] = t1.x; x[8 * b + 5] = t1.y; x[8 * b + 6] = t1.z; x[8 * b + 7] = t1.w;
+        }
+    } else {
+        static_assert(CIN % 4 == 0, "unblocked rows are read as float4");
+#pragma unroll
+        for (int v = 0; v < CIN / 4; ++v) {
+            const float4 t = *reinterpret_cast<const float4*>(a.in[0] + row * CIN + 4 * v);
+            x[4 * v] = t.x; x[4 * v + 1] = t.y; x[4 * v + 2] = t.z; x[4 * v + 3] = t.w;
+        }
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = a.bias ? a.bias[o] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < CIN; ++i)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(x[i], a.W[i * a.ws_ci + o * a.ws_co], acc[o]);
+    constexpr int OP = OUTB ? COUT / 8 : 1, OW = OUTB ? 8 : COUT;          // output pieces and their width
+    static_assert(OW % 4 == 0, "output rows are written as float4");
+#pragma unroll
+    for (int b = 0; b < OP; ++b) {
+        float* op = a.out[b] + row * OW;
+        float* y = acc + b * OW;
+        if (a.res[b]) {
+#pragma unroll
+            for (int v = 0; v < OW / 4; ++v) {
+                const float4 t = *reinterpret_cast<const float4*>(a.res[b] + row * OW + 4 * v);
+                y[4 * v] += t.x; y[4 * v + 1] += t.y; y[4 * v + 2] += t.z; y[4 * v + 3] += t.w;
+            }
+        }
+        if (a.flags & LINR_ACCUM) {
+#pragma unroll
+            for (int v = 0; v < OW / 4; ++v) {
+                const float4 t = *reinterpret_cast<const float4*>(op + 4 * v);
+                y[4 * v] += t.x; y[4 * v + 1] += t.y; y[4 * v + 2] += t.z; y[4 * v + 3] += t.w;
+            }
+        }
+        if (a.flags & LINR_RELU_MASK) {
+#pragma unroll
+            for (int v = 0; v < OW / 4; ++v) {
+                const float4 t = *reinterpret_cast<const float4*>(a.act[b] + row * OW + 4 * v);
+                y[4 * v] = t.x > 0.0f ? y[4 * v] : 0.0f; y[4 * v + 1] = t.y > 0.0f ? y[4 * v + 1] : 0.0f;
+                y[4 * v + 2] = t.z > 0.0f ? y[4 * v + 2] : 0.0f; y[4 * v + 3] = t.w > 0.0f ? y[4 * v + 3] : 0.0f;
+            }
+        }
+        if (a.flags & LINR_RELU) {
+#pragma unroll
+            for (int o = 0; o < OW; ++o) y[o] = fmaxf(y[o], 0.0f);
+        }
+#pragma unroll
+        for (int v = 0; v < OW / 4; ++v) *reinterpret_cast<float4*>(op + 4 * v) = make_float4(y[4 * v], y[4 * v + 1], y[4 * v + 2], y[4 * v + 3]);
+    }
+}
+
+// in_h / out_h / res_h / act_h: HOST arrays of device pointers (blocked: channels / 8 entries of [n][8] matrices; unblocked: one entry,
+// a dense [n][channels] matrix).  Shapes: blocked -> blocked with (cin, cout) in {8, 16, 32} x {8, 16, 32}; blocked -> [n][24] and
+// [n][24] -> blocked with the blocked side 16 or 32 (the head's first Linear and its backward-data pass).
+extern "C" int linr_linear_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* W, int32_t ws_ci, int32_t ws_co,
+                                const float* bias, int32_t cout, int32_t out_blocked, const float* const* res_h, const float* const* act_h,
+                                float* const* out_h, int64_t n, uint32_t flags, void* stream) {
+    if (n < 0 || cin < 1 || cout < 1 || cin > 32 || cout > 32 || !in_h || !out_h || !W) return LINR_EINVAL;
+    if ((flags & LINR_RELU_MASK) && !act_h) return LINR_EINVAL;
+    if (n == 0) return 0;
+    const int ni = in_blocked ? cin / 8 : 1, no = out_blocked ? cout / 8 : 1;
+    if ((in_blocked && cin % 8) || (out_blocked && cout % 8)) return LINR_EINVAL;
+    WlArgs a;
+    for (int i = 0; i < WC_MAXB; ++i) { a.in[i] = nullptr; a.out[i] = nullptr; a.res[i] = nullptr; a.act[i] = nullptr; }
+    for (int i = 0; i < ni; ++i) {
+        if (!in_h[i]) return LINR_EINVAL;
+        if (!linr_aligned16(in_h[i])) return LINR_EALIGN;
+        a.in[i] = in_h[i];
+    }
+    for (int i = 0; i < no; ++i) {
+        if (!out_h[i]) return LINR_EINVAL;
+        if (!linr_aligned16(out_h[i])) return LINR_EALIGN;
+        a.out[i] = out_h[i];
+        if (res_h && res_h[i]) { if (!linr_aligned16(res_h[i])) return LINR_EALIGN; a.res[i] = res_h[i]; }
+        if (flags & LINR_RELU_MASK) {
+            if (!act_h[i]) return LINR_EINVAL;
+            if (!linr_aligned16(act_h[i])) return LINR_EALIGN;
+            a.act[i] = act_h[i];
+        }
+    }
+    a.W = W; a.ws_ci = ws_ci; a.ws_co = ws_co; a.bias = (flags & LINR_NO_BIAS) ? nullptr : bias; a.flags = flags;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = linr_grid(n, LINR_BLOCK);
+#define WL_GO(CI, CO, IB, OB)                                                                         \
+    if (cin == CI && cout == CO && (in_blocked != 0) == IB && (out_blocked != 0) == OB) {             \
+        wlin_k<CI, CO, IB, OB><<<grid, LINR_BLOCK, 0, s>>>(a, n);                                     \
+        return linr_launch_rc();                                                                      \
+    }
+    WL_GO(8, 8, true, true) WL_GO(8, 16, true, true) WL_GO(16, 8, true, true) WL_GO(16, 16, true, true)
+    WL_GO(16, 32, true, true) WL_GO(32, 16, true, true) WL_GO(32, 32, true, true) WL_GO(8, 32, true, true) WL_GO(32, 8, true, true)
+    WL_GO(16, 24, true, false) WL_GO(32, 24, true, false) WL_GO(24, 16, false, true) WL_GO(24, 32, false, true)
+#undef WL_GO
+    return LINR_EINVAL;
+}
+
+// Weight gradient of such a layer: gW(ci, co) = sum_r x[r][ci] g[r][co] at gW[ci * ws_ci + co * ws_co], gb[co] = sum_r g[r][co]
+// (gb may be NULL; LINR_ACCUM adds to the destinations).  Every (input piece, gradient piece) pair is a group of ONE grouped launch of
+// xtg_wgrad_k (csrc/linear.hip: the rows as the K dimension of v_mfma_f32_16x16x4_f32) into a dense [cin + 1][cout] partial per slab
+// row, then one fixed-order reduction scattered to the strides - the blocked form ran a launch and a reduction per pair.
+extern "C" size_t linr_linear_wgrad_wide_workspace_bytes(int64_t n, int32_t cin, int32_t cout) {
+    if (n <= 0 || cin < 1 || cout < 1) return 0;
+    return (size_t)linr_lin_blocks(n) * ((size_t)(cin + 2) * cout) * sizeof(float);
+}
+
+extern "C" int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* const* g_h, int32_t cout,
+                                      int32_t g_blocked, int64_t n, float* gW, int32_t ws_ci, int32_t ws_co, float* gb, uint32_t flags,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || cin < 1 || cout < 1 || cin > 32 || cout > 32 || !in_h || !g_h || !gW) return LINR_EINVAL;
+    if ((in_blocked && cin % 8) || (g_blocked && cout % 8) || (!in_blocked && cin > 31)) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!ws) return LINR_EINVAL;
+    if (ws_bytes < linr_linear_wgrad_wide_workspace_bytes(n, cin, cout)) return LINR_ENOSPC;
+    const int ni = in_blocked ? cin / 8 : 1, no = g_blocked ? cout / 8 : 1;
+    const int mi = in_blocked ? 8 : cin, nn = g_blocked ? 8 : cout;              // channels per piece = its leading dimension
+    if (ni * no > LINR_MAXG) return LINR_EINVAL;
+    for (int i = 0; i < ni; ++i) if (!in_h[i]) return LINR_EINVAL;
+    for (int i = 0; i < no; ++i) if (!g_h[i]) return LINR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = linr_lin_blocks(n);
+    const int64_t stride = (int64_t)(cin + 2) * cout;                             // [cin + 1][cout] + a dump row for the duplicate bias sums
+    Grp gp = Grp();
+    for (int pi = 0; pi < ni; ++pi)
+        for (int po = 0; po < no; ++po) {
+            const int g = pi * no + po;
+            gp.in[g] = in_h[pi] - in_h[0];
+            gp.res[g] = g_h[po] - g_h[0];
+            gp.w[g] = (int64_t)(mi * pi) * cout + nn * po;
+            gp.b[g] = (int64_t)(pi == 0 ? cin : cin + 1) * cout + nn * po;        // the column sums of g: kept from the first input piece
+        }
+    LinrLinDst d = {(float*)ws, stride, 0, cout, 1, 0};
+    const int rc = linr_linear_wgrad_partial(in_h[0], mi, g_h[0], nn, n, mi, nn, d, nb, s, &gp, ni * no);
+    if (rc) return rc;
+    return linr_linear_slab_reduce_launch((const float*)ws, nb, stride, cin, cout, gW, ws_ci, ws_co, gb, flags, s);
 }

@@ -546,11 +546,11 @@ def train_step(model, opt, frame, point_num, out=None):
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device) if out is None else out
     if model._wide is not None:          # hidden_channel_conv 16 / 32: the channel-blocked executor + the segment-wise Adam
         with torch.no_grad():
-            tape = model._wide.forward(frame, 0, 8, None, bits, keep=True)
+            tape = model._wide.forward(frame, 0, 8, None, bits, keep=True, pool=True)
             model._ensure_grad_views()
             model._flat_grad.zero_()
             if tape is not None:
-                model._wide.backward(frame, tape, 1.0 / float(point_num))
+                model._wide.backward(frame, tape, 1.0 / float(point_num), pool=True)
             opt.grad.copy_(model._flat_grad)
             opt.step(frame)
         opt.scheduler_step()

@@ -221,6 +221,30 @@ def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None):
     return gw, gb
 
 
+def linear_wide(xs, cin, w, ws_ci, ws_co, bias, cout, outs, in_blocked=True, out_blocked=True, res=None, act=None, relu=False,
+                accumulate=False):
+    """linr_linear_wide: a pointwise layer on blocked activations as one launch.  xs / outs / res / act: lists of [n, 8] blocks, or
+    (in_blocked / out_blocked False) one-element lists with a dense [n, channels] matrix.  Weight element (ci, co) at
+    w.data_ptr() + 4 (ci ws_ci + co ws_co); backward-data: swap cin / cout and the strides."""
+    n = xs[0].shape[0]
+    flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0) | \
+        (_lib.LINR_NO_BIAS if bias is None else 0)
+    check(_lib.lib().linr_linear_wide(_ptr_array(xs), cin, 1 if in_blocked else 0, w.data_ptr(), ws_ci, ws_co, _ptr(bias), cout,
+                                      1 if out_blocked else 0, None if res is None else _ptr_array(res),
+                                      None if act is None else _ptr_array(act), _ptr_array(outs), n, flags, _stream()), 'linr_linear_wide')
+    return outs
+
+
+def linear_wgrad_wide(xs, cin, gouts, cout, gw, ws_ci, ws_co, gb, in_blocked=True, g_blocked=True, accumulate=False):
+    """linr_linear_wgrad_wide: gw(ci, co) (+)= sum_r x[r][ci] g[r][co] at gw.data_ptr() + 4 (ci ws_ci + co ws_co), gb[co] (+)= column sums."""
+    L = _lib.lib()
+    n = xs[0].shape[0]
+    ws = _lib.scratch(max(L.linr_linear_wgrad_wide_workspace_bytes(n, cin, cout), 4), xs[0].device)
+    check(L.linr_linear_wgrad_wide(_ptr_array(xs), cin, 1 if in_blocked else 0, _ptr_array(gouts), cout, 1 if g_blocked else 0, n,
+                                   gw.data_ptr(), ws_ci, ws_co, _ptr(gb), LINR_ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                   _stream()), 'linr_linear_wgrad_wide')
+
+
 def kmap_tile8t(nbr, n=None):
     """linr_kmap_tile8t: the tiled copy of the kernel map in the lane order of the transposing weight-gradient kernel."""
     L = _lib.lib()

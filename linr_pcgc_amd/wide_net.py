@@ -26,21 +26,43 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Pool:
+    """Zero-padded block buffers reused from step to step (train_step's schedule asks for the same sequence every time): the kernels
+    never write a block's row 0, so it is cleared once when the buffer is made instead of once per request (88 fill launches per step at
+    width 16).  A buffer is [nb][cap + 1][8]; a request for fewer rows gets views of its first rows."""
+
+    def __init__(self):
+        self.bufs, self.i = [], 0
+
+    def reset(self):
+        self.i = 0
+
+    def take(self, n, nb, dev):
+        i = self.i
+        self.i += 1
+        if i < len(self.bufs):
+            b = self.bufs[i]
+            if b.shape[0] == nb and b.shape[1] > n and b.device == dev:
+                return [b[j, 1:n + 1] for j in range(nb)]
+        b = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
+        b[:, 0].zero_()
+        if i < len(self.bufs):
+            self.bufs[i] = b
+        else:
+            self.bufs.append(b)
+        return [b[j, 1:] for j in range(nb)]
+
+
+_POOL = None          # the pool of the running forward / backward (WideNet.forward(pool=True)), else fresh buffers
+
+
 def _blocks(n, nb, dev):
     """nb zero-padded [n, 8] matrices (views buf[1:] of [n + 1, 8] buffers whose row 0 is zero)."""
+    if _POOL is not None:
+        return _POOL.take(n, nb, dev if isinstance(dev, torch.device) else torch.device(dev))
     buf = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
     buf[:, 0].zero_()
     return [buf[i, 1:] for i in range(nb)]
-
-
-def _lin(x, w, w_off, ws_ci, ws_co, bias, cin, cout, out, res=None, relu=False, accumulate=False):
-    """out (+)= x @ W[sub-block] (+ bias) (+ res) (ReLU): linr_linear_fwd with explicit weight strides."""
-    n = x.shape[0]
-    flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_NO_BIAS if bias is None else 0)
-    check(_lib.lib().linr_linear_fwd(x.data_ptr(), x.stride(0), n, w.data_ptr() + 4 * w_off, ws_ci, ws_co,
-                                     0 if bias is None else bias.data_ptr(), cin, cout, 0 if res is None else res.data_ptr(),
-                                     0 if res is None else res.stride(0), out.data_ptr(), out.stride(0), flags, _stream()),
-          'linr_linear_fwd')
 
 
 def _lin_bwd_data(gout, w, w_off, ws_ci, ws_co, cin, cout, out, act=None, accumulate=False):
@@ -49,15 +71,6 @@ def _lin_bwd_data(gout, w, w_off, ws_ci, ws_co, cin, cout, out, act=None, accumu
     check(_lib.lib().linr_linear_bwd_data(gout.data_ptr(), gout.stride(0), n, w.data_ptr() + 4 * w_off, ws_ci, ws_co, cin, cout,
                                           0 if act is None else act.data_ptr(), 0 if act is None else act.stride(0),
                                           out.data_ptr(), out.stride(0), flags, _stream()), 'linr_linear_bwd_data')
-
-
-def _lin_bwd_weight(x, gout, cin, cout, gw, gw_off, ws_ci, ws_co, gb):
-    n = x.shape[0]
-    L = _lib.lib()
-    ws = _lib.scratch(max(L.linr_linear_bwd_weight_workspace_bytes(n, cin, cout), 4), x.device)
-    check(L.linr_linear_bwd_weight(x.data_ptr(), x.stride(0), gout.data_ptr(), gout.stride(0), n, cin, cout,
-                                   gw.data_ptr() + 4 * gw_off, ws_ci, ws_co, 0 if gb is None else gb.data_ptr(), 0, ws.data_ptr(),
-                                   ws.numel(), _stream()), 'linr_linear_bwd_weight')
 
 
 def _axpy(src, dst, accumulate=True):
@@ -79,8 +92,8 @@ class _Conv:
         ops.spconv_wide(xs[:self.nbi], net.lo, net.mask, n, self.mod.kernel, self.mod.bias.reshape(-1), res=res, relu=relu, outs=outs)
         return outs
 
-    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True):
-        """Parameter gradients into .grad; input gradient (masked by act > 0: the ReLU that produced xs) accumulated into
+    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True, res=None):
+        """Parameter gradients into .grad; input gradient (+ res, masked by act > 0: the ReLU that produced xs) accumulated into
         gins (list of (buffer, has_content)) or returned as fresh blocks."""
         n = gouts[0].shape[0]
         # weight gradients: all (input block, gradient block) pairs as groups of grouped launches of the transposing 8-wide kernel, ONE
@@ -96,16 +109,16 @@ class _Conv:
         # already hold a gradient are accumulated into (all of them or none: the callers fill a list uniformly)
         acc = gins[0][1]
         assert all(g[1] == acc for g in gins)
-        ops.spconv_wide(gouts[:self.nbo], net.lo, net.mask, n, self.mod.kernel, None, bwd=True, act=act, outs=[g[0] for g in gins],
-                        accumulate=acc)
+        ops.spconv_wide(gouts[:self.nbo], net.lo, net.mask, n, self.mod.kernel, None, bwd=True, act=act, res=res,
+                        outs=[g[0] for g in gins], accumulate=acc)
         for g in gins:
             g[1] = True
         return [g for g, _ in gins] if fresh else None
 
 
 class _Pointwise:
-    """A 1x1 convolution (ME layout [Cin][Cout]) or an nn.Linear (torch layout [Cout][Cin]) on blocked inputs; the output is
-    blocked when cout is a multiple of 8, else one [n, cout] matrix."""
+    """A 1x1 convolution (ME layout [Cin][Cout]) or an nn.Linear (torch layout [Cout][Cin]) on blocked inputs as ONE launch
+    (linr_linear_wide); the output is blocked when cout is a multiple of 8, else one dense [n, cout] matrix."""
 
     def __init__(self, weight, bias, cin, cout, layout, blocked_out=True):
         self.w, self.b, self.cin, self.cout, self.layout = weight, bias, cin, cout, layout
@@ -113,45 +126,33 @@ class _Pointwise:
         self.blocked_out = blocked_out and cout % B == 0
         self.nbo = cout // B if self.blocked_out else 1
         self.cw = B if self.blocked_out else cout
-
-    def _addr(self, bi, bo):
-        if self.layout == 'me':
-            return (B * bi) * self.cout + self.cw * bo, self.cout, 1
-        return (self.cw * bo) * self.cin + B * bi, 1, self.cin
+        self.ws = (cout, 1) if layout == 'me' else (1, cin)          # element (ci, co) at ci ws[0] + co ws[1]
 
     def fwd(self, xs, relu=False, res=None, padded=True):
         n, dev = xs[0].shape[0], xs[0].device
         outs = _blocks(n, self.nbo, dev) if (self.blocked_out and padded) else \
             [torch.empty((n, self.cw), dtype=torch.float32, device=dev) for _ in range(self.nbo)]
-        bflat = self.b.reshape(-1)
-        for bo in range(self.nbo):
-            for bi in range(self.nbi):
-                off, ws_ci, ws_co = self._addr(bi, bo)
-                last = bi == self.nbi - 1
-                _lin(xs[bi], self.w, off, ws_ci, ws_co, bflat[self.cw * bo:self.cw * bo + self.cw] if bi == 0 else None, B, self.cw,
-                     outs[bo], res=res[bo] if (res is not None and bi == 0) else None, relu=relu and last, accumulate=bi > 0)
-        return outs
+        return ops.linear_wide(xs[:self.nbi], self.cin, self.w, self.ws[0], self.ws[1], self.b.reshape(-1), self.cout, outs,
+                               out_blocked=self.blocked_out, res=res, relu=relu)
 
     def bwd(self, xs, gouts, gins=None, act=None, need_input_grad=True):
+        """Parameter gradients into .grad (one grouped launch + one reduction); the input gradient (masked by act > 0) accumulated
+        into gins (list of [buffer, has_content]) or returned as fresh blocks."""
         n = gouts[0].shape[0]
-        gw, gb = self.w.grad, self.b.grad.reshape(-1)
-        for bi in range(self.nbi):
-            for bo in range(self.nbo):
-                off, ws_ci, ws_co = self._addr(bi, bo)
-                _lin_bwd_weight(xs[bi], gouts[bo], B, self.cw, gw, off, ws_ci, ws_co,
-                                gb[self.cw * bo:self.cw * bo + self.cw] if bi == 0 else None)
+        ops.linear_wgrad_wide(xs[:self.nbi], self.cin, gouts[:self.nbo], self.cout, self.w.grad, self.ws[0], self.ws[1],
+                              self.b.grad.reshape(-1), g_blocked=self.blocked_out)
         if not need_input_grad:
             return None
         fresh = gins is None
         if fresh:
             gins = [[g, False] for g in _blocks(n, self.nbi, gouts[0].device)]
-        for bi in range(self.nbi):
-            for bo in range(self.nbo):
-                off, ws_ci, ws_co = self._addr(bi, bo)
-                last = bo == self.nbo - 1
-                _lin_bwd_data(gouts[bo], self.w, off, ws_ci, ws_co, B, self.cw, gins[bi][0],
-                              act=act[bi] if (act is not None and last) else None, accumulate=gins[bi][1] or bo > 0)
-            gins[bi][1] = True
+        acc = gins[0][1]
+        assert all(g[1] == acc for g in gins)
+        # backward-data: the same kernel with the roles of cin / cout and the weight strides swapped
+        ops.linear_wide(gouts[:self.nbo], self.cout, self.w, self.ws[1], self.ws[0], None, self.cin, [g[0] for g in gins],
+                        in_blocked=self.blocked_out, act=act, accumulate=acc)
+        for g in gins:
+            g[1] = True
         return [g for g, _ in gins] if fresh else None
 
 
@@ -198,25 +199,25 @@ class _Block:
             for s, d in zip(g_il, g_a):
                 _axpy(s, d, accumulate=False)
         g_i = g_il
-        for q, t in zip(reversed(self.layers), reversed(tape['layers'])):
+        nl = len(self.layers)
+        for li, (q, t) in enumerate(zip(reversed(self.layers), reversed(tape['layers']))):
             x = t['x']
-            # the layer's input gradient starts as the residual's share: a copy of g_i
-            g_x = _blocks(n, self.C // B, dev)
-            for s, d in zip(g_i, g_x):
-                _axpy(s, d, accumulate=False)
-            gx = [[g, True] for g in g_x]
             g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
             g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'])
-            q['c10'].bwd(x, g_h1, gins=gx)
             g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'])
-            q['c00'].bwd(net, x, g_h0, gins=gx)
+            # the layer's input gradient: the residual's share g_i rides in conv0_0's backward-data epilogue (+ res), conv1_0's share
+            # is accumulated last - and with it, for the block's first layer of a one-layer block, the ReLU mask of a = relu(first conv)
+            g_x = q['c00'].bwd(net, x, g_h0, res=g_i)
+            last_mask = tape['a'] if (nl == 1 and li == nl - 1) else None
+            q['c10'].bwd(x, g_h1, gins=[[g, True] for g in g_x], act=last_mask)
             g_i = g_x
         if g_a is not None:
             for s, d in zip(g_a, g_i):
                 _axpy(s, d)
-        # g_i is the gradient of a = relu(first conv): mask and go through the first convolution
-        for g, ab in zip(g_i, tape['a']):
-            _mask_inplace(g, ab)
+        if nl != 1:
+            # g_i is the gradient of a = relu(first conv): mask it
+            for g, ab in zip(g_i, tape['a']):
+                _mask_inplace(g, ab)
         return self.first.bwd(net, tape['in'], g_i, need_input_grad=need_input_grad)
 
 
@@ -243,6 +244,7 @@ class WideNet:
             raise ValueError('hidden_channel_conv must be 8 (the tuned kernels) or 16 / 32 (channel-blocked executor), got %d' % hidden)
         self.model, self.C = model, hidden
         self._built = False
+        self._pool = None
 
     def _build(self):
         up = self.model.upsampler
@@ -295,12 +297,25 @@ class WideNet:
         return z, ({'prior': prior, 'c': c, 'hh': hh} if keep else None)
 
     # ---- forward ---------------------------------------------------------------------------------------------------------
-    def forward(self, frame, k0, k1, probs, bits, keep=False):
+    def forward(self, frame, k0, k1, probs, bits, keep=False, pool=False):
         """Stages [k0, k1) teacher-forced on frame.occ (decoder: the columns decoded so far): probs [8, rows] rows k0..k1-1, bits
-        (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8)."""
+        (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8).  pool: the padded block buffers
+        come from this executor's pool, i.e. they are valid until the NEXT pooled forward (train_step: forward, backward, done)."""
+        global _POOL
         self._bind(frame)
         if frame.rows == 0:
             return None
+        if pool:
+            if self._pool is None:
+                self._pool = _Pool()
+            self._pool.reset()
+        _POOL = self._pool if pool else None
+        try:
+            return self._forward(frame, k0, k1, probs, bits, keep)
+        finally:
+            _POOL = None
+
+    def _forward(self, frame, k0, k1, probs, bits, keep):
         x0, sce_tape = self._scale_context(frame, keep)
         xg, bin_tape = self.block_in.fwd(self, x0)
         tape = {'sce': sce_tape, 'bin': bin_tape, 'xg': xg, 'stages': []} if keep else None
@@ -324,8 +339,17 @@ class WideNet:
         return tape
 
     # ---- backward --------------------------------------------------------------------------------------------------------
-    def backward(self, frame, tape, gscale):
-        """d (gscale * bits) / d params into the parameters' .grad (model._ensure_grad_views(): views of the flat gradient)."""
+    def backward(self, frame, tape, gscale, pool=False):
+        """d (gscale * bits) / d params into the parameters' .grad (model._ensure_grad_views(): views of the flat gradient).
+        pool: continue in the pool of the forward that made `tape`."""
+        global _POOL
+        _POOL = self._pool if pool else None
+        try:
+            self._backward(frame, tape, gscale)
+        finally:
+            _POOL = None
+
+    def _backward(self, frame, tape, gscale):
         self._bind(frame)
         self.model._ensure_grad_views()
         n, dev = frame.rows, frame.device
@@ -336,9 +360,7 @@ class WideNet:
             st = tape['stages'][k]
             lin0, lin2 = self.heads[k]
             gz = ops.bce_bits_bwd(st['p'], frame.occ[:, k], gz_scale).reshape(n, 1)
-            gw2, gb2 = ops.linear_bwd_weight(st['hh'], gz, 24, 1, 'torch')
-            lin2.weight.grad.copy_(gw2)
-            lin2.bias.grad.copy_(gb2)
+            ops.linear_wgrad_wide([st['hh']], 24, [gz], 1, lin2.weight.grad, 1, 24, lin2.bias.grad, in_blocked=False, g_blocked=False)
             g_hh = ops.linear_bwd_data(gz, lin2.weight, 24, 1, 'torch', act=st['hh'])
             g_c = lin0.bwd(st['c'], [g_hh])
             if k == 0:
