@@ -368,6 +368,15 @@ LINR_API int linr_decode_scale(const int32_t* coord, int64_t n, int32_t scale_id
 LINR_API int linr_sce_fwd(const float* params, const linr_frame* f, float* mix, float* hid, float* x0, void* stream);
 LINR_API int linr_sce_bwd(const float* params, const linr_frame* f, const float* gx0, const float* hid, float* ghid,
                  void* stream);
+/* The complete backward of the scale context (model_core.py:48-53 under autograd) as one call: d loss / d (scale_emb, every scale MLP
+ * of the frame) into grads[0 .. linr_sce_param_count(model_scale_num)) - these parameters lead the flat parameter order
+ * (scale_emb, scale_mlp.{s}.{0,2}) whatever the width of the rest of the network, so `params` / `grads` may be the flat buffers of a
+ * hidden_channel_conv 16 / 32 model.  gx0 [rows][8], hid [rows][16] as kept by linr_sce_fwd (whose mix may be NULL); scales the frame
+ * does not contain get zero gradients.  slab: linr_sce_bwd_params_slab_bytes(model_scale_num) bytes of scratch. */
+LINR_API int64_t linr_sce_param_count(int32_t model_scale_num);
+LINR_API size_t linr_sce_bwd_params_slab_bytes(int32_t model_scale_num);
+LINR_API int linr_sce_bwd_params(const float* params, const linr_frame* f, const float* gx0, const float* hid, float* slab,
+                                 size_t slab_bytes, float* grads, void* stream);
 
 /* Occupancy head of one stage = CNP.basic_module + the stage's BCE term (models/upsample.py:137-161,
  * models/model_core.py:76-81): c = conv3(prior; Wp, bp) (gathers `prior` [n][8]), z = w2 . relu(W1 c + b1) + b2,

@@ -98,6 +98,9 @@ _PROTOS = {
                                              c_ptr, c_ptr]),
     'linr_sce_fwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_sce_bwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_sce_param_count': (ctypes.c_int64, [ctypes.c_int32]),
+    'linr_sce_bwd_params_slab_bytes': (ctypes.c_size_t, [ctypes.c_int32]),
+    'linr_sce_bwd_params': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr, c_ptr]),
     'linr_head_workspace_bytes': (c_size, [c_i64]),
     'linr_head_fwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32,
                                      c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

@@ -956,8 +956,8 @@ extern "C" int linr_sce_fwd(const float* params, const linr_frame* f, float* mix
     Ctx c;
     TRY(sce_frame_check(f, c.L));
     if (f->rows == 0) return 0;
-    if (!params || !f->offset_feat || !mix || !hid || !x0) return LINR_EINVAL;
-    if (!linr_aligned16(mix) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
+    if (!params || !f->offset_feat || !hid || !x0) return LINR_EINVAL;
+    if ((mix && !linr_aligned16(mix)) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
     c.f = f;
     const SceArgs sa = sce_args(c);
     sce_fwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sa, f->rows, mix, hid, x0, nullptr,
@@ -975,6 +975,65 @@ extern "C" int linr_sce_bwd(const float* params, const linr_frame* f, const floa
     c.f = f;
     const SceArgs sa = sce_args(c);
     sce_bwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, sa, f->rows, gx0, hid, ghid);
+    return linr_launch_rc();
+}
+
+// The whole backward of the scale context as one call (what linr_net_backward launches for it): the gradients of scale_emb and of
+// every scale MLP of the frame into grads[0 .. linr_sce_param_count) - the scale context's parameters lead the flat layout whatever
+// the width of the rest of the network - from gx0 [rows][8] and the hid [rows][16] that linr_sce_fwd kept.  The MLPs of scales the
+// frame does not contain and their embedding rows get zeros.  slab: linr_sce_bwd_params_slab_bytes(model_scale_num) bytes.
+#define SCE_SLAB_ROWS 256
+extern "C" int64_t linr_sce_param_count(int32_t model_scale_num) {
+    Layout L;
+    return make_layout(L, model_scale_num, 1) ? L.block_in.a_w : (int64_t)LINR_EINVAL;
+}
+extern "C" size_t linr_sce_bwd_params_slab_bytes(int32_t model_scale_num) {
+    const int64_t t = linr_sce_param_count(model_scale_num);
+    return t > 0 ? (size_t)SCE_SLAB_ROWS * (size_t)t * sizeof(float) : 0;
+}
+extern "C" int linr_sce_bwd_params(const float* params, const linr_frame* f, const float* gx0, const float* hid, float* slab,
+                                   size_t slab_bytes, float* grads, void* stream) {
+    Ctx c;
+    TRY(sce_frame_check(f, c.L));
+    if (!params || !gx0 || !hid || !slab || !grads) return LINR_EINVAL;
+    if (f->rows > 0 && !f->offset_feat) return LINR_EINVAL;
+    if (!linr_aligned16(gx0) || !linr_aligned16(hid)) return LINR_EALIGN;
+    const int64_t total = c.L.block_in.a_w;
+    if (slab_bytes < (size_t)SCE_SLAB_ROWS * (size_t)total * sizeof(float)) return LINR_ENOSPC;
+    c.f = f;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = SCE_SLAB_ROWS;
+    SceArgs sa = sce_args(c);
+    ZeroRanges zr;
+    zr.n = 0; zr.prefix = total;
+    zr.b[zr.n] = c.L.emb; zr.e[zr.n] = c.L.emb + (int64_t)c.L.S * 8; ++zr.n;
+    ShortRanges sr;
+    sr.n = 0;
+    bool present[MAX_SCALES] = {};
+    EmbArgs ea;
+    int ns = 0;
+    sa.wg_off[0] = 0;
+    for (int j = 0; j < f->n_scales; ++j) {
+        const int64_t nj = f->row_off_h[j + 1] - f->row_off_h[j];
+        int64_t wg = nj > 0 ? (nj + LINR_BLOCK - 1) / LINR_BLOCK : 0;
+        if (wg > nb) wg = nb;
+        sa.wg_off[j + 1] = sa.wg_off[j] + (int)wg;
+        if (wg == 0) continue;
+        const int si = f->scale_idx_h[j];
+        if (present[si]) return LINR_EINVAL;                 // two row ranges of one scale would share slab rows
+        present[si] = true;
+        if (wg < nb) { sr.b[sr.n] = c.L.m0_w[si]; sr.e[sr.n] = c.L.m2_b[si] + 8; sr.rows[sr.n] = (int)wg; ++sr.n; }
+        ea.gb1[ns] = c.L.m0_b[si]; ea.w1[ns] = c.L.m0_w[si]; ea.gemb[ns] = c.L.emb + si * 8; ++ns;
+    }
+    for (int si = 0; si < c.L.S; ++si)
+        if (!present[si]) {
+            zr.b[zr.n] = c.L.m0_w[si];
+            zr.e[zr.n] = si + 1 < c.L.S ? c.L.m0_w[si + 1] : total;
+            ++zr.n;
+        }
+    if (ns > 0) sce_bwd_all_k<<<sa.wg_off[f->n_scales], SB_WAVES * 64, 0, s>>>(params, f->offset_feat, sa, gx0, hid, slab, total);
+    wgrad_reduce_k<<<linr_grid(total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, s>>>(slab, nb, total, grads, zr, sr);
+    if (ns > 0) sce_emb_grad_all_k<<<ns, LINR_WAVE, 0, s>>>(params, grads, ea);
     return linr_launch_rc();
 }
 

@@ -268,22 +268,14 @@ class WideNet:
         self.n = frame.rows
 
     def _scale_context(self, frame, keep):
-        """x0 [rows, 8] (one block): PointwiseMLP([15, 16, 8]) of the rows' scale on [emb | offset features] (model_core.py:48-53)."""
-        m = self.model
+        """x0 [rows, 8] (one block): PointwiseMLP([15, 16, 8]) of the rows' scale on [emb | offset features] (model_core.py:48-53) - all
+        scales in ONE launch of the library's scale-context kernel (linr_sce_fwd: the parameters of the scale context lead the flat
+        parameter order whatever the width of the rest of the network); the hidden layer is kept for the backward pass."""
         x0 = _blocks(frame.rows, 1, frame.device)
-        tape = []
-        for j in range(frame.n_scales):
-            r0, r1 = int(frame.row_off[j]), int(frame.row_off[j + 1])
-            if r1 == r0:
-                continue
-            si = int(frame.scale_idx[j])
-            lin0, lin2 = m.scale_mlp[si][0], m.scale_mlp[si][2]
-            mix = torch.cat([m.scale_emb.weight[si].detach().unsqueeze(0).expand(r1 - r0, -1), frame.offset_feat[r0:r1]], dim=1).contiguous()
-            hid = ops.linear_fwd(mix, lin0.weight, lin0.bias, 15, 16, 'torch', relu=True)
-            ops.linear_fwd(hid, lin2.weight, lin2.bias, 16, 8, 'torch', out=x0[0][r0:r1])
-            if keep:
-                tape.append((si, r0, r1, mix, hid))
-        return x0, tape
+        hid = torch.empty((frame.rows, 16), dtype=torch.float32, device=frame.device)
+        check(_lib.lib().linr_sce_fwd(self.model.flat_parameters().data_ptr(), frame.cref(), None, hid.data_ptr(), x0[0].data_ptr(),
+                                      _stream()), 'linr_sce_fwd')
+        return x0, (hid if keep else None)
 
     def _occ_block(self, frame):
         return [frame.occ]                     # [rows, 8] view of a buffer with the zero row in front (engine.Frame)
@@ -372,24 +364,13 @@ class WideNet:
                     d[1] = True
                 self.outter[k - 1].bwd(self, st['blk'], g_prior, need_input_grad=False)
         g_x0 = self.block_in.bwd(self, tape['bin'], [g for g, _ in g_xg], need_input_grad=True)[0]
+        # scale context: ghid, the four parameter gradients of every scale's MLP and the embedding rows in one call, straight into the
+        # flat gradient (its leading linr_sce_param_count floats)
+        L = _lib.lib()
         m = self.model
-        m.scale_emb.weight.grad.zero_()
-        for si, r0, r1, mix, hid in tape['sce']:
-            lin0, lin2 = m.scale_mlp[si][0], m.scale_mlp[si][2]
-            g = g_x0[r0:r1]
-            gw, gb = ops.linear_bwd_weight(hid, g, 16, 8, 'torch')
-            lin2.weight.grad.copy_(gw)
-            lin2.bias.grad.copy_(gb)
-            g_hid = ops.linear_bwd_data(g, lin2.weight, 16, 8, 'torch', act=hid)
-            gw, gb = ops.linear_bwd_weight(mix, g_hid, 15, 16, 'torch')
-            lin0.weight.grad.copy_(gw)
-            lin0.bias.grad.copy_(gb)
-            # the embedding row is a constant input of every row of its scale: its gradient is the column sums of the input
-            # gradient's first 8 channels = W1[:, :8]^T gb1 (what sce_emb_grad_all_k computes for the 8-wide model)
-            g_mix = ops.linear_bwd_data(g_hid, lin0.weight, 15, 16, 'torch')
-            ones = torch.ones((r1 - r0, 1), dtype=torch.float32, device=dev)
-            gemb, _ = ops.linear_bwd_weight(ones, g_mix[:, :8].contiguous(), 1, 8, 'me')
-            m.scale_emb.weight.grad[si].copy_(gemb.reshape(-1))
+        slab = _lib.scratch(L.linr_sce_bwd_params_slab_bytes(m.scale_num), dev)
+        check(L.linr_sce_bwd_params(m.flat_parameters().data_ptr(), frame.cref(), g_x0.data_ptr(), tape['sce'].data_ptr(), slab.data_ptr(),
+                                    slab.numel(), m._flat_grad.data_ptr(), _stream()), 'linr_sce_bwd_params')
 
 
 def _axpy_f64(src, dst):

@@ -265,6 +265,28 @@ def test_scale_context_forward_backward(env, golden_dir):
         gh_ref = (gx0_h[a:b] @ sd['scale_mlp.%d.2.weight' % si]) * (h_ref > 0)
         _close(ghid[a:b], gh_ref, 1e-4, 1e-5, 'hidden gradient')
         assert torch.equal(mix[a:b, 8:15].cpu(), offs[j]) and bool((mix[a:b, 15] == 0).all())
+    # the complete backward (linr_sce_bwd_params): gradients of scale_emb and the three scales' MLPs against autograd, zeros for the
+    # scales the frame does not contain; mix is optional in the forward
+    hid2, x02 = torch.empty_like(hid), torch.empty_like(x0)
+    env['lib'].check(L.linr_sce_fwd(model.flat_parameters().data_ptr(), ctypes.byref(fr), None, hid2.data_ptr(), x02.data_ptr(), _stream()),
+                     'linr_sce_fwd')
+    assert torch.equal(hid2, hid) and torch.equal(x02, x0)
+    npar = int(L.linr_sce_param_count(5))
+    assert npar == 5 * 8 + 5 * (16 * 15 + 16 + 8 * 16 + 8)
+    slab = env['lib'].scratch(L.linr_sce_bwd_params_slab_bytes(5), dev)
+    grads = torch.full((npar,), float('nan'), device=dev)
+    env['lib'].check(L.linr_sce_bwd_params(model.flat_parameters().data_ptr(), ctypes.byref(fr), gx0.data_ptr(), hid.data_ptr(),
+                                           slab.data_ptr(), slab.numel(), grads.data_ptr(), _stream()), 'linr_sce_bwd_params')
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items() if k.startswith('scale_')}
+    loss = sum((onet.scale_context(sdg, offs[j], si) * gx0_h[int(row_off[j]):int(row_off[j + 1])]).sum() for j, (_, si) in enumerate(use))
+    loss.backward()
+    names = ['scale_emb.weight'] + ['scale_mlp.%d.%d.%s' % (si, l, w) for si in range(5) for l in (0, 2) for w in ('weight', 'bias')]
+    want = torch.cat([(sdg[k].grad if sdg[k].grad is not None else torch.zeros_like(sdg[k])).reshape(-1) for k in names])
+    assert want.numel() == npar
+    _close(grads, want, 1e-4, 1e-4 * float(want.abs().max()), 'scale-context parameter gradients')
+    for si in (1, 3):                      # absent scales: exact zeros
+        a0 = 40 + si * 392
+        assert bool((grads[a0:a0 + 392] == 0).all()) and bool((grads[8 * si:8 * si + 8] == 0).all())
     # a frame descriptor that names a scale the model does not have is rejected
     bad = np.asarray([0, 1, 5], dtype=np.int32)
     fr.scale_idx_h = bad.ctypes.data
