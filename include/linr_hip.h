@@ -151,8 +151,8 @@ LINR_API int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, const
  * conv1_2; the head's nn.Linear(C, 24): models/upsample.py:73-76) as ONE launch: out = [ReLU]([mask]((bias + in @ W) + res + old)).
  * in_h / out_h / res_h / act_h: HOST arrays of device pointers - blocked (channels / 8 matrices [n][8]) or, with *_blocked = 0, ONE
  * dense [n][channels] matrix (the head's 24 hidden units); res / act are laid out like out.  Weight element (ci, co) at
- * W[ci * ws_ci + co * ws_co]: ME layout (cout, 1), torch layout (1, cin); backward-data = the same call with the roles of cin / cout
- * and the two strides swapped (as linr_linear_bwd_data).  Shapes: blocked -> blocked with cin, cout in {8, 16, 32}; blocked (16, 32)
+ * W[ci * ws_ci + co * ws_co] of a DENSE matrix: (ws_ci, ws_co) = (cout, 1) (ME layout) or (1, cin) (torch layout), nothing else;
+ * backward-data = the same call with the roles of cin / cout and the two strides swapped (as linr_linear_bwd_data).  Shapes: blocked -> blocked with cin, cout in {8, 16, 32}; blocked (16, 32)
  * -> dense 24 and dense 24 -> blocked (16, 32).  flags: LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS. */
 LINR_API int linr_linear_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* W, int32_t ws_ci, int32_t ws_co,
                               const float* bias, int32_t cout, int32_t out_blocked, const float* const* res_h, const float* const* act_h,
