@@ -165,6 +165,23 @@ LINR_API int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32
                                     int32_t g_blocked, int64_t n, float* gW, int32_t ws_ci, int32_t ws_co, float* gb, uint32_t flags,
                                     void* ws, size_t ws_bytes, void* stream);
 
+/* The occupancy head of the wide network behind the prune convolution (CNP.basic_module, models/upsample.py:137-161):
+ * p = sigmoid(Linear(24, 1)(ReLU(Linear(C, 24)(c)))) and the stage's bits (model_core.py:72-81) in one launch.  c_h: HOST array of the
+ * C / 8 blocks [n][8] (C = 16 / 32); w1 [24][C], b1 [24], w2 [24], b2 [1] (torch layouts); target: the occupancy column (stride
+ * target_ld) or NULL; p [n]; bits_acc (double[1], += bits) or NULL; ws: linr_head_wide_workspace_bytes(n) bytes when bits are wanted. */
+LINR_API size_t linr_head_wide_workspace_bytes(int64_t n);
+LINR_API int linr_head_wide_fwd(const float* const* c_h, int32_t C, const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* target, int32_t target_ld, int64_t n, float* p, double* bits_acc, void* ws, size_t ws_bytes,
+                                void* stream);
+/* Backward of nstages (<= 8) such heads in ONE grouped launch: gc = d (gscale * bits) / d c per stage and the parameter gradients
+ * grads[nstages][W1 (24 x C) | b1 (24) | w2 (24) | b2 (1)] (written, not accumulated; the inner_mlps of consecutive stages are
+ * consecutive in the reference's parameter order).  c_h / gc_h: HOST arrays [nstages][C / 8] of block pointers (stage-major);
+ * p_h / target_h / w1_h / b1_h / w2_h: [nstages].  slab: linr_head_wide_bwd_slab_bytes(C, nstages) bytes of scratch. */
+LINR_API size_t linr_head_wide_bwd_slab_bytes(int32_t C, int32_t nstages);
+LINR_API int linr_head_wide_bwd(const float* const* c_h, const float* const* p_h, const float* const* target_h, int32_t target_ld,
+                                const float* const* w1_h, const float* const* b1_h, const float* const* w2_h, int32_t C, int32_t nstages,
+                                float gscale, float* const* gc_h, int64_t n, float* slab, size_t slab_bytes, float* grads, void* stream);
+
 /* Backward-weight of the same convolution as a stand-alone kernel (the executor uses it for the first convolutions of the outter
  * blocks, whose inputs need no gradient, and for the schedules without the fused backward below): lane = (offset, channel quad),
  * gathered quad x broadcast gradient tile on v_mfma_f32_4x4x1, row order fixed => reproducible.

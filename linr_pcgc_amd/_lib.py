@@ -67,6 +67,12 @@ _PROTOS = {
     'linr_spconv_wgrad_wide': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_linear_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32,
                                         ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_uint32, c_ptr]),
+    'linr_head_wide_workspace_bytes': (ctypes.c_size_t, [c_i64]),
+    'linr_head_wide_fwd': (ctypes.c_int, [c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_i64, c_ptr, c_ptr, c_ptr,
+                                          ctypes.c_size_t, c_ptr]),
+    'linr_head_wide_bwd_slab_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    'linr_head_wide_bwd': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_float, c_ptr, c_i64, c_ptr, ctypes.c_size_t, c_ptr, c_ptr]),
     'linr_linear_wgrad_wide_workspace_bytes': (ctypes.c_size_t, [c_i64, ctypes.c_int32, ctypes.c_int32]),
     'linr_linear_wgrad_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_i64, c_ptr,
                                               ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_uint32, c_ptr, ctypes.c_size_t, c_ptr]),

@@ -632,3 +632,332 @@ extern "C" int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int
     if (rc) return rc;
     return linr_linear_slab_reduce_launch((const float*)ws, nb, stride, cin, cout, gW, ws_ci, ws_co, gb, flags, s);
 }
+
+// ---- the occupancy head on channel-blocked activations -------------------------------------------------------------------------------
+// CNP.basic_module behind the prune convolution (models/upsample.py:137-161): p = sigmoid(Linear(24, 1)(ReLU(Linear(C, 24)(c)))) and the
+// stage's bits (model_core.py:72-81: BCELoss sums with the log clamp at -100) in ONE launch: a lane owns a row; per unit the fmaf chain
+// of the pointwise kernels (bias first, inputs ascending), so p is what linr_linear_wide + linr_linear_fwd + linr_bce_bits_fwd gave.
+// The hidden layer is not kept: the backward kernel recomputes it from c.
+struct WhArgs {
+    const float* c[WC_MAXB];
+    const float* w1; const float* b1; const float* w2; const float* b2;      // torch layouts: W1 [24][C], b1 [24], w2 [24], b2 [1]
+    const float* target; int target_ld;                                       // occupancy column or nullptr
+    float* p; double* partial;                                                // partial[blockIdx.x]: the block's nats (target != nullptr)
+};
+
+template <int C>
+__device__ __forceinline__ void whead_hidden(const float* const (&cb)[WC_MAXB], int64_t row, const float* __restrict__ w1,
+                                             const float* __restrict__ b1, float (&c)[C], float (&h)[24]) {
+#pragma unroll
+    for (int b = 0; b < C / 8; ++b) {
+        const float4 t0 = *reinterpret_cast<const float4*>(cb[b] + row * 8), t1 = *reinterpret_cast<const float4*>(cb[b] + row * 8 + 4);
+        c[8 * b] = t0.x; c[8 * b + 1] = t0.y; c[8 * b + 2] = t0.z; c[8 * b + 3] = t0.w;
+        c[8 * b + 4] = t1.x; c[8 * b + 5] = t1.y; c[8 * b + 6] = t1.z; c[8 * b + 7] = t1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 24; ++j) h[j] = b1[j];
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int j = 0; j < 24; ++j) h[j] = fmaf(c[i], w1[j * C + i], h[j]);
+}
+
+template <int C>
+__global__ __launch_bounds__(LINR_BLOCK) void whead_fwd_k(WhArgs a, int64_t n) {
+    __shared__ double sred[LINR_BLOCK];
+    const int64_t row = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    double nats = 0.0;
+    if (row < n) {
+        float c[C], h[24];
+        whead_hidden<C>(a.c, row, a.w1, a.b1, c, h);
+        float z = a.b2[0];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) z = fmaf(fmaxf(h[j], 0.0f), a.w2[j], z);
+        const float p = 1.0f / (1.0f + expf(-z));
+        a.p[row] = p;
+        if (a.target) {
+            const float t = a.target[row * a.target_ld];
+            const float lp = fmaxf(logf(p), -100.0f), lq = fmaxf(logf(1.0f - p), -100.0f);
+            nats = (double)((t - 1.0f) * lq - t * lp);
+        }
+    }
+    if (!a.partial) return;                                   // uniform
+    sred[threadIdx.x] = nats;
+    __syncthreads();
+    for (int s = LINR_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sred[threadIdx.x] += sred[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = sred[0];
+}
+
+extern "C" size_t linr_head_wide_workspace_bytes(int64_t n) {
+    return n > 0 ? (size_t)linr_grid(n, LINR_BLOCK) * sizeof(double) : 0;
+}
+
+// c_h: HOST array of the C / 8 blocks of the prune convolution's output; target: the stage's occupancy column (stride target_ld) or
+// NULL; p [n]; bits_acc (double[1], += the stage's bits) or NULL; ws: linr_head_wide_workspace_bytes(n) bytes when bits are wanted.
+extern "C" int linr_head_wide_fwd(const float* const* c_h, int32_t C, const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* target, int32_t target_ld, int64_t n, float* p, double* bits_acc, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    if (n < 0 || (C != 16 && C != 32) || !c_h || !w1 || !b1 || !w2 || !b2 || !p) return LINR_EINVAL;
+    if (bits_acc && (!target || target_ld < 1 || !ws)) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (bits_acc && ws_bytes < linr_head_wide_workspace_bytes(n)) return LINR_ENOSPC;
+    if (bits_acc && (((uintptr_t)ws) & 7u)) return LINR_EALIGN;
+    WhArgs a;
+    for (int i = 0; i < WC_MAXB; ++i) a.c[i] = nullptr;
+    for (int i = 0; i < C / 8; ++i) {
+        if (!c_h[i]) return LINR_EINVAL;
+        if (!linr_aligned16(c_h[i])) return LINR_EALIGN;
+        a.c[i] = c_h[i];
+    }
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.target = target; a.target_ld = target_ld; a.p = p;
+    a.partial = bits_acc ? (double*)ws : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = linr_grid(n, LINR_BLOCK);
+    if (C == 16) whead_fwd_k<16><<<nb, LINR_BLOCK, 0, s>>>(a, n);
+    else whead_fwd_k<32><<<nb, LINR_BLOCK, 0, s>>>(a, n);
+    if (bits_acc) return linr_bits_finish_launch((const double*)ws, (int)nb, bits_acc, s);
+    return linr_launch_rc();
+}
+
+// Backward of up to 8 heads in ONE grouped launch (blockIdx.y = stage; every stage's inputs - c, p, the occupancy column - exist once
+// the forward has run): per row the hidden layer again from c, gz = d bits / d z from (p, t) (torch's binary_cross_entropy backward
+// with its 1e-12 clamp, then the sigmoid's), gh = gz w2 [h > 0], gc = W1^T gh; the weight gradients
+//   gW1[24][C] = sum_r gh[r] (x) c[r],  gb1 = sum_r gh[r]     as X^T G products with the rows as the K dimension of
+//   v_mfma_f32_16x16x4_f32 (each wave turns its 64 rows of [gh | c | 1] into fragments through a wave-private LDS tile),
+//   gw2[24] = sum_r gz[r] relu(h[r]),  gb2 = sum_r gz[r]       per lane, folded by a fixed shuffle tree and the waves in order.
+// Persistent blocks: one slab row [stage][W1 | b1 | w2 | b2] per block, summed by the fixed-order reduction of the executor.
+#define WH_MAXS 8
+struct WhbArgs {
+    const float* c[WH_MAXS][WC_MAXB]; float* gc[WH_MAXS][WC_MAXB];
+    const float* p[WH_MAXS]; const float* target[WH_MAXS]; int target_ld;
+    const float* w1[WH_MAXS]; const float* b1[WH_MAXS]; const float* w2[WH_MAXS];
+    float gscale;
+    float* slab; int64_t block_stride;
+};
+
+template <int C>
+__global__ __launch_bounds__(LINR_BLOCK) void whead_bwd_k(WhbArgs A, int64_t n) {
+    constexpr int LDW = 24 + C + 1;                         // [gh 24 | c C | 1]: 41 / 57 floats, odd
+    constexpr int NT = (C + 1 + 15) / 16;                   // N tiles of the X^T G product (C + 1 columns)
+    constexpr int PER = 24 * C + 49;                        // a stage's parameters: W1, b1, w2, b2
+    __shared__ float sT[(LINR_BLOCK / 64) * 64 * LDW];
+    __shared__ float sfold[64 * (8 * NT + 1)];
+    __shared__ float sw2[(LINR_BLOCK / 64) * 25];
+    const int st = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mm = lane & 15, rr = lane >> 4;
+    const float* w1 = A.w1[st];
+    const float* b1 = A.b1[st];
+    const float* w2 = A.w2[st];
+    const float* pp_ = A.p[st];
+    const float* tg = A.target[st];
+    // The per-row MLP runs on the matrix cores like the convolutions (v_mfma_f32_4x4x1 with CBSZ = 4: the A operand - four weights -
+    // of block ABID broadcast, B = the lane's own scalar; K = 1 keeps the fmaf chains of the forward head: bias first, inputs
+    // ascending).  A-operand images, block (lane >> 2) of register v = "combo" 16 v + block, j = lane & 3:
+    //   wA: combo 6 i + hq -> W1[4 hq + j][i] (i < C); combos 6 C .. 6 C + 5 -> b1[4 (combo - 6 C) + j]
+    //   wB: combo (C / 4) jj + q -> W1[jj][4 q + j]  (jj < 24, q < C / 4)
+    //   wC: block hq < 6 -> w2[4 hq + j]
+    constexpr int NWA = (6 * C + 6 + 15) / 16, NWB = 24 * (C / 4) / 16, CQ = C / 4;
+    float wA[NWA], wB[NWB], wC;
+    {
+        const int blk = lane >> 2, j = lane & 3;
+#pragma unroll
+        for (int v = 0; v < NWA; ++v) {
+            const int cb = 16 * v + blk;
+            wA[v] = cb < 6 * C ? w1[(4 * (cb % 6) + j) * C + cb / 6] : (cb < 6 * C + 6 ? b1[4 * (cb - 6 * C) + j] : 0.0f);
+        }
+#pragma unroll
+        for (int v = 0; v < NWB; ++v) {
+            const int cb = 16 * v + blk;
+            wB[v] = w1[(cb / CQ) * C + 4 * (cb % CQ) + j];
+        }
+        wC = blk < 6 ? w2[4 * blk + j] : 0.0f;
+    }
+    float* T = sT + wave * 64 * LDW;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float gw2[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) gw2[j] = 0.0f;
+    float gz_sum = 0.0f;
+    const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t row_raw = t * LINR_BLOCK + threadIdx.x;
+        const bool live = row_raw < n;
+        const int64_t row = live ? row_raw : n - 1;          // every lane stays in the MFMAs (they ignore EXEC)
+        float c[C];
+#pragma unroll
+        for (int b = 0; b < C / 8; ++b) {
+            const float4 t0 = *reinterpret_cast<const float4*>(A.c[st][b] + row * 8), t1 = *reinterpret_cast<const float4*>(A.c[st][b] + row * 8 + 4);
+            c[8 * b] = t0.x; c[8 * b + 1] = t0.y; c[8 * b + 2] = t0.z; c[8 * b + 3] = t0.w;
+            c[8 * b + 4] = t1.x; c[8 * b + 5] = t1.y; c[8 * b + 6] = t1.z; c[8 * b + 7] = t1.w;
+        }
+        float gz = 0.0f;
+        if (live) {
+            const float pp = pp_[row], tt = tg[row * A.target_ld];
+            const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
+            gz = gp * ((1.0f - pp) * pp);
+        }
+        // hpre = b1 + W1 c  (6 output quads; the bias through x = 1, then the inputs ascending)
+        f32x4 hp[6];
+        static_for<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            constexpr int cb = 6 * C + hq;
+            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, cb % 16, 0);
+        });
+        static_for<C>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            static_for<6>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                constexpr int cb = 6 * i + hq;
+                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
+            });
+        });
+        // gh = [hpre > 0] gz w2 ;  gw2 += gz relu(hpre)
+        float gh[24];
+        static_for<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            const f32x4 g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wC, gz, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hv = hp[hq][j];
+                gh[4 * hq + j] = (live && hv > 0.0f) ? g4[j] : 0.0f;
+                gw2[4 * hq + j] = fmaf(gz, fmaxf(hv, 0.0f), gw2[4 * hq + j]);
+            }
+        });
+        gz_sum += gz;
+        // gc = W1^T gh  (C / 4 output quads, hidden units ascending)
+        f32x4 gcq[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) gcq[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        static_for<24>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<CQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int cb = CQ * jj + q;
+                gcq[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wB[cb / 16], gh[jj], gcq[q], 4, cb % 16, 0);
+            });
+        });
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+                *reinterpret_cast<float4*>(A.gc[st][q / 2] + row * 8 + 4 * (q % 2)) = make_float4(gcq[q][0], gcq[q][1], gcq[q][2], gcq[q][3]);
+        }
+        float* Tr = T + lane * LDW;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) Tr[j] = gh[j];                       // zero for rows beyond n (gz = 0)
+#pragma unroll
+        for (int i = 0; i < C; ++i) Tr[24 + i] = c[i];
+        Tr[24 + C] = live ? 1.0f : 0.0f;
+        // X^T G over this wave's 64 rows (wave-private tile: LDS operations of a wave execute in order, no block barrier)
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float* Tq = T + (4 * s4 + rr) * LDW;
+            const float a0 = Tq[mm];
+            const float a1 = (mm < 8) ? Tq[16 + mm] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int col = 16 * b + mm;
+                const float bv = (col < C + 1) ? Tq[24 + col] : 0.0f;
+                acc[0][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][b], 0, 0, 0);
+            }
+        }
+    }
+    // fold the waves in wave order, then one partial per destination element (C/D map: row = (lane >> 4) * 4 + reg, col = lane & 15)
+    float* mine = sfold + lane * (8 * NT + 1);
+    for (int w = 0; w < LINR_BLOCK / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (a * NT + b) * 4 + j;
+                        mine[e] = (w == 0) ? acc[a][b][j] : mine[e] + acc[a][b][j];
+                    }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) gw2[j] += __shfl_xor(gw2[j], d, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) sw2[wave * 25 + j] = gw2[j];
+        sw2[wave * 25 + 24] = gz_sum;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = A.slab + (int64_t)blockIdx.x * A.block_stride + (int64_t)st * PER;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = 16 * a + rr * 4 + j, col = 16 * b + mm;
+                    const float v = mine[(a * NT + b) * 4 + j];
+                    if (m < 24) {
+                        if (col < C) dst[m * C + col] = v;
+                        else if (col == C) dst[24 * C + m] = v;
+                    }
+                }
+        if (lane < 25) {
+            const float v = ((sw2[lane] + sw2[25 + lane]) + sw2[50 + lane]) + sw2[75 + lane];
+            dst[24 * C + 24 + lane] = v;                     // w2 [24], then b2
+        }
+    }
+}
+
+#define WH_BLOCKS 256
+extern "C" size_t linr_head_wide_bwd_slab_bytes(int32_t C, int32_t nstages) {
+    if ((C != 16 && C != 32) || nstages < 1 || nstages > WH_MAXS) return 0;
+    return (size_t)WH_BLOCKS * nstages * (24 * C + 49) * sizeof(float);
+}
+
+// c_h / gc_h: HOST arrays [nstages][C / 8] of block pointers (stage-major); p_h / target_h / w1_h / b1_h / w2_h: [nstages].  grads: the
+// stages' parameter gradients [nstages][W1 (24 x C) | b1 (24) | w2 (24) | b2 (1)] - the inner_mlps of consecutive stages are
+// consecutive in the reference's parameter order - written, not accumulated.
+extern "C" int linr_head_wide_bwd(const float* const* c_h, const float* const* p_h, const float* const* target_h, int32_t target_ld,
+                                  const float* const* w1_h, const float* const* b1_h, const float* const* w2_h, int32_t C, int32_t nstages,
+                                  float gscale, float* const* gc_h, int64_t n, float* slab, size_t slab_bytes, float* grads, void* stream) {
+    if (n < 0 || (C != 16 && C != 32) || nstages < 1 || nstages > WH_MAXS || target_ld < 1) return LINR_EINVAL;
+    if (!c_h || !p_h || !target_h || !w1_h || !b1_h || !w2_h || !gc_h || !slab || !grads) return LINR_EINVAL;
+    if (slab_bytes < linr_head_wide_bwd_slab_bytes(C, nstages)) return LINR_ENOSPC;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)nstages * (24 * C + 49);
+    if (n == 0) return linr_hip_rc(hipMemsetAsync(grads, 0, (size_t)total * sizeof(float), s));
+    WhbArgs A;
+    const int nb = C / 8;
+    for (int k = 0; k < WH_MAXS; ++k) {
+        const int kk = k < nstages ? k : 0;
+        for (int b = 0; b < WC_MAXB; ++b) {
+            const int bb = b < nb ? b : 0;
+            A.c[k][b] = c_h[kk * nb + bb]; A.gc[k][b] = gc_h[kk * nb + bb];
+            if (!A.c[k][b] || !A.gc[k][b]) return LINR_EINVAL;
+            if (!linr_aligned16(A.c[k][b]) || !linr_aligned16(A.gc[k][b])) return LINR_EALIGN;
+        }
+        A.p[k] = p_h[kk]; A.target[k] = target_h[kk]; A.w1[k] = w1_h[kk]; A.b1[k] = b1_h[kk]; A.w2[k] = w2_h[kk];
+        if (!A.p[k] || !A.target[k] || !A.w1[k] || !A.b1[k] || !A.w2[k]) return LINR_EINVAL;
+    }
+    A.target_ld = target_ld; A.gscale = gscale; A.slab = slab; A.block_stride = total;
+    const dim3 grid(WH_BLOCKS, nstages);
+    if (C == 16) whead_bwd_k<16><<<grid, LINR_BLOCK, 0, s>>>(A, n);
+    else whead_bwd_k<32><<<grid, LINR_BLOCK, 0, s>>>(A, n);
+    const int rc = linr_launch_rc();
+    if (rc) return rc;
+    return linr_slab_reduce_launch(slab, WH_BLOCKS, total, grads, s);
+}

@@ -245,6 +245,35 @@ def linear_wgrad_wide(xs, cin, gouts, cout, gw, ws_ci, ws_co, gb, in_blocked=Tru
                                    _stream()), 'linr_linear_wgrad_wide')
 
 
+def head_wide_fwd(cs, w1, b1, w2, b2, target, p, bits=None):
+    """linr_head_wide_fwd: p = sigmoid(w2 . relu(W1 c + b1) + b2) of a wide head on the blocks cs; bits (float64[1]) += the stage's bits
+    against the occupancy column `target` (a strided view) when given."""
+    L = _lib.lib()
+    n, C = cs[0].shape[0], 8 * len(cs)
+    ws = _lib.scratch(max(L.linr_head_wide_workspace_bytes(n), 8), cs[0].device) if bits is not None else None
+    check(L.linr_head_wide_fwd(_ptr_array(cs), C, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(target),
+                               1 if target is None else target.stride(0), n, p.data_ptr(), _ptr(bits), _ptr(ws),
+                               0 if ws is None else ws.numel(), _stream()), 'linr_head_wide_fwd')
+    return p
+
+
+def head_wide_bwd(cs, ps, targets, w1s, b1s, w2s, gscale, gcs, grads):
+    """linr_head_wide_bwd: the backward of len(ps) wide heads in one grouped launch.  cs / gcs: per stage the list of C / 8 blocks;
+    grads: the contiguous [stages][W1 | b1 | w2 | b2] gradient region (a view of the flat gradient)."""
+    import ctypes
+    L = _lib.lib()
+    ns, nb = len(ps), len(cs[0])
+    n, C = cs[0][0].shape[0], 8 * nb
+
+    def arr(ts):
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    slab = _lib.scratch(L.linr_head_wide_bwd_slab_bytes(C, ns), cs[0][0].device)
+    assert grads.is_contiguous() and grads.numel() == ns * (24 * C + 49)
+    check(L.linr_head_wide_bwd(arr([b for c in cs for b in c]), arr(ps), arr(targets), targets[0].stride(0), arr(w1s), arr(b1s), arr(w2s),
+                               C, ns, float(gscale), arr([b for g in gcs for b in g]), n, slab.data_ptr(), slab.numel(), grads.data_ptr(),
+                               _stream()), 'linr_head_wide_bwd')
+
+
 def kmap_tile8t(nbr, n=None):
     """linr_kmap_tile8t: the tiled copy of the kernel map in the lane order of the transposing weight-gradient kernel."""
     L = _lib.lib()

@@ -252,10 +252,7 @@ class WideNet:
         self.block_in = _Block(up.block_in, C)
         self.outter = [_Block(b, C) for b in up.outter_blocks]
         self.prune = [_Conv(p[0].conv) for p in up.prune_blocks]
-        self.heads = []
-        for mlp in up.inner_mlps:
-            lin0, lin2 = mlp[0][0], mlp[0][2]                # PointwiseMLP([C, 24, 1]) = Linear, ReLU, Linear
-            self.heads.append((_Pointwise(lin0.weight, lin0.bias, C, 24, 'torch', blocked_out=False), lin2))
+        self.heads = [(mlp[0][0], mlp[0][2]) for mlp in up.inner_mlps]          # PointwiseMLP([C, 24, 1]) = Linear, ReLU, Linear
         self._built = True
 
     # ---- shared pieces ------------------------------------------------------------------------------------------------
@@ -280,13 +277,12 @@ class WideNet:
     def _occ_block(self, frame):
         return [frame.occ]                     # [rows, 8] view of a buffer with the zero row in front (engine.Frame)
 
-    def _head(self, k, prior, frame, keep):
-        n = frame.rows
+    def _head(self, k, prior, frame, p, bits):
+        """Stage k behind `prior`: the prune convolution, then the head MLP + sigmoid (+ the stage's bits) as one launch."""
         c = self.prune[k].fwd(self, prior)
         lin0, lin2 = self.heads[k]
-        hh = lin0.fwd(c, relu=True, padded=False)[0]
-        z = ops.linear_fwd(hh, lin2.weight, lin2.bias, 24, 1, 'torch').reshape(n)
-        return z, ({'prior': prior, 'c': c, 'hh': hh} if keep else None)
+        ops.head_wide_fwd(c, lin0.weight, lin0.bias, lin2.weight, lin2.bias, frame.occ[:, k] if bits is not None else None, p, bits)
+        return c
 
     # ---- forward ---------------------------------------------------------------------------------------------------------
     def forward(self, frame, k0, k1, probs, bits, keep=False, pool=False):
@@ -318,16 +314,10 @@ class WideNet:
             else:
                 occ = self._occ_block(frame)
                 prior, blk_tape = self.outter[k - 1].fwd(self, occ, res=xg)
-            z, head_tape = self._head(k, prior, frame, keep)
-            target = frame.occ[:, k]
-            p, b = ops.bce_bits_fwd(z, target)
-            if probs is not None:
-                probs[k].copy_(p)
-            if bits is not None:
-                _axpy_f64(b, bits)
+            p = probs[k] if probs is not None else torch.empty((frame.rows,), dtype=torch.float32, device=frame.device)
+            c = self._head(k, prior, frame, p, bits)
             if keep:
-                head_tape.update({'p': p, 'blk': blk_tape})
-                tape['stages'].append(head_tape)
+                tape['stages'].append({'prior': prior, 'c': c, 'p': p, 'blk': blk_tape})
         return tape
 
     # ---- backward --------------------------------------------------------------------------------------------------------
@@ -348,13 +338,22 @@ class WideNet:
         C = self.C
         gz_scale = float(gscale) * 1.4426950408889634          # d(bits)/d(nats) = 1 / ln 2
         g_xg = [[g, False] for g in _blocks(n, C // B, dev)]
+        # all 8 heads first, as one grouped launch (their inputs - c, p, the occupancy columns - exist once the forward has run): the
+        # gradients of the prune convolutions' outputs and the heads' parameter gradients, straight into the flat gradient
+        stages = tape['stages']
+        g_cs = [_blocks(n, C // B, dev) for _ in range(8)]
+        first = self.heads[0][0].weight.grad
+        per = 24 * C + 49
+        for k, (lin0, lin2) in enumerate(self.heads):           # the reference's parameter order: the 8 inner_mlps back to back
+            assert lin0.weight.grad.data_ptr() == first.data_ptr() + 4 * k * per and lin2.bias.grad.data_ptr() == \
+                first.data_ptr() + 4 * (k * per + per - 1)
+        off0 = (first.data_ptr() - self.model._flat_grad.data_ptr()) // 4
+        ops.head_wide_bwd([st['c'] for st in stages], [st['p'] for st in stages], [frame.occ[:, k] for k in range(8)],
+                          [h[0].weight for h in self.heads], [h[0].bias for h in self.heads], [h[1].weight for h in self.heads],
+                          gz_scale, g_cs, self.model._flat_grad[off0:off0 + 8 * per])
         for k in range(7, -1, -1):
-            st = tape['stages'][k]
-            lin0, lin2 = self.heads[k]
-            gz = ops.bce_bits_bwd(st['p'], frame.occ[:, k], gz_scale).reshape(n, 1)
-            ops.linear_wgrad_wide([st['hh']], 24, [gz], 1, lin2.weight.grad, 1, 24, lin2.bias.grad, in_blocked=False, g_blocked=False)
-            g_hh = ops.linear_bwd_data(gz, lin2.weight, 24, 1, 'torch', act=st['hh'])
-            g_c = lin0.bwd(st['c'], [g_hh])
+            st = stages[k]
+            g_c = g_cs[k]
             if k == 0:
                 self.prune[k].bwd(self, st['prior'], g_c, gins=g_xg)
             else:
@@ -371,7 +370,3 @@ class WideNet:
         slab = _lib.scratch(L.linr_sce_bwd_params_slab_bytes(m.scale_num), dev)
         check(L.linr_sce_bwd_params(m.flat_parameters().data_ptr(), frame.cref(), g_x0.data_ptr(), tape['sce'].data_ptr(), slab.data_ptr(),
                                     slab.numel(), m._flat_grad.data_ptr(), _stream()), 'linr_sce_bwd_params')
-
-
-def _axpy_f64(src, dst):
-    dst.add_(src)          # the float64[1] bits accumulator (two scalars; the per-row sums are linr_bce_bits_fwd's)
