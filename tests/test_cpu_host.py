@@ -101,7 +101,27 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
     tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
     assert lib.linr_prof_read(14, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
-
+    # round-4 entries on blocked activations: pointwise layers, their weight gradients, the occupancy head, the scale context's backward
+    b4 = (ctypes.c_void_p * 4)(p16, p16, p16, p16)
+    assert lib.linr_linear_wide(b4, 12, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 8, 0, None) == -1            # blocked cin not a multiple of 8
+    assert lib.linr_linear_wide(b4, 16, 1, p16, 7, 1, p16, 8, 1, None, None, b4, 8, 0, None) == -1            # strides of no dense layout
+    assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, -1, 0, None) == -1           # n < 0
+    assert lib.linr_linear_wide(None, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 8, 0, None) == -1
+    assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 8, 4, None) == -1            # LINR_RELU_MASK without act
+    assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 0, 0, None) == 0             # empty input is fine
+    assert lib.linr_linear_wgrad_wide(b4, 16, 1, b4, 8, 1, 8, p16, 8, 1, p16, 0, p16, 16, None) == -2         # workspace too small
+    assert lib.linr_linear_wgrad_wide(b4, 16, 1, b4, 8, 1, 8, None, 8, 1, p16, 0, p16, 4096, None) == -1      # no destination
+    assert lib.linr_linear_wgrad_wide(b4, 32, 0, b4, 8, 1, 8, p16, 8, 1, p16, 0, p16, 4096, None) == -1       # a dense side has <= 31 channels
+    assert lib.linr_head_wide_fwd(b4, 24, p16, p16, p16, p16, None, 1, 8, p16, None, None, 0, None) == -1     # C is 16 or 32
+    assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, None, 1, 8, p16, p16, p16, 64, None) == -1      # bits without a target
+    assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, p16, 8, 8, p16, p16, p16, 4, None) == -2        # workspace too small
+    assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, None, 1, 0, p16, None, None, 0, None) == 0      # empty input is fine
+    assert lib.linr_head_wide_bwd_slab_bytes(16, 8) == 256 * 8 * (24 * 16 + 49) * 4 and lib.linr_head_wide_bwd_slab_bytes(8, 8) == 0
+    assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 9, 1.0, b4, 8, p16, 1 << 30, p16, None) == -1      # more than 8 stages
+    assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 1, 1.0, b4, 8, p16, 64, p16, None) == -2           # slab too small
+    assert lib.linr_sce_param_count(7) == 7 * 8 + 7 * 392 and lib.linr_sce_param_count(0) == -1
+    assert lib.linr_sce_bwd_params_slab_bytes(7) == 256 * (7 * 8 + 7 * 392) * 4
+    assert lib.linr_sce_bwd_params(p16, None, p16, p16, p16, 1 << 30, p16, None) == -1                           # no frame
 
 def test_param_count_matches_reference_checkpoint(lib, golden_dir):
     g = np.load(os.path.join(golden_dir, 'loot_model_kat.npz'))

@@ -230,3 +230,97 @@ def test_wide_conv_entries_match_the_oracle_conv(pkg, shell, cin, cout):
         gi = ops.spconv_wide(gs, lo, mask, n, W.detach(), None, bwd=True, act=acts)
         want = gx_ref * (act > 0)
         assert float((torch.cat(gi, dim=1) - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def _to_blocks(t, padded=True):
+    """[n, 8 nb] -> nb blocks [n, 8] (views buf[i, 1:] of [n + 1, 8] buffers whose row 0 is zero when padded)."""
+    n, nb = t.shape[0], t.shape[1] // 8
+    buf = torch.zeros((nb, n + 1, 8), device=t.device)
+    for i in range(nb):
+        buf[i, 1:] = t[:, 8 * i:8 * i + 8]
+    return [buf[i, 1:] for i in range(nb)]
+
+
+@pytest.mark.parametrize('cin,cout,layout', [(16, 8, 'me'), (32, 16, 'me'), (8, 8, 'me'), (16, 16, 'me'), (16, 24, 'torch'), (32, 24, 'torch')])
+def test_wide_pointwise_entries_match_torch(pkg, cin, cout, layout):
+    """linr_linear_wide (forward with bias / residual / ReLU; backward-data with accumulation and the ReLU mask) and
+    linr_linear_wgrad_wide on blocked activations against torch matmuls and autograd (MinkowskiConvolution kernel_size 1:
+    models/resnet.py:25-46; nn.Linear of the head: models/upsample.py:73-76).  n = 1000: not a multiple of any tile.  Tolerance: fp32
+    sums of <= 32 products in another order (1e-5 of the largest entry); the weight gradients sum 1000 rows (1e-4)."""
+    from linr_pcgc_amd import ops
+    n = 1000
+    torch.manual_seed(7 * cin + cout)
+    x = torch.randn(n, cin, device='cuda', requires_grad=True)
+    W = (torch.randn((cin, cout) if layout == 'me' else (cout, cin), device='cuda') * 0.3).requires_grad_()
+    b = torch.randn(cout, device='cuda', requires_grad=True)
+    ws = (cout, 1) if layout == 'me' else (1, cin)
+    blocked_out = cout % 8 == 0 and layout == 'me'
+    xs = _to_blocks(x.detach())
+    res = torch.randn(n, cout, device='cuda')
+    y_ref = x @ (W if layout == 'me' else W.t()) + b
+    outs = _to_blocks(torch.zeros(n, cout, device='cuda')) if blocked_out else [torch.empty(n, cout, device='cuda')]
+    ops.linear_wide(xs, cin, W.detach(), ws[0], ws[1], b.detach(), cout, outs, out_blocked=blocked_out,
+                    res=_to_blocks(res) if blocked_out else [res], relu=True)
+    want = torch.relu(y_ref + res)
+    got = torch.cat(outs, dim=1)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # backward-data (+ old, masked) and the weight gradients
+    g = torch.randn(n, cout, device='cuda')
+    gx_ref, gw_ref, gb_ref = torch.autograd.grad(y_ref, [x, W, b], g)
+    gs = _to_blocks(g) if blocked_out else [g]
+    old, act = torch.randn(n, cin, device='cuda'), torch.randn(n, cin, device='cuda')
+    gins = _to_blocks(old)
+    ops.linear_wide(gs, cout, W.detach(), ws[1], ws[0], None, cin, gins, in_blocked=blocked_out, act=_to_blocks(act), accumulate=True)
+    want = (gx_ref + old) * (act > 0)
+    assert float((torch.cat(gins, dim=1) - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    gw, gb = torch.full_like(W, float('nan')), torch.full_like(b, float('nan'))
+    ops.linear_wgrad_wide(xs, cin, gs, cout, gw, ws[0], ws[1], gb, g_blocked=blocked_out)
+    assert float((gw - gw_ref).abs().max()) <= 1e-4 * float(gw_ref.abs().max())
+    assert float((gb - gb_ref).abs().max()) <= 1e-4 * float(gb_ref.abs().max())
+    ops.linear_wgrad_wide(xs, cin, gs, cout, gw, ws[0], ws[1], gb, g_blocked=blocked_out, accumulate=True)       # LINR_ACCUM
+    assert float((gw - 2 * gw_ref).abs().max()) <= 2e-4 * float(gw_ref.abs().max())
+
+
+@pytest.mark.parametrize('C,stages,n', [(16, 8, 1000), (32, 3, 777), (16, 1, 64 * 300 + 5)])
+def test_wide_head_entries_match_torch(pkg, C, stages, n):
+    """linr_head_wide_fwd (p and the stage's bits) and linr_head_wide_bwd (all stages in one grouped launch: gc and the parameter
+    gradients [W1 | b1 | w2 | b2] per stage) against torch: Linear(C, 24) -> ReLU -> Linear(24, 1) -> sigmoid -> BCELoss(sum) / ln 2
+    (models/upsample.py:137-161, model_core.py:72-81) and its autograd.  Tolerances: p 1e-6 absolute, bits 1e-6 relative, gradients
+    1e-4 of the largest entry (sums over n rows in another order)."""
+    from linr_pcgc_amd import ops
+    torch.manual_seed(C + stages)
+    occ = (torch.rand(n, 8, device='cuda') < 0.4).float()
+    per = 24 * C + 49
+    grads = torch.full((stages * per,), float('nan'), device='cuda')
+    cs, ps, gcs, params, refs = [], [], [], [], []
+    bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+    bits_ref = 0.0
+    gscale = 0.37
+    for k in range(stages):
+        c = torch.randn(n, C, device='cuda', requires_grad=True)
+        w1 = (torch.randn(24, C, device='cuda') * 0.3).requires_grad_()
+        b1 = (torch.randn(24, device='cuda') * 0.3).requires_grad_()
+        w2 = (torch.randn(1, 24, device='cuda') * 0.3).requires_grad_()
+        b2 = (torch.randn(1, device='cuda') * 0.3).requires_grad_()
+        z = torch.relu(c @ w1.t() + b1) @ w2.t() + b2
+        p_ref = torch.sigmoid(z).reshape(-1)
+        nats = torch.nn.functional.binary_cross_entropy(p_ref, occ[:, k], reduction='sum')
+        bits_ref += float(nats) / np.log(2.0)
+        refs.append(torch.autograd.grad(nats * gscale, [c, w1, b1, w2, b2]))
+        blocks = _to_blocks(c.detach())
+        p = torch.empty(n, device='cuda')
+        ops.head_wide_fwd(blocks, w1.detach(), b1.detach(), w2.detach(), b2.detach(), occ[:, k], p, bits)
+        assert float((p - p_ref).abs().max()) <= 1e-6
+        cs.append(blocks); ps.append(p); gcs.append(_to_blocks(torch.zeros(n, C, device='cuda')))
+        params.append((w1.detach(), b1.detach(), w2.detach()))
+    assert abs(float(bits) - bits_ref) <= 1e-6 * bits_ref
+    p_only = torch.empty(n, device='cuda')                      # without a target: probabilities only (the decoder's call)
+    ops.head_wide_fwd(cs[0], params[0][0], params[0][1], params[0][2], torch.zeros(1, device='cuda'), None, p_only)
+    ops.head_wide_bwd(cs, ps, [occ[:, k] for k in range(stages)], [q[0] for q in params], [q[1] for q in params], [q[2] for q in params],
+                      gscale, gcs, grads)
+    for k in range(stages):
+        gc_ref, gw1, gb1, gw2, gb2 = refs[k]
+        got = torch.cat(gcs[k], dim=1)
+        assert float((got - gc_ref).abs().max()) <= 1e-5 * float(gc_ref.abs().max())
+        want = torch.cat([gw1.reshape(-1), gb1, gw2.reshape(-1), gb2])
+        assert float((grads[k * per:(k + 1) * per] - want).abs().max()) <= 1e-4 * float(want.abs().max())
