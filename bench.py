@@ -659,8 +659,9 @@ def main():
                 train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
             torch.cuda.synchronize()
             wide_leg = {'hidden_channel_conv': 16, 'ms_per_step': round((time.time() - t0) * 1e3 / 5, 2), 'parameters': int(mw.flat_parameters().numel()),
-                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py): convolutions as single launches of csrc/wide.hip (one gather per tap for all '
-                                    'output channels), weight gradients in grouped launches, pointwise layers block pair by block pair, Python schedule'}
+                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py) on csrc/wide.hip: a convolution, its backward-data, its weight gradient '
+                                    '(one gather per input block for all gradient blocks), a pointwise layer, a head and the backward of all 8 heads '
+                                    'are one launch each; the scale context runs on the 8-wide kernels; Python schedule'}
             del mw, ow
         except Exception as e:
             wide_leg = {'error': repr(e)}
