@@ -12,6 +12,7 @@
 // the same in training, encoding and stage-by-stage decoding (wide_net.py runs the same launches in all three).
 #include "common.h"
 #include "conv_common.h"
+#include <stdlib.h>
 
 #ifndef LINR_CONV_BLOCK
 #define LINR_CONV_BLOCK 256
@@ -36,15 +37,33 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void wconv_k(WcArgs a, const int32
     constexpr int GIN = 8 * GB, NQ = 2 * PB, NV = GB * PB;          // NV = GIN * NQ / 16 A-operand registers per tap
     constexpr int PL = NV >= 4 ? NV / 4 : 1, PW = NV >= 4 ? 4 : NV;  // planes of PW registers: wl[k][plane][lane][PW]
     extern __shared__ float wl[];
-    for (int e = threadIdx.x; e < 27 * NV * 64; e += LINR_CONV_BLOCK) {
-        const int w = e % PW, lane = (e / PW) % 64, pl = (e / (PW * 64)) % PL, k = e / (NV * 64);
-        const int v = pl * PW + w, blk = lane >> 2, j = lane & 3;
-        const int c = 16 * v + blk, gi = c / NQ, oq = c % NQ, po = 8 * a.pb0 + 4 * oq + j;
-        float val = 0.0f;
-        if (gi < a.gvalid) val = BWD ? a.W[((int64_t)k * a.cin + po) * a.cout + gi] : a.W[((int64_t)k * a.cin + gi) * a.cout + po];
-        wl[e] = val;
+    {   // the weight image: all of a thread's (scattered, L2-resident) loads in flight at once, then the LDS stores - as a rolled loop
+        // every element waited for its own load: 27 round trips to the L2 in front of the first tile of a 16 -> 16 convolution
+        constexpr int TOT = 27 * NV * 64, IT = (TOT + LINR_CONV_BLOCK - 1) / LINR_CONV_BLOCK;
+        float wv[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = (int)threadIdx.x + LINR_CONV_BLOCK * i;
+            const int w = e % PW, ln = (e / PW) % 64, pl = (e / (PW * 64)) % PL, k = e / (NV * 64);
+            const int v = pl * PW + w, blk = ln >> 2, j = ln & 3;
+            const int c = 16 * v + blk, gi = c / NQ, oq = c % NQ, po = 8 * a.pb0 + 4 * oq + j;
+            float val = 0.0f;
+            if (e < TOT && gi < a.gvalid) val = BWD ? a.W[((int64_t)k * a.cin + po) * a.cout + gi] : a.W[((int64_t)k * a.cin + gi) * a.cout + po];
+            wv[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = (int)threadIdx.x + LINR_CONV_BLOCK * i;
+            if (e < TOT) wl[e] = wv[i];
+        }
     }
     __syncthreads();
+    // the produced channels' bias: once per workgroup (uniform loads), not once per tile
+    float bz[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bz[q][j] = (!BWD && a.bias) ? a.bias[8 * a.pb0 + 4 * q + j] : 0.0f;
     const int lane = threadIdx.x & 63;
     const char* pad[GB];
 #pragma unroll
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void wconv_k(WcArgs a, const int32
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[q][j] = (!BWD && a.bias) ? a.bias[8 * a.pb0 + 4 * q + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) acc[q][j] = bz[q][j];
         constexpr int PF = GB >= 4 ? 1 : 2;
         f32x4 x[PF + 1][2 * GB];
         float wr[2][NV];
@@ -142,7 +161,8 @@ static int wc_launch(const WcArgs& a, const int32_t* lo, const uint32_t* mask, i
     }();
     // the weight image is built once per workgroup, which then loops over row tiles (two workgroups per CU as in occ_conv7_k)
     const int64_t tiles = linr_grid(n, LINR_CONV_BLOCK);
-    const int64_t want = (int64_t)cus * 2;
+    static const int per_cu = getenv("LINR_WC_PER_CU") ? atoi(getenv("LINR_WC_PER_CU")) : 2;
+    const int64_t want = (int64_t)cus * per_cu;
     const int64_t per = (tiles + want - 1) / want;
     const int64_t grid = (tiles + per - 1) / per;
     wconv_k<GB, PB, BWD><<<(unsigned)grid, LINR_CONV_BLOCK, lds, s>>>(a, lo, mask, ld, n);
