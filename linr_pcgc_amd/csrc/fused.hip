@@ -557,14 +557,21 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void occ_conv7_k(const float* __re
                                                                const float* __restrict__ P, Occ7Args a,
                                                                float* __restrict__ out) {
     __shared__ float wl[27 * 4 * 64];
-    for (int e = threadIdx.x; e < 27 * 256; e += LINR_CONV_BLOCK) {
-        const int k = e >> 8, c = (e & 255) >> 2, j = e & 3;
-        float w = 0.0f;
-        if (c < 56) {
-            const int pr = c >> 1, h = c & 1, g = occ7_g(pr), ci = pr - g * (g + 1) / 2;
-            w = P[a.w[g] + (k * (g + 1) + ci) * 8 + 4 * h + j];
-        }
-        wl[e] = w;
+    {   // the weight image: a thread's 27 loads all in flight, then the LDS stores (as a rolled loop every element waited for two
+        // dependent loads - the block's parameter offset out of the argument struct, then the weight: 54 round trips to the L2 in
+        // front of the first tile).  Element e = threadIdx.x + 256 i: the combo (e & 255) >> 2 and j = e & 3 do not depend on i.
+        const int c = (int)(threadIdx.x >> 2), j = (int)(threadIdx.x & 3);
+        const int pr = c >> 1, h = c & 1, g = occ7_g(pr), ci = pr - g * (g + 1) / 2;
+        int64_t wg = a.w[0];
+#pragma unroll
+        for (int q = 1; q < 7; ++q) wg = (g == q) ? a.w[q] : wg;          // constant indices: scalar loads + selects
+        const float* src = P + wg + ci * 8 + 4 * h + j;
+        const int kstride = (g + 1) * 8;
+        float wv[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) wv[k] = c < 56 ? src[k * kstride] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) wl[k * 256 + threadIdx.x] = wv[k];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
