@@ -197,6 +197,10 @@ __global__ __launch_bounds__(OW_WAVES * 64, 1) void occ_wgrad7_k(OccWgArgs a, co
 #pragma unroll
                 for (int v = 0; v < 4; ++v) mine[(s * 7 + q) * 4 + v] = acc[s][q][v];
     }
+    // the blocks' slab offsets through LDS: indexed straight out of the argument struct they are a dependent vector load per element
+    __shared__ int64_t s_off[14];
+    if (threadIdx.x < 7) s_off[threadIdx.x] = a.w_off[threadIdx.x];
+    else if (threadIdx.x < 14) s_off[threadIdx.x] = a.b_off[threadIdx.x - 7];
     __syncthreads();
     float* dst = a.big + (int64_t)blockIdx.x * a.block_stride;
     // outputs: for block g (cin = g + 1): kernel (27 x cin x 8) then bias (8): 28 x 8 x 27 + 56 elements
@@ -207,8 +211,8 @@ __global__ __launch_bounds__(OW_WAVES * 64, 1) void occ_wgrad7_k(OccWgArgs a, co
         const int c = 2 * p + (co >> 2), s = c >> 4, bk = c & 15, q = tap >> 2, tt = tap & 3, v = co & 3;
         const int idx = (bk * 4 + tt) * OW_ACC + (s * 7 + q) * 4 + v;
         const float sum = ((sacc[idx] + sacc[64 * OW_ACC + idx]) + sacc[2 * 64 * OW_ACC + idx]) + sacc[3 * 64 * OW_ACC + idx];
-        if (tap < 27) dst[a.w_off[g] + (tap * (g + 1) + ci) * 8 + co] = sum;
-        else dst[a.b_off[g] + co] = sum;
+        if (tap < 27) dst[s_off[g] + (tap * (g + 1) + ci) * 8 + co] = sum;
+        else dst[s_off[7 + g] + co] = sum;
     }
 }
 
