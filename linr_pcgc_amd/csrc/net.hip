@@ -242,9 +242,22 @@ __global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __re
     float* T = sT + wave * 64 * SB_LD;
     // W2 in VECTOR registers: 128 uniform values are more than the scalar file holds beside the rest (the compiler spilled them
     // into register lanes: 742 v_readlane per tile, 40 us per launch) - the empty asm pins each into a VGPR
+    // ... and through VECTOR loads (the address made lane-dependent in form only): as scalar loads pinned one by one they were 128
+    // s_load / s_waitcnt round trips in front of every workgroup's first tile; 32 dwordx4 loads are in flight together
     float w2v[128];
+    {
+        const float* w2p = W2 + __builtin_amdgcn_mbcnt_lo(0u, 0u);          // + 0, but a per-lane value to the compiler
+        if ((reinterpret_cast<uintptr_t>(w2p) & 15u) == 0) {
 #pragma unroll
-    for (int j = 0; j < 128; ++j) { w2v[j] = W2[j]; asm volatile("" : "+v"(w2v[j])); }
+            for (int j = 0; j < 32; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(w2p + 4 * j);
+                w2v[4 * j] = t.x; w2v[4 * j + 1] = t.y; w2v[4 * j + 2] = t.z; w2v[4 * j + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 128; ++j) w2v[j] = w2p[j];
+        }
+    }
     f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f}, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
     float bs[8];
 #pragma unroll
