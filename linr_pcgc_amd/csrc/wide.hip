@@ -341,6 +341,12 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
 #pragma unroll
         for (int b = 0; b < NGB; ++b) gvn[b] = (g1r + gu < n) ? a.g[b][(g1r + gu) * 8 + gc] : 0.0f;
     }
+    float4 xo[4];                          // rows 4 .. 7 of the previous group (zeros in front of the first: they add +0)
+    float gvo[NGB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < NGB; ++b) gvo[b] = 0.0f;
     for (int64_t g0r = g00; g0r < b1; g0r += 8 * WW_WAVES) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) *reinterpret_cast<float4*>(img + wofs[j]) = xg[j];
@@ -366,13 +372,29 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
         for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(img + rd0 + (uint32_t)(u * 32));
 #pragma unroll
         for (int b = 0; b < NGB; ++b) bsum[b] += gv[b];
+        // rows 4 .. 7 of the PREVIOUS group first (operands in registers since the last iteration): they run while this group's
+        // transposed reads are in flight; then rows 0 .. 3 of this group.  Per accumulator the rows keep their order.
         static_for<NGB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            static_for<8>([&](auto uc) {
-                constexpr int u = decltype(uc)::value;
+            static_for<4>([&](auto uc) {
+                constexpr int u = 4 + decltype(uc)::value;
                 static_for<2>([&](auto hc) {
                     constexpr int h = decltype(hc)::value;
                     constexpr int ab = u * 2 + h;           // the block holding g[row u][4h .. 4h+3]
+                    acc[b][0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].x, acc[b][0][h], 4, ab, 0);
+                    acc[b][1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].y, acc[b][1][h], 4, ab, 0);
+                    acc[b][2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].z, acc[b][2][h], 4, ab, 0);
+                    acc[b][3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].w, acc[b][3][h], 4, ab, 0);
+                });
+            });
+        });
+        static_for<NGB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            static_for<4>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                static_for<2>([&](auto hc) {
+                    constexpr int h = decltype(hc)::value;
+                    constexpr int ab = u * 2 + h;
                     acc[b][0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].x, acc[b][0][h], 4, ab, 0);
                     acc[b][1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].y, acc[b][1][h], 4, ab, 0);
                     acc[b][2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gv[b], x[u].z, acc[b][2][h], 4, ab, 0);
@@ -380,7 +402,26 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
                 });
             });
         });
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xo[u] = x[4 + u];
+#pragma unroll
+        for (int b = 0; b < NGB; ++b) gvo[b] = gv[b];
     }
+    // the last group's rows 4 .. 7
+    static_for<NGB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        static_for<4>([&](auto uc) {
+            constexpr int u = 4 + decltype(uc)::value;
+            static_for<2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                constexpr int ab = u * 2 + h;
+                acc[b][0][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].x, acc[b][0][h], 4, ab, 0);
+                acc[b][1][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].y, acc[b][1][h], 4, ab, 0);
+                acc[b][2][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].z, acc[b][2][h], 4, ab, 0);
+                acc[b][3][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(gvo[b], xo[u - 4].w, acc[b][3][h], 4, ab, 0);
+            });
+        });
+    });
     // bias sums: lane l holds the partial column sum of channel gc over rows gu, gu + 8, ...: the 8 row phases by a fixed xor tree
 #pragma unroll
     for (int b = 0; b < NGB; ++b) {
