@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 7
+#define LINR_ABI_VERSION 8
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -164,6 +164,20 @@ LINR_API size_t linr_linear_wgrad_wide_workspace_bytes(int64_t n, int32_t cin, i
 LINR_API int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* const* g_h, int32_t cout,
                                     int32_t g_blocked, int64_t n, float* gW, int32_t ws_ci, int32_t ws_co, float* gb, uint32_t flags,
                                     void* ws, size_t ws_bytes, void* stream);
+
+/* Deferred reductions: with gW = NULL linr_spconv_wgrad_wide / linr_linear_wgrad_wide only write their per-block partials (slab / ws stay
+ * in use); linr_wide_reduce_many then sums up to any number of them, 32 per launch, in the same fixed order as the entries' own
+ * reductions.  kind 0: a convolution (nblocks = linr_spconv_wgrad_wide_blocks(cout, tiled table given), gW [27][cin][cout], gb [cout] or
+ * NULL); kind 1: a pointwise layer (nblocks = linr_linear_wgrad_wide_blocks(n), gW at the strides ws_ci / ws_co, gb or NULL). */
+typedef struct {
+    int32_t kind, nblocks, cin, cout, ws_ci, ws_co;
+    const float* slab;
+    float* gW;
+    float* gb;
+} linr_wide_reduce;
+LINR_API int32_t linr_spconv_wgrad_wide_blocks(int32_t cout, int32_t tiled);
+LINR_API int32_t linr_linear_wgrad_wide_blocks(int64_t n);
+LINR_API int linr_wide_reduce_many(const linr_wide_reduce* items_h, int32_t count, void* stream);
 
 /* The occupancy head of the wide network behind the prune convolution (CNP.basic_module, models/upsample.py:137-161):
  * p = sigmoid(Linear(24, 1)(ReLU(Linear(C, 24)(c)))) and the stage's bits (model_core.py:72-81) in one launch.  c_h: HOST array of the

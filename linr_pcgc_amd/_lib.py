@@ -11,10 +11,17 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+
+class LinrWideReduce(ctypes.Structure):
+    """linr_wide_reduce of include/linr_hip.h: one deferred weight-gradient reduction."""
+    _fields_ = [('kind', ctypes.c_int32), ('nblocks', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout', ctypes.c_int32),
+                ('ws_ci', ctypes.c_int32), ('ws_co', ctypes.c_int32), ('slab', ctypes.c_void_p), ('gW', ctypes.c_void_p),
+                ('gb', ctypes.c_void_p)]
 
 
 class LinrFrame(ctypes.Structure):
@@ -67,6 +74,9 @@ _PROTOS = {
     'linr_spconv_wgrad_wide': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_linear_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32,
                                         ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_uint32, c_ptr]),
+    'linr_spconv_wgrad_wide_blocks': (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
+    'linr_linear_wgrad_wide_blocks': (ctypes.c_int32, [c_i64]),
+    'linr_wide_reduce_many': (ctypes.c_int, [ctypes.POINTER(LinrWideReduce), ctypes.c_int32, c_ptr]),
     'linr_head_wide_workspace_bytes': (ctypes.c_size_t, [c_i64]),
     'linr_head_wide_fwd': (ctypes.c_int, [c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_i64, c_ptr, c_ptr, c_ptr,
                                           ctypes.c_size_t, c_ptr]),

@@ -477,11 +477,12 @@ extern "C" size_t linr_spconv_wgrad_wide_slab_bytes(int32_t cin, int32_t cout) {
 extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, const float* const* g_h, int32_t cout, const int32_t* nbr,
                                       const int32_t* tile8t, int64_t ld, int64_t n, float* slab, float* gW, float* gb, void* stream) {
     if (n < 0 || ld < n || cin < 1 || cin > 32 || cout < 8 || cout > 32 || cout % 8 || (cin > 8 && cin % 8)) return LINR_EINVAL;
-    if (!in_h || !g_h || !nbr || !slab || !gW) return LINR_EINVAL;
+    if (!in_h || !g_h || !nbr || !slab) return LINR_EINVAL;
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nbi = (cin + 7) / 8, nbo = cout / 8, npairs = nbi * nbo;
     if (n == 0) {
+        if (!gW) return LINR_EINVAL;                     // deferred reductions (gW == NULL) need rows
         if (hipMemsetAsync(gW, 0, (size_t)27 * cin * cout * sizeof(float), s) != hipSuccess) return LINR_EINVAL;
         return gb ? linr_hip_rc(hipMemsetAsync(gb, 0, (size_t)cout * sizeof(float), s)) : 0;
     }
@@ -518,9 +519,16 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
         const int rc = linr_conv3_wgrad_mfma(in_h[0], 8, g_h[0], 8, nbr, ld, n, 8, 8, d, LINR_WG_BLOCKS, s, &gp, ng, tile8t);
         if (rc) return rc;
     }
+    if (!gW) return linr_launch_rc();                   // partials only: the caller reduces them with linr_wide_reduce_many
     const int total = 27 * cin * cout + cout;
     wide_slab_reduce_k<<<linr_grid(total, 16), LINR_BLOCK, 0, s>>>(slab, nblk, npairs, cin, cout, gW, gb);
     return linr_launch_rc();
+}
+
+// slab rows linr_spconv_wgrad_wide writes (the `nblocks` of its deferred reduction): 256 with the tiled table and cout in {8, 16, 32}
+extern "C" int32_t linr_spconv_wgrad_wide_blocks(int32_t cout, int32_t tiled) {
+    const int nbo = cout / 8;
+    return (tiled && (nbo == 1 || nbo == 2 || nbo == 4)) ? 256 : LINR_WG_BLOCKS;
 }
 
 // ---- pointwise layers on channel-blocked activations ---------------------------------------------------------------------------------
@@ -666,7 +674,7 @@ extern "C" size_t linr_linear_wgrad_wide_workspace_bytes(int64_t n, int32_t cin,
 extern "C" int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32_t in_blocked, const float* const* g_h, int32_t cout,
                                       int32_t g_blocked, int64_t n, float* gW, int32_t ws_ci, int32_t ws_co, float* gb, uint32_t flags,
                                       void* ws, size_t ws_bytes, void* stream) {
-    if (n < 0 || cin < 1 || cout < 1 || cin > 32 || cout > 32 || !in_h || !g_h || !gW) return LINR_EINVAL;
+    if (n < 0 || cin < 1 || cout < 1 || cin > 32 || cout > 32 || !in_h || !g_h) return LINR_EINVAL;
     if ((in_blocked && cin % 8) || (g_blocked && cout % 8) || (!in_blocked && cin > 31)) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!ws) return LINR_EINVAL;
@@ -690,8 +698,96 @@ extern "C" int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int
         }
     LinrLinDst d = {(float*)ws, stride, 0, cout, 1, 0};
     const int rc = linr_linear_wgrad_partial(in_h[0], mi, g_h[0], nn, n, mi, nn, d, nb, s, &gp, ni * no);
-    if (rc) return rc;
+    if (rc || !gW) return rc;                            // gW == NULL: partials only (linr_wide_reduce_many)
     return linr_linear_slab_reduce_launch((const float*)ws, nb, stride, cin, cout, gW, ws_ci, ws_co, gb, flags, s);
+}
+
+extern "C" int32_t linr_linear_wgrad_wide_blocks(int64_t n) { return n > 0 ? linr_lin_blocks(n) : 0; }
+
+// ---- many deferred reductions in one launch --------------------------------------------------------------------------------------------
+// A backward pass of the wide network ends ~64 weight-gradient launches, each followed by a 5 us reduction of its slab; with gW = NULL
+// linr_spconv_wgrad_wide / linr_linear_wgrad_wide leave the partials in their slabs and this entry reduces up to 32 of them per launch
+// (the same fixed-order sums: 16 elements per workgroup, 16 slices of the slab rows, four interleaved partial sums per slice).
+#define RD_MAX 32
+struct RdItem { const float* slab; float* gW; float* gb; int kind, nblocks, cin, cout, ws_ci, ws_co, blk0; };
+struct RdArgs { RdItem it[RD_MAX]; int n; };
+__global__ __launch_bounds__(LINR_BLOCK) void wide_reduce_many_k(RdArgs A) {
+    __shared__ float part[16][17];
+    int ii = 0;
+    for (int i = 1; i < A.n; ++i) ii += ((int)blockIdx.x >= A.it[i].blk0) ? 1 : 0;          // uniform: this workgroup's item
+    const RdItem& d = A.it[ii];
+    const float* slab = d.slab;
+    const int cin = d.cin, cout = d.cout, nblocks = d.nblocks;
+    const int el = threadIdx.x % 16, sl = threadIdx.x / 16;
+    const int e = ((int)blockIdx.x - d.blk0) * 16 + el;
+    const int total = d.kind == 0 ? 27 * cin * cout + cout : (cin + 1) * cout;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    float* dst = nullptr;
+    if (e < total) {
+        int64_t src, stride;
+        if (d.kind == 0) {                      // slab of linr_spconv_wgrad_wide (wide_slab_reduce_k's addressing)
+            const int nbo = cout / 8, npairs = ((cin + 7) / 8) * nbo;
+            stride = (int64_t)npairs * WW_PAIR;
+            if (e < 27 * cin * cout) {
+                const int co = e % cout, ci = (e / cout) % cin, k = e / (cout * cin);
+                const int bi = ci / 8, bo = co / 8, cw = cin - 8 * bi < 8 ? cin - 8 * bi : 8;
+                src = (int64_t)(bi * nbo + bo) * WW_PAIR + (k * cw + (ci % 8)) * 8 + (co % 8);
+                dst = d.gW + e;
+            } else {
+                const int co = e - 27 * cin * cout;
+                src = (int64_t)(co / 8) * WW_PAIR + 1728 + (co % 8);
+                dst = d.gb ? d.gb + co : nullptr;
+            }
+        } else {                                // slab of linr_linear_wgrad_wide: rows of a dense [cin + 1][cout] partial + a dump row
+            stride = (int64_t)(cin + 2) * cout;
+            src = e;
+            const int ci = e / cout, co = e % cout;
+            dst = ci < cin ? d.gW + ci * d.ws_ci + co * d.ws_co : (d.gb ? d.gb + co : nullptr);
+        }
+        int b = sl;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += slab[(int64_t)(b + 0) * stride + src];
+            s1 += slab[(int64_t)(b + 16) * stride + src];
+            s2 += slab[(int64_t)(b + 32) * stride + src];
+            s3 += slab[(int64_t)(b + 48) * stride + src];
+        }
+        for (; b < nblocks; b += 16) s0 += slab[(int64_t)b * stride + src];
+    }
+    part[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0 || dst == nullptr) return;
+    float s = part[0][el];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) s += part[q][el];
+    *dst = s;
+}
+
+// items_h: HOST array of `count` reductions - kind 0: a convolution's slab (nblocks = linr_spconv_wgrad_wide_blocks) into gW [27][cin][cout]
+// and gb [cout]; kind 1: a pointwise layer's workspace (nblocks = linr_linear_wgrad_wide_blocks(n)) into gW at the strides and gb.
+extern "C" int linr_wide_reduce_many(const linr_wide_reduce* items_h, int32_t count, void* stream) {
+    if (count < 0 || (count > 0 && !items_h)) return LINR_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        const linr_wide_reduce& t = items_h[i];
+        if ((t.kind != 0 && t.kind != 1) || !t.slab || !t.gW || t.nblocks < 1 || t.cin < 1 || t.cout < 1 || t.cin > 32 || t.cout > 32) return LINR_EINVAL;
+        if (t.kind == 0 && t.cout % 8) return LINR_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int i0 = 0; i0 < count; i0 += RD_MAX) {
+        RdArgs A;
+        A.n = count - i0 < RD_MAX ? count - i0 : RD_MAX;
+        int blk = 0;
+        for (int i = 0; i < A.n; ++i) {
+            const linr_wide_reduce& t = items_h[i0 + i];
+            const int total = t.kind == 0 ? 27 * t.cin * t.cout + t.cout : (t.cin + 1) * t.cout;
+            A.it[i] = {t.slab, t.gW, t.gb, t.kind, t.nblocks, t.cin, t.cout, t.ws_ci, t.ws_co, blk};
+            blk += (total + 15) / 16;
+        }
+        for (int i = A.n; i < RD_MAX; ++i) A.it[i] = A.it[0];
+        wide_reduce_many_k<<<blk, LINR_BLOCK, 0, s>>>(A);
+        const int rc = linr_launch_rc();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ---- the occupancy head on channel-blocked activations -------------------------------------------------------------------------------

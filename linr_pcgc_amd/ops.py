@@ -205,9 +205,10 @@ def spconv_wide(xs, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=Non
     return outs
 
 
-def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None):
-    """linr_spconv_wgrad_wide: kernel / bias gradient of a convolution on channel-blocked activations (all block pairs in grouped
-    launches, one reduction).  gw [27, cin, cout] / gb [cout]: contiguous destinations (e.g. views of the flat gradient) or None."""
+def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None, defer=None):
+    """linr_spconv_wgrad_wide: kernel / bias gradient of a convolution on channel-blocked activations (one launch whose groups are the
+    input blocks, one reduction).  gw [27, cin, cout] / gb [cout]: contiguous destinations (e.g. views of the flat gradient) or None.
+    defer: a list - the partials stay in their slab and the reduction is appended to it for wide_reduce_many()."""
     L = _lib.lib()
     dev = xs[0].device
     if gw is None:
@@ -216,9 +217,22 @@ def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None):
         gb = torch.empty((cout,), dtype=torch.float32, device=dev)
     assert gw.is_contiguous() and gb.is_contiguous()
     slab = _lib.scratch(L.linr_spconv_wgrad_wide_slab_bytes(cin, cout), dev)
+    deferred = defer is not None and n > 0
     check(L.linr_spconv_wgrad_wide(_ptr_array(xs), cin, _ptr_array(gouts), cout, nbr.data_ptr(), _ptr(tile8t), nbr.stride(0), n,
-                                   slab.data_ptr(), gw.data_ptr(), gb.data_ptr(), _stream()), 'linr_spconv_wgrad_wide')
+                                   slab.data_ptr(), None if deferred else gw.data_ptr(), gb.data_ptr(), _stream()), 'linr_spconv_wgrad_wide')
+    if deferred:
+        nblk = int(L.linr_spconv_wgrad_wide_blocks(cout, 1 if tile8t is not None else 0))
+        defer.append((_lib.LinrWideReduce(0, nblk, cin, cout, 0, 0, slab.data_ptr(), gw.data_ptr(), gb.data_ptr()), slab, gw, gb))
     return gw, gb
+
+
+def wide_reduce_many(deferred):
+    """linr_wide_reduce_many: the reductions collected by spconv_wgrad_wide / linear_wgrad_wide(defer=...), 32 per launch."""
+    if not deferred:
+        return
+    arr = (_lib.LinrWideReduce * len(deferred))(*[d[0] for d in deferred])
+    check(_lib.lib().linr_wide_reduce_many(arr, len(deferred), _stream()), 'linr_wide_reduce_many')
+    deferred.clear()
 
 
 def linear_wide(xs, cin, w, ws_ci, ws_co, bias, cout, outs, in_blocked=True, out_blocked=True, res=None, act=None, relu=False,
@@ -235,14 +249,19 @@ def linear_wide(xs, cin, w, ws_ci, ws_co, bias, cout, outs, in_blocked=True, out
     return outs
 
 
-def linear_wgrad_wide(xs, cin, gouts, cout, gw, ws_ci, ws_co, gb, in_blocked=True, g_blocked=True, accumulate=False):
-    """linr_linear_wgrad_wide: gw(ci, co) (+)= sum_r x[r][ci] g[r][co] at gw.data_ptr() + 4 (ci ws_ci + co ws_co), gb[co] (+)= column sums."""
+def linear_wgrad_wide(xs, cin, gouts, cout, gw, ws_ci, ws_co, gb, in_blocked=True, g_blocked=True, accumulate=False, defer=None):
+    """linr_linear_wgrad_wide: gw(ci, co) (+)= sum_r x[r][ci] g[r][co] at gw.data_ptr() + 4 (ci ws_ci + co ws_co), gb[co] (+)= column sums.
+    defer (a list, not with accumulate): the partials stay in the workspace, the reduction is appended for wide_reduce_many()."""
     L = _lib.lib()
     n = xs[0].shape[0]
     ws = _lib.scratch(max(L.linr_linear_wgrad_wide_workspace_bytes(n, cin, cout), 4), xs[0].device)
+    deferred = defer is not None and n > 0 and not accumulate
     check(L.linr_linear_wgrad_wide(_ptr_array(xs), cin, 1 if in_blocked else 0, _ptr_array(gouts), cout, 1 if g_blocked else 0, n,
-                                   gw.data_ptr(), ws_ci, ws_co, _ptr(gb), LINR_ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(),
-                                   _stream()), 'linr_linear_wgrad_wide')
+                                   None if deferred else gw.data_ptr(), ws_ci, ws_co, _ptr(gb), LINR_ACCUM if accumulate else 0,
+                                   ws.data_ptr(), ws.numel(), _stream()), 'linr_linear_wgrad_wide')
+    if deferred:
+        defer.append((_lib.LinrWideReduce(1, int(L.linr_linear_wgrad_wide_blocks(n)), cin, cout, ws_ci, ws_co, ws.data_ptr(), gw.data_ptr(),
+                                          _ptr(gb)), ws, gw, gb))
 
 
 def head_wide_fwd(cs, w1, b1, w2, b2, target, p, bits=None):

@@ -54,6 +54,7 @@ class _Pool:
 
 
 _POOL = None          # the pool of the running forward / backward (WideNet.forward(pool=True)), else fresh buffers
+_DEFER = None         # the running backward's list of deferred weight-gradient reductions (one launch per 32 at its end), else None
 
 
 def _blocks(n, nb, dev):
@@ -99,7 +100,7 @@ class _Conv:
         # weight gradients: all (input block, gradient block) pairs as groups of grouped launches of the transposing 8-wide kernel, ONE
         # fixed-order reduction straight into the parameter gradients (views of the flat gradient)
         ops.spconv_wgrad_wide(xs[:self.nbi], gouts[:self.nbo], net.nbr_full, net.tile8t, n, self.ci, self.co,
-                              gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1))
+                              gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1), defer=_DEFER)
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -140,7 +141,7 @@ class _Pointwise:
         into gins (list of [buffer, has_content]) or returned as fresh blocks."""
         n = gouts[0].shape[0]
         ops.linear_wgrad_wide(xs[:self.nbi], self.cin, gouts[:self.nbo], self.cout, self.w.grad, self.ws[0], self.ws[1],
-                              self.b.grad.reshape(-1), g_blocked=self.blocked_out)
+                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_DEFER)
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -324,12 +325,14 @@ class WideNet:
     def backward(self, frame, tape, gscale, pool=False):
         """d (gscale * bits) / d params into the parameters' .grad (model._ensure_grad_views(): views of the flat gradient).
         pool: continue in the pool of the forward that made `tape`."""
-        global _POOL
+        global _POOL, _DEFER
         _POOL = self._pool if pool else None
+        _DEFER = []
         try:
             self._backward(frame, tape, gscale)
+            ops.wide_reduce_many(_DEFER)          # the ~64 slab reductions of the pass, 32 per launch
         finally:
-            _POOL = None
+            _POOL, _DEFER = None, None
 
     def _backward(self, frame, tape, gscale):
         self._bind(frame)

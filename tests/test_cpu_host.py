@@ -110,7 +110,18 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 8, 4, None) == -1            # LINR_RELU_MASK without act
     assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 0, 0, None) == 0             # empty input is fine
     assert lib.linr_linear_wgrad_wide(b4, 16, 1, b4, 8, 1, 8, p16, 8, 1, p16, 0, p16, 16, None) == -2         # workspace too small
-    assert lib.linr_linear_wgrad_wide(b4, 16, 1, b4, 8, 1, 8, None, 8, 1, p16, 0, p16, 4096, None) == -1      # no destination
+    assert lib.linr_linear_wgrad_wide(None, 16, 1, b4, 8, 1, 8, None, 8, 1, p16, 0, p16, 4096, None) == -1    # no inputs (gW = NULL alone: partials only)
+    assert lib.linr_spconv_wgrad_wide_blocks(16, 1) == 256 and lib.linr_spconv_wgrad_wide_blocks(24, 1) == 512 and lib.linr_spconv_wgrad_wide_blocks(16, 0) == 512
+    assert lib.linr_linear_wgrad_wide_blocks(0) == 0 and lib.linr_linear_wgrad_wide_blocks(1000) == 4 and lib.linr_linear_wgrad_wide_blocks(10 ** 7) == 512
+    from linr_pcgc_amd._lib import LinrWideReduce
+    items = (LinrWideReduce * 2)(LinrWideReduce(0, 256, 16, 16, 0, 0, p16, p16, p16), LinrWideReduce(1, 4, 16, 8, 8, 1, p16, p16, None))
+    assert lib.linr_wide_reduce_many(items, 0, None) == 0 and lib.linr_wide_reduce_many(None, 2, None) == -1
+    items[1].kind = 2
+    assert lib.linr_wide_reduce_many(items, 2, None) == -1                                                       # unknown kind
+    items[1].kind, items[0].cout = 1, 12
+    assert lib.linr_wide_reduce_many(items, 2, None) == -1                                                       # a convolution's cout is a multiple of 8
+    items[0].cout, items[0].gW = 16, None
+    assert lib.linr_wide_reduce_many(items, 2, None) == -1                                                       # no destination
     assert lib.linr_linear_wgrad_wide(b4, 32, 0, b4, 8, 1, 8, p16, 8, 1, p16, 0, p16, 4096, None) == -1       # a dense side has <= 31 channels
     assert lib.linr_head_wide_fwd(b4, 24, p16, p16, p16, p16, None, 1, 8, p16, None, None, 0, None) == -1     # C is 16 or 32
     assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, None, 1, 8, p16, p16, p16, 64, None) == -1      # bits without a target

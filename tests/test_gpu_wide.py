@@ -324,3 +324,38 @@ def test_wide_head_entries_match_torch(pkg, C, stages, n):
         assert float((got - gc_ref).abs().max()) <= 1e-5 * float(gc_ref.abs().max())
         want = torch.cat([gw1.reshape(-1), gb1, gw2.reshape(-1), gb2])
         assert float((grads[k * per:(k + 1) * per] - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_wide_deferred_reductions_equal_the_immediate_ones(pkg, shell):
+    """linr_wide_reduce_many over the partials that linr_spconv_wgrad_wide / linr_linear_wgrad_wide leave behind with gW = NULL gives the
+    bits of the entries' own reductions (same slab, same fixed-order sums), for several layers in ONE launch."""
+    from linr_pcgc_amd import ops
+    sc = shell['scales'][0]
+    n = len(sc['coord'])
+    ld = (n + 63) // 64 * 64
+    nbr = torch.full((27, ld), -1, dtype=torch.int32, device='cuda')
+    nbr[:, :n] = ops.kmap_build(torch.from_numpy(sc['coord']).cuda())
+    tile8t = ops.kmap_tile8t(nbr, n)
+    torch.manual_seed(5)
+    deferred, want, got = [], [], []
+    for cin, cout in [(16, 16), (3, 16), (32, 8), (16, 32)]:
+        xs, gs = _to_blocks(torch.randn(n, (cin + 7) // 8 * 8, device='cuda')), _to_blocks(torch.randn(n, cout, device='cuda'))
+        want.append(ops.spconv_wgrad_wide(xs, gs, nbr, tile8t, n, cin, cout))
+        gw, gb = torch.full((27, cin, cout), float('nan'), device='cuda'), torch.full((cout,), float('nan'), device='cuda')
+        ops.spconv_wgrad_wide(xs, gs, nbr, tile8t, n, cin, cout, gw=gw, gb=gb, defer=deferred)
+        got.append((gw, gb))
+    for cin, cout, ws in [(16, 8, (8, 1)), (32, 16, (16, 1)), (16, 24, (1, 16))]:
+        blocked = cout % 8 == 0 and ws[1] == 1
+        xs = _to_blocks(torch.randn(n, cin, device='cuda'))
+        g = torch.randn(n, cout, device='cuda')
+        gs = _to_blocks(g) if blocked else [g]
+        a = (torch.full((cin * cout,), float('nan'), device='cuda'), torch.full((cout,), float('nan'), device='cuda'))
+        b = (torch.full((cin * cout,), float('nan'), device='cuda'), torch.full((cout,), float('nan'), device='cuda'))
+        ops.linear_wgrad_wide(xs, cin, gs, cout, a[0], ws[0], ws[1], a[1], g_blocked=blocked)
+        ops.linear_wgrad_wide(xs, cin, gs, cout, b[0], ws[0], ws[1], b[1], g_blocked=blocked, defer=deferred)
+        want.append(a); got.append(b)
+    assert len(deferred) == 7 and bool(torch.isnan(got[0][0]).all())
+    ops.wide_reduce_many(deferred)
+    assert deferred == []
+    for (w0, w1), (g0, g1) in zip(want, got):
+        assert torch.equal(w0, g0) and torch.equal(w1, g1)
