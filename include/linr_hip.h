@@ -269,6 +269,9 @@ LINR_API int linr_linear_bwd_weight(const float* in, int32_t in_ld, const float*
 /* dst[i] (+)= src[i] over n floats: the residual / gradient fan-in adds of the width-generic executor (linr_pcgc_amd/wide_net.py);
  * torch's `x + y` in models/resnet.py:59,161 and autograd's accumulation. */
 LINR_API int linr_axpy(const float* src, int64_t n, float* dst, int32_t accumulate, void* stream);
+/* dst (+)= src[0] + ... + src[count - 1] over n floats (count 1..8, n a multiple of 4, 16-byte aligned pointers; src_h: HOST array),
+ * the sources added in list order: a gradient fan-in (e.g. x_glob's: upsample.py:206-214 under autograd) in one pass. */
+LINR_API int linr_sum_many(const float* const* src_h, int32_t count, int64_t n, float* dst, int32_t accumulate, void* stream);
 
 /* ---- occupancy head loss -------------------------------------------------------------------------------------
  * Replaces sigmoid + nn.BCELoss(reduction='sum') / ln 2 (models/upsample.py:160, models/model_core.py:14,76-81).

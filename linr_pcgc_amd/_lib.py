@@ -50,6 +50,7 @@ _PROTOS = {
                                                 ctypes.POINTER(LinrInceptionParams), c_ptr, c_ptr, c_u32, c_ptr, c_i32, c_ptr]),
     'linr_slab_reduce': (ctypes.c_int, [c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_u32, c_ptr]),
     'linr_axpy': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i32, c_ptr]),
+    'linr_sum_many': (ctypes.c_int, [c_ptr, c_i32, c_i64, c_ptr, c_i32, c_ptr]),
     'linr_occ_wgrad7': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_ptr, c_ptr]),
     'linr_kmap_tile8t_bytes': (c_size, [c_i64]),
     'linr_kmap_tile8t': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_size, c_ptr]),

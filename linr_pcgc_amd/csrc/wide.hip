@@ -1118,3 +1118,34 @@ extern "C" int linr_head_wide_bwd(const float* const* c_h, const float* const* p
     if (rc) return rc;
     return linr_slab_reduce_launch(slab, WH_BLOCKS, total, grads, s);
 }
+
+// dst (+)= src[0] + src[1] + ... over n floats, the sources added in list order (the gradient fan-in of x_glob: the seven stage priors'
+// gradients in one pass instead of one read-modify-write pass each).
+#define SM_MAX 8
+struct SmArgs { const float* src[SM_MAX]; int count; };
+__global__ __launch_bounds__(LINR_BLOCK) void sum_many_k(SmArgs a, int64_t n4, float* __restrict__ dst, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (i >= n4) return;
+    float4 t = accumulate ? reinterpret_cast<const float4*>(dst)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < a.count; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(a.src[k])[i];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(dst)[i] = t;
+}
+
+// src_h: HOST array of `count` (1..8) device pointers, each n floats (n a multiple of 4, everything 16-byte aligned).
+extern "C" int linr_sum_many(const float* const* src_h, int32_t count, int64_t n, float* dst, int32_t accumulate, void* stream) {
+    if (n < 0 || (n & 3) || count < 1 || count > SM_MAX || !src_h || !dst) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!linr_aligned16(dst)) return LINR_EALIGN;
+    SmArgs a;
+    a.count = count;
+    for (int k = 0; k < SM_MAX; ++k) {
+        a.src[k] = src_h[k < count ? k : 0];
+        if (!a.src[k]) return LINR_EINVAL;
+        if (!linr_aligned16(a.src[k])) return LINR_EALIGN;
+    }
+    sum_many_k<<<linr_grid(n / 4, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(a, n / 4, dst, accumulate ? 1 : 0);
+    return linr_launch_rc();
+}

@@ -354,6 +354,7 @@ class WideNet:
         ops.head_wide_bwd([st['c'] for st in stages], [st['p'] for st in stages], [frame.occ[:, k] for k in range(8)],
                           [h[0].weight for h in self.heads], [h[0].bias for h in self.heads], [h[1].weight for h in self.heads],
                           gz_scale, g_cs, self.model._flat_grad[off0:off0 + 8 * per])
+        g_priors = []
         for k in range(7, -1, -1):
             st = stages[k]
             g_c = g_cs[k]
@@ -361,10 +362,12 @@ class WideNet:
                 self.prune[k].bwd(self, st['prior'], g_c, gins=g_xg)
             else:
                 g_prior = self.prune[k].bwd(self, st['prior'], g_c)
-                for s, d in zip(g_prior, g_xg):                     # prior_k = x_glob + block output: both receive g_prior
-                    _axpy(s, d[0], accumulate=d[1])
-                    d[1] = True
+                g_priors.append(g_prior)                            # prior_k = x_glob + block output: both receive g_prior
                 self.outter[k - 1].bwd(self, st['blk'], g_prior, need_input_grad=False)
+        # x_glob's gradient: stage 0's (in g_xg) + the seven priors' - one pass per block instead of a read-modify-write pass per stage
+        for b, (dst, _) in enumerate(g_xg):
+            check(_lib.lib().linr_sum_many(ops._ptr_array([gp[b] for gp in g_priors]), len(g_priors), dst.numel(), dst.data_ptr(), 1,
+                                           _stream()), 'linr_sum_many')
         g_x0 = self.block_in.bwd(self, tape['bin'], [g for g, _ in g_xg], need_input_grad=True)[0]
         # scale context: ghid, the four parameter gradients of every scale's MLP and the embedding rows in one call, straight into the
         # flat gradient (its leading linr_sce_param_count floats)

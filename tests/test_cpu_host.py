@@ -130,6 +130,8 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_head_wide_bwd_slab_bytes(16, 8) == 256 * 8 * (24 * 16 + 49) * 4 and lib.linr_head_wide_bwd_slab_bytes(8, 8) == 0
     assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 9, 1.0, b4, 8, p16, 1 << 30, p16, None) == -1      # more than 8 stages
     assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 1, 1.0, b4, 8, p16, 64, p16, None) == -2           # slab too small
+    assert lib.linr_sum_many(b4, 9, 8, p16, 0, None) == -1 and lib.linr_sum_many(b4, 2, 6, p16, 0, None) == -1      # count <= 8, n % 4 == 0
+    assert lib.linr_sum_many(b4, 2, 8, p16 + 4, 0, None) == -3 and lib.linr_sum_many(b4, 2, 0, p16, 1, None) == 0
     assert lib.linr_sce_param_count(7) == 7 * 8 + 7 * 392 and lib.linr_sce_param_count(0) == -1
     assert lib.linr_sce_bwd_params_slab_bytes(7) == 256 * (7 * 8 + 7 * 392) * 4
     assert lib.linr_sce_bwd_params(p16, None, p16, p16, p16, 1 << 30, p16, None) == -1                           # no frame

@@ -359,3 +359,22 @@ def test_wide_deferred_reductions_equal_the_immediate_ones(pkg, shell):
     assert deferred == []
     for (w0, w1), (g0, g1) in zip(want, got):
         assert torch.equal(w0, g0) and torch.equal(w1, g1)
+
+
+def test_sum_many_adds_in_list_order(pkg):
+    """linr_sum_many: dst (+)= src[0] + src[1] + ... with the sources added in list order - bitwise what chained additions give."""
+    import ctypes
+    from linr_pcgc_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(3)
+    n = 4 * 12345
+    srcs = [torch.randn(n, device='cuda') for _ in range(7)]
+    dst = torch.randn(n, device='cuda')
+    want = dst.clone()
+    for t in srcs:
+        want = want + t
+    arr = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in srcs])
+    _lib.check(L.linr_sum_many(arr, 7, n, dst.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), 'linr_sum_many')
+    assert torch.equal(dst, want)
+    _lib.check(L.linr_sum_many(arr, 3, n, dst.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), 'linr_sum_many')
+    assert torch.equal(dst, (srcs[0] + srcs[1]) + srcs[2])
