@@ -467,10 +467,16 @@ class FlatAdam:
         the gradient came from, None = all)."""
         t, t_scale = self.advance(frame)
         flat = self.model.flat_parameters()
+        runs = []                                   # adjacent segments with the same step count are one launch (usually: all of them)
         for b, e, own in self._param_segments():
             ts = t if own < 0 else int(t_scale[own])
             if ts < 1:
                 continue
+            if runs and runs[-1][1] == b and runs[-1][2] == ts:
+                runs[-1][1] = e
+            else:
+                runs.append([b, e, ts])
+        for b, e, ts in runs:
             ops.adam_step(flat[b:e], self.grad[b:e], self.exp_avg[b:e], self.exp_avg_sq[b:e], ts, self.lr,
                           self.betas[0], self.betas[1], self.eps, self.weight_decay)
         self.t, self.t_scale = t, t_scale
