@@ -42,7 +42,7 @@ class _Pool:
         self.i += 1
         if i < len(self.bufs):
             b = self.bufs[i]
-            if b.shape[0] == nb and b.shape[1] > n and b.device == dev:
+            if b.shape[0] == nb and b.shape[1] > n and b.device.type == dev.type and (dev.index is None or dev.index == b.device.index):
                 return [b[j, 1:n + 1] for j in range(nb)]
         b = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
         b[:, 0].zero_()
