@@ -15,7 +15,7 @@ for grp in \
   i=$((i+1))
   rm -rf /tmp/wdc_$i
   echo "== pass $i: $grp" >> $OUT
-  if timeout -k 10 150 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc $grp --output-format csv -d /tmp/wdc_$i -- python3 $R/tools/_lab/wide16_prof.py 16 3 > /tmp/wdc_$i.log 2>&1; then
+  if timeout -k 10 150 rocprofv3 --kernel-trace --kernel-include-regex "$KREG" --pmc $grp --output-format csv -d /tmp/wdc_$i -- python3 $R/tools/wide_step_prof.py 16 3 > /tmp/wdc_$i.log 2>&1; then
     python3 $R/tools/pmc_summary.py /tmp/wdc_$i "wconv_k,wwgrad_k" >> $OUT 2>&1 || echo "   (no counter file)" >> $OUT
   else
     echo "   pass failed or timed out: $(tail -2 /tmp/wdc_$i.log | tr '\n' ' ')" >> $OUT
