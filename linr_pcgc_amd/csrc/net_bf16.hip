@@ -31,11 +31,14 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(floa
 // torch: recon = q / sym_max * ten_range + min_n, each step ONE fp32 rounding: hipcc contracts a * b + c into an fma by
 // default (-ffp-contract=fast-honor-pragmas), which changes the last bit where the sum cancels, so contraction is switched
 // off here; the division is IEEE (correctly rounded is hipcc's default for fp32 divide)
-__device__ __forceinline__ float dequant(const uint8_t* __restrict__ codes, int64_t i, float range, float minv) {
+__device__ __forceinline__ float dequant_code(uint8_t code, float range, float minv) {
 #pragma clang fp contract(off)
-    const float t = (float)codes[i] / 255.0f;
+    const float t = (float)code / 255.0f;
     const float u = t * range;
     return u + minv;
+}
+__device__ __forceinline__ float dequant(const uint8_t* __restrict__ codes, int64_t i, float range, float minv) {
+    return dequant_code(codes[i], range, minv);
 }
 
 __global__ __launch_bounds__(LINR_BLOCK) void dequant_all_k(const uint8_t* __restrict__ codes, int64_t n, float range, float minv,
@@ -110,30 +113,42 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
     //   MODE 3  : c = 2 k + t        -> t = 0: W01[k][kk][i], t = 1: W11[k][kk][i]
     s16x4 wv[NG];
     {
+        // all of the lane's code bytes first (unconditional loads from clamped, always valid indices: in flight together), then the
+        // de-quantisation - with the loads under `if (k < 27)` / `if (ci < cinv)` every byte was a load-and-wait of its own, up to 28
+        // round trips in front of the first tap of every 256-row workgroup
         const int blk = lane >> 2, i = lane & 3;
         const int cinv = (MODE == 0) ? a.cin[gi] : 8;
+        uint8_t raw[NG][4];
+        bool ok[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int c = 16 * g + blk;
-            const int k = c / CPT;
-            s16x4 v = {0, 0, 0, 0};
-            if (k < 27) {
+            const int k0 = c / CPT, k = k0 < 27 ? k0 : 26;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    float wf = 0.0f;
-                    if constexpr (MODE == 0 || MODE == 1) {
-                        const int h = (c >> 1) & 1, q = c & 1, ci = 4 * q + kk;
-                        if (ci < cinv) wf = dequant(a.codes, a.w[gi] + ((int64_t)k * cinv + ci) * 8 + 4 * h + i, a.range, a.minv);
-                    } else if constexpr (MODE == 2) {
-                        const int q = c & 1;
-                        wf = dequant(a.codes, a.w[gi] + ((int64_t)k * 8 + 4 * q + kk) * 4 + i, a.range, a.minv);
-                    } else {
-                        const int t = c & 1;
-                        wf = dequant(a.codes, (t ? a.w2[gi] : a.w[gi]) + ((int64_t)k * 4 + kk) * 4 + i, a.range, a.minv);
-                    }
-                    v[kk] = (short)f2bf(wf);
+            for (int kk = 0; kk < 4; ++kk) {
+                int64_t idx;
+                bool valid = k0 < 27;
+                if constexpr (MODE == 0 || MODE == 1) {
+                    const int h = (c >> 1) & 1, q = c & 1, ci0 = 4 * q + kk;
+                    valid = valid && ci0 < cinv;
+                    const int ci = ci0 < cinv ? ci0 : 0;
+                    idx = a.w[gi] + ((int64_t)k * cinv + ci) * 8 + 4 * h + i;
+                } else if constexpr (MODE == 2) {
+                    const int q = c & 1;
+                    idx = a.w[gi] + ((int64_t)k * 8 + 4 * q + kk) * 4 + i;
+                } else {
+                    const int t = c & 1;
+                    idx = (t ? a.w2[gi] : a.w[gi]) + ((int64_t)k * 4 + kk) * 4 + i;
                 }
+                raw[g][kk] = a.codes[idx];
+                ok[g][kk] = valid;
             }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            s16x4 v;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = ok[g][kk] ? (short)f2bf(dequant_code(raw[g][kk], a.range, a.minv)) : (short)0;
             wv[g] = v;
         }
     }
