@@ -246,7 +246,7 @@ LINR_API int linr_prof_mask(uint32_t mask);
  * linr_net_forward / _backward / _train_step whose kernel class (the list above) has its bit set in kind_mask is preceded by a kernel that fills the LDS of every CU with 0xFFFFFFFF (a NaN
  * pattern) - results must not change: a kernel may not read on-chip state it did not write (on a GPU shared with another
  * process the leftovers are not one's own finite numbers). */
-LINR_API int linr_debug_poison(uint32_t kind_mask);          /* bits 0..13: the classes above; 14: bf16 executor; 15: linr_decode_scale */
+LINR_API int linr_debug_poison(uint32_t kind_mask);          /* bits 0..13: the classes above; 14: bf16 executor; 15: linr_decode_scale; 16: the entries of csrc/wide.hip */
 LINR_API int linr_debug_poison_now(void* stream);           /* the same poisoning, once, on `stream` (in front of an op-level call) */
 LINR_API int linr_prof_enable(int32_t mode);
 LINR_API int linr_prof_read(int32_t kind, double* total_ms, int64_t* launches, int64_t* passes);

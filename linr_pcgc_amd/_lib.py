@@ -177,7 +177,7 @@ class _Poisoned:
 
     def __init__(self, handle):
         self._h = handle
-        handle.linr_debug_poison(0xFFFF)
+        handle.linr_debug_poison(0x1FFFF)
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)

@@ -204,6 +204,7 @@ extern "C" int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int
         if (!a.in[g] || !linr_aligned16(a.in[g])) return a.in[g] ? LINR_EALIGN : LINR_EINVAL;
     a.W = W; a.bias = bwd ? nullptr : bias; a.cin = cin; a.cout = cout; a.gvalid = gch; a.flags = flags;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     for (int p0 = 0; p0 < npb; p0 += 2) {
         const int pb = npb - p0 >= 2 ? 2 : 1;
         for (int q = 0; q < 2; ++q) {
@@ -480,6 +481,7 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
     if (!in_h || !g_h || !nbr || !slab) return LINR_EINVAL;
     if ((uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     const int nbi = (cin + 7) / 8, nbo = cout / 8, npairs = nbi * nbo;
     if (n == 0) {
         if (!gW) return LINR_EINVAL;                     // deferred reductions (gW == NULL) need rows
@@ -646,6 +648,7 @@ extern "C" int linr_linear_wide(const float* const* in_h, int32_t cin, int32_t i
     }
     a.W = W; a.ws_ci = ws_ci; a.ws_co = ws_co; a.bias = (flags & LINR_NO_BIAS) ? nullptr : bias; a.flags = flags;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     const unsigned grid = linr_grid(n, LINR_BLOCK);
     const bool com = (ws_ci == cout && ws_co == 1);
     if (!com && !(ws_ci == 1 && ws_co == cin)) return LINR_EINVAL;          // dense [cin][cout] or dense [cout][cin]
@@ -685,6 +688,7 @@ extern "C" int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int
     for (int i = 0; i < ni; ++i) if (!in_h[i]) return LINR_EINVAL;
     for (int i = 0; i < no; ++i) if (!g_h[i]) return LINR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     const int nb = linr_lin_blocks(n);
     const int64_t stride = (int64_t)(cin + 2) * cout;                             // [cin + 1][cout] + a dump row for the duplicate bias sums
     Grp gp = Grp();
@@ -772,6 +776,7 @@ extern "C" int linr_wide_reduce_many(const linr_wide_reduce* items_h, int32_t co
         if (t.kind == 0 && t.cout % 8) return LINR_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     for (int i0 = 0; i0 < count; i0 += RD_MAX) {
         RdArgs A;
         A.n = count - i0 < RD_MAX ? count - i0 : RD_MAX;
@@ -872,6 +877,7 @@ extern "C" int linr_head_wide_fwd(const float* const* c_h, int32_t C, const floa
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.target = target; a.target_ld = target_ld; a.p = p;
     a.partial = bits_acc ? (double*)ws : nullptr;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     const unsigned nb = linr_grid(n, LINR_BLOCK);
     if (C == 16) whead_fwd_k<16><<<nb, LINR_BLOCK, 0, s>>>(a, n);
     else whead_fwd_k<32><<<nb, LINR_BLOCK, 0, s>>>(a, n);
@@ -1095,6 +1101,7 @@ extern "C" int linr_head_wide_bwd(const float* const* c_h, const float* const* p
     if (!c_h || !p_h || !target_h || !w1_h || !b1_h || !w2_h || !gc_h || !slab || !grads) return LINR_EINVAL;
     if (slab_bytes < linr_head_wide_bwd_slab_bytes(C, nstages)) return LINR_ENOSPC;
     hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
     const int64_t total = (int64_t)nstages * (24 * C + 49);
     if (n == 0) return linr_hip_rc(hipMemsetAsync(grads, 0, (size_t)total * sizeof(float), s));
     WhbArgs A;
@@ -1146,6 +1153,7 @@ extern "C" int linr_sum_many(const float* const* src_h, int32_t count, int64_t n
         if (!a.src[k]) return LINR_EINVAL;
         if (!linr_aligned16(a.src[k])) return LINR_EALIGN;
     }
+    linr_poison_hook((hipStream_t)stream, 16);
     sum_many_k<<<linr_grid(n / 4, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(a, n / 4, dst, accumulate ? 1 : 0);
     return linr_launch_rc();
 }

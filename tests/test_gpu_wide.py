@@ -378,3 +378,31 @@ def test_sum_many_adds_in_list_order(pkg):
     assert torch.equal(dst, want)
     _lib.check(L.linr_sum_many(arr, 3, n, dst.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), 'linr_sum_many')
     assert torch.equal(dst, (srcs[0] + srcs[1]) + srcs[2])
+
+
+def test_wide_results_do_not_depend_on_leftover_onchip_state(pkg):
+    """The wide executor's kernels may not read LDS or registers they did not write (tests/test_gpu_parity.py::
+    test_results_do_not_depend_on_leftover_onchip_state for the 8-wide executor): with every entry of csrc/wide.hip preceded by the
+    kernel that fills the LDS and vector registers of all CUs with 0xFFFFFFFF (linr_debug_poison bit 16; the scale context's kernels:
+    bits 11, 12) three training steps at width 16 give the same parameters, moments and bits, bit for bit."""
+    from linr_pcgc_amd import _lib, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    gop = overfit.Gop(None, [synthetic.sequence_frame_device('sphere8', 0, 'cuda')], None, 64, 'cuda')
+    L = _lib.lib()
+
+    def run(mask):
+        m = overfit.gen_model(gop.scale_num, 'cuda', seed=8807, hidden=16)
+        o = FlatAdam(m)
+        bits = torch.zeros(3, dtype=torch.float64, device='cuda')
+        L.linr_debug_poison(mask)
+        try:
+            for s in range(3):
+                train_step(m, o, gop.frames[0], gop.point_nums[0], out=bits[s:s + 1])
+            torch.cuda.synchronize()
+        finally:
+            L.linr_debug_poison(0x1FFFF if os.environ.get('LINR_DEBUG_POISON') else 0)
+        return m.flat_parameters().clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), bits.cpu()
+    clean, dirty = run(0), run(0x1FFFF)
+    assert bool(torch.isfinite(dirty[0]).all())
+    for a, b in zip(clean, dirty):
+        assert torch.equal(a, b)
