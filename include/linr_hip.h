@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 8
+#define LINR_ABI_VERSION 9
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -138,6 +138,23 @@ LINR_API int linr_spconv_cmap(int32_t bwd, const float* in, int32_t in_ld, const
 LINR_API int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
                               const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
                               const float* const* act_h, float* const* out_h, uint32_t flags, void* stream);
+/* ... with a pointwise layer of the wide Inception layer (models/resnet.py:55-60) fused into the epilogue - pw->mode:
+ *   1 forward conv0_0 (C -> h = C / 2): out2 = relu(in @ W10 + b10) of the row itself (conv1_0)
+ *   2 forward conv1_1 (h -> h): out2 = (the produced row) @ W12 + b12 + aux (conv1_2 and the residual's upper half)
+ *   3 backward of the block's tail convolution (C <- C): out2 = ((produced upper half) @ W12^T) * (aux > 0), aux = M
+ *   4 backward of conv0_0 (C <- h): produced += aux @ W10^T in front of the ReLU mask, aux = the gradient of H1
+ * W [cin_pw][cout_pw] (ME layout), b or NULL; aux_h / out2_h: HOST arrays of h / 8 block pointers; C in {16, 32}.  The fmaf chains are
+ * those of linr_linear_wide: the fused and the two-launch forms give the same bits. */
+typedef struct {
+    int32_t mode;
+    const float* W;
+    const float* b;
+    const float* const* aux_h;
+    float* const* out2_h;
+} linr_wide_pw;
+LINR_API int linr_spconv_wide_pw(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                 const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
+                                 const float* const* act_h, float* const* out_h, uint32_t flags, const linr_wide_pw* pw, void* stream);
 /* Weight gradient of that convolution: gW [27][cin][cout], gb [cout] (may be NULL) from the ceil(cin / 8) input blocks in_h (zero row in
  * front) and the cout / 8 output-gradient blocks g_h: one launch whose groups are the input blocks - the gathered, LDS-transposed rows
  * of a block multiply the tiles of ALL gradient blocks (cout 8 / 16 / 32 with the tiled table; else block pair by block pair) - into

@@ -11,10 +11,15 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+
+class LinrWidePw(ctypes.Structure):
+    """linr_wide_pw of include/linr_hip.h: a pointwise layer fused into a wide convolution's epilogue."""
+    _fields_ = [('mode', ctypes.c_int32), ('W', ctypes.c_void_p), ('b', ctypes.c_void_p), ('aux_h', ctypes.c_void_p), ('out2_h', ctypes.c_void_p)]
 
 
 class LinrWideReduce(ctypes.Structure):
@@ -75,6 +80,8 @@ _PROTOS = {
     'linr_spconv_wgrad_wide': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_linear_wide': (ctypes.c_int, [c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32, ctypes.c_int32, c_ptr, ctypes.c_int32,
                                         ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_uint32, c_ptr]),
+    'linr_spconv_wide_pw': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_u32,
+                                           ctypes.POINTER(LinrWidePw), c_ptr]),
     'linr_spconv_wgrad_wide_blocks': (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     'linr_linear_wgrad_wide_blocks': (ctypes.c_int32, [c_i64]),
     'linr_wide_reduce_many': (ctypes.c_int, [ctypes.POINTER(LinrWideReduce), ctypes.c_int32, c_ptr]),

@@ -29,9 +29,20 @@ struct WcArgs {
     int gvalid;                    // gathered channels that exist (first convolutions of the outter blocks: cin = k < 8)
     int pb0;                       // first produced block of this launch
     unsigned flags;
+    // pointwise side path of a wide Inception layer fused into the epilogue (models/resnet.py:55-60; template parameter EPI):
+    //   EPI 1 (fwd conv0_0 C -> h): out2 = relu(own input row @ W10 + b10)                         (conv1_0 reads the centre tap's row)
+    //   EPI 2 (fwd conv1_1 h -> h): out2 = (this kernel's output row) @ W12 + b12 + aux            (conv1_2 + the residual's upper half)
+    //   EPI 3 (bwd tail conv):      out2 = ((produced upper half) @ W12^T) * (aux > 0)             (backward of conv1_2 and of M's ReLU)
+    //   EPI 4 (bwd conv0_0):        produced += (aux own row) @ W10^T, in front of the mask        (backward-data of conv1_0; aux = gH1)
+    // pw_W: [cin_pw][cout_pw] (ME layout), pw_b [cout_pw] or nullptr; pw_on: this launch runs the side path (EPI 3: the launch that
+    // produces the upper half, whose first local block is pw_hi0)
+    const float* pw_W; const float* pw_b;
+    const float* pw_aux[2];
+    float* pw_out[2];
+    int pw_on, pw_hi0;
 };
 
-template <int GB, int PB, bool BWD>
+template <int GB, int PB, bool BWD, int EPI = 0>
 __global__ __launch_bounds__(LINR_CONV_BLOCK) void wconv_k(WcArgs a, const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask,
                                                           int64_t ld, int64_t n) {
     constexpr int GIN = 8 * GB, NQ = 2 * PB, NV = GB * PB;          // NV = GIN * NQ / 16 A-operand registers per tap
@@ -56,6 +67,16 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void wconv_k(WcArgs a, const int32
             const int e = (int)threadIdx.x + LINR_CONV_BLOCK * i;
             if (e < TOT) wl[e] = wv[i];
         }
+    }
+    // the side path's weights behind the image (read back with uniform addresses: LDS broadcasts)
+    constexpr int PWI = EPI == 1 ? 8 * GB : EPI == 2 ? 8 * PB : EPI == 3 ? 4 * GB : EPI == 4 ? 16 * GB : 0;      // rows of pw_W (cin_pw)
+    constexpr int PWO = EPI == 1 ? 8 * PB : EPI == 2 ? 8 * PB : EPI == 3 ? 4 * GB : EPI == 4 ? 8 * GB : 0;       // columns (cout_pw)
+    float* wp = wl + 27 * NV * 64;
+    // read through a pointer that is per-lane in form: with a uniform one the compiler keeps the weights in SGPRs and spills hundreds
+    const float* wq = wp + __builtin_amdgcn_mbcnt_lo(0u, 0u);
+    if constexpr (EPI != 0) {
+        for (int e = threadIdx.x; e < PWI * PWO; e += LINR_CONV_BLOCK) wp[e] = a.pw_W[e];
+        if (EPI <= 2) for (int e = threadIdx.x; e < PWO; e += LINR_CONV_BLOCK) wp[PWI * PWO + e] = a.pw_b ? a.pw_b[e] : 0.0f;
     }
     __syncthreads();
     // the produced channels' bias: once per workgroup (uniform loads), not once per tile
@@ -118,42 +139,133 @@ __global__ __launch_bounds__(LINR_CONV_BLOCK) void wconv_k(WcArgs a, const int32
             __builtin_amdgcn_sched_barrier(0);
         });
         if (!live) continue;
-        // epilogue order of the 8-wide kernels: + res, + old (LINR_ACCUM), * (act > 0) (LINR_RELU_MASK), ReLU
+        // epilogue order of the 8-wide kernels: + res, + old (LINR_ACCUM), [EPI 4: + the pointwise backward], * (act > 0)
+        // (LINR_RELU_MASK), ReLU
+        float o[PB][8];
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) {
-            float o[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[4 * h + j] = acc[2 * pb + h][j];
+                for (int j = 0; j < 4; ++j) o[pb][4 * h + j] = acc[2 * pb + h][j];
             if (a.res[pb]) {
                 const float* r = a.res[pb] + row * 8;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += r[j];
+                for (int j = 0; j < 8; ++j) o[pb][j] += r[j];
             }
-            float* op = a.out[pb] + row * 8;
             if (a.flags & LINR_ACCUM) {
+                const float* op = a.out[pb] + row * 8;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += op[j];
+                for (int j = 0; j < 8; ++j) o[pb][j] += op[j];
             }
+        }
+        if constexpr (EPI == 4) {
+            // + gH1[row] @ W10^T: per produced channel ci the chain of linr_linear_wide's backward-data pass (gradient channels
+            // ascending from 0), added to what the convolution, the residual's share and the old content gave
+            float gh[8 * GB];
+#pragma unroll
+            for (int b = 0; b < GB; ++b) {
+                const float4 t0 = *reinterpret_cast<const float4*>(a.pw_aux[b] + row * 8), t1 = *reinterpret_cast<const float4*>(a.pw_aux[b] + row * 8 + 4);
+                gh[8 * b] = t0.x; gh[8 * b + 1] = t0.y; gh[8 * b + 2] = t0.z; gh[8 * b + 3] = t0.w;
+                gh[8 * b + 4] = t1.x; gh[8 * b + 5] = t1.y; gh[8 * b + 6] = t1.z; gh[8 * b + 7] = t1.w;
+            }
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float* wrow = wq + (8 * (a.pb0 + pb) + j) * PWO;
+                    float t = 0.0f;
+#pragma unroll
+                    for (int co = 0; co < PWO; ++co) t = fmaf(gh[co], wrow[co], t);
+                    o[pb][j] = t + o[pb][j];
+                }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
             if (a.flags & LINR_RELU_MASK) {
                 const float* m = a.act[pb] + row * 8;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = m[j] > 0.0f ? o[j] : 0.0f;
+                for (int j = 0; j < 8; ++j) o[pb][j] = m[j] > 0.0f ? o[pb][j] : 0.0f;
             }
             if (a.flags & LINR_RELU) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
+                for (int j = 0; j < 8; ++j) o[pb][j] = fmaxf(o[pb][j], 0.0f);
             }
-            *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            float* op = a.out[pb] + row * 8;
+            *reinterpret_cast<float4*>(op) = make_float4(o[pb][0], o[pb][1], o[pb][2], o[pb][3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(o[pb][4], o[pb][5], o[pb][6], o[pb][7]);
+        }
+        if constexpr (EPI == 1) {
+            // conv1_0 on the row itself: bias, then the input channels ascending (linr_linear_wide's chain), ReLU
+            float xin[8 * GB];
+#pragma unroll
+            for (int b = 0; b < GB; ++b) {
+                const float4 t0 = *reinterpret_cast<const float4*>(a.in[b] + row * 8), t1 = *reinterpret_cast<const float4*>(a.in[b] + row * 8 + 4);
+                xin[8 * b] = t0.x; xin[8 * b + 1] = t0.y; xin[8 * b + 2] = t0.z; xin[8 * b + 3] = t0.w;
+                xin[8 * b + 4] = t1.x; xin[8 * b + 5] = t1.y; xin[8 * b + 6] = t1.z; xin[8 * b + 7] = t1.w;
+            }
+            float y[PWO];
+#pragma unroll
+            for (int j = 0; j < PWO; ++j) y[j] = wq[PWI * PWO + j];
+#pragma unroll
+            for (int i = 0; i < PWI; ++i)
+#pragma unroll
+                for (int j = 0; j < PWO; ++j) y[j] = fmaf(xin[i], wq[i * PWO + j], y[j]);
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                float* q = a.pw_out[b] + row * 8;
+                *reinterpret_cast<float4*>(q) = make_float4(fmaxf(y[8 * b], 0.f), fmaxf(y[8 * b + 1], 0.f), fmaxf(y[8 * b + 2], 0.f), fmaxf(y[8 * b + 3], 0.f));
+                *reinterpret_cast<float4*>(q + 4) = make_float4(fmaxf(y[8 * b + 4], 0.f), fmaxf(y[8 * b + 5], 0.f), fmaxf(y[8 * b + 6], 0.f), fmaxf(y[8 * b + 7], 0.f));
+            }
+        }
+        if constexpr (EPI == 2) {
+            // conv1_2 on this kernel's own output row M, + the residual's upper half
+            float y[PWO];
+#pragma unroll
+            for (int j = 0; j < PWO; ++j) y[j] = wq[PWI * PWO + j];
+#pragma unroll
+            for (int i = 0; i < PWI; ++i)
+#pragma unroll
+                for (int j = 0; j < PWO; ++j) y[j] = fmaf(o[i / 8][i % 8], wq[i * PWO + j], y[j]);
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const float* r = a.pw_aux[b] + row * 8;
+                float* q = a.pw_out[b] + row * 8;
+                *reinterpret_cast<float4*>(q) = make_float4(y[8 * b] + r[0], y[8 * b + 1] + r[1], y[8 * b + 2] + r[2], y[8 * b + 3] + r[3]);
+                *reinterpret_cast<float4*>(q + 4) = make_float4(y[8 * b + 4] + r[4], y[8 * b + 5] + r[5], y[8 * b + 6] + r[6], y[8 * b + 7] + r[7]);
+            }
+        }
+        if constexpr (EPI == 3) {
+            // gM = (gI[upper half] @ W12^T) * (M > 0): per channel ci of M the gradient channels ascending (the backward-data chain)
+            if (a.pw_on) {          // uniform
+                constexpr int NHB = PWI / 8;                         // blocks of the upper half = of M
+                constexpr int HI0 = GB == 2 ? 1 : 0;                 // its first local block: C = 16: the launch makes blocks 0, 1; C = 32: 2, 3
+#pragma unroll
+                for (int b = 0; b < NHB; ++b) {
+                    const float* mrow = a.pw_aux[b] + row * 8;
+                    float g[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float* wrow = wq + (8 * b + j) * PWO;
+                        float t = 0.0f;
+#pragma unroll
+                        for (int co = 0; co < PWO; ++co) t = fmaf(o[HI0 + co / 8][co % 8], wrow[co], t);
+                        g[j] = mrow[j] > 0.0f ? t : 0.0f;
+                    }
+                    float* q = a.pw_out[b] + row * 8;
+                    *reinterpret_cast<float4*>(q) = make_float4(g[0], g[1], g[2], g[3]);
+                    *reinterpret_cast<float4*>(q + 4) = make_float4(g[4], g[5], g[6], g[7]);
+                }
+            }
         }
     }
 }
 
-template <int GB, int PB, bool BWD>
+template <int GB, int PB, bool BWD, int EPI = 0>
 static int wc_launch(const WcArgs& a, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, hipStream_t s) {
-    constexpr size_t lds = (size_t)27 * GB * PB * 64 * 4;
+    constexpr int PWI = EPI == 1 ? 8 * GB : EPI == 2 ? 8 * PB : EPI == 3 ? 4 * GB : EPI == 4 ? 16 * GB : 0;
+    constexpr int PWO = EPI == 1 ? 8 * PB : EPI == 2 ? 8 * PB : EPI == 3 ? 4 * GB : EPI == 4 ? 8 * GB : 0;
+    constexpr size_t lds = ((size_t)27 * GB * PB * 64 + (size_t)PWI * PWO + PWO) * 4;
     static const int cus = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
@@ -161,22 +273,36 @@ static int wc_launch(const WcArgs& a, const int32_t* lo, const uint32_t* mask, i
     }();
     // the weight image is built once per workgroup, which then loops over row tiles (two workgroups per CU as in occ_conv7_k)
     const int64_t tiles = linr_grid(n, LINR_CONV_BLOCK);
-    static const int per_cu = getenv("LINR_WC_PER_CU") ? atoi(getenv("LINR_WC_PER_CU")) : 2;
-    const int64_t want = (int64_t)cus * per_cu;
+    const int64_t want = (int64_t)cus * 2;
     const int64_t per = (tiles + want - 1) / want;
     const int64_t grid = (tiles + per - 1) / per;
-    wconv_k<GB, PB, BWD><<<(unsigned)grid, LINR_CONV_BLOCK, lds, s>>>(a, lo, mask, ld, n);
+    wconv_k<GB, PB, BWD, EPI><<<(unsigned)grid, LINR_CONV_BLOCK, lds, s>>>(a, lo, mask, ld, n);
     return linr_launch_rc();
 }
 
 template <bool BWD>
-static int wc_dispatch(int gb, int pb, const WcArgs& a, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, hipStream_t s) {
-    if (gb == 1 && pb == 1) return wc_launch<1, 1, BWD>(a, lo, mask, ld, n, s);
-    if (gb == 1 && pb == 2) return wc_launch<1, 2, BWD>(a, lo, mask, ld, n, s);
-    if (gb == 2 && pb == 1) return wc_launch<2, 1, BWD>(a, lo, mask, ld, n, s);
-    if (gb == 2 && pb == 2) return wc_launch<2, 2, BWD>(a, lo, mask, ld, n, s);
-    if (gb == 4 && pb == 1) return wc_launch<4, 1, BWD>(a, lo, mask, ld, n, s);
-    if (gb == 4 && pb == 2) return wc_launch<4, 2, BWD>(a, lo, mask, ld, n, s);
+static int wc_dispatch(int gb, int pb, int epi, const WcArgs& a, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n, hipStream_t s) {
+    if (epi == 0) {
+        if (gb == 1 && pb == 1) return wc_launch<1, 1, BWD>(a, lo, mask, ld, n, s);
+        if (gb == 1 && pb == 2) return wc_launch<1, 2, BWD>(a, lo, mask, ld, n, s);
+        if (gb == 2 && pb == 1) return wc_launch<2, 1, BWD>(a, lo, mask, ld, n, s);
+        if (gb == 2 && pb == 2) return wc_launch<2, 2, BWD>(a, lo, mask, ld, n, s);
+        if (gb == 4 && pb == 1) return wc_launch<4, 1, BWD>(a, lo, mask, ld, n, s);
+        if (gb == 4 && pb == 2) return wc_launch<4, 2, BWD>(a, lo, mask, ld, n, s);
+        return LINR_EINVAL;
+    }
+    // the side paths of a wide Inception layer: C = 16 (h = 8) and C = 32 (h = 16)
+    if constexpr (!BWD) {
+        if (epi == 1 && gb == 2 && pb == 1) return wc_launch<2, 1, false, 1>(a, lo, mask, ld, n, s);      // conv0_0 16 -> 8 (+ conv1_0)
+        if (epi == 1 && gb == 4 && pb == 2) return wc_launch<4, 2, false, 1>(a, lo, mask, ld, n, s);      // conv0_0 32 -> 16
+        if (epi == 2 && gb == 1 && pb == 1) return wc_launch<1, 1, false, 2>(a, lo, mask, ld, n, s);      // conv1_1 8 -> 8 (+ conv1_2)
+        if (epi == 2 && gb == 2 && pb == 2) return wc_launch<2, 2, false, 2>(a, lo, mask, ld, n, s);      // conv1_1 16 -> 16
+    } else {
+        if (epi == 3 && gb == 2 && pb == 2) return wc_launch<2, 2, true, 3>(a, lo, mask, ld, n, s);       // tail conv 16 <- 16 (+ gM)
+        if (epi == 3 && gb == 4 && pb == 2) return wc_launch<4, 2, true, 3>(a, lo, mask, ld, n, s);       // tail conv 32 <- 32
+        if (epi == 4 && gb == 1 && pb == 2) return wc_launch<1, 2, true, 4>(a, lo, mask, ld, n, s);       // conv0_0 16 <- 8 (+ conv1_0's)
+        if (epi == 4 && gb == 2 && pb == 2) return wc_launch<2, 2, true, 4>(a, lo, mask, ld, n, s);       // conv0_0 32 <- 16
+    }
     return LINR_EINVAL;
 }
 
@@ -184,9 +310,9 @@ static int wc_dispatch(int gb, int pb, const WcArgs& a, const int32_t* lo, const
 // fwd (bwd = 0): gathers cin channels in ceil(cin / 8) blocks (cin < 8: one block whose channels >= cin are ignored), produces cout / 8
 // blocks.  bwd (bwd = 1): gathers the output gradient in cout / 8 blocks at the mirrored taps, produces the input gradient in cin / 8
 // blocks (cin a multiple of 8).  flags: LINR_RELU, LINR_ACCUM, LINR_RELU_MASK as in linr_spconv_cmap.  Up to 32 channels either side.
-extern "C" int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
-                                const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
-                                const float* const* act_h, float* const* out_h, uint32_t flags, void* stream) {
+static int spconv_wide_impl(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                            const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
+                            const float* const* act_h, float* const* out_h, uint32_t flags, const linr_wide_pw* pw, void* stream) {
     if (n < 0 || ld < n || cin < 1 || cin > 32 || cout < 8 || cout > 32 || cout % 8) return LINR_EINVAL;
     if (n == 0) return 0;
     if (!in_h || !out_h || !lo || !mask || !W) return LINR_EINVAL;
@@ -203,6 +329,27 @@ extern "C" int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int
     for (int g = 0; g < gb; ++g)
         if (!a.in[g] || !linr_aligned16(a.in[g])) return a.in[g] ? LINR_EALIGN : LINR_EINVAL;
     a.W = W; a.bias = bwd ? nullptr : bias; a.cin = cin; a.cout = cout; a.gvalid = gch; a.flags = flags;
+    a.pw_W = nullptr; a.pw_b = nullptr; a.pw_aux[0] = a.pw_aux[1] = nullptr; a.pw_out[0] = a.pw_out[1] = nullptr; a.pw_on = 0; a.pw_hi0 = 0;
+    int epi = 0;
+    if (pw && pw->mode != 0) {
+        // the side path of a wide Inception layer: C = 2 h in {16, 32}
+        epi = pw->mode;
+        const int C = epi == 1 ? cin : epi == 2 ? 2 * cin : epi == 3 ? cin : 2 * cout;       // EPI 4: bwd conv0_0, cout = h
+        const int h = C / 2, nhb = h / 8;
+        if ((C != 16 && C != 32) || epi < 1 || epi > 4 || !pw->W) return LINR_EINVAL;
+        if ((epi <= 2) == (bwd != 0)) return LINR_EINVAL;
+        if (epi == 1 && (cout != h)) return LINR_EINVAL;
+        if (epi == 2 && (cin != h || cout != h)) return LINR_EINVAL;
+        if (epi == 3 && (cout != C)) return LINR_EINVAL;
+        if (epi == 4 && (cin != C)) return LINR_EINVAL;
+        if (epi != 1 && !pw->aux_h) return LINR_EINVAL;
+        if (epi != 4 && !pw->out2_h) return LINR_EINVAL;
+        a.pw_W = pw->W; a.pw_b = pw->b;
+        for (int q = 0; q < nhb; ++q) {
+            if (epi != 1) { a.pw_aux[q] = pw->aux_h[q]; if (!a.pw_aux[q] || !linr_aligned16(a.pw_aux[q])) return a.pw_aux[q] ? LINR_EALIGN : LINR_EINVAL; }
+            if (epi != 4) { a.pw_out[q] = pw->out2_h[q]; if (!a.pw_out[q] || !linr_aligned16(a.pw_out[q])) return a.pw_out[q] ? LINR_EALIGN : LINR_EINVAL; }
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     linr_poison_hook(s, 16);
     for (int p0 = 0; p0 < npb; p0 += 2) {
@@ -215,10 +362,37 @@ extern "C" int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int
             if (q < pb && (flags & LINR_RELU_MASK) && !a.act[q]) return LINR_EINVAL;
         }
         a.pb0 = p0;
-        const int rc = bwd ? wc_dispatch<true>(gb, pb, a, lo, mask, ld, n, s) : wc_dispatch<false>(gb, pb, a, lo, mask, ld, n, s);
+        int e = epi;
+        if (epi == 3) {          // gM rides in the launch that produces the upper half of the input gradient
+            const int nh = npb / 2;
+            a.pw_on = (p0 + pb > nh) ? 1 : 0;
+            a.pw_hi0 = nh > p0 ? nh - p0 : 0;
+            if (!a.pw_on) e = 0;
+            else if (a.pw_hi0 != (gb == 2 ? 1 : 0)) return LINR_EINVAL;          // the kernel's compile-time layout
+        }
+        const int rc = bwd ? wc_dispatch<true>(gb, pb, e, a, lo, mask, ld, n, s) : wc_dispatch<false>(gb, pb, e, a, lo, mask, ld, n, s);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int linr_spconv_wide(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
+                                const float* const* act_h, float* const* out_h, uint32_t flags, void* stream) {
+    return spconv_wide_impl(bwd, in_h, lo, mask, ld, n, W, bias, cin, cout, res_h, act_h, out_h, flags, nullptr, stream);
+}
+
+// The same convolution with a pointwise layer of the wide Inception layer fused into its epilogue (pw->mode, models/resnet.py:55-60):
+//   1  forward conv0_0 (C -> h):   out2 = relu(in @ W10 + b10) of the row itself (conv1_0);            W = W10 [C][h], b = b10
+//   2  forward conv1_1 (h -> h):   out2 = (the produced row) @ W12 + b12 + aux (conv1_2 + residual);     W = W12 [h][h], b = b12
+//   3  backward of the tail conv (C <- C): out2 = ((produced upper half) @ W12^T) * (aux > 0)  (gM);      W = W12, aux = M
+//   4  backward of conv0_0 (C <- h): produced += aux @ W10^T in front of the ReLU mask (aux = gH1);       W = W10
+// aux_h / out2_h: HOST arrays of h / 8 block pointers.  Per output the fmaf chains of linr_linear_wide, so the fused and the two-launch
+// forms give the same bits.
+extern "C" int linr_spconv_wide_pw(int32_t bwd, const float* const* in_h, const int32_t* lo, const uint32_t* mask, int64_t ld, int64_t n,
+                                   const float* W, const float* bias, int32_t cin, int32_t cout, const float* const* res_h,
+                                   const float* const* act_h, float* const* out_h, uint32_t flags, const linr_wide_pw* pw, void* stream) {
+    return spconv_wide_impl(bwd, in_h, lo, mask, ld, n, W, bias, cin, cout, res_h, act_h, out_h, flags, pw, stream);
 }
 
 // ---- weight gradient of a wide convolution -------------------------------------------------------------------------------------------

@@ -190,18 +190,28 @@ def _ptr_array(blocks):
     return (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
 
 
-def spconv_wide(xs, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None, relu=False, outs=None, accumulate=False):
+def spconv_wide(xs, lo, mask, n, kernel, bias=None, bwd=False, res=None, act=None, relu=False, outs=None, accumulate=False, pw=None):
     """linr_spconv_wide: a 3x3x3 convolution on channel-blocked activations, one gather of all input blocks per tap.
     xs: the gathered blocks (views buf[1:] of [n+1, 8] buffers whose row 0 is zero); kernel [27, cin, cout]; outs / res / act: lists
-    of [n, 8] blocks of the produced side (cout / 8 forward, cin / 8 backward)."""
+    of [n, 8] blocks of the produced side (cout / 8 forward, cin / 8 backward).  pw = (mode, W, b, aux blocks, out2 blocks): a pointwise
+    layer of the wide Inception layer fused into the epilogue (linr_spconv_wide_pw, include/linr_hip.h)."""
+    import ctypes
     cin, cout = kernel.shape[1], kernel.shape[2]
     npb = (cin if bwd else cout) // 8
     if outs is None:
         outs = [torch.empty((n, 8), dtype=torch.float32, device=xs[0].device) for _ in range(npb)]
     flags = (LINR_RELU if relu else 0) | (LINR_ACCUM if accumulate else 0) | (LINR_RELU_MASK if act is not None else 0)
-    check(_lib.lib().linr_spconv_wide(1 if bwd else 0, _ptr_array(xs), lo.data_ptr(), mask.data_ptr(), lo.stride(0), n, kernel.data_ptr(),
-                                      _ptr(bias), cin, cout, None if res is None else _ptr_array(res), None if act is None else _ptr_array(act),
-                                      _ptr_array(outs), flags, _stream()), 'linr_spconv_wide')
+    args = (1 if bwd else 0, _ptr_array(xs), lo.data_ptr(), mask.data_ptr(), lo.stride(0), n, kernel.data_ptr(), _ptr(bias), cin, cout,
+            None if res is None else _ptr_array(res), None if act is None else _ptr_array(act), _ptr_array(outs), flags)
+    if pw is None:
+        check(_lib.lib().linr_spconv_wide(*args, _stream()), 'linr_spconv_wide')
+    else:
+        mode, w, b, aux, out2 = pw
+        aux_a = None if aux is None else _ptr_array(aux)
+        out_a = None if out2 is None else _ptr_array(out2)
+        st = _lib.LinrWidePw(mode, w.data_ptr(), _ptr(b), None if aux_a is None else ctypes.cast(aux_a, ctypes.c_void_p),
+                             None if out_a is None else ctypes.cast(out_a, ctypes.c_void_p))
+        check(_lib.lib().linr_spconv_wide_pw(*args, ctypes.byref(st), _stream()), 'linr_spconv_wide_pw')
     return outs
 
 

@@ -14,6 +14,8 @@ Partly tuned: ~3.7x the convolution work of the 8-wide network; forward and back
 cores' rate, the weight gradients block pair by block pair, unfused backward, schedule in Python (profiles/r04_wide.txt).  The 8-wide model
 (every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -53,6 +55,7 @@ class _Pool:
         return [b[j, 1:] for j in range(nb)]
 
 
+_FUSE_PW = os.environ.get('LINR_WIDE_FUSE_PW', '1') != '0'          # the pointwise layers of an Inception layer in the convolutions' epilogues
 _POOL = None          # the pool of the running forward / backward (WideNet.forward(pool=True)), else fresh buffers
 _DEFER = None         # the running backward's list of deferred weight-gradient reductions (one launch per 32 at its end), else None
 
@@ -86,14 +89,15 @@ class _Conv:
         self.ci, self.co = mod.kernel.shape[1], mod.kernel.shape[2]
         self.nbi, self.nbo = (self.ci + B - 1) // B, self.co // B
 
-    def fwd(self, net, xs, relu=False, res=None):
-        """ONE launch (linr_spconv_wide): every input block of a row is gathered once per tap and feeds all output channels."""
+    def fwd(self, net, xs, relu=False, res=None, pw=None):
+        """ONE launch (linr_spconv_wide): every input block of a row is gathered once per tap and feeds all output channels.
+        pw: a pointwise layer fused into the epilogue (ops.spconv_wide)."""
         n = xs[0].shape[0]
         outs = _blocks(n, self.nbo, xs[0].device)
-        ops.spconv_wide(xs[:self.nbi], net.lo, net.mask, n, self.mod.kernel, self.mod.bias.reshape(-1), res=res, relu=relu, outs=outs)
+        ops.spconv_wide(xs[:self.nbi], net.lo, net.mask, n, self.mod.kernel, self.mod.bias.reshape(-1), res=res, relu=relu, outs=outs, pw=pw)
         return outs
 
-    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True, res=None):
+    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True, res=None, pw=None):
         """Parameter gradients into .grad; input gradient (+ res, masked by act > 0: the ReLU that produced xs) accumulated into
         gins (list of (buffer, has_content)) or returned as fresh blocks."""
         n = gouts[0].shape[0]
@@ -111,7 +115,7 @@ class _Conv:
         acc = gins[0][1]
         assert all(g[1] == acc for g in gins)
         ops.spconv_wide(gouts[:self.nbo], net.lo, net.mask, n, self.mod.kernel, None, bwd=True, act=act, res=res,
-                        outs=[g[0] for g in gins], accumulate=acc)
+                        outs=[g[0] for g in gins], accumulate=acc, pw=pw)
         for g in gins:
             g[1] = True
         return [g for g, _ in gins] if fresh else None
@@ -135,6 +139,11 @@ class _Pointwise:
             [torch.empty((n, self.cw), dtype=torch.float32, device=dev) for _ in range(self.nbo)]
         return ops.linear_wide(xs[:self.nbi], self.cin, self.w, self.ws[0], self.ws[1], self.b.reshape(-1), self.cout, outs,
                                out_blocked=self.blocked_out, res=res, relu=relu)
+
+    def wgrad(self, xs, gouts):
+        """Parameter gradients only (the backward-data pass rides in a convolution's epilogue)."""
+        ops.linear_wgrad_wide(xs[:self.nbi], self.cin, gouts[:self.nbo], self.cout, self.w.grad, self.ws[0], self.ws[1],
+                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_DEFER)
 
     def bwd(self, xs, gouts, gins=None, act=None, need_input_grad=True):
         """Parameter gradients into .grad (one grouped launch + one reduction); the input gradient (masked by act > 0) accumulated
@@ -175,12 +184,23 @@ class _Block:
         a = self.first.fwd(net, xs, relu=True)
         tape = {'in': xs, 'a': a, 'layers': []}
         x = a
+        n, dev = xs[0].shape[0], xs[0].device
         for q in self.layers:
-            h0 = q['c00'].fwd(net, x, relu=True)
-            h1 = q['c10'].fwd(x, relu=True)
+            # conv1_0 rides in conv0_0's launch (it reads the row itself: the centre tap), conv1_2 + the residual in conv1_1's: the
+            # fmaf chains of the stand-alone pointwise kernel, so the bits are those of the five-launch form (LINR_WIDE_FUSE_PW=0)
+            if _FUSE_PW:
+                h1 = _blocks(n, nh, dev)
+                h0 = q['c00'].fwd(net, x, relu=True, pw=(1, q['c10'].w, q['c10'].b.reshape(-1), None, h1))
+            else:
+                h0 = q['c00'].fwd(net, x, relu=True)
+                h1 = q['c10'].fwd(x, relu=True)
             i_lo = q['c01'].fwd(net, h0, res=x[:nh])
-            m = q['c11'].fwd(net, h1, relu=True)
-            i_hi = q['c12'].fwd(m, res=x[nh:])
+            if _FUSE_PW:
+                i_hi = _blocks(n, nh, dev)
+                m = q['c11'].fwd(net, h1, relu=True, pw=(2, q['c12'].w, q['c12'].b.reshape(-1), x[nh:], i_hi))
+            else:
+                m = q['c11'].fwd(net, h1, relu=True)
+                i_hi = q['c12'].fwd(m, res=x[nh:])
             tape['layers'].append({'x': x, 'h0': h0, 'h1': h1, 'm': m})
             x = i_lo + i_hi
         if len(self.layers) > 1:           # ResNetBlock.forward: out += x (models/resnet.py:160-161)
@@ -193,24 +213,40 @@ class _Block:
         """g_out: gradient blocks of the block output.  Returns the input gradient blocks (or None)."""
         nh = self.h // B
         n, dev = g_out[0].shape[0], g_out[0].device
-        g_il = self.tail.bwd(net, tape['il'], g_out)
+        nl = len(self.layers)
+        fuse = _FUSE_PW
+        g_m_last = None
+        if fuse:
+            # gM of the LAST Inception layer (backward of conv1_2 and of M's ReLU) rides in the tail convolution's backward-data launch
+            lastq, lastt = self.layers[-1], tape['layers'][-1]
+            g_m_last = _blocks(n, nh, dev)
+            g_il = self.tail.bwd(net, tape['il'], g_out, pw=(3, lastq['c12'].w, None, lastt['m'], g_m_last))
+        else:
+            g_il = self.tail.bwd(net, tape['il'], g_out)
         g_a = None
         if len(self.layers) > 1:           # the extra skip: a receives g_il as well
             g_a = _blocks(n, self.C // B, dev)
             for s, d in zip(g_il, g_a):
                 _axpy(s, d, accumulate=False)
         g_i = g_il
-        nl = len(self.layers)
         for li, (q, t) in enumerate(zip(reversed(self.layers), reversed(tape['layers']))):
             x = t['x']
-            g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
+            if fuse and li == 0:
+                g_m = g_m_last
+                q['c12'].wgrad(t['m'], g_i[nh:])
+            else:
+                g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
             g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'])
             g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'])
             # the layer's input gradient: the residual's share g_i rides in conv0_0's backward-data epilogue (+ res), conv1_0's share
-            # is accumulated last - and with it, for the block's first layer of a one-layer block, the ReLU mask of a = relu(first conv)
-            g_x = q['c00'].bwd(net, x, g_h0, res=g_i)
+            # is added last - and with it, for the block's first layer of a one-layer block, the ReLU mask of a = relu(first conv)
             last_mask = tape['a'] if (nl == 1 and li == nl - 1) else None
-            q['c10'].bwd(x, g_h1, gins=[[g, True] for g in g_x], act=last_mask)
+            if fuse:
+                q['c10'].wgrad(x, g_h1)
+                g_x = q['c00'].bwd(net, x, g_h0, res=g_i, act=last_mask, pw=(4, q['c10'].w, None, g_h1, None))
+            else:
+                g_x = q['c00'].bwd(net, x, g_h0, res=g_i)
+                q['c10'].bwd(x, g_h1, gins=[[g, True] for g in g_x], act=last_mask)
             g_i = g_x
         if g_a is not None:
             for s, d in zip(g_a, g_i):

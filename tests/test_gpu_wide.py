@@ -406,3 +406,31 @@ def test_wide_results_do_not_depend_on_leftover_onchip_state(pkg):
     assert bool(torch.isfinite(dirty[0]).all())
     for a, b in zip(clean, dirty):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (32, 1), (16, 2)])
+def test_wide_fused_pointwise_epilogues_equal_the_separate_launches(pkg, hidden, block_layers):
+    """conv1_0 / conv1_2 of a wide Inception layer and their backward-data passes in the convolutions' epilogues (linr_spconv_wide_pw)
+    keep the fmaf chains of the stand-alone pointwise kernel: two training steps give the same parameters, moments and bits, bit for
+    bit, as with LINR_WIDE_FUSE_PW=0 (one launch per pointwise layer)."""
+    from linr_pcgc_amd import overfit, synthetic, wide_net
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    gop = overfit.Gop(None, [synthetic.sequence_frame_device('sphere8', 0, 'cuda')], None, 64, 'cuda', block_layers=block_layers)
+
+    def run(fuse):
+        old = wide_net._FUSE_PW
+        wide_net._FUSE_PW = fuse
+        try:
+            m = overfit.gen_model(gop.scale_num, 'cuda', seed=8807, hidden=hidden, block_layers=block_layers)
+            o = FlatAdam(m)
+            bits = torch.zeros(2, dtype=torch.float64, device='cuda')
+            for s in range(2):
+                train_step(m, o, gop.frames[0], gop.point_nums[0], out=bits[s:s + 1])
+            torch.cuda.synchronize()
+        finally:
+            wide_net._FUSE_PW = old
+        return m.flat_parameters().clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), bits.cpu()
+    a, b = run(True), run(False)
+    assert bool(torch.isfinite(a[0]).all())
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
