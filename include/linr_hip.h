@@ -201,6 +201,9 @@ LINR_API int linr_wide_reduce_many(const linr_wide_reduce* items_h, int32_t coun
  * C / 8 blocks [n][8] (C = 16 / 32); w1 [24][C], b1 [24], w2 [24], b2 [1] (torch layouts); target: the occupancy column (stride
  * target_ld) or NULL; p [n]; bits_acc (double[1], += bits) or NULL; ws: linr_head_wide_workspace_bytes(n) bytes when bits are wanted. */
 LINR_API size_t linr_head_wide_workspace_bytes(int64_t n);
+/* (with bits_acc = NULL but target and ws given the stage's per-block partials stay in ws - linr_head_wide_workspace_bytes(n) / 8 doubles -
+ * and linr_bits_finish adds the partials of any number of stages to bits_acc in one launch) */
+LINR_API int linr_bits_finish(const double* partial, int64_t count, double* bits_acc, void* stream);
 LINR_API int linr_head_wide_fwd(const float* const* c_h, int32_t C, const float* w1, const float* b1, const float* w2, const float* b2,
                                 const float* target, int32_t target_ld, int64_t n, float* p, double* bits_acc, void* ws, size_t ws_bytes,
                                 void* stream);

@@ -86,6 +86,7 @@ _PROTOS = {
     'linr_linear_wgrad_wide_blocks': (ctypes.c_int32, [c_i64]),
     'linr_wide_reduce_many': (ctypes.c_int, [ctypes.POINTER(LinrWideReduce), ctypes.c_int32, c_ptr]),
     'linr_head_wide_workspace_bytes': (ctypes.c_size_t, [c_i64]),
+    'linr_bits_finish': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_head_wide_fwd': (ctypes.c_int, [c_ptr, ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_int32, c_i64, c_ptr, c_ptr, c_ptr,
                                           ctypes.c_size_t, c_ptr]),
     'linr_head_wide_bwd_slab_bytes': (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),

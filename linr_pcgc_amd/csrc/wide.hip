@@ -1039,8 +1039,9 @@ extern "C" int linr_head_wide_fwd(const float* const* c_h, int32_t C, const floa
     if (n < 0 || (C != 16 && C != 32) || !c_h || !w1 || !b1 || !w2 || !b2 || !p) return LINR_EINVAL;
     if (bits_acc && (!target || target_ld < 1 || !ws)) return LINR_EINVAL;
     if (n == 0) return 0;
-    if (bits_acc && ws_bytes < linr_head_wide_workspace_bytes(n)) return LINR_ENOSPC;
-    if (bits_acc && (((uintptr_t)ws) & 7u)) return LINR_EALIGN;
+    const bool want_bits = bits_acc || (ws && target);           // ws without bits_acc: the block partials only (linr_bits_finish adds them up)
+    if (want_bits && (target_ld < 1 || ws_bytes < linr_head_wide_workspace_bytes(n))) return target_ld < 1 ? LINR_EINVAL : LINR_ENOSPC;
+    if (want_bits && (((uintptr_t)ws) & 7u)) return LINR_EALIGN;
     WhArgs a;
     for (int i = 0; i < WC_MAXB; ++i) a.c[i] = nullptr;
     for (int i = 0; i < C / 8; ++i) {
@@ -1049,7 +1050,7 @@ extern "C" int linr_head_wide_fwd(const float* const* c_h, int32_t C, const floa
         a.c[i] = c_h[i];
     }
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.target = target; a.target_ld = target_ld; a.p = p;
-    a.partial = bits_acc ? (double*)ws : nullptr;
+    a.partial = want_bits ? (double*)ws : nullptr;
     hipStream_t s = (hipStream_t)stream;
     linr_poison_hook(s, 16);
     const unsigned nb = linr_grid(n, LINR_BLOCK);
@@ -1330,4 +1331,12 @@ extern "C" int linr_sum_many(const float* const* src_h, int32_t count, int64_t n
     linr_poison_hook((hipStream_t)stream, 16);
     sum_many_k<<<linr_grid(n / 4, LINR_BLOCK), LINR_BLOCK, 0, (hipStream_t)stream>>>(a, n / 4, dst, accumulate ? 1 : 0);
     return linr_launch_rc();
+}
+
+// bits_acc += (sum of `count` per-block nats partials) / ln 2 in a fixed order: the tail of linr_head_wide_fwd for callers that collected
+// the partials of several stages (ws given, bits_acc NULL) and finish them in one launch.
+extern "C" int linr_bits_finish(const double* partial, int64_t count, double* bits_acc, void* stream) {
+    if (count < 0 || count > 0x7fffffff || !bits_acc || (count > 0 && !partial)) return LINR_EINVAL;
+    if (count == 0) return 0;
+    return linr_bits_finish_launch(partial, (int)count, bits_acc, (hipStream_t)stream);
 }

@@ -274,16 +274,24 @@ def linear_wgrad_wide(xs, cin, gouts, cout, gw, ws_ci, ws_co, gb, in_blocked=Tru
                                           _ptr(gb)), ws, gw, gb))
 
 
-def head_wide_fwd(cs, w1, b1, w2, b2, target, p, bits=None):
+def head_wide_fwd(cs, w1, b1, w2, b2, target, p, bits=None, partial=None):
     """linr_head_wide_fwd: p = sigmoid(w2 . relu(W1 c + b1) + b2) of a wide head on the blocks cs; bits (float64[1]) += the stage's bits
-    against the occupancy column `target` (a strided view) when given."""
+    against the occupancy column `target` (a strided view) when given; partial (float64 tensor, >= linr_head_wide_workspace_bytes / 8
+    elements) instead: the stage's per-block partials stay there for bits_finish()."""
     L = _lib.lib()
     n, C = cs[0].shape[0], 8 * len(cs)
-    ws = _lib.scratch(max(L.linr_head_wide_workspace_bytes(n), 8), cs[0].device) if bits is not None else None
+    ws = partial
+    if bits is not None and ws is None:
+        ws = _lib.scratch(max(L.linr_head_wide_workspace_bytes(n), 8), cs[0].device)
     check(L.linr_head_wide_fwd(_ptr_array(cs), C, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr(target),
-                               1 if target is None else target.stride(0), n, p.data_ptr(), _ptr(bits), _ptr(ws),
-                               0 if ws is None else ws.numel(), _stream()), 'linr_head_wide_fwd')
+                               1 if target is None else target.stride(0), n, p.data_ptr(), _ptr(bits) if partial is None else None,
+                               _ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(), _stream()), 'linr_head_wide_fwd')
     return p
+
+
+def bits_finish(partial, count, bits):
+    """linr_bits_finish: bits (float64[1]) += the sum of the first `count` partials / ln 2."""
+    check(_lib.lib().linr_bits_finish(partial.data_ptr(), count, bits.data_ptr(), _stream()), 'linr_bits_finish')
 
 
 def head_wide_bwd(cs, ps, targets, w1s, b1s, w2s, gscale, gcs, grads):

@@ -314,11 +314,12 @@ class WideNet:
     def _occ_block(self, frame):
         return [frame.occ]                     # [rows, 8] view of a buffer with the zero row in front (engine.Frame)
 
-    def _head(self, k, prior, frame, p, bits):
-        """Stage k behind `prior`: the prune convolution, then the head MLP + sigmoid (+ the stage's bits) as one launch."""
+    def _head(self, k, prior, frame, p, partial):
+        """Stage k behind `prior`: the prune convolution, then the head MLP + sigmoid (+ the stage's bits partials) as one launch."""
         c = self.prune[k].fwd(self, prior)
         lin0, lin2 = self.heads[k]
-        ops.head_wide_fwd(c, lin0.weight, lin0.bias, lin2.weight, lin2.bias, frame.occ[:, k] if bits is not None else None, p, bits)
+        ops.head_wide_fwd(c, lin0.weight, lin0.bias, lin2.weight, lin2.bias, frame.occ[:, k] if partial is not None else None, p,
+                          partial=partial)
         return c
 
     # ---- forward ---------------------------------------------------------------------------------------------------------
@@ -344,6 +345,8 @@ class WideNet:
         x0, sce_tape = self._scale_context(frame, keep)
         xg, bin_tape = self.block_in.fwd(self, x0)
         tape = {'sce': sce_tape, 'bin': bin_tape, 'xg': xg, 'stages': []} if keep else None
+        nb = (frame.rows + 255) // 256                      # per-block bits partials of a stage (linr_head_wide_workspace_bytes / 8)
+        parts = torch.empty(((k1 - k0) * nb,), dtype=torch.float64, device=frame.device) if bits is not None else None
         for k in range(k0, k1):
             blk_tape = None
             if k == 0:
@@ -352,9 +355,11 @@ class WideNet:
                 occ = self._occ_block(frame)
                 prior, blk_tape = self.outter[k - 1].fwd(self, occ, res=xg)
             p = probs[k] if probs is not None else torch.empty((frame.rows,), dtype=torch.float32, device=frame.device)
-            c = self._head(k, prior, frame, p, bits)
+            c = self._head(k, prior, frame, p, None if parts is None else parts[(k - k0) * nb:(k - k0 + 1) * nb])
             if keep:
                 tape['stages'].append({'prior': prior, 'c': c, 'p': p, 'blk': blk_tape})
+        if parts is not None:
+            ops.bits_finish(parts, (k1 - k0) * nb, bits)          # all stages' partials in one fixed-order pass
         return tape
 
     # ---- backward --------------------------------------------------------------------------------------------------------

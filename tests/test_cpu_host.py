@@ -103,6 +103,13 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_prof_read(14, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
     # round-4 entries on blocked activations: pointwise layers, their weight gradients, the occupancy head, the scale context's backward
     b4 = (ctypes.c_void_p * 4)(p16, p16, p16, p16)
+    from linr_pcgc_amd._lib import LinrWidePw
+    pw = LinrWidePw(1, p16, p16, None, None)
+    assert lib.linr_spconv_wide_pw(0, b4, p16, p16, 16, 16, p16, p16, 16, 8, None, None, b4, 1, ctypes.byref(pw), None) == -1      # mode 1 without out2
+    pw = LinrWidePw(3, p16, None, ctypes.cast(b4, ctypes.c_void_p), ctypes.cast(b4, ctypes.c_void_p))
+    assert lib.linr_spconv_wide_pw(0, b4, p16, p16, 16, 16, p16, p16, 16, 16, None, None, b4, 0, ctypes.byref(pw), None) == -1     # mode 3 is a backward epilogue
+    pw = LinrWidePw(2, p16, p16, ctypes.cast(b4, ctypes.c_void_p), ctypes.cast(b4, ctypes.c_void_p))
+    assert lib.linr_spconv_wide_pw(0, b4, p16, p16, 16, 16, p16, p16, 16, 8, None, None, b4, 1, ctypes.byref(pw), None) == -1      # mode 2 needs h -> h
     assert lib.linr_linear_wide(b4, 12, 1, p16, 8, 1, p16, 8, 1, None, None, b4, 8, 0, None) == -1            # blocked cin not a multiple of 8
     assert lib.linr_linear_wide(b4, 16, 1, p16, 7, 1, p16, 8, 1, None, None, b4, 8, 0, None) == -1            # strides of no dense layout
     assert lib.linr_linear_wide(b4, 16, 1, p16, 8, 1, p16, 8, 1, None, None, b4, -1, 0, None) == -1           # n < 0
@@ -127,6 +134,7 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, None, 1, 8, p16, p16, p16, 64, None) == -1      # bits without a target
     assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, p16, 8, 8, p16, p16, p16, 4, None) == -2        # workspace too small
     assert lib.linr_head_wide_fwd(b4, 16, p16, p16, p16, p16, None, 1, 0, p16, None, None, 0, None) == 0      # empty input is fine
+    assert lib.linr_bits_finish(p16, -1, p16, None) == -1 and lib.linr_bits_finish(None, 4, p16, None) == -1 and lib.linr_bits_finish(p16, 0, p16, None) == 0
     assert lib.linr_head_wide_bwd_slab_bytes(16, 8) == 256 * 8 * (24 * 16 + 49) * 4 and lib.linr_head_wide_bwd_slab_bytes(8, 8) == 0
     assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 9, 1.0, b4, 8, p16, 1 << 30, p16, None) == -1      # more than 8 stages
     assert lib.linr_head_wide_bwd(b4, b4, b4, 8, b4, b4, b4, 16, 1, 1.0, b4, 8, p16, 64, p16, None) == -2           # slab too small
