@@ -185,7 +185,7 @@ LINR_API int linr_linear_wgrad_wide(const float* const* in_h, int32_t cin, int32
 /* Deferred reductions: with gW = NULL linr_spconv_wgrad_wide / linr_linear_wgrad_wide only write their per-block partials (slab / ws stay
  * in use); linr_wide_reduce_many then sums up to any number of them, 32 per launch, in the same fixed order as the entries' own
  * reductions.  kind 0: a convolution (nblocks = linr_spconv_wgrad_wide_blocks(cout, tiled table given), gW [27][cin][cout], gb [cout] or
- * NULL); kind 1: a pointwise layer (nblocks = linr_linear_wgrad_wide_blocks(n), gW at the strides ws_ci / ws_co, gb or NULL). */
+ * NULL; ws_ci > 0: the slab's row stride in floats when several convolutions share the rows); kind 1: a pointwise layer (nblocks = linr_linear_wgrad_wide_blocks(n), gW at the strides ws_ci / ws_co, gb or NULL). */
 typedef struct {
     int32_t kind, nblocks, cin, cout, ws_ci, ws_co;
     const float* slab;
@@ -193,6 +193,11 @@ typedef struct {
     float* gb;
 } linr_wide_reduce;
 LINR_API int32_t linr_spconv_wgrad_wide_blocks(int32_t cout, int32_t tiled);
+/* The weight gradients of TWO convolutions of the same shape h -> h (h in {8, 16}: conv0_1 and conv1_1 of a wide Inception layer) as one
+ * launch - partials only: a slab row (2 (h / 8)^2 x 1736 floats; 256 rows) holds A's block pairs, then B's; reduce each with
+ * linr_wide_reduce_many: kind 0, slab = the start of its part, nblocks 256, ws_ci = the row stride in floats. */
+LINR_API int linr_spconv_wgrad_wide2(const float* const* inA_h, const float* const* gA_h, const float* const* inB_h, const float* const* gB_h,
+                                     int32_t h, const int32_t* tile8t, int64_t n, float* slab, void* stream);
 LINR_API int32_t linr_linear_wgrad_wide_blocks(int64_t n);
 LINR_API int linr_wide_reduce_many(const linr_wide_reduce* items_h, int32_t count, void* stream);
 

@@ -82,6 +82,7 @@ _PROTOS = {
                                         ctypes.c_int32, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_uint32, c_ptr]),
     'linr_spconv_wide_pw': (ctypes.c_int, [c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_u32,
                                            ctypes.POINTER(LinrWidePw), c_ptr]),
+    'linr_spconv_wgrad_wide2': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_spconv_wgrad_wide_blocks': (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     'linr_linear_wgrad_wide_blocks': (ctypes.c_int32, [c_i64]),
     'linr_wide_reduce_many': (ctypes.c_int, [ctypes.POINTER(LinrWideReduce), ctypes.c_int32, c_ptr]),

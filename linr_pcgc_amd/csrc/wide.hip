@@ -449,10 +449,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void wide_slab_reduce_k(const float* __
 #define WW_PITCH 288                  // bytes per tap in the LDS image: 8 rows x 32 B + 32 B
 #define WW_TAPS 28                    // 27 taps + the dump slot of the 7th gather's unused lane group
 struct WwArgs {
-    const float* in[WC_MAXB];         // input blocks (zero row at [-8, 0))
-    const float* g[WC_MAXB];          // gradient blocks [n][8]
-    int cw[WC_MAXB];                  // live channels of an input block
-    int nbo;                          // gradient blocks of the convolution (pair p = bi * nbo + bo)
+    const float* in[WC_MAXB];         // the groups' input blocks (zero row at [-8, 0))
+    const float* g[WC_MAXB][WC_MAXB]; // per group: the gradient blocks [n][8] (one convolution: the same for every group)
+    int cw[WC_MAXB];                  // live channels of a group's input block
+    int64_t slab_off[WC_MAXB];        // per group: where its NGB pairs start in a slab row (one convolution: bi * nbo * WW_PAIR)
     float* slab; int64_t block_stride;
 };
 
@@ -467,6 +467,9 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
     float* sacc = reinterpret_cast<float*>(smem);
     const int bi = blockIdx.y;
     const float* in = a.in[bi];
+    const float* gsrc[NGB];
+#pragma unroll
+    for (int b = 0; b < NGB; ++b) gsrc[b] = a.g[bi][b];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane & 1, kk = lane >> 1, k = kk < 27 ? kk : 26;              // MFMA-side role: (tap, quad)
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
         const int4 a0 = *reinterpret_cast<const int4*>(tk + g00 * 32);
         const int4 c0 = *reinterpret_cast<const int4*>(tk + g00 * 32 + 4);
 #pragma unroll
-        for (int b = 0; b < NGB; ++b) gvc[b] = (g00 + gu < n) ? a.g[b][(g00 + gu) * 8 + gc] : 0.0f;
+        for (int b = 0; b < NGB; ++b) gvc[b] = (g00 + gu < n) ? gsrc[b][(g00 + gu) * 8 + gc] : 0.0f;
         const int32_t i0[8] = {a0.x, a0.y, a0.z, a0.w, c0.x, c0.y, c0.z, c0.w};
 #pragma unroll
         for (int j = 0; j < 7; ++j) xg[j] = *reinterpret_cast<const float4*>(ubase + (((uint32_t)i0[j] << 5) + uoff));
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
         ia = *reinterpret_cast<const int4*>(tk + g1r * 32);
         ib = *reinterpret_cast<const int4*>(tk + g1r * 32 + 4);
 #pragma unroll
-        for (int b = 0; b < NGB; ++b) gvn[b] = (g1r + gu < n) ? a.g[b][(g1r + gu) * 8 + gc] : 0.0f;
+        for (int b = 0; b < NGB; ++b) gvn[b] = (g1r + gu < n) ? gsrc[b][(g1r + gu) * 8 + gc] : 0.0f;
     }
     float4 xo[4];                          // rows 4 .. 7 of the previous group (zeros in front of the first: they add +0)
     float gvo[NGB];
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
 #pragma unroll
             for (int b = 0; b < NGB; ++b) {
                 gvc[b] = gvn[b];
-                gvn[b] = (g2r + gu < n) ? a.g[b][(g2r + gu) * 8 + gc] : 0.0f;
+                gvn[b] = (g2r + gu < n) ? gsrc[b][(g2r + gu) * 8 + gc] : 0.0f;
             }
         }
         float4 x[8];
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(WW_WAVES * 64) void wwgrad_k(WwArgs a, const int32_
     }
     const int cinv = a.cw[bi];
     const int per_k = cinv * 8, total = 27 * per_k;
-    float* dst0 = a.slab + (int64_t)blockIdx.x * a.block_stride + (int64_t)bi * a.nbo * WW_PAIR;
+    float* dst0 = a.slab + (int64_t)blockIdx.x * a.block_stride + a.slab_off[bi];
     static_for<NGB>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         __syncthreads();                       // the images (b = 0) or the previous block's fold are done with
@@ -668,9 +671,12 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
     if (tile8t && linr_aligned16(tile8t) && (nbo == 1 || nbo == 2 || nbo == 4)) {
         // one launch: group = input block, all gradient blocks from its one gather
         WwArgs a;
-        for (int i = 0; i < WC_MAXB; ++i) { a.in[i] = in_h[i < nbi ? i : 0]; a.g[i] = g_h[i < nbo ? i : 0]; a.cw[i] = 8; }
+        for (int i = 0; i < WC_MAXB; ++i) {
+            a.in[i] = in_h[i < nbi ? i : 0]; a.cw[i] = 8; a.slab_off[i] = (int64_t)(i < nbi ? i : 0) * nbo * WW_PAIR;
+            for (int b = 0; b < WC_MAXB; ++b) a.g[i][b] = g_h[b < nbo ? b : 0];
+        }
         for (int i = 0; i < nbi; ++i) a.cw[i] = cin - 8 * i < 8 ? cin - 8 * i : 8;
-        a.nbo = nbo; a.slab = slab; a.block_stride = (int64_t)npairs * WW_PAIR;
+        a.slab = slab; a.block_stride = (int64_t)npairs * WW_PAIR;
         // 256 persistent blocks per input block (sweep 128 .. 512 on loot10, profiles/r04_wide.txt: 16 -> 16 86 us at 256, 96 at 384, 108 at 512)
         nblk = 256;
         const dim3 grid(nblk, nbi);
@@ -698,6 +704,35 @@ extern "C" int linr_spconv_wgrad_wide(const float* const* in_h, int32_t cin, con
     if (!gW) return linr_launch_rc();                   // partials only: the caller reduces them with linr_wide_reduce_many
     const int total = 27 * cin * cout + cout;
     wide_slab_reduce_k<<<linr_grid(total, 16), LINR_BLOCK, 0, s>>>(slab, nblk, npairs, cin, cout, gW, gb);
+    return linr_launch_rc();
+}
+
+// Two convolutions of the SAME shape (cin = cout = h in {8, 16}: conv0_1 and conv1_1 of a wide Inception layer, which do not depend on
+// each other) as ONE launch of 2 h / 8 groups: alone, an 8 -> 8 weight gradient is 256 workgroups - one wave per SIMD.  Partials only:
+// a slab row holds convolution A's pairs, then B's (row stride 2 (h / 8)^2 WW_PAIR floats); reduce with linr_wide_reduce_many (kind 0,
+// slab = the row's A or B part, ws_ci = the row stride).
+extern "C" int linr_spconv_wgrad_wide2(const float* const* inA_h, const float* const* gA_h, const float* const* inB_h, const float* const* gB_h,
+                                       int32_t h, const int32_t* tile8t, int64_t n, float* slab, void* stream) {
+    if (n < 1 || (h != 8 && h != 16) || !inA_h || !gA_h || !inB_h || !gB_h || !tile8t || !slab) return LINR_EINVAL;
+    if (!linr_aligned16(tile8t) || (uint64_t)(n + 1) * 32u >= 0xFFFFFFFFull) return LINR_EINVAL;
+    const int nb = h / 8, npairs = nb * nb;
+    WwArgs a;
+    for (int i = 0; i < WC_MAXB; ++i) {
+        const int cv = (i / nb) & 1, bi = i % nb;                    // group i: convolution cv, its input block bi
+        const float* const* in_h = cv ? inB_h : inA_h;
+        const float* const* g_h = cv ? gB_h : gA_h;
+        a.in[i] = in_h[bi]; a.cw[i] = 8;
+        a.slab_off[i] = (int64_t)(cv * npairs + bi * nb) * WW_PAIR;
+        if (!a.in[i]) return LINR_EINVAL;
+        if (!linr_aligned16(a.in[i])) return LINR_EALIGN;
+        for (int b = 0; b < WC_MAXB; ++b) { a.g[i][b] = g_h[b < nb ? b : 0]; if (!a.g[i][b]) return LINR_EINVAL; }
+    }
+    a.slab = slab; a.block_stride = (int64_t)2 * npairs * WW_PAIR;
+    hipStream_t s = (hipStream_t)stream;
+    linr_poison_hook(s, 16);
+    const dim3 grid(256, 2 * nb);
+    if (nb == 1) wwgrad_k<1><<<grid, WW_WAVES * 64, 0, s>>>(a, tile8t, n);
+    else wwgrad_k<2><<<grid, WW_WAVES * 64, 0, s>>>(a, tile8t, n);
     return linr_launch_rc();
 }
 
@@ -905,7 +940,7 @@ __global__ __launch_bounds__(LINR_BLOCK) void wide_reduce_many_k(RdArgs A) {
         int64_t src, stride;
         if (d.kind == 0) {                      // slab of linr_spconv_wgrad_wide (wide_slab_reduce_k's addressing)
             const int nbo = cout / 8, npairs = ((cin + 7) / 8) * nbo;
-            stride = (int64_t)npairs * WW_PAIR;
+            stride = d.ws_ci > 0 ? (int64_t)d.ws_ci : (int64_t)npairs * WW_PAIR;          // ws_ci: the slab's row stride when it is shared
             if (e < 27 * cin * cout) {
                 const int co = e % cout, ci = (e / cout) % cin, k = e / (cout * cin);
                 const int bi = ci / 8, bo = co / 8, cw = cin - 8 * bi < 8 ? cin - 8 * bi : 8;

@@ -236,6 +236,22 @@ def spconv_wgrad_wide(xs, gouts, nbr, tile8t, n, cin, cout, gw=None, gb=None, de
     return gw, gb
 
 
+def spconv_wgrad_wide2(xsA, gsA, gwA, gbA, xsB, gsB, gwB, gbB, tile8t, n, defer):
+    """linr_spconv_wgrad_wide2: the weight gradients of two h -> h convolutions (h = 8 len(xsA)) as one launch; their reductions are
+    appended to `defer` (wide_reduce_many)."""
+    L = _lib.lib()
+    nb = len(xsA)
+    h = 8 * nb
+    stride = 2 * nb * nb * 1736
+    slab = _lib.scratch(256 * stride * 4, xsA[0].device)
+    check(L.linr_spconv_wgrad_wide2(_ptr_array(xsA), _ptr_array(gsA), _ptr_array(xsB), _ptr_array(gsB), h, tile8t.data_ptr(), n,
+                                    slab.data_ptr(), _stream()), 'linr_spconv_wgrad_wide2')
+    for cv, (gw, gb) in enumerate(((gwA, gbA), (gwB, gbB))):
+        assert gw.is_contiguous() and gb.is_contiguous()
+        defer.append((_lib.LinrWideReduce(0, 256, h, h, stride, 0, slab.data_ptr() + 4 * cv * nb * nb * 1736, gw.data_ptr(), gb.data_ptr()),
+                      slab, gw, gb))
+
+
 def wide_reduce_many(deferred):
     """linr_wide_reduce_many: the reductions collected by spconv_wgrad_wide / linear_wgrad_wide(defer=...), 32 per launch."""
     if not deferred:

@@ -97,14 +97,15 @@ class _Conv:
         ops.spconv_wide(xs[:self.nbi], net.lo, net.mask, n, self.mod.kernel, self.mod.bias.reshape(-1), res=res, relu=relu, outs=outs, pw=pw)
         return outs
 
-    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True, res=None, pw=None):
+    def bwd(self, net, xs, gouts, gins=None, act=None, need_input_grad=True, res=None, pw=None, wgrad=True):
         """Parameter gradients into .grad; input gradient (+ res, masked by act > 0: the ReLU that produced xs) accumulated into
         gins (list of (buffer, has_content)) or returned as fresh blocks."""
         n = gouts[0].shape[0]
         # weight gradients: all (input block, gradient block) pairs as groups of grouped launches of the transposing 8-wide kernel, ONE
         # fixed-order reduction straight into the parameter gradients (views of the flat gradient)
-        ops.spconv_wgrad_wide(xs[:self.nbi], gouts[:self.nbo], net.nbr_full, net.tile8t, n, self.ci, self.co,
-                              gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1), defer=_DEFER)
+        if wgrad:
+            ops.spconv_wgrad_wide(xs[:self.nbi], gouts[:self.nbo], net.nbr_full, net.tile8t, n, self.ci, self.co,
+                                  gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1), defer=_DEFER)
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -236,8 +237,14 @@ class _Block:
                 q['c12'].wgrad(t['m'], g_i[nh:])
             else:
                 g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
-            g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'])
-            g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'])
+            # the weight gradients of conv0_1 and conv1_1 (same shape, independent) as ONE launch: alone each is one wave per SIMD
+            pair = fuse and _DEFER is not None and net.tile8t is not None and n > 0
+            g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'], wgrad=not pair)
+            g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'], wgrad=not pair)
+            if pair:
+                c01, c11 = q['c01'].mod, q['c11'].mod
+                ops.spconv_wgrad_wide2(t['h0'], g_i[:nh], c01.kernel.grad, c01.bias.grad.reshape(-1), t['h1'], g_m, c11.kernel.grad,
+                                       c11.bias.grad.reshape(-1), net.tile8t, n, _DEFER)
             # the layer's input gradient: the residual's share g_i rides in conv0_0's backward-data epilogue (+ res), conv1_0's share
             # is added last - and with it, for the block's first layer of a one-layer block, the ReLU mask of a = relu(first conv)
             last_mask = tape['a'] if (nl == 1 and li == nl - 1) else None
