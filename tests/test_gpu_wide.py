@@ -59,7 +59,7 @@ def test_wide_state_dict_has_the_reference_shapes(pkg):
         _model(12)
 
 
-@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (16, 2), (32, 1)])
+@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (16, 2), (32, 1), (32, 3)])
 def test_wide_forward_and_backward_match_the_oracle(pkg, shell, hidden, block_layers):
     model, sd = _model(hidden, block_layers=block_layers)
     frame = model.make_frame(shell['scales'])
@@ -408,7 +408,7 @@ def test_wide_results_do_not_depend_on_leftover_onchip_state(pkg):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (32, 1), (16, 2)])
+@pytest.mark.parametrize('hidden,block_layers', [(16, 1), (32, 1), (16, 2), (32, 3)])
 def test_wide_fused_pointwise_epilogues_equal_the_separate_launches(pkg, hidden, block_layers):
     """conv1_0 / conv1_2 of a wide Inception layer and their backward-data passes in the convolutions' epilogues (linr_spconv_wide_pw)
     keep the fmaf chains of the stand-alone pointwise kernel: two training steps give the same parameters, moments and bits, bit for
