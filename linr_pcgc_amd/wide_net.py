@@ -1,18 +1,21 @@
 """Executor for ``hidden_channel_conv`` = 16 / 32 (main.py:520; models/upsample.py:38-76 ``channels=``, models/resnet.py:12-51
-``channels // 2``): the same network with wider feature rows, run on the library's 8-wide kernels by CHANNEL BLOCKING.
+``channels // 2``): the same network with wider feature rows, on CHANNEL-BLOCKED activations.
 
-Every C-wide activation is kept as C / 8 separate [rows + 1][8] matrices (zero row in front, what the kernels gather from), so
-a convolution Ci -> Co is ONE launch of ``linr_spconv_wide`` (csrc/wide.hip: every input block of a row gathered once per tap, the
-weights of a tap as an A-operand image in LDS, all output channels from that one gather; the same for backward-data at the mirrored
-taps), a pointwise layer is (Ci / 8) x (Co / 8) launches of ``linr_linear_fwd`` on sub-blocks of its weight matrix (addressed through the kernel's weight strides, no copies), weight
-gradients block by block with ``linr_spconv_bwd_weight`` / ``linr_linear_bwd_weight``; concatenations are free.  Only data
-movement is left to torch (slices of the 3x3x3 kernels, the [emb | offsets] input of the scale MLP); every arithmetic
-instruction runs in liblinr_hip.so.  Deterministic (fixed launch order, no atomics); the forward is the same launches in
-training, encoding and stage-by-stage decoding, so streams decode losslessly.
+Every C-wide activation is kept as C / 8 separate [rows + 1][8] matrices (zero row in front, what the kernels gather from).  Every
+layer is ONE launch of a kernel of csrc/wide.hip: a convolution Ci -> Co ``linr_spconv_wide`` (every input block of a row gathered
+once per tap, the weights of a tap as an A-operand image in LDS, all output channels from that one gather; the same for
+backward-data at the mirrored taps; the Inception layer's pointwise convolutions conv1_0 / conv1_2 and their backward-data passes ride
+in its epilogue: ``linr_spconv_wide_pw``), its weight gradient ``linr_spconv_wgrad_wide`` (one gather per input block for all gradient
+blocks; conv0_1 and conv1_1 together: ``linr_spconv_wgrad_wide2``), the pointwise weight gradients ``linr_linear_wgrad_wide``, a stage's
+head ``linr_head_wide_fwd`` and the backward of all 8 heads ``linr_head_wide_bwd``; the scale context (width-independent) runs on the
+8-wide network's kernels (``linr_sce_fwd``, ``linr_sce_bwd_params``).  The ~64 slab reductions of a backward pass are deferred into
+two launches (``linr_wide_reduce_many``).  Concatenations are free; the padded block buffers of a training step come from a pool.
+Deterministic (fixed launch order, no atomics); the forward is the same launches in training, encoding and stage-by-stage decoding,
+so streams decode losslessly.
 
-Partly tuned: ~3.7x the convolution work of the 8-wide network; forward and backward-data convolutions run at ~65 % of the matrix
-cores' rate, the weight gradients block pair by block pair, unfused backward, schedule in Python (profiles/r04_wide.txt).  The 8-wide model
-(every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
+The schedule is Python (~190 launches per step; GPU-bound on the BASELINE-sized frames, launch-bound on small ones): 5.9 / 18.1 ms per
+training step at widths 16 / 32 on the loot-like frame (profiles/r04_wide.txt; ~3.7x / ~14x the convolution work of width 8).  The
+8-wide model (every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
 """
 import os
 
