@@ -72,13 +72,34 @@ def _claim(claim_dir, g, rank):
     return True
 
 
+def mark_alive(work_dir, rank):
+    """Leaves rank<N>_pid (this process's id) in work_dir: wait_all_done() tells a rank that was killed by a signal - it writes
+    neither a done nor a failed marker - from one that is still working by probing that process."""
+    os.makedirs(work_dir, exist_ok=True)
+    tmp = os.path.join(work_dir, 'rank%d_pid.tmp.%d' % (rank, os.getpid()))
+    with open(tmp, 'w') as f:
+        f.write('%d\n' % os.getpid())
+    os.replace(tmp, os.path.join(work_dir, 'rank%d_pid' % rank))
+
+
+def mark_done(work_dir, rank):
+    open(os.path.join(work_dir, 'rank%d_done' % rank), 'w').close()
+
+
+def mark_failed(work_dir, rank):
+    os.makedirs(work_dir, exist_ok=True)
+    open(os.path.join(work_dir, 'rank%d_failed' % rank), 'w').close()
+
+
 def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=None, prepare_fn=None, schedule='static',
-                 prepared=None):
+                 prepared=None, done_marker=True):
     """Drives the two phases.  first_fn(group[, prepared]) -> checkpoint object (GOP 0, rank 0 only);
     other_fn(group, checkpoint[, prepared]) -> result for GOPs >= 1.  prepare_fn(group) (optional) stages a GOP's
     inputs (octrees / kernel maps in HBM) and its return value is handed to first_fn / other_fn as `prepared`; ranks
     >= 1 call it for their first GOP BEFORE the checkpoint exists (phase-A overlap).  `prepared`: {gop index: object}
     already staged by the caller (bench.py stages everything before its timed region).
+    done_marker=False: the caller writes rank<N>_done itself (mark_done) once its own tail - device synchronisation, worker
+    shutdown - has succeeded, and rank<N>_failed (mark_failed) if that tail raises.
     Returns {gop_index: result} of THIS rank.  The checkpoint crosses ranks through
     ``work_dir/<gop_0>/model.pth`` (atomic rename), like the reference.  With `dist` (behind a start-up barrier) or with a single rank,
     rank 0 clears what an earlier run left in work_dir; several ranks without `dist` must be given a fresh directory."""
@@ -97,7 +118,7 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
             # without a barrier between them cannot clean up safely: such callers pass a fresh directory.)
             if os.path.isdir(work_dir):
                 for f in os.listdir(work_dir):
-                    if f.endswith('_failed') or f.endswith('_done'):
+                    if f.endswith('_failed') or f.endswith('_done') or f.endswith('_pid'):
                         os.remove(os.path.join(work_dir, f))
             if os.path.exists(ck_path):
                 os.remove(ck_path)
@@ -107,6 +128,7 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     if dist is not None and world > 1:
         dist.barrier()                                   # start-up only: nothing long-running is pending behind it
     os.makedirs(claim_dir, exist_ok=True)
+    mark_alive(work_dir, rank)                           # behind the barrier: rank 0's clean-up has run
 
     def staged(g):
         if g not in prepared and prepare_fn is not None:
@@ -148,9 +170,10 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
     try:
         _phase_b(schedule, static_mine, first_claim, order, claim_dir, rank, groups, results, load, call, other_fn)
     except BaseException:
-        open(os.path.join(work_dir, 'rank%d_failed' % rank), 'w').close()       # wait_all_done() lets the others skip the final reduce
+        mark_failed(work_dir, rank)                      # wait_all_done() lets the others skip the final reduce
         raise
-    open(os.path.join(work_dir, 'rank%d_done' % rank), 'w').close()
+    if done_marker:
+        mark_done(work_dir, rank)
     return results
 
 
@@ -162,19 +185,48 @@ def check_failures(work_dir):
         raise RuntimeError('ranks failed: %s' % ', '.join(bad))
 
 
-def wait_all_done(work_dir, world, poll_s=0.05, timeout_s=None):
-    """File rendezvous in front of the final reductions: returns once every rank of the job has left its rank<N>_done marker
-    (run_sequence writes it on success), raises as soon as ANY rank<N>_failed marker exists.  check_failures() alone only covers
-    'fail first, check later': a rank that finishes before another one fails would see no marker and wait in the collective for
-    a rank that is gone.  Nothing is pending in a collective while this polls."""
+def _pid_alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:                                                 # a killed child that nobody has reaped yet still answers the probe
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[0] != 'Z'
+    except (OSError, IndexError):
+        return True
+
+
+def wait_all_done(work_dir, world, poll_s=0.05, timeout_s=12 * 3600.0, grace_s=2.0):
+    """File rendezvous in front of the final reductions: returns once every rank of the job has left its rank<N>_done marker,
+    raises as soon as ANY rank<N>_failed marker exists.  check_failures() alone only covers 'fail first, check later': a rank
+    that finishes before another one fails would see no marker and wait in the collective for a rank that is gone.  A rank killed
+    by a signal (GPU fault abort, out-of-memory kill) writes no marker at all: its rank<N>_pid file (mark_alive) names the
+    process, and when that process is gone - and still no marker after `grace_s` - the wait raises instead of polling for ever.
+    `timeout_s` bounds the wait whatever happens (default: the 12 h of the collectives' own watchdog).  Nothing is pending in a
+    collective while this polls."""
     t0 = time.time()
+    gone_since = {}
     while True:
         check_failures(work_dir)
-        if all(os.path.exists(os.path.join(work_dir, 'rank%d_done' % r)) for r in range(world)):
+        missing = [r for r in range(world) if not os.path.exists(os.path.join(work_dir, 'rank%d_done' % r))]
+        if not missing:
             return
-        if timeout_s is not None and time.time() - t0 > timeout_s:
-            raise RuntimeError('ranks still running after %.0f s: %s' % (timeout_s, ', '.join(
-                str(r) for r in range(world) if not os.path.exists(os.path.join(work_dir, 'rank%d_done' % r)))))
+        now = time.time()
+        for r in missing:
+            try:
+                with open(os.path.join(work_dir, 'rank%d_pid' % r)) as f:
+                    pid = int(f.read().strip())
+            except (OSError, ValueError):
+                continue                                 # not started yet (or an external launcher without pid files)
+            if _pid_alive(pid):
+                gone_since.pop(r, None)
+            elif now - gone_since.setdefault(r, now) > grace_s:
+                raise RuntimeError('rank %d (process %d) is gone without a done or failed marker: killed by a signal?' % (r, pid))
+        if timeout_s is not None and now - t0 > timeout_s:
+            raise RuntimeError('ranks still running after %.0f s: %s' % (timeout_s, ', '.join(str(r) for r in missing)))
         time.sleep(poll_s)
 
 

@@ -231,16 +231,22 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
     if dist is not None:
         dist.barrier()
     t0 = time.time()
+    work_dir = os.path.join(args.out, 'output')
     try:
-        results = gop_parallel.run_sequence(groups, os.path.join(args.out, 'output'), first_fn, other_fn, rank, world, dist,
-                                            prepare_fn=stage, schedule=schedule, prepared=prepared)
-    finally:
-        if ahead is not None:
-            ahead['pool'].shutdown(wait=True)
-    torch.cuda.synchronize()
+        try:
+            results = gop_parallel.run_sequence(groups, work_dir, first_fn, other_fn, rank, world, dist,
+                                                prepare_fn=stage, schedule=schedule, prepared=prepared, done_marker=False)
+        finally:
+            if ahead is not None:
+                ahead['pool'].shutdown(wait=True)
+        torch.cuda.synchronize()                 # an asynchronous GPU error of the last GOP surfaces here ...
+    except BaseException:
+        gop_parallel.mark_failed(work_dir, rank)         # ... and releases the other ranks from wait_all_done
+        raise
+    gop_parallel.mark_done(work_dir, rank)       # only now: this rank will reach the final reductions
     my_wall = time.time() - t0
     # every rank has finished (its done marker) or one has failed (its marker: raise here, outside any collective)
-    gop_parallel.wait_all_done(os.path.join(args.out, 'output'), world)
+    gop_parallel.wait_all_done(work_dir, world)
     wall = gop_parallel.max_over_ranks(my_wall, dist, 'cuda')
     # phase A = rank 0's GOP 0; phase B = the rest of the wall.  Phase-B efficiency = busy GPU-seconds of the GOPs >= 1
     # over (ranks x phase-B wall): what SURVEY.md section 8e asks to be reported next to the whole-sequence wall.

@@ -211,3 +211,46 @@ def test_wait_all_done_rendezvous(tmp_path):
     threading.Timer(0.2, lambda: open(os.path.join(work, 'rank3_failed'), 'w').close()).start()
     with pytest.raises(RuntimeError, match='rank3_failed'):
         gp.wait_all_done(work, 4, poll_s=0.01, timeout_s=10)     # ... and fails late: the waiting ranks raise, nobody hangs
+
+
+def _doomed_rank(work, started):
+    """A rank that registers, starts working and is killed by a signal: no done marker, no failed marker."""
+    import time
+    gp.mark_alive(work, 1)
+    started.set()
+    time.sleep(60)
+
+
+def test_wait_all_done_notices_a_rank_killed_by_a_signal(tmp_path):
+    """a SIGKILLed rank (GPU-fault abort, out-of-memory kill) runs no `except` block and leaves no marker; the
+    survivors must not poll for ever.  wait_all_done probes the process named in rank<N>_pid and raises once it is gone."""
+    import signal
+    import time
+    work = str(tmp_path / 'work')
+    os.makedirs(work)
+    ctx = mp.get_context('spawn')
+    started = ctx.Event()
+    p = ctx.Process(target=_doomed_rank, args=(work, started))
+    p.start()
+    assert started.wait(60)
+    gp.mark_alive(work, 0)
+    gp.mark_done(work, 0)
+    with pytest.raises(RuntimeError, match='still running'):      # alive and working: only the bound ends the wait
+        gp.wait_all_done(work, 2, poll_s=0.01, timeout_s=0.3, grace_s=0.1)
+    os.kill(p.pid, signal.SIGKILL)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='rank 1 .* is gone'):
+        gp.wait_all_done(work, 2, poll_s=0.01, timeout_s=60, grace_s=0.2)     # (the unreaped child is a zombie: counted as gone)
+    assert time.time() - t0 < 10
+    p.join()
+    assert gp.wait_all_done.__defaults__[1] is not None           # the default wait is bounded
+
+
+def test_done_marker_is_the_callers_when_asked(tmp_path):
+    """run.py writes rank<N>_done itself, after its device synchronisation: run_sequence(done_marker=False) leaves only the pid file."""
+    work = str(tmp_path / 'work')
+    groups = gp.split_gops(8, 4)
+    gp.run_sequence(groups, work, lambda g: {'result': 0}, lambda g, ck: 1, done_marker=False)
+    assert os.path.exists(os.path.join(work, 'rank0_pid')) and not os.path.exists(os.path.join(work, 'rank0_done'))
+    gp.mark_done(work, 0)
+    gp.wait_all_done(work, 1, timeout_s=5)
