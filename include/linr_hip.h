@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 9
+#define LINR_ABI_VERSION 10
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -261,11 +261,15 @@ LINR_API int linr_spconv_bwd_fused(const float* gout, const float* in, const int
  *   6 both 4->4 convs forward                     7 shared occupancy conv               8 head backward
  *   9 first-conv / stand-alone weight gradients  10 pointwise weight gradients         11 scale context (forward, backward)
  *  12 sums, reduction, Adam                      13 stand-alone backward-data convolutions (schedules without the fused backward)
+ * and of the bf16 training executor (linr_net_train_step_bf16; 14..16 are poison-only classes, see linr_debug_poison):
+ *  17 fused backward 8->8 (bbwd_k<0>)            18 fused backward of the two 4->4 convs 19 fused backward of conv0_0 8->4
+ *  20 forward convolutions (bconv_k)             21 head backward                       22 first-conv weight gradients
+ *  23 scale context forward, sums, conversions, Adam
  * linr_prof_mask selects the classes that are recorded (default: 0 and 1; an event pair costs a few microseconds of stream
  * time).  linr_prof_read waits for the recorded events and returns their summed elapsed time, the number of launches and the
  * number of row passes (a grouped launch over g layers counts g).  mode 1 = clear the records and start, 2 = resume,
  * 0 = stop (records are kept).  Mutex-guarded; 4096 launches in total. */
-#define LINR_PROF_KINDS 14
+#define LINR_PROF_KINDS 24
 LINR_API int linr_prof_mask(uint32_t mask);
 /* Test hook (tests/test_gpu_parity.py::test_results_do_not_depend_on_leftover_onchip_state): every launch of
  * linr_net_forward / _backward / _train_step whose kernel class (the list above) has its bit set in kind_mask is preceded by a kernel that fills the LDS of every CU with 0xFFFFFFFF (a NaN
@@ -384,6 +388,40 @@ LINR_API size_t linr_net_bf16_arena_bytes(int64_t rows, int32_t block_layers);
 LINR_API int linr_net_forward_bf16(const linr_frame* f, const uint8_t* codes, float min_param, float max_param, void* arena,
                           size_t arena_bytes, int32_t stage_begin, int32_t stage_end, float* probs, double* bits_acc,
                           void* stream);
+
+/* ---- bf16 training executor (BASELINE config[4]: "bf16 SparseConv"; beside the fp32 step above, never instead of it) --
+ * The overfit iteration of main.py:305-321 - forward of models/model_core.py:38-81 / models/upsample.py:88-97,137-217 /
+ * models/resnet.py:12-60, the autograd backward of main.py:315-316, Adam of main.py:231-237,319 - with bf16 feature AND gradient
+ * rows ([1 + rows][8], 16-byte rows: one gather per tap), fp32 master parameters (`params`, updated by Adam in fp32), fp32
+ * accumulation.  ONE rounding rule: every matrix written to memory is rounded to bf16 (RNE) and every consumer sees the stored
+ * value; the 3x3x3 kernels are rounded to bf16 inside the kernels; biases, 1x1 convolutions, scale-context and head MLPs, sigmoid
+ * and the bits are fp32 (bits accumulate in double).  oracle/network_bf16.py emulates these roundings with autograd; tolerances
+ * are in tests/test_gpu_bf16_train.py.  block_layers 1 and the compressed kernel map only.
+ * arena: linr_net_train_bf16_arena_bytes(rows, 1) bytes, 64-byte aligned, shared by the calls of one step.
+ * occ_bf16: NULL, or the frame's occupancy converted once by linr_occ_to_bf16 ([1 + rows][8] bf16, zero row in front; the
+ * pointer passed is that of the ZERO row) - a frame's occupancy does not change over the epochs.
+ * linr_net_forward_train_bf16: teacher-forced forward of all 8 stages, every activation the backward needs kept in the arena;
+ *   probs [8][rows] stage-major or NULL; bits_acc double[1] (accumulated into) or NULL.
+ * linr_net_backward_bf16: gradient of gscale * bits, ADDED into grads (fp32, linr_param_count floats); needs the forward above on
+ *   the same arena.
+ * linr_net_train_step_bf16: forward + backward + fixed-order reduction + Adam, arguments as linr_net_train_step. */
+LINR_API size_t linr_net_train_bf16_arena_bytes(int64_t rows, int32_t block_layers);
+LINR_API int linr_occ_to_bf16(const float* occ, int64_t rows, uint16_t* out_padded, void* stream);
+LINR_API int linr_net_forward_train_bf16(const linr_frame* f, const float* params, void* arena, size_t arena_bytes,
+                                const uint16_t* occ_bf16, float* probs, double* bits_acc, void* stream);
+LINR_API int linr_net_backward_bf16(const linr_frame* f, const float* params, void* arena, size_t arena_bytes,
+                           const uint16_t* occ_bf16, float gscale, float* grads, void* stream);
+LINR_API int linr_net_train_step_bf16(const linr_frame* f, float* params, void* arena, size_t arena_bytes, const uint16_t* occ_bf16,
+                             float gscale, float* exp_avg, float* exp_avg_sq, double lr, int64_t step,
+                             const int64_t* scale_steps_h, double beta1, double beta2, double eps, double weight_decay,
+                             double* bits_acc, void* stream);
+/* The backward of ONE convolution 8->8 of that executor as a stand-alone op (ME.MinkowskiConvolution's backward, models/resnet.py:15-51
+ * under autograd): gin = bwd-data(gout; W) rounded to bf16 AND the kernel / bias gradient from one gather of gout.  gout / in / gin:
+ * bf16 [n][8] whose row -1 exists (gout's must be zero); W fp32 [27][8][8] (rounded to bf16 in-kernel for backward-data);
+ * slab: [nblocks][1736] floats = per-block partials [kernel 1728 | bias 8]; *rows_written of its rows are written (sum them). */
+LINR_API int linr_spconv_bwd_fused_bf16(const uint16_t* gout, const uint16_t* in, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                               int64_t n, const float* W, uint16_t* gin, float* slab, int32_t nblocks, int32_t* rows_written,
+                               void* stream);
 
 /* Staged DECODE of one frame object (decoder.decode_one_frame, decoder.py:153-176 + CNP.decode, models/upsample.py:249-295) as
  * ONE call: for stage k = 0..7 { linr_net_forward[_bf16](k, k+1); probabilities of the stage -> pinned host buffer; the range

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -122,6 +122,13 @@ _PROTOS = {
     'linr_net_bf16_arena_bytes': (c_size, [c_i64, c_i32]),
     'linr_net_forward_bf16': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_f32, c_f32, c_ptr, c_size, c_i32, c_i32, c_ptr,
                                              c_ptr, c_ptr]),
+    'linr_net_train_bf16_arena_bytes': (c_size, [c_i64, c_i32]),
+    'linr_occ_to_bf16': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    'linr_net_forward_train_bf16': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'linr_net_backward_bf16': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_ptr, c_f32, c_ptr, c_ptr]),
+    'linr_net_train_step_bf16': (ctypes.c_int, [ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_size, c_ptr, c_f32, c_ptr, c_ptr, c_f64,
+                                                c_i64, c_ptr, c_f64, c_f64, c_f64, c_f64, c_ptr, c_ptr]),
+    'linr_spconv_bwd_fused_bf16': (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr]),
     'linr_sce_fwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_sce_bwd': (ctypes.c_int, [c_ptr, ctypes.POINTER(LinrFrame), c_ptr, c_ptr, c_ptr, c_ptr]),
     'linr_sce_param_count': (ctypes.c_int64, [ctypes.c_int32]),
@@ -186,7 +193,7 @@ class _Poisoned:
 
     def __init__(self, handle):
         self._h = handle
-        handle.linr_debug_poison(0x1FFFF)
+        handle.linr_debug_poison(0xFFFFFF)
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)

@@ -9,6 +9,8 @@
 #include "common.h"
 #include "conv_common.h"
 #include "layout.h"
+#include "sce.h"
+#include "net_shared.h"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -102,84 +104,6 @@ extern "C" size_t linr_net_arena_bytes(int64_t rows, int32_t block_layers) {
     make_layout(L, MAX_SCALES, block_layers);                 // sized for the largest scale_num: one arena serves any model of this depth
     make_arena(a, rows, nullptr, L.total, block_layers);
     return (size_t)a.cur * sizeof(float) + 64;
-}
-
-struct PadList { int64_t off[200]; int w[200]; int n; };
-
-// Scale context of all scales in one launch (model_core.py:48-53): x0[r] = W2 relu(W1 [emb | offset_feat[r]] + b1) + b2 with
-// the weights of r's scale: fmaf chains with the bias first and the inputs ascending, like linear_k<15,16> + linear_k<16,8> on
-// [emb | offset_feat | 0].  HID is kept for the backward pass (sce_bwd_all_k); the op-level entry also returns the MLP input.
-// A workgroup never straddles two scales (blk_off: first workgroup of every scale), so the scale - and with it every weight
-// address - is uniform: the weights come through the scalar cache into SGPRs (s_load + v_fmac with an SGPR operand) instead of
-// ~400 broadcast vector loads per row (46.8 -> ~12 us for the forward kernel at 337 k rows, 18.9 -> ~9 for the backward one).
-struct SceArgs {
-    int64_t row_off[MAX_SCALES + 1];
-    int64_t emb[MAX_SCALES], w1[MAX_SCALES], b1[MAX_SCALES], w2[MAX_SCALES], b2[MAX_SCALES];   // parameter offsets per scale
-    int blk_off[MAX_SCALES + 1];
-    int wg_off[MAX_SCALES + 1];          // sce_bwd_all_k: first workgroup of every scale (= its slab rows in front)
-    int n_scales;
-};
-
-// scale of workgroup b and the row of this thread (-1: none)
-__device__ __forceinline__ int64_t sce_row_of(const SceArgs& a, int b, int& s) {
-    s = 0;
-    for (int i = 1; i < a.n_scales; ++i) s += (b >= a.blk_off[i]) ? 1 : 0;
-    const int64_t r = a.row_off[s] + (int64_t)(b - a.blk_off[s]) * LINR_BLOCK + threadIdx.x;
-    return r < a.row_off[s + 1] ? r : -1;
-}
-
-// The blocks behind the last row block clear the arena's pad rows (PadList; one pad per 32 threads): the first kernel that reads
-// a pad row comes after this one on the stream.
-__global__ __launch_bounds__(LINR_BLOCK) void sce_fwd_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
-                                                        int64_t n, float* __restrict__ mix, float* __restrict__ hid,
-                                                        float* __restrict__ x0, float* __restrict__ pad_base, PadList pl) {
-    const int row_blocks = a.blk_off[a.n_scales];
-    if ((int)blockIdx.x >= row_blocks) {
-        const int b = ((int)blockIdx.x - row_blocks) * (LINR_BLOCK / 32) + (int)(threadIdx.x >> 5), t = threadIdx.x & 31;
-        if (b < pl.n && t < pl.w[b]) pad_base[pl.off[b] + t] = 0.0f;
-        return;
-    }
-    int s;
-    const int64_t r = sce_row_of(a, (int)blockIdx.x, s);
-    if (r < 0) return;
-    const float* emb = P + a.emb[s];
-    const float* W1 = P + a.w1[s];
-    const float* b1 = P + a.b1[s];
-    const float* W2 = P + a.w2[s];
-    const float* b2 = P + a.b2[s];
-    float x[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = emb[i];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) x[8 + i] = off[r * 7 + i];
-    x[15] = 0.0f;
-    if (mix) {                                 // only the op-level entry wants the MLP input back (uniform)
-        float4* mp = reinterpret_cast<float4*>(mix + r * 16);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) mp[v] = make_float4(x[4 * v], x[4 * v + 1], x[4 * v + 2], x[4 * v + 3]);
-    }
-    float h[16];
-#pragma unroll
-    for (int o = 0; o < 16; ++o) h[o] = b1[o];
-#pragma unroll
-    for (int i = 0; i < 15; ++i)
-#pragma unroll
-        for (int o = 0; o < 16; ++o) h[o] = fmaf(x[i], W1[o * 15 + i], h[o]);
-#pragma unroll
-    for (int o = 0; o < 16; ++o) h[o] = fmaxf(h[o], 0.0f);
-    float4* hp = reinterpret_cast<float4*>(hid + r * 16);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) hp[v] = make_float4(h[4 * v], h[4 * v + 1], h[4 * v + 2], h[4 * v + 3]);
-    float y[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) y[o] = b2[o];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int o = 0; o < 8; ++o) y[o] = fmaf(h[i], W2[o * 16 + i], y[o]);
-    float4* yp = reinterpret_cast<float4*>(x0 + r * 8);
-    yp[0] = make_float4(y[0], y[1], y[2], y[3]);
-    yp[1] = make_float4(y[4], y[5], y[6], y[7]);
 }
 
 // ghid[r] = (W2^T gx0[r]) * (hid[r] > 0)     (linear_k<8,16> with the ReLU mask, weights of r's scale)
@@ -471,6 +395,7 @@ static int wg_blocks_for(int64_t rows) {
     if (forced >= 32 && forced <= LINR_WG_BLOCKS && forced % 32 == 0) return forced;
     return rows >= 100000 ? 256 : 128;
 }
+int linr_wg_blocks_for(int64_t rows) { return wg_blocks_for(rows); }
 
 // ---- live kernel timing for bench.py's roofline (include/linr_hip.h: linr_prof_*) --------------------------------------
 // While enabled, the launches of a training step are bracketed by an event pair on their stream, by kernel class (the list is
@@ -549,6 +474,9 @@ struct ProfScope {
         g_prof[kind].push_back(r);
     }
 };
+
+LinrProf::LinrProf(hipStream_t s, int kind, int passes) : impl(new ProfScope(s, kind, passes)) {}
+LinrProf::~LinrProf() { delete static_cast<ProfScope*>(impl); }
 
 extern "C" int linr_prof_mask(uint32_t mask) { g_prof_mask = mask; return 0; }
 
@@ -908,7 +836,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
         {   // scale context: one small MLP per scale (model_core.py:48-53), all scales in one launch; its spare blocks clear the pad rows
             ProfScope ps(c.s, PK_SCE, 1);
             const SceArgs sa = sce_args(c);
-            sce_fwd_k<<<sa.blk_off[sa.n_scales] + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
+            sce_fwd_k<float><<<sa.blk_off[sa.n_scales] + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
                 P, f->offset_feat, sa, c.R, nullptr, a.HID, a.X0, a.base, pl);
         }
         if (all_grouped && join_block_in(c)) {
@@ -973,7 +901,7 @@ extern "C" int linr_sce_fwd(const float* params, const linr_frame* f, float* mix
     if ((mix && !linr_aligned16(mix)) || !linr_aligned16(hid) || !linr_aligned16(x0)) return LINR_EALIGN;
     c.f = f;
     const SceArgs sa = sce_args(c);
-    sce_fwd_k<<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sa, f->rows, mix, hid, x0, nullptr,
+    sce_fwd_k<float><<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, (hipStream_t)stream>>>(params, f->offset_feat, sa, f->rows, mix, hid, x0, nullptr,
                                                                               PadList{{}, {}, 0});
     return linr_launch_rc();
 }
@@ -1272,6 +1200,65 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
     return 0;
 }
 
+// The tail of every backward pass (fp32 executor: backward_core below; bf16 training executor: csrc/train_bf16.hip): the scale
+// context's backward from gx0 [rows][8] fp32 and the hid [rows][16] its forward kept (ghid and all four parameter gradients of every
+// scale's context MLP in one launch), the fixed-order reduction of the [nb][total] slab `big` into gsum - `sh` lists the parameter
+// ranges whose producers wrote fewer than nb slab rows - and the scale-embedding gradients derived from the reduced sums.
+int linr_bwd_tail_launch(const linr_frame* f, const Layout& L, const float* P, const float* gx0, const float* hid, float* big,
+                         float* gsum, int nb, const LinrShortRange* sh, int nsh, hipStream_t stream) {
+    Ctx c;
+    c.f = f; c.L = L; c.s = stream; c.nb = nb;
+    for (int i = 0; i < nsh; ++i) c.note_short(sh[i].b, sh[i].e, sh[i].rows);
+    int ns = 0, sl[MAX_SCALES];
+    for (int s = 0; s < f->n_scales; ++s)
+        if (f->row_off_h[s + 1] > f->row_off_h[s]) sl[ns++] = s;
+    if (ns >= 1) {          // ghid and all four parameter gradients of every scale's context MLP in one launch
+        ProfScope ps(c.s, PK_SCE, 1);
+        SceArgs sa = sce_args(c);
+        // slab rows per scale: one workgroup per 256 rows, at most nb; a scale with fewer leaves a short range for the reduction
+        sa.wg_off[0] = 0;
+        for (int j = 0; j < f->n_scales; ++j) {
+            const int64_t nj = f->row_off_h[j + 1] - f->row_off_h[j];
+            int64_t wg = nj > 0 ? (nj + LINR_BLOCK - 1) / LINR_BLOCK : 0;
+            if (wg > c.nb) wg = c.nb;
+            sa.wg_off[j + 1] = sa.wg_off[j] + (int)wg;
+            if (wg > 0) {
+                const int si = f->scale_idx_h[j];
+                c.note_short(c.L.m0_w[si], c.L.m2_b[si] + 8, (int)wg);
+            }
+        }
+        sce_bwd_all_k<<<sa.wg_off[f->n_scales], SB_WAVES * 64, 0, c.s>>>(P, f->offset_feat, sa, gx0, hid, big, c.L.total);
+    }
+    // one pass sums every parameter's per-block partials in fixed order
+    ProfScope ps_tail(c.s, PK_MISC, 0);
+    {   // the scale embedding and the context MLPs of absent scales get no partials: the reduction writes their zeros itself
+        ZeroRanges zr;
+        zr.n = 0; zr.prefix = c.L.block_in.a_w;
+        zr.b[zr.n] = c.L.emb; zr.e[zr.n] = c.L.emb + (int64_t)c.L.S * 8; ++zr.n;
+        bool present[MAX_SCALES] = {};
+        for (int j = 0; j < ns; ++j) present[f->scale_idx_h[sl[j]]] = true;
+        for (int si = 0; si < c.L.S; ++si)
+            if (!present[si]) {
+                zr.b[zr.n] = c.L.m0_w[si];
+                zr.e[zr.n] = si + 1 < c.L.S ? c.L.m0_w[si + 1] : c.L.block_in.a_w;
+                ++zr.n;
+            }
+        ShortRanges sr;
+        sr.n = (int)c.shortr.size();
+        for (int i = 0; i < sr.n; ++i) { sr.b[i] = c.shortr[i].b; sr.e[i] = c.shortr[i].e; sr.rows[i] = c.shortr[i].rows; }
+        wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(big, c.nb, c.L.total, gsum, zr, sr);
+    }
+    if (ns > 0) {
+        EmbArgs ea;
+        for (int j = 0; j < ns; ++j) {
+            const int si = f->scale_idx_h[sl[j]];
+            ea.gb1[j] = c.L.m0_b[si]; ea.w1[j] = c.L.m0_w[si]; ea.gemb[j] = c.L.emb + si * 8;
+        }
+        sce_emb_grad_all_k<<<ns, LINR_WAVE, 0, c.s>>>(P, gsum, ea);
+    }
+    return linr_launch_rc();
+}
+
 // backward of gscale * bits: leaves the parameter gradient of THIS call in arena GSUM (flat, parameters() order)
 static int backward_core(Ctx& c, float gscale) {
     const linr_frame* f = c.f;
@@ -1315,55 +1302,9 @@ static int backward_core(Ctx& c, float gscale) {
     } else {
         TRY(block_bwd(c, c.L.block_in, a.X0, 8, 0, a.gXG, a.gX0));
     }
-    // scale context: all non-empty scales as one launch per layer when they fit one grouped launch
-    int ns = 0, sl[MAX_SCALES];
-    for (int s = 0; s < f->n_scales; ++s)
-        if (f->row_off_h[s + 1] > f->row_off_h[s]) sl[ns++] = s;
-    if (ns >= 1) {          // ghid and all four parameter gradients of every scale's context MLP in one launch
-        ProfScope ps(c.s, PK_SCE, 1);
-        SceArgs sa = sce_args(c);
-        // slab rows per scale: one workgroup per 256 rows, at most nb; a scale with fewer leaves a short range for the reduction
-        sa.wg_off[0] = 0;
-        for (int j = 0; j < f->n_scales; ++j) {
-            const int64_t nj = f->row_off_h[j + 1] - f->row_off_h[j];
-            int64_t wg = nj > 0 ? (nj + LINR_BLOCK - 1) / LINR_BLOCK : 0;
-            if (wg > c.nb) wg = c.nb;
-            sa.wg_off[j + 1] = sa.wg_off[j] + (int)wg;
-            if (wg > 0) {
-                const int si = f->scale_idx_h[j];
-                c.note_short(c.L.m0_w[si], c.L.m2_b[si] + 8, (int)wg);
-            }
-        }
-        sce_bwd_all_k<<<sa.wg_off[f->n_scales], SB_WAVES * 64, 0, c.s>>>(P, f->offset_feat, sa, a.gX0, a.HID, a.BIG, c.L.total);
-    }
-    // one pass sums every parameter's per-block partials in fixed order
-    ProfScope ps_tail(c.s, PK_MISC, 0);
-    {   // the scale embedding and the context MLPs of absent scales get no partials: the reduction writes their zeros itself
-        ZeroRanges zr;
-        zr.n = 0; zr.prefix = c.L.block_in.a_w;
-        zr.b[zr.n] = c.L.emb; zr.e[zr.n] = c.L.emb + (int64_t)c.L.S * 8; ++zr.n;
-        bool present[MAX_SCALES] = {};
-        for (int j = 0; j < ns; ++j) present[f->scale_idx_h[sl[j]]] = true;
-        for (int si = 0; si < c.L.S; ++si)
-            if (!present[si]) {
-                zr.b[zr.n] = c.L.m0_w[si];
-                zr.e[zr.n] = si + 1 < c.L.S ? c.L.m0_w[si + 1] : c.L.block_in.a_w;
-                ++zr.n;
-            }
-        ShortRanges sr;
-        sr.n = (int)c.shortr.size();
-        for (int i = 0; i < sr.n; ++i) { sr.b[i] = c.shortr[i].b; sr.e[i] = c.shortr[i].e; sr.rows[i] = c.shortr[i].rows; }
-        wgrad_reduce_k<<<linr_grid(c.L.total, LINR_BLOCK / RED_SPLIT), LINR_BLOCK, 0, c.s>>>(a.BIG, c.nb, c.L.total, a.GSUM, zr, sr);
-    }
-    if (ns > 0) {
-        EmbArgs ea;
-        for (int j = 0; j < ns; ++j) {
-            const int si = f->scale_idx_h[sl[j]];
-            ea.gb1[j] = c.L.m0_b[si]; ea.w1[j] = c.L.m0_w[si]; ea.gemb[j] = c.L.emb + si * 8;
-        }
-        sce_emb_grad_all_k<<<ns, LINR_WAVE, 0, c.s>>>(P, a.GSUM, ea);
-    }
-    return linr_launch_rc();
+    std::vector<LinrShortRange> sh(c.shortr.size());
+    for (size_t i = 0; i < sh.size(); ++i) sh[i] = {c.shortr[i].b, c.shortr[i].e, c.shortr[i].rows};
+    return linr_bwd_tail_launch(f, c.L, P, a.gX0, a.HID, a.BIG, a.GSUM, c.nb, sh.data(), (int)sh.size(), c.s);
 }
 
 extern "C" int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes, float gscale,
@@ -1412,6 +1353,29 @@ extern "C" int linr_net_decode_stages(const linr_frame* f, const float* params, 
     return linr_hip_rc(hipStreamSynchronize(s));       // s_pinned / p_pinned may be reused by the caller right away
 }
 
+// torch.optim.Adam's step over the flat parameter buffer with the per-scale step counters of the scale-context MLPs (shared with
+// csrc/train_bf16.hip): bias corrections in double, like torch.optim.Adam's Python scalars
+int linr_adam_step_launch(const Layout& L, float* params, const float* gsum, float* exp_avg, float* exp_avg_sq, double lr, int64_t step,
+                          const int64_t* scale_steps_h, double beta1, double beta2, double eps, double weight_decay, hipStream_t s) {
+    LinrAdamRanges rg;
+    rg.count = 0; rg.begin = L.m0_w[0]; rg.len = L.S > 1 ? L.m0_w[1] - L.m0_w[0] : L.block_in.a_w - L.m0_w[0];
+    if (scale_steps_h) {
+        rg.count = L.S;
+        // scale_steps_h[s] = updates applied to the context MLP of scale s INCLUDING this one; 0 = it has never had a gradient and
+        // is skipped (torch.optim.Adam skips .grad None; torch 1.13's zero_grad() leaves zeros afterwards, so a started scale is
+        // updated on every step - with the zero gradient the reduction writes for a scale this frame lacks)
+        for (int sc = 0; sc < L.S; ++sc) {
+            const int64_t t = scale_steps_h[sc];
+            rg.active[sc] = t >= 1 ? 1 : 0;
+            rg.step_size[sc] = t >= 1 ? (float)(lr / (1.0 - pow(beta1, (double)t))) : 0.0f;
+            rg.bc2_sqrt[sc] = t >= 1 ? (float)sqrt(1.0 - pow(beta2, (double)t)) : 1.0f;
+        }
+    }
+    return linr_adam_launch(params, gsum, exp_avg, exp_avg_sq, L.total, lr / (1.0 - pow(beta1, (double)step)),
+                            sqrt(1.0 - pow(beta2, (double)step)), beta1, beta2, eps, weight_decay,
+                            scale_steps_h ? &rg : nullptr, s);
+}
+
 extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* arena, size_t arena_bytes, float gscale,
                                    float* exp_avg, float* exp_avg_sq, double lr, int64_t step, const int64_t* scale_steps_h,
                                    double beta1, double beta2, double eps, double weight_decay, double* bits_acc,
@@ -1429,23 +1393,6 @@ extern "C" int linr_net_train_step(const linr_frame* f, float* params, float* ar
     c.s = (hipStream_t)stream;
     if (c.R == 0) return 0;
     TRY(backward_core(c, gscale));
-    // bias corrections in double, like torch.optim.Adam's Python scalars
-    LinrAdamRanges rg;
-    rg.count = 0; rg.begin = c.L.m0_w[0]; rg.len = c.L.S > 1 ? c.L.m0_w[1] - c.L.m0_w[0] : c.L.block_in.a_w - c.L.m0_w[0];
-    if (scale_steps_h) {
-        rg.count = c.L.S;
-        // scale_steps_h[s] = updates applied to the context MLP of scale s INCLUDING this one; 0 = it has never had a gradient and
-        // is skipped (torch.optim.Adam skips .grad None; torch 1.13's zero_grad() leaves zeros afterwards, so a started scale is
-        // updated on every step - with the zero gradient the reduction writes for a scale this frame lacks)
-        for (int s = 0; s < c.L.S; ++s) {
-            const int64_t t = scale_steps_h[s];
-            rg.active[s] = t >= 1 ? 1 : 0;
-            rg.step_size[s] = t >= 1 ? (float)(lr / (1.0 - pow(beta1, (double)t))) : 0.0f;
-            rg.bc2_sqrt[s] = t >= 1 ? (float)sqrt(1.0 - pow(beta2, (double)t)) : 1.0f;
-        }
-    }
     ProfScope ps(c.s, PK_MISC, 0);
-    return linr_adam_launch(params, c.A.GSUM, exp_avg, exp_avg_sq, c.L.total, lr / (1.0 - pow(beta1, (double)step)),
-                            sqrt(1.0 - pow(beta2, (double)step)), beta1, beta2, eps, weight_decay,
-                            scale_steps_h ? &rg : nullptr, c.s);
+    return linr_adam_step_launch(c.L, params, c.A.GSUM, exp_avg, exp_avg_sq, lr, step, scale_steps_h, beta1, beta2, eps, weight_decay, c.s);
 }

@@ -1,0 +1,973 @@
+// bf16 training executor (BASELINE config[4]: "bf16 SparseConv"): the overfit step of main.py:305-321 with bf16 feature and
+// gradient rows, fp32 master weights and fp32 accumulation - beside the fp32 executor of csrc/net.hip, never instead of it.
+//
+// Replaces, like csrc/net.hip: LINR_PCGC_Model.logic_core / forward (models/model_core.py:38-81), CNP.forward
+// (models/upsample.py:163-217), make_block (:88-97), InceptionResNet.forward (models/resnet.py:12-60) and the autograd graph that
+// main.py:315-316 differentiates; the optimiser step (main.py:231-237,319) runs on the fp32 master parameters.
+//
+// Numerics - ONE rule: every matrix that is written to memory is rounded to bf16 (RNE) and every consumer, also one fused into the
+// producing kernel, sees the STORED value.  Stored forward: x_low, A, H, M, I, O / x_glob, the prune convolutions' outputs C;
+// stored backward: gC, gO, the fan-in sum of x_glob's gradient, gI, gM, gH, gA, gx_low.  The 3x3x3 kernels are rounded to bf16
+// inside the kernels from the fp32 master; biases, the 1x1 convolutions, the scale-context MLP, the head MLP, sigmoid and the
+// bits are fp32 arithmetic on fp32 parameters; every product is accumulated in fp32; weight gradients are fp32 sums of products
+// of stored (bf16) rows; probabilities and bits are fp32 / fp64.  oracle/network_bf16.py (train_forward_backward) emulates
+// exactly these roundings with autograd.
+//
+// Layout: feature / gradient matrices are bf16 [1 + rows][8] (16-byte rows, an all-zero row in front: absent neighbours gather
+// it) - ONE dwordx4 gather per tap where the fp32 executor needs two.
+//
+// Kernels:
+//   forward    bconv_k<MODE, 1, true> (csrc/bf16_common.h): lane = output row, v_mfma_f32_4x4x4_16b_bf16 with the weight block
+//              broadcast (CBSZ = 4): 64 rows x 4 cout x 4 cin per instruction, a quarter of the fp32 path's matrix instructions
+//   backward   bbwd_k<KIND>: backward-data AND weight gradient of a convolution from ONE gather of the output gradient (the
+//              re-indexing of csrc/fused_bwd.hip: gW[k] = sum_i in[i]^T g[nbr(i, 26 - k)]).  Backward-data is the forward kernel
+//              at the mirrored taps.  For the weight gradient the ROWS are the K dimension of v_mfma_f32_4x4x4_16b_bf16 (four rows
+//              per instruction, 16 independent 4 x 4 blocks = (tap, input quad, output quad) combos, no padding, no broadcast):
+//              the gathered rows are parked in a wave-private LDS image [tap slot][row][16 B] as they arrive (one ds_write_b128
+//              per tap) and read back TRANSPOSED by ds_read_b64_tr_b16 - lane (block, j) receives channel j of four consecutive
+//              rows - as are the rows' own inputs.  220 matrix instructions per 64-row tile for a convolution 8->8 (fp32: 880),
+//              ~170 registers and 10 KB of LDS per wave: two to three waves per SIMD hide the gather latency that the fp32 kernel,
+//              at one wave per SIMD, has to software-pipeline around.
+#include "bf16_common.h"
+#include "sce.h"
+#include "net_shared.h"
+#include <stdlib.h>
+#include <vector>
+
+#define TRY(e) do { int rc_ = (e); if (rc_) return rc_; } while (0)
+
+// profiling / poison classes of this executor (include/linr_hip.h: linr_prof_*)
+enum { TK_BWD88 = 17, TK_BWD_DUAL = 18, TK_BWD_C00 = 19, TK_FWD = 20, TK_HEAD_BWD = 21, TK_FIRST_WGRAD = 22, TK_MISC = 23 };
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// transposed LDS read (ds_read_b64_tr_b16): per 16-lane group, lane 4 q + p supplies the address of an 8-byte piece (q, p); lane
+// 4 p + j of the group receives element j of the pieces (0, p) .. (3, p) - four rows of one 16-bit column
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+}
+
+// ---- fused backward: backward-data + weight gradient from one gather ----------------------------------------------------------------
+#define BB_WAVES 4
+#define BB_SLOT 1088                    // bytes of one image slot: 64 rows x 16 B + 64 (consecutive slots start 16 banks apart)
+#define TB_NO_BWD 1u                    // weight gradient only (first convolutions of the outter blocks: their input is data)
+#define TB_OUT_F32 2u                   // input gradient stored as fp32 [n][8] (rounded to bf16 first): gx_low for the scale context
+#define TB_MAXG 8
+//   KIND 0  conv 8->8 (prune convolutions, tail convolutions, first convolutions): g [n][8] gathered whole, own rows = its input
+//   KIND 1  the two 4->4 convolutions of an Inception layer: gathers G2 = [gI[:, 0:4] | gM], own rows H (also the ReLU mask)
+//   KIND 2  conv0_0 8->4: gathers gH[:, 0:4] (8 bytes per tap), own rows A (also the mask); conv1_0 (1x1) rides along
+//   EPI 3 (KIND 0, tail convolution): also gM = (gI[:, 4:8] @ W12^T) * (M > 0), G2 = [gI[:, 0:4] | gM]; conv1_2's gradients ride along
+struct BbArgs {
+    const bf16_t* g;  const bf16_t* xin;  const float* P;
+    bf16_t* out;  float* out_f32;
+    const bf16_t* m;  bf16_t* g2;  const bf16_t* res;
+    const int32_t* lo;  const uint32_t* mask;  int64_t ld, n;
+    int tiles_per_wave;
+    float* big;  int64_t block_stride;
+    unsigned flags;
+    int64_t g_g[TB_MAXG], g_x[TB_MAXG], g_out[TB_MAXG], g_m[TB_MAXG], g_g2[TB_MAXG], g_res[TB_MAXG];     // element offsets per group
+    int64_t w[TB_MAXG], b[TB_MAXG];            // parameter (= slab) offsets: the kernel / bias (KIND 1: conv0_1)
+    int64_t w1[TB_MAXG], b1[TB_MAXG];          // KIND 1: conv1_1
+    int64_t wp[TB_MAXG], bp[TB_MAXG];          // EPI 3: conv1_2;  KIND 2: conv1_0
+    int cin[TB_MAXG];                          // KIND 0: input channels of the kernel [27][cin][8]
+};
+
+template <int KIND> struct BbT {
+    static constexpr int CT = KIND == 0 ? 4 : 8;                // taps per chunk = taps per weight-gradient instruction
+    static constexpr int SL = KIND == 1 ? 8 : 4;                // image slots per chunk
+    static constexpr int NCH = (27 + CT - 1) / CT;              // chunks per tile: 7 / 4 / 4
+    static constexpr int WAVE_BYTES = BB_SLOT * (1 + 2 * SL);   // own rows + two chunk buffers
+    static constexpr int NW = KIND == 0 ? 108 : 54;             // backward-data weight blocks
+};
+
+template <int KIND, int EPI>
+__global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
+    using T = BbT<KIND>;
+    constexpr int CT = T::CT, SL = T::SL, NCH = T::NCH, NG = (T::NW + 15) / 16;
+    __shared__ uint4 smem[BB_WAVES * T::WAVE_BYTES / 16];
+    __shared__ float sbias[BB_WAVES][8];
+    __shared__ float s12[BB_WAVES][20];
+    const int gi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bf16_t* gbase = a.g + a.g_g[gi];
+    const bf16_t* xin = a.xin + a.g_x[gi];
+    const float* P = a.P;
+    // ---- backward-data weight blocks: block (lane >> 2) of wv[r] is combo c = 16 r + block; lane i = lane & 3 holds A[i][0..3] ------
+    //   KIND 0: c = 4 k + 2 h + q -> W[k][4 h + i][4 q + kk]     (produced = input channel 4 h + i, gathered = output channel 4 q + kk)
+    //   KIND 1: c = 2 k + t       -> (t ? W11 : W01)[k][i][kk]
+    //   KIND 2: c = 2 k + h       -> W00[k][4 h + i][kk]
+    s16x4 wv[NG];
+    if (!(a.flags & TB_NO_BWD)) {
+        const int blk = lane >> 2, i = lane & 3;
+        float raw[NG][4];
+        bool ok[NG];
+#pragma unroll
+        for (int r = 0; r < NG; ++r) {
+            const int c = 16 * r + blk;
+            const int k0 = KIND == 0 ? c / 4 : c / 2, k = k0 < 27 ? k0 : 26;
+            ok[r] = k0 < 27;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                int64_t idx;
+                if constexpr (KIND == 0) idx = a.w[gi] + ((int64_t)k * 8 + 4 * ((c >> 1) & 1) + i) * 8 + 4 * (c & 1) + kk;
+                else if constexpr (KIND == 1) idx = ((c & 1) ? a.w1[gi] : a.w[gi]) + ((int64_t)k * 4 + i) * 4 + kk;
+                else idx = a.w[gi] + ((int64_t)k * 8 + 4 * (c & 1) + i) * 4 + kk;
+                raw[r][kk] = P[idx];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NG; ++r) {
+            s16x4 v;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = ok[r] ? (short)f2bf(raw[r][kk]) : (short)0;
+            wv[r] = v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NG; ++r) wv[r] = (s16x4){0, 0, 0, 0};
+    }
+    // ---- the lane's roles in the transposed reads: group tg = lane >> 4, piece row tq = (lane >> 2) & 3, piece column tp = lane & 3 ---
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    char* img = reinterpret_cast<char*>(smem) + wave * T::WAVE_BYTES;
+    char* ximgW = img + lane * 16;
+    const char* ximgR = img + tq * 16 + 8 * (tp & 1);                       // own rows: channel quad tp & 1
+    char* bufW = img + BB_SLOT + lane * 16;
+    // gathered rows: KIND 0: slot tg (tap 4 c + tg), channel quad tp >> 1; KIND 1: slot 2 tg + (tp >> 1), quad tp & 1 (the
+    // convolution); KIND 2: slot tg holds the tap PAIR 2 tg, 2 tg + 1 as the two halves of a 16-byte row: half tp >> 1
+    const char* bufR = img + BB_SLOT + (KIND == 1 ? (2 * tg + (tp >> 1)) * BB_SLOT + 8 * (tp & 1) : tg * BB_SLOT + 8 * (tp >> 1)) + tq * 16;
+    f32x4 wacc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) wacc[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
+    float g12[20];                                                            // EPI 3: conv1_2's kernel [4][4] and bias gradients
+#pragma unroll
+    for (int j = 0; j < 20; ++j) g12[j] = 0.0f;
+    float wpw[32];                                                            // EPI 3: W12 [4][4];  KIND 2: W10 [8][4]
+#pragma unroll
+    for (int j = 0; j < 32; ++j) wpw[j] = 0.0f;
+    if constexpr (EPI == 3) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wpw[j] = P[a.wp[gi] + j];
+    }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wpw[j] = P[a.wp[gi] + j];
+    }
+    const int64_t n = a.n;
+    const int64_t T64 = (n + 63) >> 6;
+    const int64_t tb0 = (int64_t)blockIdx.x * (BB_WAVES * a.tiles_per_wave);
+    const int64_t tb1 = (tb0 + BB_WAVES * a.tiles_per_wave < T64) ? tb0 + BB_WAVES * a.tiles_per_wave : T64;
+    const char* pad = reinterpret_cast<const char*>(gbase - 8);
+    constexpr int PF = 6;
+    typedef typename std::conditional<KIND == 2, uint2, uint4>::type XR;
+    for (int64_t tile = tb0 + wave; tile < tb1; tile += BB_WAVES) {
+        const int64_t row_raw = (tile << 6) + lane;
+        const bool live = row_raw < n;
+        const int64_t row = live ? row_raw : n - 1;                          // every lane stays in the matrix instructions (they ignore EXEC)
+        uint32_t off[27];
+        {   // mirrored taps: off[k] pairs with W[k] (backward-data gathers nbr(row, 26 - k))
+            uint32_t fo[27];
+            decode_offsets16(a.lo, a.mask, a.ld, row, fo);
+#pragma unroll
+            for (int k = 0; k < 27; ++k) off[k] = fo[26 - k];
+        }
+        // own row (dead lanes: zeros, so that nothing of them reaches a weight gradient) -> LDS, then the 16 A operands of the tile
+        uint4 xr = make_uint4(0u, 0u, 0u, 0u);
+        if (live) xr = *reinterpret_cast<const uint4*>(xin + row * 8);
+        // own-row operands of the epilogue
+        uint4 e_res = make_uint4(0u, 0u, 0u, 0u), e_gh = e_res;
+        uint2 e_m = make_uint2(0u, 0u);
+        if constexpr (EPI == 3) e_m = *reinterpret_cast<const uint2*>(a.m + a.g_m[gi] + row * 4);
+        if constexpr (KIND == 2) {
+            e_res = *reinterpret_cast<const uint4*>(a.res + a.g_res[gi] + row * 8);
+            e_gh = *reinterpret_cast<const uint4*>(gbase + row * 8);
+        }
+        XR x[PF + 1];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
+        *reinterpret_cast<uint4*>(ximgW) = xr;
+        s16x4 av[16];
+#pragma unroll
+        for (int rq = 0; rq < 16; ++rq) av[rq] = tr_read(ximgR + rq * 64);
+        f32x4 acc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+        sfor<27>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;                          // step; k = LINR_TAP(kk) the tap it handles
+            constexpr int k = LINR_TAP(kk);
+            constexpr int ch = kk / CT, s = kk % CT;
+            if constexpr (kk + PF < 27) x[(kk + PF) % (PF + 1)] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(kk + PF)]);
+            const XR xk = x[kk % (PF + 1)];
+            if (!(a.flags & TB_NO_BWD)) {
+                if constexpr (KIND == 0) {
+                    const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
+                    const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
+                    constexpr int c0 = 4 * k;
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 2) / 16], q0, acc[1], 4, (c0 + 2) % 16, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[0], 4, (c0 + 1) % 16, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 3) / 16], q1, acc[1], 4, (c0 + 3) % 16, 0);
+                } else if constexpr (KIND == 1) {
+                    const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
+                    const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
+                    constexpr int c0 = 2 * k;
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[1], 4, (c0 + 1) % 16, 0);
+                } else {
+                    const s16x4 q0 = __builtin_bit_cast(s16x4, xk);
+                    constexpr int c0 = 2 * k;
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q0, acc[1], 4, (c0 + 1) % 16, 0);
+                }
+            }
+            if constexpr (KIND == 2 && kk == 24) {
+                // conv1_0 (1x1, 8 -> 4) rides along: its weight gradient sum_rows A[row]^T gH[row][4:8] is what the idle pseudo-tap 27
+                // of the last chunk computes when its half-slot holds the rows' OWN gH[:, 4:8] (written here, behind the reads of
+                // chunk 1, which shares the buffer)
+                uint2 own = make_uint2(0u, 0u);
+                if (live) own = make_uint2(e_gh.z, e_gh.w);
+                *reinterpret_cast<uint2*>(bufW + (((NCH - 1) & 1) * SL + 1) * BB_SLOT + 8) = own;
+            }
+            // park the gathered row in the chunk's image
+            if constexpr (KIND == 2) *reinterpret_cast<uint2*>(bufW + ((ch & 1) * SL + (s >> 1)) * BB_SLOT + 8 * (s & 1)) = xk;
+            else *reinterpret_cast<uint4*>(bufW + ((ch & 1) * SL + s) * BB_SLOT) = xk;
+            if constexpr (k == 13) {                                          // the centre tap is the row's own gradient: bias gradient
+                if (live) {
+                    if constexpr (KIND == 2) {
+                        bsum[0] += bf2f((bf16_t)(xk.x & 0xffff)); bsum[1] += bf2f((bf16_t)(xk.x >> 16));
+                        bsum[2] += bf2f((bf16_t)(xk.y & 0xffff)); bsum[3] += bf2f((bf16_t)(xk.y >> 16));
+                    } else {
+                        float t[8];
+                        unpack_row(xk, t);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[j] += t[j];
+                    }
+                }
+            }
+            if constexpr (s == CT - 1 || kk == 26) {
+                // the chunk is complete: its weight gradient, four rows per instruction
+#pragma unroll
+                for (int rq = 0; rq < 16; ++rq) {
+                    const s16x4 bv = tr_read(bufR + (ch & 1) * SL * BB_SLOT + rq * 64);
+                    wacc[ch] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv, wacc[ch], 0, 0, 0);
+                }
+            }
+        });
+        // ---- epilogue: the row's input gradient, rounded to bf16; everything derived from it uses the rounded value -------------------
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = acc[0][j]; o[4 + j] = acc[1][j]; }
+        if constexpr (KIND == 1) {                // gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)
+            float hv[8];
+            unpack_row(xr, hv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = hv[j] > 0.0f ? o[j] : 0.0f;
+        }
+        if constexpr (KIND == 2) {                // gA = (bwd(gH[:, 0:4]; W00) + gI + gH[:, 4:8] @ W10^T) * (A > 0)
+            float rv[8], gh[8], av8[8];
+            unpack_row(e_res, rv);
+            unpack_row(e_gh, gh);
+            unpack_row(xr, av8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += rv[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t = fmaf(gh[4 + q], wpw[i * 4 + q], t);
+                o[i] += t;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = av8[j] > 0.0f ? o[j] : 0.0f;
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bsum[4 + q] += gh[4 + q];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bf2f(f2bf(o[j]));
+        if (live && !(a.flags & TB_NO_BWD)) {
+            if (a.flags & TB_OUT_F32) {
+                float* op = a.out_f32 + row * 8;
+                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+                *reinterpret_cast<uint4*>(a.out + a.g_out[gi] + row * 8) = pack_row(o);
+            }
+            if constexpr (EPI == 3) {             // gM = (gI[:, 4:8] @ W12^T) * (M > 0);  G2 = [gI[:, 0:4] | gM]
+                const float mv[4] = {bf2f((bf16_t)(e_m.x & 0xffff)), bf2f((bf16_t)(e_m.x >> 16)), bf2f((bf16_t)(e_m.y & 0xffff)),
+                                     bf2f((bf16_t)(e_m.y >> 16))};
+                float g2[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g2[j] = o[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t = fmaf(o[4 + q], wpw[i * 4 + q], t);
+                    g2[4 + i] = mv[i] > 0.0f ? t : 0.0f;
+                }
+                *reinterpret_cast<uint4*>(a.g2 + a.g_g2[gi] + row * 8) = pack_row(g2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g12[i * 4 + q] = fmaf(mv[i], o[4 + q], g12[i * 4 + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g12[16 + q] += o[4 + q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- fold: the four waves' partial sums of every element in wave order, one slab row per block ------------------------------------
+    float* sacc = reinterpret_cast<float*>(smem);                            // [wave][NCH * 4][64]
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sacc[((wave * NCH + c) * 4 + i) * 64 + lane] = wacc[c][i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = bsum[j];
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_xor(t, dd, 64);
+        if (lane == 0) sbias[wave][j] = t;
+    }
+    if constexpr (EPI == 3) {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            float t = g12[j];
+#pragma unroll
+            for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_xor(t, dd, 64);
+            if (lane == 0) s12[wave][j] = t;
+        }
+    }
+    __syncthreads();
+    float* dst = a.big + (int64_t)blockIdx.x * a.block_stride;
+    const int tid = threadIdx.x;
+    const int cinv = KIND == 0 ? a.cin[gi] : 8;
+    constexpr int per_tap = KIND == 0 ? 64 : 32;                             // kernel elements per tap (KIND 1: both convolutions)
+    constexpr int nsteps = KIND == 2 ? 28 : 27;                              // KIND 2: pseudo-step 27 = conv1_0
+    for (int e = tid; e < nsteps * per_tap; e += BB_WAVES * 64) {
+        const int kk = e / per_tap, r = e % per_tap;                         // step kk handled tap k (common.h: LINR_TAP)
+        const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+        const int c = kk / CT, s = kk % CT;
+        int L, i;
+        int64_t dofs;
+        bool valid = true;
+        if constexpr (KIND == 0) {          // r = ci * 8 + co: group s, block (ci / 4) | (co / 4) << 1, lane co % 4, register ci % 4
+            const int ci = r >> 3, co = r & 7;
+            L = 16 * s + 4 * ((ci >> 2) | ((co >> 2) << 1)) + (co & 3); i = ci & 3;
+            valid = ci < cinv;
+            dofs = a.w[gi] + ((int64_t)k * cinv + ci) * 8 + co;
+        } else if constexpr (KIND == 1) {   // r = conv * 16 + ci * 4 + co: group s / 2, block conv | (s % 2) << 1, lane co, register ci
+            const int cv = r >> 4, ci = (r >> 2) & 3, co = r & 3;
+            L = 16 * (s >> 1) + 4 * (cv | ((s & 1) << 1)) + co; i = ci;
+            dofs = (cv ? a.w1[gi] : a.w[gi]) + (int64_t)k * 16 + (r & 15);
+        } else {                            // r = ci * 4 + co: group s / 2, block (ci / 4) | (s % 2) << 1, lane co, register ci % 4
+            const int ci = r >> 2, co = r & 3;
+            L = 16 * (s >> 1) + 4 * ((ci >> 2) | ((s & 1) << 1)) + co; i = ci & 3;
+            dofs = kk < 27 ? a.w[gi] + (int64_t)k * 32 + r : a.wp[gi] + r;  // conv1_0.kernel [8][4]
+        }
+        if (!valid) continue;
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < BB_WAVES; ++w) t += sacc[((w * NCH + c) * 4 + i) * 64 + L];
+        dst[dofs] = t;
+    }
+    if (tid < 8) {
+        const float t = ((sbias[0][tid] + sbias[1][tid]) + sbias[2][tid]) + sbias[3][tid];
+        if constexpr (KIND == 0) dst[a.b[gi] + tid] = t;
+        else if constexpr (KIND == 1) dst[(tid < 4 ? a.b[gi] : a.b1[gi]) + (tid & 3)] = t;
+        else dst[(tid < 4 ? a.b[gi] : a.bp[gi]) + (tid & 3)] = t;
+    }
+    if constexpr (EPI == 3) {
+        if (tid < 20) {
+            const float t = ((s12[0][tid] + s12[1][tid]) + s12[2][tid]) + s12[3][tid];
+            dst[tid < 16 ? a.wp[gi] + tid : a.bp[gi] + (tid - 16)] = t;
+        }
+    }
+}
+
+static int tb_cus() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    return v;
+}
+// one round of long-lived blocks: about 2 x CUs / groups blocks per group (two blocks are resident per CU), never more than nb
+static void tb_grid(int64_t n, int nb, int ngroups, int& tiles_per_wave, int& blocks) {
+    const int64_t t64 = (n + 63) >> 6;
+    int64_t target = 2 * tb_cus() / (ngroups < 1 ? 1 : ngroups);
+    if (target < 1) target = 1;
+    if (target > nb) target = nb;
+    int64_t m = (t64 + BB_WAVES * target - 1) / (BB_WAVES * target);
+    if (m < 1) m = 1;
+    tiles_per_wave = (int)m;
+    blocks = (int)((t64 + BB_WAVES * m - 1) / (BB_WAVES * m));
+    if (blocks < 1) blocks = 1;
+}
+
+// ---- backward of the occupancy heads (csrc/fused.hip: head_bwd_k with bf16 rows in and out) ---------------------------------------------
+// Per row: recompute the hidden layer from the STORED C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]) -> bf16; the weight
+// gradients gW1 = sum_r gh[r] (x) c[r], gb1, gw2, gb2 in fp32 (v_mfma_f32_4x4x1 for the per-row MLP, v_mfma_f32_16x16x4_f32 for
+// X^T G through a wave-private LDS tile) - the MLP is fp32 arithmetic in this executor, only its input and output rows are bf16.
+#define THB_LDW 33
+struct THeadArgs {
+    const bf16_t* c;  const float* p;  const float* target;  int target_ld;
+    const float* P;  float gscale;  bf16_t* gc;  int64_t n;
+    float* big;  int64_t block_stride;
+    int64_t g_c[8], g_p[8], g_t[8], g_gc[8];
+    int64_t w1[8], b1[8], w2[8], b2[8];
+};
+
+__global__ __launch_bounds__(LINR_BLOCK, 4) void thead_bwd_k(THeadArgs A) {
+    const int gi = blockIdx.y;
+    const bf16_t* Cm = A.c + A.g_c[gi];
+    const float* Pp = A.p + A.g_p[gi];
+    const float* Tg = A.target + A.g_t[gi];
+    bf16_t* GC = A.gc + A.g_gc[gi];
+    const float* W1 = A.P + A.w1[gi];
+    const float* B1 = A.P + A.b1[gi];
+    const float* W2 = A.P + A.w2[gi];
+    const int64_t n = A.n;
+    __shared__ float sT[(LINR_BLOCK / 64) * 64 * THB_LDW];
+    __shared__ float sfold[64 * 9];
+    __shared__ float sw2[(LINR_BLOCK / 64) * 25];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mm = lane & 15, rr = lane >> 4;
+    float wA[4], wB[3], wC;
+    {
+        const int blk = lane >> 2, j = lane & 3;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int cb = 16 * v + blk;
+            wA[v] = cb < 48 ? W1[(4 * (cb % 6) + j) * 8 + cb / 6] : (cb < 54 ? B1[4 * (cb - 48) + j] : 0.0f);
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int cb = 16 * v + blk;
+            wB[v] = W1[(cb / 2) * 8 + 4 * (cb % 2) + j];
+        }
+        wC = blk < 6 ? W2[4 * blk + j] : 0.0f;
+    }
+    float* T = sT + wave * 64 * THB_LDW;
+    f32x4 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float gw2[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) gw2[j] = 0.0f;
+    float gz_sum = 0.0f;
+    const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t row = t * LINR_BLOCK + threadIdx.x;
+        const bool live = row < n;
+        float c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = 0.0f;
+        float gz = 0.0f;
+        if (live) {
+            unpack_row(*reinterpret_cast<const uint4*>(Cm + row * 8), c);
+            const float pp = Pp[row], tt = Tg[row * A.target_ld];
+            const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
+            gz = gp * ((1.0f - pp) * pp);
+        }
+        f32x4 hp[6];
+        sfor<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
+        });
+        sfor<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            sfor<6>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                constexpr int cb = 6 * i + hq;
+                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
+            });
+        });
+        float gh[24];
+        sfor<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            const f32x4 g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wC, gz, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hv = hp[hq][j];
+                gh[4 * hq + j] = (live && hv > 0.0f) ? g4[j] : 0.0f;
+                gw2[4 * hq + j] = fmaf(gz, fmaxf(hv, 0.0f), gw2[4 * hq + j]);
+            }
+        });
+        f32x4 gcq[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+        sfor<24>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            sfor<2>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int cb = 2 * jj + q;
+                gcq[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wB[cb / 16], gh[jj], gcq[q], 4, cb % 16, 0);
+            });
+        });
+        if (live) {
+            const float o[8] = {gcq[0][0], gcq[0][1], gcq[0][2], gcq[0][3], gcq[1][0], gcq[1][1], gcq[1][2], gcq[1][3]};
+            *reinterpret_cast<uint4*>(GC + row * 8) = pack_row(o);
+        }
+        gz_sum += gz;
+        float* Tr = T + lane * THB_LDW;
+#pragma unroll
+        for (int j = 0; j < 24; ++j) Tr[j] = gh[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Tr[24 + i] = c[i];
+        Tr[32] = live ? 1.0f : 0.0f;
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const float* Tq = T + (4 * s4 + rr) * THB_LDW;
+            const float b = (mm < 9) ? Tq[24 + mm] : 0.0f;
+            const float a0 = Tq[mm];
+            const float a1 = (mm < 8) ? Tq[16 + mm] : 0.0f;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
+        }
+    }
+    float* mine = sfold + lane * 9;
+    for (int w = 0; w < LINR_BLOCK / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[q * 4 + j] = (w == 0) ? acc[q][j] : mine[q * 4 + j] + acc[q][j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) gw2[j] += __shfl_xor(gw2[j], d, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 24; ++j) sw2[wave * 25 + j] = gw2[j];
+        sw2[wave * 25 + 24] = gz_sum;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = A.big + (int64_t)blockIdx.x * A.block_stride;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = 16 * q + rr * 4 + j;
+                const float v = mine[q * 4 + j];
+                if (m < 24) {
+                    if (mm < 8) dst[A.w1[gi] + m * 8 + mm] = v;
+                    else if (mm == 8) dst[A.b1[gi] + m] = v;
+                }
+            }
+        if (lane < 25) {
+            const float v = ((sw2[lane] + sw2[25 + lane]) + sw2[50 + lane]) + sw2[75 + lane];
+            if (lane < 24) dst[A.w2[gi] + lane] = v;
+            else dst[A.b2[gi]] = v;
+        }
+    }
+}
+
+// x_glob's gradient: the fan-in of the eight priors (models/upsample.py:206-214 under autograd), summed in fp32 in the order of the
+// fp32 executor's sum8_k, stored once as bf16
+struct TPtr8 { const bf16_t* p[8]; };
+__global__ __launch_bounds__(LINR_BLOCK) void tsum8_k(TPtr8 src, int64_t n, bf16_t* __restrict__ dst) {
+    const int64_t r = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    float t[8], u[8];
+    unpack_row(*reinterpret_cast<const uint4*>(src.p[7] + r * 8), t);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) {
+        unpack_row(*reinterpret_cast<const uint4*>(src.p[k] + r * 8), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = t[j] + u[j];
+    }
+    *reinterpret_cast<uint4*>(dst + r * 8) = pack_row(t);
+}
+
+// ---- arena --------------------------------------------------------------------------------------------------------------------------
+struct TArena {
+    int64_t rows;
+    char* base;
+    int64_t cur;                     // bytes
+    float *HID, *gX0, *PR, *GSUM, *BIG;
+    double* part;
+    bf16_t *X0, *OCC, *A[8], *H[8], *I[8], *O[8], *C[8], *M[8];
+    bf16_t *gC[8], *gO[8], *gXG, *gI[8], *G2[8], *gH[8], *gA[8];
+    BPads pads;
+    bf16_t* mats;
+    int64_t n_params;
+};
+
+static void* tbytes(TArena& a, int64_t nbytes) {
+    void* p = a.base ? a.base + a.cur : nullptr;
+    a.cur += (nbytes + 63) & ~(int64_t)63;
+    return p;
+}
+static bf16_t* tmat(TArena& a, int w = 8) {          // [1 + rows][w] with the zero row in front
+    bf16_t* p = a.base ? reinterpret_cast<bf16_t*>(a.base + a.cur) : nullptr;
+    if (a.pads.n >= BPADS_MAX) abort();                  // (99 matrices today)
+    a.pads.off[a.pads.n] = (a.cur - (int64_t)(reinterpret_cast<char*>(a.mats) - a.base)) / 2;
+    a.pads.w[a.pads.n++] = w;
+    a.cur += (((a.rows + 1) * w * 2) + 63) & ~(int64_t)63;
+    return p ? p + w : nullptr;
+}
+
+static void make_tarena(TArena& a, int64_t rows, char* base, int64_t n_params, bool own_occ) {
+    a.rows = rows; a.base = base; a.cur = 0; a.pads.n = 0; a.n_params = n_params;
+    a.HID = (float*)tbytes(a, rows * 16 * 4);
+    a.gX0 = (float*)tbytes(a, rows * 8 * 4);
+    a.PR = (float*)tbytes(a, rows * 8 * 4);
+    a.part = (double*)tbytes(a, (int64_t)8 * linr_grid(rows, LINR_BLOCK) * 8);
+    a.GSUM = (float*)tbytes(a, n_params * 4);
+    a.BIG = (float*)tbytes(a, (int64_t)LINR_WG_BLOCKS * n_params * 4);
+    a.mats = reinterpret_cast<bf16_t*>(base + a.cur);
+    a.X0 = tmat(a);
+    a.OCC = own_occ ? tmat(a) : nullptr;
+    for (int b = 0; b < 8; ++b) { a.A[b] = tmat(a); a.H[b] = tmat(a); a.I[b] = tmat(a); a.O[b] = tmat(a); a.M[b] = tmat(a, 4); }
+    for (int k = 0; k < 8; ++k) { a.C[k] = tmat(a); a.gC[k] = tmat(a); a.gO[k] = tmat(a); }
+    a.gXG = tmat(a);
+    for (int b = 0; b < 8; ++b) { a.gI[b] = tmat(a); a.G2[b] = tmat(a); a.gH[b] = tmat(a); a.gA[b] = tmat(a); }
+}
+
+extern "C" size_t linr_net_train_bf16_arena_bytes(int64_t rows, int32_t block_layers) {
+    if (rows < 0 || block_layers > 1) return 0;                  // block_layers 1 only (every BASELINE config)
+    Layout L;
+    make_layout(L, MAX_SCALES, 1);
+    TArena a;
+    make_tarena(a, rows, nullptr, L.total, true);
+    return (size_t)a.cur + 64;
+}
+
+// occupancy fp32 [rows][8] -> bf16 [1 + rows][8] with the zero row in front (out points at the pad row): a frame's occupancy does
+// not change over the epochs, so a caller can convert it once and hand it to every step (occ_bf16 of the entries below)
+extern "C" int linr_occ_to_bf16(const float* occ, int64_t rows, uint16_t* out_padded, void* stream) {
+    if (rows < 0) return LINR_EINVAL;
+    if (!out_padded) return LINR_EINVAL;
+    if ((((uintptr_t)out_padded) & 15u) || (occ && !linr_aligned16(occ))) return LINR_EALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    BPads pl;
+    pl.n = 1; pl.off[0] = 0; pl.w[0] = 8;
+    zero_pads16_k<<<1, 64, 0, s>>>(out_padded, pl);
+    if (rows > 0) {
+        if (!occ) return LINR_EINVAL;
+        occ_bf16_k<<<linr_grid(rows, LINR_BLOCK), LINR_BLOCK, 0, s>>>(occ, rows, out_padded + 8);
+    }
+    return linr_launch_rc();
+}
+
+// ---- executor -------------------------------------------------------------------------------------------------------------------------
+struct TCtx {
+    const linr_frame* f;
+    Layout L;
+    TArena A;
+    const float* P;
+    const bf16_t* OCC;               // bf16 occupancy rows (zero row in front): the caller's copy or the arena's
+    hipStream_t s;
+    int64_t R;
+    int nb;
+    std::vector<LinrShortRange> shortr;
+    void note_short(int64_t b, int64_t e, int rows) { if (rows < nb) shortr.push_back({b, e, rows}); }
+};
+
+static int tcheck(const linr_frame* f, const float* params, void* arena, size_t arena_bytes, const uint16_t* occ_bf16, TCtx& c) {
+    if (!f || !params || !arena) return LINR_EINVAL;
+    if (f->rows < 0 || f->n_scales < 1 || f->n_scales > MAX_SCALES || !f->row_off_h || !f->scale_idx_h) return LINR_EINVAL;
+    if (f->block_layers > 1) return LINR_EINVAL;                // block_layers 1 only
+    if (!make_layout(c.L, f->model_scale_num, 1)) return LINR_EINVAL;
+    if (f->row_off_h[0] != 0 || f->row_off_h[f->n_scales] != f->rows) return LINR_EINVAL;
+    for (int s = 0; s < f->n_scales; ++s) {
+        if (f->row_off_h[s + 1] < f->row_off_h[s]) return LINR_EINVAL;
+        if (f->scale_idx_h[s] < 0 || f->scale_idx_h[s] >= f->model_scale_num) return LINR_EINVAL;
+    }
+    if (f->rows > 0 && (!f->nbr_lo || !f->nbr_mask || !f->offset_feat || !f->occ || f->nbr_ld < f->rows)) return LINR_EINVAL;   // compressed map only
+    if (f->rows >= ((int64_t)1 << 27) - 1) return LINR_EINVAL;                    // 32-bit byte offsets of the 16-byte gathers
+    if (arena_bytes < linr_net_train_bf16_arena_bytes(f->rows, 1)) return LINR_ENOSPC;
+    if (((uintptr_t)arena) & 63u) return LINR_EALIGN;
+    if (occ_bf16 && (((uintptr_t)occ_bf16) & 15u)) return LINR_EALIGN;
+    c.f = f; c.P = params; c.R = f->rows;
+    c.nb = linr_wg_blocks_for(f->rows);
+    make_tarena(c.A, f->rows, (char*)arena, c.L.total, true);
+    c.OCC = occ_bf16 ? reinterpret_cast<const bf16_t*>(occ_bf16) + 8 : c.A.OCC;
+    return 0;
+}
+
+static BArgs tbase(const TCtx& c) {
+    BArgs a = BArgs();
+    a.lo = c.f->nbr_lo; a.mask = c.f->nbr_mask; a.ld = c.f->nbr_ld; a.n = c.R;
+    a.codes = nullptr; a.minv = 0.0f; a.range = 0.0f; a.pf = c.P;
+    for (int g = 0; g < BMAXG; ++g) a.cin[g] = 8;
+    return a;
+}
+
+template <int MODE>
+static int tlaunch(const TCtx& c, const BArgs& a, int groups) {
+    LinrProf ps(c.s, TK_FWD, groups);
+    bconv_k<MODE, 1, true><<<dim3(linr_grid(c.R, LINR_BLOCK), groups), LINR_BLOCK, 0, c.s>>>(a);
+    return linr_launch_rc();
+}
+
+// conv3 cin->8 (+ res) (ReLU) over `groups` layers; ptrs[g] are the groups' matrices (offsets are taken against ptrs[0])
+static int tconv(const TCtx& c, const bf16_t* const* in, bf16_t* const* out, const bf16_t* const* res, int relu, int groups,
+                 const int64_t* w, const int64_t* b, const int* cin) {
+    BArgs a = tbase(c);
+    a.in = in[0]; a.out = out[0]; a.res = res ? res[0] : nullptr; a.relu = relu;
+    for (int g = 0; g < groups; ++g) {
+        a.g_in[g] = in[g] - in[0]; a.g_out[g] = out[g] - out[0]; a.g_res[g] = res ? res[g] - res[0] : 0;
+        a.w[g] = w[g]; a.b[g] = b[g]; a.cin[g] = cin ? cin[g] : 8;
+    }
+    return tlaunch<0>(c, a, groups);
+}
+
+// the teacher-forced forward of all 8 stages with every activation the backward pass needs kept in the arena
+static int tforward(TCtx& c, float* probs, double* bits_acc) {
+    const TArena& a = c.A;
+    const Layout& L = c.L;
+    const linr_frame* f = c.f;
+    const int64_t nblk = linr_grid(c.R, LINR_BLOCK);
+    {
+        LinrProf ps(c.s, TK_MISC, 1);
+        if (c.OCC == a.OCC) occ_bf16_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(f->occ, c.R, a.OCC);
+        zero_pads16_k<<<a.pads.n, 64, 0, c.s>>>(a.mats, a.pads);
+        SceArgs sa;
+        sa.n_scales = f->n_scales;
+        for (int s = 0; s < f->n_scales; ++s) {
+            const int si = f->scale_idx_h[s];
+            sa.row_off[s] = f->row_off_h[s];
+            sa.emb[s] = L.emb + si * 8; sa.w1[s] = L.m0_w[si]; sa.b1[s] = L.m0_b[si]; sa.w2[s] = L.m2_w[si]; sa.b2[s] = L.m2_b[si];
+        }
+        sa.row_off[f->n_scales] = f->rows;
+        sa.blk_off[0] = 0;
+        for (int s = 0; s < f->n_scales; ++s)
+            sa.blk_off[s + 1] = sa.blk_off[s] + (int)linr_grid(sa.row_off[s + 1] - sa.row_off[s], LINR_BLOCK);
+        PadList none;
+        none.n = 0;
+        sce_fwd_k<bf16_t><<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, c.s>>>(c.P, f->offset_feat, sa, c.R, nullptr, a.HID, a.X0, nullptr, none);
+    }
+    {   // A[0] = relu(conv3(x_low)) (block_in) and A[b] = relu(conv3(occ[:, :b])) (outter block b)
+        const bf16_t* in0[1] = {a.X0};
+        bf16_t* out0[1] = {a.A[0]};
+        TRY(tconv(c, in0, out0, nullptr, 1, 1, &L.block_in.a_w, &L.block_in.a_b, nullptr));
+        const bf16_t* in[7]; bf16_t* out[7]; int64_t w[7], b[7]; int cin[7];
+        for (int g = 0; g < 7; ++g) { in[g] = c.OCC; out[g] = a.A[g + 1]; w[g] = L.outter[g].a_w; b[g] = L.outter[g].a_b; cin[g] = g + 1; }
+        TRY(tconv(c, in, out, nullptr, 1, 7, w, b, cin));
+    }
+    {   // the Inception layer of all eight blocks: H = [relu(conv0_0(A)) | relu(conv1_0(A))], then I, M
+        BArgs h = tbase(c), i2 = tbase(c);
+        h.in = a.A[0]; h.out = a.H[0];
+        i2.in = a.H[0]; i2.out = a.I[0]; i2.res = a.A[0]; i2.m_out = a.M[0];
+        for (int g = 0; g < 8; ++g) {
+            const IncP& q = (g == 0 ? L.block_in : L.outter[g - 1]).inc[0];
+            h.g_in[g] = a.A[g] - a.A[0]; h.g_out[g] = a.H[g] - a.H[0];
+            h.w[g] = q.c00_w; h.b[g] = q.c00_b; h.w2[g] = q.c10_w; h.b2[g] = q.c10_b;
+            i2.g_in[g] = a.H[g] - a.H[0]; i2.g_out[g] = a.I[g] - a.I[0]; i2.g_res[g] = a.A[g] - a.A[0]; i2.g_m[g] = a.M[g] - a.M[0];
+            i2.w[g] = q.c01_w; i2.b[g] = q.c01_b; i2.w2[g] = q.c11_w; i2.b2[g] = q.c11_b; i2.w3[g] = q.c12_w; i2.b3[g] = q.c12_b;
+        }
+        TRY(tlaunch<2>(c, h, 8));
+        TRY(tlaunch<3>(c, i2, 8));
+    }
+    {   // x_glob = O[0] = conv3(I[0]); prior_b = O[b] = conv3(I[b]) + x_glob
+        const bf16_t* in0[1] = {a.I[0]};
+        bf16_t* out0[1] = {a.O[0]};
+        TRY(tconv(c, in0, out0, nullptr, 0, 1, &L.block_in.b_w, &L.block_in.b_b, nullptr));
+        const bf16_t* in[7]; bf16_t* out[7]; const bf16_t* res[7]; int64_t w[7], b[7];
+        for (int g = 0; g < 7; ++g) { in[g] = a.I[g + 1]; out[g] = a.O[g + 1]; res[g] = a.O[0]; w[g] = L.outter[g].b_w; b[g] = L.outter[g].b_b; }
+        TRY(tconv(c, in, out, res, 0, 7, w, b, nullptr));
+    }
+    {   // the 8 heads: C_k = prune conv(prior_k) (stored), p_k, bits partials
+        BArgs h = tbase(c);
+        h.in = a.O[0]; h.out = a.C[0];
+        h.target = f->occ; h.target_ld = 8;
+        h.p_out = a.PR; h.partial = a.part;
+        for (int k = 0; k < 8; ++k) {
+            h.g_in[k] = a.O[k] - a.O[0]; h.g_out[k] = a.C[k] - a.C[0];
+            h.w[k] = L.pr_w[k]; h.b[k] = L.pr_b[k];
+            h.h_w1[k] = L.h0_w[k]; h.h_b1[k] = L.h0_b[k]; h.h_w2[k] = L.h2_w[k]; h.h_b2[k] = L.h2_b[k];
+            h.t_col[k] = k; h.p_off[k] = (int64_t)k * c.R; h.part_off[k] = (int64_t)k * nblk;
+        }
+        TRY(tlaunch<1>(c, h, 8));
+    }
+    if (bits_acc) TRY(linr_bits_finish_launch(a.part, (int)(8 * nblk), bits_acc, c.s));
+    if (probs) TRY(linr_hip_rc(hipMemcpyAsync(probs, a.PR, (size_t)c.R * 8 * sizeof(float), hipMemcpyDeviceToDevice, c.s)));
+    return linr_launch_rc();
+}
+
+static BbArgs bb_base(const TCtx& c) {
+    BbArgs a = BbArgs();
+    a.P = c.P; a.lo = c.f->nbr_lo; a.mask = c.f->nbr_mask; a.ld = c.f->nbr_ld; a.n = c.R;
+    a.big = c.A.BIG; a.block_stride = c.L.total;
+    for (int g = 0; g < TB_MAXG; ++g) a.cin[g] = 8;
+    return a;
+}
+
+template <int KIND, int EPI>
+static int bb_launch(TCtx& c, BbArgs& a, int groups, int kind_prof, int* rows) {
+    int blocks = 1;
+    tb_grid(c.R, c.nb, groups, a.tiles_per_wave, blocks);
+    *rows = blocks;
+    LinrProf ps(c.s, kind_prof, groups);
+    bbwd_k<KIND, EPI><<<dim3(blocks, groups), BB_WAVES * 64, 0, c.s>>>(a);
+    return linr_launch_rc();
+}
+
+// backward of gscale * bits: leaves the parameter gradient in the arena's GSUM (flat, parameters() order)
+static int tbackward(TCtx& c, float gscale) {
+    const TArena& a = c.A;
+    const Layout& L = c.L;
+    const float gz_scale = gscale * 1.4426950408889634f;       // d(bits)/d(nats) = 1/ln 2
+    c.shortr.clear();
+    {   // heads: gC and the four head-parameter gradients
+        THeadArgs h = THeadArgs();
+        h.c = a.C[0]; h.p = a.PR; h.target = c.f->occ; h.target_ld = 8; h.P = c.P; h.gscale = gz_scale; h.gc = a.gC[0]; h.n = c.R;
+        h.big = a.BIG; h.block_stride = L.total;
+        for (int k = 0; k < 8; ++k) {
+            h.g_c[k] = a.C[k] - a.C[0]; h.g_p[k] = (int64_t)k * c.R; h.g_t[k] = k; h.g_gc[k] = a.gC[k] - a.gC[0];
+            h.w1[k] = L.h0_w[k]; h.b1[k] = L.h0_b[k]; h.w2[k] = L.h2_w[k]; h.b2[k] = L.h2_b[k];
+        }
+        LinrProf ps(c.s, TK_HEAD_BWD, 8);
+        thead_bwd_k<<<dim3(c.nb, 8), LINR_BLOCK, 0, c.s>>>(h);
+        TRY(linr_launch_rc());
+    }
+    int rows = 0;
+    {   // C_k = conv3(prior_k; prune_k): gO[k] = bwd(gC[k]) and the kernel / bias gradients, one gather of gC
+        BbArgs b = bb_base(c);
+        b.g = a.gC[0]; b.xin = a.O[0]; b.out = a.gO[0];
+        for (int k = 0; k < 8; ++k) {
+            b.g_g[k] = a.gC[k] - a.gC[0]; b.g_x[k] = a.O[k] - a.O[0]; b.g_out[k] = a.gO[k] - a.gO[0];
+            b.w[k] = L.pr_w[k]; b.b[k] = L.pr_b[k];
+        }
+        TRY((bb_launch<0, 0>(c, b, 8, TK_BWD88, &rows)));
+        c.note_short(L.pr_w[0], L.pr_b[7] + 8, rows);
+    }
+    {   // prior_k = x_glob (+ outter block k): x_glob receives every gO
+        TPtr8 src;
+        for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
+        LinrProf ps(c.s, TK_MISC, 1);
+        tsum8_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(src, c.R, a.gXG);
+    }
+    {   // O = conv3(I; b): gI = bwd(gO), gM, G2 = [gI[:, 0:4] | gM], the kernel / bias gradients and conv1_2's
+        BbArgs b = bb_base(c);
+        const bf16_t* gO0 = a.gXG;                             // slot 0 = block_in, whose output gradient is the fan-in sum
+        b.g = gO0; b.xin = a.I[0]; b.out = a.gI[0]; b.m = a.M[0]; b.g2 = a.G2[0];
+        for (int g = 0; g < 8; ++g) {
+            const BlockP& bp = g == 0 ? L.block_in : L.outter[g - 1];
+            b.g_g[g] = (g == 0 ? a.gXG : a.gO[g]) - gO0; b.g_x[g] = a.I[g] - a.I[0]; b.g_out[g] = a.gI[g] - a.gI[0];
+            b.g_m[g] = a.M[g] - a.M[0]; b.g_g2[g] = a.G2[g] - a.G2[0];
+            b.w[g] = bp.b_w; b.b[g] = bp.b_b; b.wp[g] = bp.inc[0].c12_w; b.bp[g] = bp.inc[0].c12_b;
+        }
+        TRY((bb_launch<0, 3>(c, b, 8, TK_BWD88, &rows)));
+        // everything of a block behind its first conv comes from fused launches over the same groups: one range per block
+        for (int g = 0; g < 8; ++g) {
+            const BlockP& bp = g == 0 ? L.block_in : L.outter[g - 1];
+            c.note_short(bp.inc[0].c00_w, bp.b_b + 8, rows);
+        }
+    }
+    {   // both 4->4 convs: gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0) and their gradients, one gather of G2
+        BbArgs b = bb_base(c);
+        b.g = a.G2[0]; b.xin = a.H[0]; b.out = a.gH[0];
+        for (int g = 0; g < 8; ++g) {
+            const IncP& q = (g == 0 ? L.block_in : L.outter[g - 1]).inc[0];
+            b.g_g[g] = a.G2[g] - a.G2[0]; b.g_x[g] = a.H[g] - a.H[0]; b.g_out[g] = a.gH[g] - a.gH[0];
+            b.w[g] = q.c01_w; b.b[g] = q.c01_b; b.w1[g] = q.c11_w; b.b1[g] = q.c11_b;
+        }
+        int r2 = 0;
+        TRY((bb_launch<1, 0>(c, b, 8, TK_BWD_DUAL, &r2)));
+        if (r2 != rows) return LINR_EINVAL;
+    }
+    {   // conv0_0 (8->4): gA = (bwd(gH[:, 0:4]; W00) + gI + gH[:, 4:8] @ W10^T) * (A > 0), its gradients and conv1_0's
+        BbArgs b = bb_base(c);
+        b.g = a.gH[0]; b.xin = a.A[0]; b.out = a.gA[0]; b.res = a.gI[0];
+        for (int g = 0; g < 8; ++g) {
+            const IncP& q = (g == 0 ? L.block_in : L.outter[g - 1]).inc[0];
+            b.g_g[g] = a.gH[g] - a.gH[0]; b.g_x[g] = a.A[g] - a.A[0]; b.g_out[g] = a.gA[g] - a.gA[0]; b.g_res[g] = a.gI[g] - a.gI[0];
+            b.w[g] = q.c00_w; b.b[g] = q.c00_b; b.wp[g] = q.c10_w; b.bp[g] = q.c10_b;
+        }
+        int r2 = 0;
+        TRY((bb_launch<2, 0>(c, b, 8, TK_BWD_C00, &r2)));
+        if (r2 != rows) return LINR_EINVAL;
+    }
+    {   // A[b] = relu(conv3(occ[:, :b]; a)): kernel / bias gradients of the seven first convolutions (their input is data)
+        BbArgs b = bb_base(c);
+        b.g = a.gA[1]; b.xin = c.OCC; b.flags = TB_NO_BWD;
+        for (int g = 0; g < 7; ++g) {
+            b.g_g[g] = a.gA[g + 1] - a.gA[1]; b.g_x[g] = 0;
+            b.w[g] = L.outter[g].a_w; b.b[g] = L.outter[g].a_b; b.cin[g] = g + 1;
+        }
+        TRY((bb_launch<0, 0>(c, b, 7, TK_FIRST_WGRAD, &rows)));
+        for (int g = 0; g < 7; ++g) c.note_short(L.outter[g].a_w, L.outter[g].a_b + 8, rows);
+    }
+    {   // A[0] = relu(conv3(x_low; a)) of block_in: gx_low (fp32 for the scale context's backward) and its gradients
+        BbArgs b = bb_base(c);
+        b.g = a.gA[0]; b.xin = a.X0; b.out_f32 = a.gX0; b.flags = TB_OUT_F32;
+        b.w[0] = L.block_in.a_w; b.b[0] = L.block_in.a_b;
+        TRY((bb_launch<0, 0>(c, b, 1, TK_BWD88, &rows)));
+        c.note_short(L.block_in.a_w, L.block_in.a_b + 8, rows);
+    }
+    return linr_bwd_tail_launch(c.f, L, c.P, a.gX0, a.HID, a.BIG, a.GSUM, c.nb, c.shortr.data(), (int)c.shortr.size(), c.s);
+}
+
+// ---- C-ABI ----------------------------------------------------------------------------------------------------------------------------
+extern "C" int linr_net_forward_train_bf16(const linr_frame* f, const float* params, void* arena, size_t arena_bytes,
+                                           const uint16_t* occ_bf16, float* probs, double* bits_acc, void* stream) {
+    TCtx c;
+    TRY(tcheck(f, params, arena, arena_bytes, occ_bf16, c));
+    c.s = (hipStream_t)stream;
+    if (c.R == 0) return 0;
+    return tforward(c, probs, bits_acc);
+}
+
+extern "C" int linr_net_backward_bf16(const linr_frame* f, const float* params, void* arena, size_t arena_bytes,
+                                      const uint16_t* occ_bf16, float gscale, float* grads, void* stream) {
+    TCtx c;
+    TRY(tcheck(f, params, arena, arena_bytes, occ_bf16, c));
+    if (!grads) return LINR_EINVAL;
+    c.s = (hipStream_t)stream;
+    if (c.R == 0) return 0;
+    TRY(tbackward(c, gscale));
+    return linr_axpy(c.A.GSUM, c.L.total, grads, 1, stream);
+}
+
+extern "C" int linr_net_train_step_bf16(const linr_frame* f, float* params, void* arena, size_t arena_bytes,
+                                        const uint16_t* occ_bf16, float gscale, float* exp_avg, float* exp_avg_sq, double lr,
+                                        int64_t step, const int64_t* scale_steps_h, double beta1, double beta2, double eps,
+                                        double weight_decay, double* bits_acc, void* stream) {
+    if (!exp_avg || !exp_avg_sq || !bits_acc || step < 1) return LINR_EINVAL;
+    TCtx c;
+    TRY(tcheck(f, params, arena, arena_bytes, occ_bf16, c));
+    if (scale_steps_h) {          // checked before anything is launched
+        for (int s = 0; s < c.L.S; ++s)
+            if (scale_steps_h[s] < 0) return LINR_EINVAL;
+        for (int j = 0; j < f->n_scales; ++j)
+            if (f->row_off_h[j + 1] > f->row_off_h[j] && scale_steps_h[f->scale_idx_h[j]] < 1) return LINR_EINVAL;
+    }
+    c.s = (hipStream_t)stream;
+    if (c.R == 0) return 0;
+    TRY(tforward(c, nullptr, bits_acc));
+    TRY(tbackward(c, gscale));
+    LinrProf ps(c.s, TK_MISC, 0);
+    return linr_adam_step_launch(c.L, params, c.A.GSUM, exp_avg, exp_avg_sq, lr, step, scale_steps_h, beta1, beta2, eps, weight_decay, c.s);
+}
+
+extern "C" int linr_spconv_bwd_fused_bf16(const uint16_t* gout, const uint16_t* in, const int32_t* lo, const uint32_t* mask, int64_t ld,
+                                          int64_t n, const float* W, uint16_t* gin, float* slab, int32_t nblocks, int32_t* rows_written,
+                                          void* stream) {
+    if (rows_written) *rows_written = 0;
+    if (n < 0 || ld < n || nblocks < 1) return LINR_EINVAL;
+    if (n == 0) return 0;
+    if (!gout || !in || !lo || !mask || !W || !gin || !slab || !rows_written) return LINR_EINVAL;
+    if ((((uintptr_t)gout) & 15u) || (((uintptr_t)in) & 15u) || (((uintptr_t)gin) & 15u)) return LINR_EALIGN;
+    if (n >= ((int64_t)1 << 27) - 1) return LINR_EINVAL;
+    BbArgs a = BbArgs();
+    a.g = gout; a.xin = in; a.P = W; a.out = gin; a.lo = lo; a.mask = mask; a.ld = ld; a.n = n;
+    a.big = slab; a.block_stride = 1736;
+    a.w[0] = 0; a.b[0] = 1728; a.cin[0] = 8;
+    int blocks = 1;
+    tb_grid(n, nblocks, 1, a.tiles_per_wave, blocks);
+    *rows_written = blocks;
+    bbwd_k<0, 0><<<dim3(blocks, 1), BB_WAVES * 64, 0, (hipStream_t)stream>>>(a);
+    return linr_launch_rc();
+}

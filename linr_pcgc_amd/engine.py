@@ -103,6 +103,27 @@ class Frame:
             self._arena_bf16 = _lib.scratch(nbytes + 64, self.device)
         return self._arena_bf16
 
+    def train_bf16_arena(self):
+        """Arena of the bf16 training executor (linr_net_train_step_bf16): the GOP's shared one when a Gop set it, else this frame's
+        own (allocated on first use).  Returns (64-byte aligned base address, usable bytes)."""
+        if getattr(self, 'arena_train_bf16', None) is None:
+            nbytes = _lib.lib().linr_net_train_bf16_arena_bytes(self.rows, self.block_layers)
+            if nbytes == 0:
+                raise _lib.LinrError('the bf16 training executor supports block_layers=1 only')
+            self.arena_train_bf16 = _lib.scratch(nbytes + 64, self.device)
+        a = self.arena_train_bf16
+        base = (a.data_ptr() + 63) & ~63
+        return base, a.numel() - (base - a.data_ptr())
+
+    def occ_bf16(self):
+        """The frame's occupancy as bf16 [1 + rows][8] with the zero row in front, converted once (linr_occ_to_bf16): it does not
+        change over the epochs of an overfit.  Returns the address of the ZERO row."""
+        if getattr(self, '_occ_bf16', None) is None:
+            t = torch.empty((self.rows + 1, 8), dtype=torch.int16, device=self.device)
+            check(_lib.lib().linr_occ_to_bf16(self.occ.data_ptr(), self.rows, t.data_ptr(), _stream()), 'linr_occ_to_bf16')
+            self._occ_bf16 = t
+        return self._occ_bf16.data_ptr()
+
     def cref(self):
         return ctypes.byref(self._c)
 
@@ -170,3 +191,29 @@ def net_train_step(frame, flat_params, exp_avg, exp_avg_sq, gscale, step, lr, be
                                          None if scale_steps is None else scale_steps.ctypes.data,
                                          beta1, beta2, eps, weight_decay, bits.data_ptr(), _stream()),
           'linr_net_train_step')
+
+
+def net_forward_train_bf16(frame, flat_params, probs=None, bits=None):
+    """linr_net_forward_train_bf16: the teacher-forced forward of the bf16 training executor (activations kept in its arena)."""
+    base, nbytes = frame.train_bf16_arena()
+    check(_lib.lib().linr_net_forward_train_bf16(frame.cref(), flat_params.data_ptr(), base, nbytes, frame.occ_bf16(),
+                                                 0 if probs is None else probs.data_ptr(), 0 if bits is None else bits.data_ptr(),
+                                                 _stream()), 'linr_net_forward_train_bf16')
+
+
+def net_backward_bf16(frame, flat_params, flat_grads, gscale):
+    """flat_grads += gscale * d bits / d params through the bf16 training executor (needs net_forward_train_bf16 before it)."""
+    base, nbytes = frame.train_bf16_arena()
+    check(_lib.lib().linr_net_backward_bf16(frame.cref(), flat_params.data_ptr(), base, nbytes, frame.occ_bf16(), float(gscale),
+                                            flat_grads.data_ptr(), _stream()), 'linr_net_backward_bf16')
+
+
+def net_train_step_bf16(frame, flat_params, exp_avg, exp_avg_sq, gscale, step, lr, beta1, beta2, eps, weight_decay, bits,
+                        scale_steps=None):
+    """linr_net_train_step_bf16: net_train_step with bf16 feature / gradient rows, fp32 master parameters and accumulation."""
+    base, nbytes = frame.train_bf16_arena()
+    check(_lib.lib().linr_net_train_step_bf16(frame.cref(), flat_params.data_ptr(), base, nbytes, frame.occ_bf16(),
+                                              float(gscale), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), float(lr), int(step),
+                                              None if scale_steps is None else scale_steps.ctypes.data,
+                                              beta1, beta2, eps, weight_decay, bits.data_ptr(), _stream()),
+          'linr_net_train_step_bf16')

@@ -104,8 +104,11 @@ class LINR_PCGC_Model(nn.Module):
         self._plist = []
         self._frame_cache = {}
         # inference numerics of frame_probs / codec / encode / decode: 'f32' (default) or 'bf16' = BASELINE config[4]'s bf16
-        # features + uint8 weight codes (needs set_quantised, which the model codec calls); training is always fp32
+        # features + uint8 weight codes (needs set_quantised, which the model codec calls)
         self.inference_precision = 'f32'
+        # arithmetic of train_step: 'f32' (default, the headline) or 'bf16' = bf16 feature / gradient rows with fp32 master
+        # parameters and accumulation (linr_net_train_step_bf16; hidden_channel_conv 8, block_layers 1)
+        self.train_precision = 'f32'
         self._qcodes = None
         self._qrange = None
         self._wide = None
@@ -551,6 +554,8 @@ def train_step(model, opt, frame, point_num, out=None):
     per-GOP vector that is cleared once per epoch) - saves the per-step allocation + fill."""
     bits = torch.zeros(1, dtype=torch.float64, device=frame.device) if out is None else out
     if model._wide is not None:          # hidden_channel_conv 16 / 32: the channel-blocked executor + the segment-wise Adam
+        if model.train_precision != 'f32':
+            raise _lib.LinrError('the bf16 training executor exists for hidden_channel_conv=8 only')
         with torch.no_grad():
             tape = model._wide.forward(frame, 0, 8, None, bits, keep=True, pool=True)
             model._ensure_grad_views()
@@ -562,8 +567,16 @@ def train_step(model, opt, frame, point_num, out=None):
         opt.scheduler_step()
         return bits
     t, t_scale = opt.advance(frame)
-    engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), t,
-                          opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=t_scale)
+    if model.train_precision == 'bf16':
+        if model.block_layers != 1:
+            raise _lib.LinrError('the bf16 training executor supports block_layers=1 only')
+        engine.net_train_step_bf16(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), t,
+                                   opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=t_scale)
+    elif model.train_precision == 'f32':
+        engine.net_train_step(frame, model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq, 1.0 / float(point_num), t,
+                              opt.lr, opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, bits, scale_steps=t_scale)
+    else:
+        raise ValueError("train_precision must be 'f32' or 'bf16'")
     opt.t, opt.t_scale = t, t_scale              # committed only after the call returned without an error
     opt.scheduler_step()
     return bits

@@ -54,6 +54,19 @@ class Gop:
         for f in self.frames:
             f.arena = arena
 
+    def share_train_bf16_arena(self):
+        """One arena of the bf16 training executor for all frames of the GOP (a step finishes before the next begins)."""
+        if all(getattr(f, 'arena_train_bf16', None) is not None for f in self.frames):
+            return
+        from . import _lib
+        rows = max(f.rows for f in self.frames)
+        nbytes = _lib.lib().linr_net_train_bf16_arena_bytes(rows, self.block_layers)
+        if nbytes == 0:
+            raise _lib.LinrError('the bf16 training executor supports block_layers=1 only')
+        arena = _lib.scratch(nbytes + 64, self.frames[0].device)
+        for f in self.frames:
+            f.arena_train_bf16 = arena
+
     def __len__(self):
         return len(self.frames)
 
@@ -135,6 +148,8 @@ def overfit_gop(model, opt, gop, epochs, min_lr=4e-4, on_epoch=None, keep='best'
     like the reference logs; `info` (a dict) receives 'coded_epoch' and 'coded_loss'."""
     if keep not in ('best', 'last'):
         raise ValueError("keep must be 'best' or 'last'")
+    if getattr(model, 'train_precision', 'f32') == 'bf16':
+        gop.share_train_bf16_arena()
     losses = []
     dev = gop.frames[0].device
     bits = torch.zeros(len(gop), dtype=torch.float64, device=dev)         # one slot per frame: no per-step torch kernels

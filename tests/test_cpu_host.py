@@ -100,7 +100,16 @@ def test_c_abi_argument_checks(lib):
     assert lib.linr_ac_encode_binary(None, None, 4, p16, 64) == -1
     assert lib.linr_ac_decode_binary(None, 4, p16, 8, p16) == -1
     tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
-    assert lib.linr_prof_read(14, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
+    assert lib.linr_prof_read(24, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)) == -1
+    # bf16 training executor: NULL frame / arena, unsupported depth
+    assert lib.linr_net_train_step_bf16(None, p16, p16, 4096, None, 1.0, None, None, 0.01, 1, None, 0.9, 0.999, 1e-8, 1e-4, None, None) == -1
+    assert lib.linr_net_forward_train_bf16(None, p16, p16, 4096, None, None, None, None) == -1
+    assert lib.linr_net_backward_bf16(None, p16, p16, 4096, None, 1.0, None, None) == -1
+    assert lib.linr_net_train_bf16_arena_bytes(-1, 1) == 0 and lib.linr_net_train_bf16_arena_bytes(100, 2) == 0
+    assert lib.linr_net_train_bf16_arena_bytes(100, 1) > 0
+    assert lib.linr_occ_to_bf16(None, 4, None, None) == -1
+    rw = ctypes.c_int32(7)
+    assert lib.linr_spconv_bwd_fused_bf16(None, None, None, None, 4, 4, None, None, None, 1, ctypes.byref(rw), None) == -1 and rw.value == 0
     # round-4 entries on blocked activations: pointwise layers, their weight gradients, the occupancy head, the scale context's backward
     b4 = (ctypes.c_void_p * 4)(p16, p16, p16, p16)
     from linr_pcgc_amd._lib import LinrWidePw

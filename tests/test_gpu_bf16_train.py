@@ -1,0 +1,276 @@
+"""GPU tests of the bf16 TRAINING executor (BASELINE config[4] "bf16 SparseConv"; csrc/train_bf16.hip: linr_net_forward_train_bf16,
+linr_net_backward_bf16, linr_net_train_step_bf16, linr_spconv_bwd_fused_bf16) - the overfit step of main.py:305-321 with bf16
+feature / gradient rows, fp32 master parameters and fp32 accumulation, beside the fp32 executor.
+
+The reference trains in fp32 only (MinkowskiEngine, models/resnet.py:12-60, models/upsample.py:88-97,137-217), so there is nothing
+of it to compare a reduced-precision step with; what is checked, with the tolerances written here:
+  * against the emulating oracle (oracle/network_bf16.py: train_forward_scale - the same roundings at the same points through
+    autograd, another fp32 summation order): logits |d| <= 2e-2, bits rel <= 1e-3, every one of the 189 gradient tensors within
+    2e-2 of ITS OWN largest entry;
+  * against the fp32 oracle (oracle/network.py): bits within 1 %, the whole gradient vector at cosine >= 0.999 (every tensor >= 0.99);
+  * the fused backward of one convolution as a stand-alone op against torch autograd on bf16-representable inputs: input
+    gradient within one bf16 rounding, kernel / bias gradients within 1e-4 of their own largest entry (their products are exact
+    in fp32; only the summation order differs);
+  * four Adam steps track torch.optim.Adam on the emulating oracle; run-to-run bit-identical; a complete small overfit reaches
+    the fp32 executor's bits/point within +1 % over three seeds and decodes losslessly through the bf16 / uint8-weight codec.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import network as onet          # noqa: E402
+from oracle import network_bf16 as obf      # noqa: E402
+from oracle import octree as ooct           # noqa: E402
+from gpu_common import _model_and_oracle    # noqa: E402
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bf16_bits(t):
+    """float32 tensor (bf16-representable) -> int16 tensor of its bf16 bit patterns"""
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+def _from_bits(t):
+    return t.view(torch.bfloat16).float()
+
+
+def _logits(p):
+    p = p.double()
+    return torch.log(p) - torch.log1p(-p)
+
+
+@pytest.fixture(scope='module')
+def env(golden_dir):
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    from linr_pcgc_amd import _lib, ops
+    g = np.load(os.path.join(golden_dir, 'octree_shell128.npz'))
+    dev = torch.device('cuda:0')
+    out = []
+    for s in (0, 2):                                   # the finest scale (ragged last tile) and a small one
+        coord = g['s%d_coord' % s]
+        nbr = ops.kmap_build(torch.from_numpy(coord).to(dev))
+        lo, mask = ops.kmap_compress(nbr)
+        out.append({'n': len(coord), 'lo': lo, 'mask': mask, 'ld': nbr.shape[1], 'nbr_t': torch.from_numpy(ooct.neighbour_table(coord)).long()})
+    return {'L': _lib.lib(), 'lib': _lib, 'dev': dev, 'scales': out}
+
+
+@pytest.mark.parametrize('which,nblocks', [(0, 256), (0, 2), (1, 256)])
+def test_conv88_backward_fused_bf16_op(env, which, nblocks):
+    """linr_spconv_bwd_fused_bf16: backward-data + kernel / bias gradient of a convolution 8->8 from ONE gather of the output
+    gradient, bf16 rows in and out (ME.MinkowskiConvolution's backward under autograd, models/resnet.py:15-51)."""
+    e = env['scales'][which]
+    dev, n, L = env['dev'], e['n'], env['L']
+    gen = torch.Generator().manual_seed(4100 + nblocks + which)
+    x_h = obf.rb(torch.randn(n, 8, generator=gen))
+    go_h = obf.rb(torch.randn(n, 8, generator=gen))
+    w_h = torch.randn(27, 8, 8, generator=gen) * 0.2
+    xo = x_h.clone().requires_grad_()
+    wo = w_h.clone().requires_grad_()
+    bo = torch.zeros(1, 8, requires_grad=True)
+    obf.conv3t(xo, e['nbr_t'], wo, bo).backward(go_h)
+    go = torch.zeros((n + 1, 8), dtype=torch.int16, device=dev)
+    go[1:] = _bf16_bits(go_h).to(dev)
+    x = torch.zeros((n + 1, 8), dtype=torch.int16, device=dev)
+    x[1:] = _bf16_bits(x_h).to(dev)
+    gin = torch.full((n + 1, 8), 0x7fc0, dtype=torch.int16, device=dev)          # NaN pattern: every row must be written
+    w = w_h.to(dev).contiguous()
+    slab = torch.full((nblocks, 1736), float('nan'), device=dev)
+    rows = ctypes.c_int32(0)
+    env['lib'].check(L.linr_spconv_bwd_fused_bf16(go[1:].data_ptr(), x[1:].data_ptr(), e['lo'].data_ptr(), e['mask'].data_ptr(),
+                                                  e['ld'], n, w.data_ptr(), gin[1:].data_ptr(), slab.data_ptr(), nblocks,
+                                                  ctypes.byref(rows), _stream()), 'linr_spconv_bwd_fused_bf16')
+    torch.cuda.synchronize()
+    r = rows.value
+    assert 1 <= r <= nblocks
+    assert bool(torch.isfinite(slab[:r]).all()) and bool(torch.isnan(slab[r:]).all()), 'exactly the reported slab rows are written'
+    tot = slab[:r].double().sum(dim=0).cpu()
+    for got, ref, what in ((tot[:1728].view(27, 8, 8), wo.grad.double(), 'kernel gradient'), (tot[1728:], bo.grad.reshape(-1).double(), 'bias gradient')):
+        gmax = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        assert err <= 1e-4 * gmax, '%s: err %.3e, own max %.3e' % (what, err, gmax)
+    got = _from_bits(gin[1:]).cpu().double()
+    ref = xo.grad.double()
+    assert bool(torch.isfinite(got).all())
+    err = (got - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-4 * float(ref.abs().max())                   # one bf16 rounding of a sum computed in another order
+    assert bool((err <= tol).all()), 'input gradient: max err %.3e' % float(err.max())
+    # run-to-run reproducible (fixed fold order)
+    slab2 = torch.zeros_like(slab)
+    gin2 = torch.zeros_like(gin)
+    env['lib'].check(L.linr_spconv_bwd_fused_bf16(go[1:].data_ptr(), x[1:].data_ptr(), e['lo'].data_ptr(), e['mask'].data_ptr(),
+                                                  e['ld'], n, w.data_ptr(), gin2[1:].data_ptr(), slab2.data_ptr(), nblocks,
+                                                  ctypes.byref(rows), _stream()), 'linr_spconv_bwd_fused_bf16')
+    assert torch.equal(slab[:r], slab2[:r]) and torch.equal(gin[1:], gin2[1:])
+
+
+def _moved_model(pkg, shell, steps):
+    """a model `steps` fp32 Adam steps away from its initialisation (GPU) and its state dict (CPU)"""
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, _ = _model_and_oracle(pkg, 5)
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    for _ in range(steps):
+        train_step(model, opt, frame, shell['point_num'])
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return model, sd, frame
+
+
+@pytest.mark.parametrize('steps', [0, 10])
+def test_bf16_train_forward_matches_the_emulating_oracle(pkg, shell, steps):
+    from linr_pcgc_amd import engine
+    model, sd, frame = _moved_model(pkg, shell, steps)
+    probs = torch.empty((8, frame.rows), dtype=torch.float32, device='cuda')
+    bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+    engine.net_forward_train_bf16(frame, model.flat_parameters(), probs, bits)
+    probs2 = torch.empty_like(probs)
+    bits2 = torch.zeros_like(bits)
+    engine.net_forward_train_bf16(frame, model.flat_parameters(), probs2, bits2)
+    assert torch.equal(probs, probs2) and torch.equal(bits, bits2)
+    tsc = onet.to_torch_scales(shell['scales'])
+    ref_bits, ref32_bits, worst = 0.0, 0.0, 0.0
+    with torch.no_grad():
+        for i, s in enumerate(tsc):
+            o = obf.train_forward_scale(sd, s)
+            o32 = onet.forward_scale(sd, s)
+            ref_bits += float(o['bits'])
+            ref32_bits += float(o32['bits'])
+            sl = frame.scale_slice(i)
+            for k in range(8):
+                d = (_logits(probs[k, sl].cpu()) - o['logits'][k].reshape(-1).double()).abs()
+                worst = max(worst, float(d.max()))
+                d32 = (_logits(probs[k, sl].cpu()) - o32['logits'][k].reshape(-1).double()).abs()
+                assert float(d32.max()) <= 1e-1, 'scale %d stage %d: logits %.3e from the fp32 oracle' % (i, k, float(d32.max()))
+    assert worst <= 2e-2, 'logits: %.3e from the emulating oracle' % worst
+    assert abs(float(bits) - ref_bits) <= 1e-3 * ref_bits, (float(bits), ref_bits)
+    assert abs(float(bits) - ref32_bits) <= 1e-2 * ref32_bits, (float(bits), ref32_bits)
+
+
+@pytest.mark.parametrize('steps', [0, 10])
+def test_bf16_train_gradients_match_the_emulating_oracle(pkg, shell, steps):
+    """every one of the 189 gradient tensors within 2e-2 of its own largest entry of the emulating oracle's autograd gradient,
+    cosine >= 0.999 with the fp32 oracle's gradient over the whole vector (>= 0.99 per tensor)"""
+    from linr_pcgc_amd import engine
+    model, sd, frame = _moved_model(pkg, shell, steps)
+    gscale = 1.0 / shell['point_num']
+    grads = torch.zeros_like(model.flat_parameters())
+    engine.net_forward_train_bf16(frame, model.flat_parameters(), None, None)
+    engine.net_backward_bf16(frame, model.flat_parameters(), grads, gscale)
+    grads2 = torch.zeros_like(grads)
+    engine.net_backward_bf16(frame, model.flat_parameters(), grads2, gscale)
+    assert torch.equal(grads, grads2), 'the backward pass must be reproducible'
+    assert bool(torch.isfinite(grads).all())
+    tsc = onet.to_torch_scales(shell['scales'])
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (obf.train_frame_bits(sdo, tsc) * gscale).backward()
+    sd32 = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (onet.frame_bits(sd32, tsc) * gscale).backward()
+    off, report = 0, []
+    g = grads.cpu().double()
+    for name, v in sdo.items():
+        n = v.numel()
+        mine = g[off:off + n].view(v.shape)
+        ref = v.grad.double()
+        r32 = sd32[name].grad.double()
+        gmax = float(ref.abs().max())
+        err = float((mine - ref).abs().max())
+        cos = float((mine * r32).sum() / (mine.norm() * r32.norm()).clamp_min(1e-300))
+        report.append((err / max(gmax, 1e-300), cos, name))
+        off += n
+    bad = [(e, c, nm) for e, c, nm in report if e > 2e-2]
+    assert not bad, 'gradient tensors off by more than 2e-2 of their own max: %s' % bad[:8]
+    flat32 = torch.cat([sd32[k].grad.reshape(-1) for k in sd32]).double()
+    cos_all = float((g * flat32).sum() / (g.norm() * flat32.norm()))
+    assert cos_all >= 0.999, cos_all
+    low = [(c, nm) for e, c, nm in report if c < 0.99]
+    assert not low, 'per-tensor cosine with the fp32 gradient below 0.99: %s' % low[:8]
+
+
+def test_bf16_train_step_tracks_adam_on_the_emulating_oracle(pkg, shell):
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model, sd = _model_and_oracle(pkg, 5)
+    model.train_precision = 'bf16'
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt_o = torch.optim.Adam(list(sdo.values()), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    tsc = onet.to_torch_scales(shell['scales'])
+    for it in range(4):
+        bits = train_step(model, opt, frame, shell['point_num'])
+        lo = obf.train_frame_bits(sdo, tsc)
+        (lo / shell['point_num']).backward()
+        opt_o.step()
+        opt_o.zero_grad()
+        assert abs(float(bits) - float(lo)) <= 2e-3 * float(lo), (it, float(bits), float(lo))
+    flat_o = torch.cat([v.detach().reshape(-1) for v in sdo.values()])
+    # Adam's first steps move every parameter by ~lr whatever the gradient's size, so a gradient entry whose sign is within the
+    # rounding noise can differ by 2 lr per step: the bound is on the bulk, the worst entries are bounded by the steps taken
+    d = (model.flat_parameters().cpu() - flat_o).abs()
+    assert float(d.max()) <= 4 * 2 * 0.01 + 1e-6
+    assert float(d.mean()) <= 2e-3, float(d.mean())
+
+
+def test_bf16_overfit_is_deterministic_and_lowers_the_bits(pkg, shell):
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    outs = []
+    for _ in range(2):
+        model, _ = _model_and_oracle(pkg, 5)
+        model.train_precision = 'bf16'
+        frame = model.make_frame(shell['scales'])
+        opt = FlatAdam(model)
+        bits = [float(train_step(model, opt, frame, shell['point_num'])) for _ in range(12)]
+        outs.append((bits, model.flat_parameters().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0][-1] < 0.8 * outs[0][0][0], outs[0][0]
+
+
+def test_bf16_training_rejects_what_it_does_not_support(pkg, shell):
+    from linr_pcgc_amd import _lib, overfit
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model = overfit.gen_model(5, 'cuda', seed=1, block_layers=2)
+    model.train_precision = 'bf16'
+    frame = model.make_frame(shell['scales'])
+    with pytest.raises(_lib.LinrError):
+        train_step(model, FlatAdam(model), frame, shell['point_num'])
+    assert _lib.lib().linr_net_train_bf16_arena_bytes(1000, 2) == 0
+
+
+def test_bf16_training_does_not_depend_on_leftover_state(pkg):
+    """Neither on what the arena held before (it comes uninitialised: here filled with 0xFF bytes = NaN patterns) nor on the LDS /
+    register contents another kernel left on the CUs (linr_debug_poison in front of every launch): three full-size training steps
+    give bit-identical parameters, moments and bits."""
+    from linr_pcgc_amd import _lib, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    L = _lib.lib()
+    cloud = synthetic.sequence_frame_device('loot10', 0, 'cuda')
+
+    def run(dirty):
+        gop = overfit.Gop(None, [cloud], None, 64, 'cuda')
+        f = gop.frames[0]
+        if dirty:
+            nbytes = L.linr_net_train_bf16_arena_bytes(f.rows, 1)
+            f.arena_train_bf16 = torch.full((nbytes + 64,), 0xFF, dtype=torch.uint8, device='cuda')
+        m = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+        m.train_precision = 'bf16'
+        o = FlatAdam(m)
+        bits = torch.zeros(3, dtype=torch.float64, device='cuda')
+        L.linr_debug_poison(0xFFFFFF if dirty else 0)
+        try:
+            for s in range(3):
+                train_step(m, o, f, gop.point_nums[0], out=bits[s:s + 1])
+            torch.cuda.synchronize()
+        finally:
+            L.linr_debug_poison(0xFFFFFF if os.environ.get('LINR_DEBUG_POISON') else 0)
+        return m.flat_parameters().clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), bits.cpu()
+    clean, dirty = run(False), run(True)
+    assert bool(torch.isfinite(dirty[0]).all()) and bool(torch.isfinite(dirty[3]).all())
+    assert float(dirty[3][2]) < float(dirty[3][0]), dirty[3]
+    for a, b in zip(clean, dirty):
+        assert torch.equal(a, b)

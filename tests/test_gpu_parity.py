@@ -373,7 +373,7 @@ def test_results_do_not_depend_on_leftover_onchip_state(pkg, golden_dir, tmp_pat
                 train_step(m, o, gop.frames[0], gop.point_nums[0], out=bits[s:s + 1])
             torch.cuda.synchronize()
         finally:
-            L.linr_debug_poison(0x1FFFF if os.environ.get('LINR_DEBUG_POISON') else 0)
+            L.linr_debug_poison(0xFFFFFF if os.environ.get('LINR_DEBUG_POISON') else 0)
         return m.flat_parameters().clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), bits.cpu()
     clean, dirty = run(0), run(0xFFFF)
     assert bool(torch.isfinite(dirty[0]).all())
