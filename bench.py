@@ -383,6 +383,87 @@ def sequence_leg(args, rank, world, dist, stage_all=True):
     return summary
 
 
+def bf16_train_leg(gop, L, _lib, epochs):
+    """BASELINE config[4]'s "bf16 SparseConv" on the overfit: the SAME GOP trained by the bf16 training executor (linr_net_train_step_bf16:
+    bf16 feature / gradient rows, fp32 master weights and accumulation) - a complete overfit from seed 8807, coded by the bf16 /
+    uint8-weight codec, frames 0..1 decoded - beside the fp32 headline, never instead of it; then one frame of config[4]'s own geometry
+    (owlii11: 11-bit, ~1.24 M rows) for ms/step of both executors.  `roofline` prices the executor's dominant kernel class, the fused
+    backward of the convolutions 8->8 (bbwd_k<0>: backward-data + weight gradient from one gather = two algorithmic row passes of
+    2 (8 + 8) + 108 bytes per group), from launch durations measured live with event pairs on the launch stream."""
+    import ctypes
+    from linr_pcgc_amd import codec, overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    out = {'dtype': 'bf16 feature and gradient rows, fp32 master parameters / accumulation / Adam (v_mfma_f32_4x4x4_16b_bf16)'}
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    model.train_precision = 'bf16'
+    gop.share_train_bf16_arena()
+    opt = FlatAdam(model)
+    init = model.flat_parameters().detach().clone()
+    bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for i in range(400):                                    # clock ramp on the kernels that are about to be timed
+        train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)], out=bits)
+    model.flat_parameters().copy_(init)
+    opt.reset()
+    L.linr_prof_mask(1 << 17)
+    L.linr_prof_enable(1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    info = {}
+    e0.record()
+    losses = overfit.overfit_gop(model, opt, gop, epochs, info=info)
+    e1.record()
+    torch.cuda.synchronize()
+    L.linr_prof_enable(0)
+    steps = epochs * len(gop)
+    ms = e0.elapsed_time(e1) / steps
+    tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(L.linr_prof_read(17, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)), 'linr_prof_read')
+    L.linr_prof_mask(3)
+    mean_rows = sum(f.rows for f in gop.frames) / float(len(gop))
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
+    nd = min(2, len(gop))
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
+    ok = all(bool(torch.equal(dec[i], torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)))
+             for i in range(nd))
+    out.update({'ms_per_step': round(ms, 4), 'steps': steps, 'note': 'the complete %d-epoch overfit incl. its per-epoch host reads of the loss (HIP events)' % epochs,
+                'epoch_loss_bpp': [round(x, 4) for x in losses], 'coded_epoch': info.get('coded_epoch'),
+                'bits_per_point': round(float(enc['bpp']['bpp_all']), 5), 'codec': 'bf16 features / uint8 weight codes', 'lossless_decode_frames0to1': ok})
+    if nl.value:
+        alg_row_pass = 2 * (8 + 8) + 108
+        us_launch = tot.value * 1e3 / nl.value
+        groups = npass.value / float(nl.value)
+        achieved = groups * mean_rows * 2 * alg_row_pass / (us_launch * 1e-6) / 1e9
+        out['roofline'] = {'kernel': 'bbwd_k<0>: fused backward-data + weight gradient of the convolutions 8->8 (17 of a step\'s 33 backward row passes, 3 launches)',
+                           'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
+                           'alg_bytes_per_row_pass': alg_row_pass, 'row_passes_per_fused_group': 2, 'mean_groups_per_launch': round(groups, 3),
+                           'mean_launch_us': round(us_launch, 2), 'us_per_group_pass': round(tot.value * 1e3 / max(npass.value, 1), 2),
+                           'launches_sampled': int(nl.value), 'traffic': None,
+                           'step': {'alg_bytes_per_row': 20514, 'achieved': round(20514 * mean_rows / (ms * 1e-3) / 1e9, 1),
+                                    'frac': round(20514 * mean_rows / (ms * 1e-3) / 1e9 / 8000.0, 4),
+                                    'note': 'SURVEY 8(d) at 2-byte features: 3 passes x (1,654 B features + 5,184 B neighbour table) per row'}}
+    del enc, dec
+    # config[4]'s own geometry: one frame of the Owlii stand-in, both executors
+    try:
+        g4 = overfit.Gop(None, [synthetic.sequence_frame_device('owlii11', 0, 'cuda')], None, 64, 'cuda')
+        res = {'rows': g4.frames[0].rows, 'points': g4.point_nums[0], 'scales': g4.scale_num}
+        for prec in ('f32', 'bf16'):
+            m4 = overfit.gen_model(g4.scale_num, 'cuda', seed=8807)
+            m4.train_precision = prec
+            o4 = FlatAdam(m4)
+            for _ in range(60):
+                train_step(m4, o4, g4.frames[0], g4.point_nums[0], out=bits)
+            res['ms_per_step_' + prec] = round(_time_launches(lambda: train_step(m4, o4, g4.frames[0], g4.point_nums[0], out=bits), 30) * 1e3, 4)
+            del m4, o4
+        res['bf16_over_f32'] = round(res['ms_per_step_bf16'] / res['ms_per_step_f32'], 3)
+        out['config4_owlii11_frame'] = res
+        del g4
+    except Exception as e:
+        out['config4_owlii11_frame'] = {'error': repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -666,6 +747,13 @@ def main():
         except Exception as e:
             wide_leg = {'error': repr(e)}
         log('hidden_channel_conv 16: %s' % wide_leg)
+    bf16_train = None
+    if rank == 0 and not os.environ.get('LINR_SKIP_BF16_TRAIN'):
+        try:
+            bf16_train = bf16_train_leg(gop, L, _lib, EPOCHS)
+        except Exception as e:
+            bf16_train = {'error': repr(e)}
+        log('bf16 training leg: %s' % bf16_train)
     # bf16 / uint8-weight codec leg (BASELINE config[4]'s numerics on this workload): the SAME trained model coded with the
     # bf16 executor (features bf16, weights as the uint8 codes of model.bin, de-quantised in-kernel).  Reported beside the fp32
     # headline, never instead of it.
@@ -753,6 +841,7 @@ def main():
                                           'decode_s_per_frame_8_in_flight': round(decode_pts.get(8, 0.0), 4),
                                           'decode_gop_setup_s': round(decode_pts.get('gop_setup_s', 0.0), 4)},
                'bf16_codec': bf16_leg,
+               'bf16_train': bf16_train,
                'hidden16': wide_leg,
                'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,

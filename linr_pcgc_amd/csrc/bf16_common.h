@@ -43,17 +43,36 @@ __device__ __forceinline__ uint4 pack_row(const float (&x)[8]) {
 }
 
 // byte offsets (from the pad row) of the 27 neighbours of `row` for 16-byte rows; absent -> 0 (the pad row itself)
-__device__ __forceinline__ void decode_offsets16(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask, int64_t ld,
-                                                 int64_t row, uint32_t (&off)[27]) {
-    const uint32_t m = mask[row];
+// (branch-free, the arithmetic of conv_common.h's decode_offsets: per column L = (lo + 1) << 4, a tap's offset is L advanced by one row per
+// present tap below it and zeroed when absent - m_j = -bit_j (v_bfe_i32), o_j = t_j & m_j, t_{j+1} = t_j - 16 m_j: 9 VALU operations per column;
+// the ten index words through 32-bit byte offsets from uniform bases (saddr-form loads) while 9 * ld * 4 < 2^32)
+__device__ __forceinline__ void decode_words16(const uint32_t (&raw)[10], uint32_t (&off)[27]) {
+    const uint32_t m = raw[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const uint32_t base = (uint32_t)lo[(int64_t)q * ld + row] + 1u;
-        const uint32_t b0 = (m >> (3 * q)) & 1u, b1 = (m >> (3 * q + 1)) & 1u, b2 = (m >> (3 * q + 2)) & 1u;
-        off[q] = b0 ? base * 16u : 0u;
-        off[q + 9] = b1 ? (base + b0) * 16u : 0u;
-        off[q + 18] = b2 ? (base + b0 + b1) * 16u : 0u;
+        const uint32_t L = (raw[q] + 1u) << 4;
+        const int m0 = __builtin_amdgcn_sbfe(m, 3 * q, 1), m1 = __builtin_amdgcn_sbfe(m, 3 * q + 1, 1), m2 = __builtin_amdgcn_sbfe(m, 3 * q + 2, 1);
+        const uint32_t t1 = L + (uint32_t)__mul24(m0, -16);
+        const uint32_t t2 = t1 + (uint32_t)__mul24(m1, -16);
+        off[q] = L & (uint32_t)m0; off[q + 9] = t1 & (uint32_t)m1; off[q + 18] = t2 & (uint32_t)m2;
     }
+}
+__device__ __forceinline__ void load_words16(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask, int64_t ld, int64_t row,
+                                             uint32_t (&raw)[10]) {
+    const uint32_t rb = (uint32_t)row << 2;
+    const char* lob = reinterpret_cast<const char*>(lo);
+    const uint32_t ld4 = (uint32_t)ld << 2;
+    const bool small = ld < ((int64_t)1 << 26);            // wave-uniform
+    raw[9] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(mask) + rb);
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        raw[q] = small ? *reinterpret_cast<const uint32_t*>(lob + (rb + (uint32_t)q * ld4)) : (uint32_t)(lo + (int64_t)q * ld)[row];
+}
+__device__ __forceinline__ void decode_offsets16(const int32_t* __restrict__ lo, const uint32_t* __restrict__ mask, int64_t ld,
+                                                 int64_t row, uint32_t (&off)[27]) {
+    uint32_t raw[10];
+    load_words16(lo, mask, ld, row, raw);
+    decode_words16(raw, off);
 }
 
 #include <utility>
@@ -83,10 +102,13 @@ struct BArgs {
     float* p_out; int64_t p_off[BMAXG];
     double* partial; int64_t part_off[BMAXG];
     bf16_t* m_out; int64_t g_m[BMAXG];                             // TRAIN, MODE 3: M = relu(conv1_1) bf16 [n][4], kept for the backward pass
+    const uint2* wimg; int wi[BMAXG];                              // SRC 2: pre-packed weight-block images [image][64 lanes], first image per group
 };
 
 // SRC 0: the model is the uint8 code vector a.codes (de-quantised here), a.pf its de-quantised fp32 copy;  SRC 1: a.pf = the fp32
-// master parameters, the 3x3x3 kernels are rounded to bf16 here (training).  TRAIN: everything the backward pass needs is stored
+// master parameters, the 3x3x3 kernels are rounded to bf16 here (training);  SRC 2: the same blocks, packed once per step by
+// csrc/train_bf16.hip's tpack_k (the lane's registers are then NG coalesced 8-byte loads instead of 4 NG scattered loads + conversions
+// in front of every 256-row workgroup).  TRAIN: everything the backward pass needs is stored
 // (MODE 3: M; MODE 1: the prune conv's output C, rounded to bf16 like every stored activation, and the head reads the STORED value -
 // the inference executor feeds the unrounded accumulators to the head).
 template <int MODE, int SRC = 0, bool TRAIN = false>
@@ -102,7 +124,11 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
     //   MODE 2  : c = 2 k + q        -> W00[k][4q + kk][i]
     //   MODE 3  : c = 2 k + t        -> t = 0: W01[k][kk][i], t = 1: W11[k][kk][i]
     s16x4 wv[NG];
-    {
+    if constexpr (SRC == 2) {
+        const uint2* wp = a.wimg + (int64_t)a.wi[gi] * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) wv[g] = __builtin_bit_cast(s16x4, wp[g * 64]);
+    } else {
         // all of the lane's code bytes first (unconditional loads from clamped, always valid indices: in flight together), then the
         // de-quantisation - with the loads under `if (k < 27)` / `if (ci < cinv)` every byte was a load-and-wait of its own, up to 28
         // round trips in front of the first tap of every 256-row workgroup
@@ -210,8 +236,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
         if constexpr (TRAIN) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[j] = bf2f(f2bf(c[j]));
-            if (live) *reinterpret_cast<uint4*>(a.out + a.g_out[gi] + row * 8) = pack_row(c);
         }
+        // (every store of this kernel comes BEHIND the MLP: with a store to memory the compiler cannot tell apart from the parameters
+        // in front of them, the 265 uniform weight loads below become per-lane vector loads - 54 extra 64-lane loads per tile, the cost
+        // of two convolution passes - instead of scalar loads)
         float z = a.pf[a.h_b2[gi]];
 #pragma unroll
         for (int j = 0; j < 24; ++j) {
@@ -221,14 +249,16 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
             z = fmaf(fmaxf(hj, 0.0f), w2[j], z);
         }
         const float p = 1.0f / (1.0f + expf(-z));
+        float t = 0.0f;
+        if (a.partial != nullptr && live) t = a.target[a.t_col[gi] + row * a.target_ld];
+        if constexpr (TRAIN) {
+            if (live) *reinterpret_cast<uint4*>(a.out + a.g_out[gi] + row * 8) = pack_row(c);
+        }
         if (live) a.p_out[a.p_off[gi] + row] = p;
         if (a.partial != nullptr) {
             __shared__ double sred[LINR_BLOCK / 64];
             double nats = 0.0;
-            if (live) {
-                const float t = a.target[a.t_col[gi] + row * a.target_ld];
-                nats = (double)((t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f));
-            }
+            if (live) nats = (double)((t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f));
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) nats += __shfl_xor(nats, d, 64);
             if (lane == 0) sred[threadIdx.x >> 6] = nats;

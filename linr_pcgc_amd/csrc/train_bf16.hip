@@ -49,7 +49,6 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 // ---- fused backward: backward-data + weight gradient from one gather ----------------------------------------------------------------
 #define BB_WAVES 4
 #define BB_SLOT 1088                    // bytes of one image slot: 64 rows x 16 B + 64 (consecutive slots start 16 banks apart)
-#define TB_NO_BWD 1u                    // weight gradient only (first convolutions of the outter blocks: their input is data)
 #define TB_OUT_F32 2u                   // input gradient stored as fp32 [n][8] (rounded to bf16 first): gx_low for the scale context
 #define TB_MAXG 8
 //   KIND 0  conv 8->8 (prune convolutions, tail convolutions, first convolutions): g [n][8] gathered whole, own rows = its input
@@ -79,7 +78,7 @@ template <int KIND> struct BbT {
     static constexpr int NW = KIND == 0 ? 108 : 54;             // backward-data weight blocks
 };
 
-template <int KIND, int EPI>
+template <int KIND, int EPI, bool NOBWD>
 __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     using T = BbT<KIND>;
     constexpr int CT = T::CT, SL = T::SL, NCH = T::NCH, NG = (T::NW + 15) / 16;
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     //   KIND 1: c = 2 k + t       -> (t ? W11 : W01)[k][i][kk]
     //   KIND 2: c = 2 k + h       -> W00[k][4 h + i][kk]
     s16x4 wv[NG];
-    if (!(a.flags & TB_NO_BWD)) {
+    if constexpr (!NOBWD) {
         const int blk = lane >> 2, i = lane & 3;
         float raw[NG][4];
         bool ok[NG];
@@ -160,161 +159,199 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     const int64_t tb0 = (int64_t)blockIdx.x * (BB_WAVES * a.tiles_per_wave);
     const int64_t tb1 = (tb0 + BB_WAVES * a.tiles_per_wave < T64) ? tb0 + BB_WAVES * a.tiles_per_wave : T64;
     const char* pad = reinterpret_cast<const char*>(gbase - 8);
-    constexpr int PF = 6;
+    constexpr int PF = 5;
     typedef typename std::conditional<KIND == 2, uint2, uint4>::type XR;
-    for (int64_t tile = tb0 + wave; tile < tb1; tile += BB_WAVES) {
+    // The row loop is software-pipelined ACROSS tiles (two to three waves share a SIMD, but every wave still walks through the same
+    // phases): the index words, the own row and the epilogue's own-row operands of the wave's NEXT tile are requested at step 1 of the
+    // current one; the 16 transposed reads of a chunk are issued behind its last tap and its 16 weight-gradient instructions are
+    // spread over the taps of the NEXT chunk, beside that chunk's gathers and backward-data instructions (independent accumulators).
+    struct Own { uint4 xr, res, gh; uint2 m; };
+    auto idx_load = [&](int64_t row, uint32_t (&raw)[10]) { load_words16(a.lo, a.mask, a.ld, row, raw); };
+    auto idx_decode = [&](const uint32_t (&raw)[10], uint32_t (&off)[27]) {      // mirrored taps: off[k] pairs with W[k] (backward-data
+        uint32_t fo[27];                                                         // gathers nbr(row, 26 - k)); absent -> 0 (the pad row)
+        decode_words16(raw, fo);
+#pragma unroll
+        for (int k = 0; k < 27; ++k) off[k] = fo[26 - k];
+    };
+    auto own_load = [&](int64_t tile, Own& o) {
         const int64_t row_raw = (tile << 6) + lane;
         const bool live = row_raw < n;
-        const int64_t row = live ? row_raw : n - 1;                          // every lane stays in the matrix instructions (they ignore EXEC)
-        uint32_t off[27];
-        {   // mirrored taps: off[k] pairs with W[k] (backward-data gathers nbr(row, 26 - k))
-            uint32_t fo[27];
-            decode_offsets16(a.lo, a.mask, a.ld, row, fo);
-#pragma unroll
-            for (int k = 0; k < 27; ++k) off[k] = fo[26 - k];
-        }
-        // own row (dead lanes: zeros, so that nothing of them reaches a weight gradient) -> LDS, then the 16 A operands of the tile
-        uint4 xr = make_uint4(0u, 0u, 0u, 0u);
-        if (live) xr = *reinterpret_cast<const uint4*>(xin + row * 8);
-        // own-row operands of the epilogue
-        uint4 e_res = make_uint4(0u, 0u, 0u, 0u), e_gh = e_res;
-        uint2 e_m = make_uint2(0u, 0u);
-        if constexpr (EPI == 3) e_m = *reinterpret_cast<const uint2*>(a.m + a.g_m[gi] + row * 4);
+        const int64_t row = live ? row_raw : n - 1;
+        // own row (dead lanes: zeros, so that nothing of them reaches a weight gradient)
+        const uint32_t rb16 = (uint32_t)row << 4;                              // rows < 2^27: byte offsets fit 32 bits (saddr-form accesses)
+        o.xr = make_uint4(0u, 0u, 0u, 0u);
+        if (live) o.xr = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(xin) + rb16);
+        o.res = make_uint4(0u, 0u, 0u, 0u); o.gh = o.res; o.m = make_uint2(0u, 0u);
+        if constexpr (EPI == 3) o.m = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.m + a.g_m[gi]) + (rb16 >> 1));
         if constexpr (KIND == 2) {
-            e_res = *reinterpret_cast<const uint4*>(a.res + a.g_res[gi] + row * 8);
-            e_gh = *reinterpret_cast<const uint4*>(gbase + row * 8);
+            o.res = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.res + a.g_res[gi]) + rb16);
+            o.gh = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(gbase) + rb16);
         }
-        XR x[PF + 1];
+    };
+    int64_t tile = tb0 + wave;
+    if (tile < tb1) {                                                        // wave-uniform
+        uint32_t off[27], raw[10];
+        Own ow, own_n;
+        {
+            const int64_t r = (tile << 6) + lane;
+            idx_load(r < n ? r : n - 1, raw);
+            idx_decode(raw, off);
+            own_load(tile, ow);
+        }
+        for (; tile < tb1; tile += BB_WAVES) {
+            const int64_t row_raw = (tile << 6) + lane;
+            const bool live = row_raw < n;
+            const int64_t row = live ? row_raw : n - 1;                      // every lane stays in the matrix instructions (they ignore EXEC)
+            const int64_t ntile = tile + BB_WAVES < tb1 ? tile + BB_WAVES : tile;          // the last tile "prefetches" itself
+            XR x[PF + 1];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
-        *reinterpret_cast<uint4*>(ximgW) = xr;
-        s16x4 av[16];
+            for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
+            *reinterpret_cast<uint4*>(ximgW) = ow.xr;
+            s16x4 av[16], bv[16];
 #pragma unroll
-        for (int rq = 0; rq < 16; ++rq) av[rq] = tr_read(ximgR + rq * 64);
-        f32x4 acc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
-        sfor<27>([&](auto kc) {
-            constexpr int kk = decltype(kc)::value;                          // step; k = LINR_TAP(kk) the tap it handles
-            constexpr int k = LINR_TAP(kk);
-            constexpr int ch = kk / CT, s = kk % CT;
-            if constexpr (kk + PF < 27) x[(kk + PF) % (PF + 1)] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(kk + PF)]);
-            const XR xk = x[kk % (PF + 1)];
-            if (!(a.flags & TB_NO_BWD)) {
-                if constexpr (KIND == 0) {
-                    const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
-                    const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
-                    constexpr int c0 = 4 * k;
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 2) / 16], q0, acc[1], 4, (c0 + 2) % 16, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[0], 4, (c0 + 1) % 16, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 3) / 16], q1, acc[1], 4, (c0 + 3) % 16, 0);
-                } else if constexpr (KIND == 1) {
-                    const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
-                    const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
-                    constexpr int c0 = 2 * k;
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[1], 4, (c0 + 1) % 16, 0);
-                } else {
-                    const s16x4 q0 = __builtin_bit_cast(s16x4, xk);
-                    constexpr int c0 = 2 * k;
-                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q0, acc[1], 4, (c0 + 1) % 16, 0);
+            for (int rq = 0; rq < 16; ++rq) av[rq] = tr_read(ximgR + rq * 64);
+            f32x4 acc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+            sfor<27>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;                      // step; k = LINR_TAP(kk) the tap it handles
+                constexpr int k = LINR_TAP(kk);
+                constexpr int ch = kk / CT, s = kk % CT;
+                constexpr int nst = 27 - ch * CT < CT ? 27 - ch * CT : CT;   // taps of this chunk
+                if constexpr (kk + PF < 27) x[(kk + PF) % (PF + 1)] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(kk + PF)]);
+                if constexpr (kk == 1) {
+                    const int64_t r = (ntile << 6) + lane;
+                    idx_load(r < n ? r : n - 1, raw);
+                    own_load(ntile, own_n);
+                }
+                const XR xk = x[kk % (PF + 1)];
+                if constexpr (!NOBWD) {
+                    if constexpr (KIND == 0) {
+                        const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
+                        const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
+                        constexpr int c0 = 4 * k;
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 2) / 16], q0, acc[1], 4, (c0 + 2) % 16, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[0], 4, (c0 + 1) % 16, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 3) / 16], q1, acc[1], 4, (c0 + 3) % 16, 0);
+                    } else if constexpr (KIND == 1) {
+                        const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
+                        const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
+                        constexpr int c0 = 2 * k;
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q1, acc[1], 4, (c0 + 1) % 16, 0);
+                    } else {
+                        const s16x4 q0 = __builtin_bit_cast(s16x4, xk);
+                        constexpr int c0 = 2 * k;
+                        acc[0] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[0], 4, c0 % 16, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[(c0 + 1) / 16], q0, acc[1], 4, (c0 + 1) % 16, 0);
+                    }
+                }
+                if constexpr (KIND == 2 && kk == 24) {
+                    // conv1_0 (1x1, 8 -> 4) rides along: its weight gradient sum_rows A[row]^T gH[row][4:8] is what the idle pseudo-tap 27
+                    // of the last chunk computes when its half-slot holds the rows' OWN gH[:, 4:8] (written here, behind the reads of
+                    // chunk 1, which shares the buffer)
+                    uint2 own = make_uint2(0u, 0u);
+                    if (live) own = make_uint2(ow.gh.z, ow.gh.w);
+                    *reinterpret_cast<uint2*>(bufW + (((NCH - 1) & 1) * SL + 1) * BB_SLOT + 8) = own;
+                }
+                // park the gathered row in the chunk's image
+                if constexpr (KIND == 2) *reinterpret_cast<uint2*>(bufW + ((ch & 1) * SL + (s >> 1)) * BB_SLOT + 8 * (s & 1)) = xk;
+                else *reinterpret_cast<uint4*>(bufW + ((ch & 1) * SL + s) * BB_SLOT) = xk;
+                if constexpr (k == 13) {                                      // the centre tap is the row's own gradient: bias gradient
+                    if (live) {
+                        if constexpr (KIND == 2) {
+                            bsum[0] += bf2f((bf16_t)(xk.x & 0xffff)); bsum[1] += bf2f((bf16_t)(xk.x >> 16));
+                            bsum[2] += bf2f((bf16_t)(xk.y & 0xffff)); bsum[3] += bf2f((bf16_t)(xk.y >> 16));
+                        } else {
+                            float t[8];
+                            unpack_row(xk, t);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) bsum[j] += t[j];
+                        }
+                    }
+                }
+                if constexpr (ch >= 1) {                                      // this step's share of the previous chunk's weight gradient
+                    constexpr int r0 = (s * 16) / nst, r1 = ((s + 1) * 16) / nst;
+                    sfor<r1 - r0>([&](auto rc) {
+                        constexpr int rq = r0 + decltype(rc)::value;
+                        wacc[ch - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[ch - 1], 0, 0, 0);
+                    });
+                }
+                if constexpr (s == nst - 1) {                                 // the chunk is complete: its 16 transposed reads
+#pragma unroll
+                    for (int rq = 0; rq < 16; ++rq) bv[rq] = tr_read(bufR + (ch & 1) * SL * BB_SLOT + rq * 64);
+                }
+            });
+#pragma unroll
+            for (int rq = 0; rq < 16; ++rq)                                   // the last chunk of the tile
+                wacc[NCH - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[NCH - 1], 0, 0, 0);
+            // ---- epilogue: the row's input gradient, rounded to bf16; everything derived from it uses the rounded value ---------------
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = acc[0][j]; o[4 + j] = acc[1][j]; }
+            if constexpr (KIND == 1) {                // gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)
+                float hv[8];
+                unpack_row(ow.xr, hv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = hv[j] > 0.0f ? o[j] : 0.0f;
+            }
+            if constexpr (KIND == 2) {                // gA = (bwd(gH[:, 0:4]; W00) + gI + gH[:, 4:8] @ W10^T) * (A > 0)
+                float rv[8], gh[8], av8[8];
+                unpack_row(ow.res, rv);
+                unpack_row(ow.gh, gh);
+                unpack_row(ow.xr, av8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += rv[j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) t = fmaf(gh[4 + q], wpw[i * 4 + q], t);
+                    o[i] += t;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = av8[j] > 0.0f ? o[j] : 0.0f;
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bsum[4 + q] += gh[4 + q];
                 }
             }
-            if constexpr (KIND == 2 && kk == 24) {
-                // conv1_0 (1x1, 8 -> 4) rides along: its weight gradient sum_rows A[row]^T gH[row][4:8] is what the idle pseudo-tap 27
-                // of the last chunk computes when its half-slot holds the rows' OWN gH[:, 4:8] (written here, behind the reads of
-                // chunk 1, which shares the buffer)
-                uint2 own = make_uint2(0u, 0u);
-                if (live) own = make_uint2(e_gh.z, e_gh.w);
-                *reinterpret_cast<uint2*>(bufW + (((NCH - 1) & 1) * SL + 1) * BB_SLOT + 8) = own;
-            }
-            // park the gathered row in the chunk's image
-            if constexpr (KIND == 2) *reinterpret_cast<uint2*>(bufW + ((ch & 1) * SL + (s >> 1)) * BB_SLOT + 8 * (s & 1)) = xk;
-            else *reinterpret_cast<uint4*>(bufW + ((ch & 1) * SL + s) * BB_SLOT) = xk;
-            if constexpr (k == 13) {                                          // the centre tap is the row's own gradient: bias gradient
+            const uint4 po = pack_row(o);                                     // the ONE rounding of the row (v_cvt_pk_bf16_f32)
+            if constexpr (!NOBWD) {
                 if (live) {
-                    if constexpr (KIND == 2) {
-                        bsum[0] += bf2f((bf16_t)(xk.x & 0xffff)); bsum[1] += bf2f((bf16_t)(xk.x >> 16));
-                        bsum[2] += bf2f((bf16_t)(xk.y & 0xffff)); bsum[3] += bf2f((bf16_t)(xk.y >> 16));
+                    const uint32_t rb16 = (uint32_t)row << 4;
+                    if (EPI == 3 || (a.flags & TB_OUT_F32)) unpack_row(po, o);   // what follows uses the STORED values
+                    if (a.flags & TB_OUT_F32) {
+                        float* op = a.out_f32 + row * 8;
+                        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
                     } else {
-                        float t[8];
-                        unpack_row(xk, t);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out + a.g_out[gi]) + rb16) = po;
+                    }
+                    if constexpr (EPI == 3) {             // gM = (gI[:, 4:8] @ W12^T) * (M > 0);  G2 = [gI[:, 0:4] | gM]
+                        const float mv[4] = {bf2f((bf16_t)(ow.m.x & 0xffff)), bf2f((bf16_t)(ow.m.x >> 16)), bf2f((bf16_t)(ow.m.y & 0xffff)),
+                                             bf2f((bf16_t)(ow.m.y >> 16))};
+                        float g2[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum[j] += t[j];
+                        for (int j = 0; j < 4; ++j) g2[j] = o[j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float t = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) t = fmaf(o[4 + q], wpw[i * 4 + q], t);
+                            g2[4 + i] = mv[i] > 0.0f ? t : 0.0f;
+                        }
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.g2 + a.g_g2[gi]) + rb16) = pack_row(g2);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) g12[i * 4 + q] = fmaf(mv[i], o[4 + q], g12[i * 4 + q]);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) g12[16 + q] += o[4 + q];
                     }
                 }
             }
-            if constexpr (s == CT - 1 || kk == 26) {
-                // the chunk is complete: its weight gradient, four rows per instruction
-#pragma unroll
-                for (int rq = 0; rq < 16; ++rq) {
-                    const s16x4 bv = tr_read(bufR + (ch & 1) * SL * BB_SLOT + rq * 64);
-                    wacc[ch] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv, wacc[ch], 0, 0, 0);
-                }
-            }
-        });
-        // ---- epilogue: the row's input gradient, rounded to bf16; everything derived from it uses the rounded value -------------------
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j] = acc[0][j]; o[4 + j] = acc[1][j]; }
-        if constexpr (KIND == 1) {                // gH = [bwd(gI[:, 0:4]; W01) | bwd(gM; W11)] * (H > 0)
-            float hv[8];
-            unpack_row(xr, hv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = hv[j] > 0.0f ? o[j] : 0.0f;
-        }
-        if constexpr (KIND == 2) {                // gA = (bwd(gH[:, 0:4]; W00) + gI + gH[:, 4:8] @ W10^T) * (A > 0)
-            float rv[8], gh[8], av8[8];
-            unpack_row(e_res, rv);
-            unpack_row(e_gh, gh);
-            unpack_row(xr, av8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += rv[j];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float t = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t = fmaf(gh[4 + q], wpw[i * 4 + q], t);
-                o[i] += t;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = av8[j] > 0.0f ? o[j] : 0.0f;
-            if (live) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bsum[4 + q] += gh[4 + q];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = bf2f(f2bf(o[j]));
-        if (live && !(a.flags & TB_NO_BWD)) {
-            if (a.flags & TB_OUT_F32) {
-                float* op = a.out_f32 + row * 8;
-                *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
-            } else {
-                *reinterpret_cast<uint4*>(a.out + a.g_out[gi] + row * 8) = pack_row(o);
-            }
-            if constexpr (EPI == 3) {             // gM = (gI[:, 4:8] @ W12^T) * (M > 0);  G2 = [gI[:, 0:4] | gM]
-                const float mv[4] = {bf2f((bf16_t)(e_m.x & 0xffff)), bf2f((bf16_t)(e_m.x >> 16)), bf2f((bf16_t)(e_m.y & 0xffff)),
-                                     bf2f((bf16_t)(e_m.y >> 16))};
-                float g2[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g2[j] = o[j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) t = fmaf(o[4 + q], wpw[i * 4 + q], t);
-                    g2[4 + i] = mv[i] > 0.0f ? t : 0.0f;
-                }
-                *reinterpret_cast<uint4*>(a.g2 + a.g_g2[gi] + row * 8) = pack_row(g2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g12[i * 4 + q] = fmaf(mv[i], o[4 + q], g12[i * 4 + q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g12[16 + q] += o[4 + q];
-            }
+            idx_decode(raw, off);                                             // the next tile's offsets (its index words came in at step 1)
+            ow = own_n;
         }
     }
     __syncthreads();
@@ -406,6 +443,262 @@ static void tb_grid(int64_t n, int nb, int ngroups, int& tiles_per_wave, int& bl
     tiles_per_wave = (int)m;
     blocks = (int)((t64 + BB_WAVES * m - 1) / (BB_WAVES * m));
     if (blocks < 1) blocks = 1;
+}
+
+// ---- weight-block images of the forward kernels, packed once per step ------------------------------------------------------------------
+// Every forward convolution keeps its bf16 weight blocks (the A operands of v_mfma_f32_4x4x4_16b_bf16) in registers; building them from
+// the fp32 master in front of every 256-row workgroup costs 4 scattered loads + conversions per register.  tpack_k builds every
+// lane's registers ONCE per step (the parameters change with every Adam update): image m = 64 lanes x 8 bytes.
+//   [0, 63)     9 convolutions cin->8 x 7 images: block_in.0, block_in.3, outter_blocks.0-6.3          (bconv_k MODE 0)
+//   [63, 119)   prune convolutions 0-7 x 7                                                              (MODE 1)
+//   [119, 151)  conv0_0 of block 0-7 x 4                                                                (MODE 2)
+//   [151, 183)  [conv0_1 | conv1_1] of block 0-7 x 4                                                    (MODE 3)
+//   [183, 217)  the shared first convolution of the 7 outter blocks x 34                                (bocc7_k)
+#define TP_CONV0 0
+#define TP_PRUNE 63
+#define TP_C00 119
+#define TP_DUAL 151
+#define TP_OCC 183
+#define TP_IMAGES 217
+struct TPack { int64_t conv0_w[9], pr_w[8], c00_w[8], c01_w[8], c11_w[8], occ_w[7]; };
+__host__ __device__ constexpr int oj_g(int j) { return j < 8 ? j >> 1 : 4 + ((j - 8) >> 2); }
+__host__ __device__ constexpr int oj_h(int j) { return j < 8 ? j & 1 : ((j - 8) >> 1) & 1; }
+__host__ __device__ constexpr int oj_q(int j) { return j < 8 ? 0 : (j - 8) & 1; }
+
+__global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack t, uint2* __restrict__ wimg) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const int blk = lane >> 2, i = lane & 3;
+    float w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (m < TP_DUAL) {
+        // block c = 16 r + blk of the layer's register r:  cin->8 / prune: c = 4 k + 2 h + q -> W[k][4 q + kk][4 h + i];
+        // conv0_0: c = 2 k + q -> W00[k][4 q + kk][i]
+        const bool c00 = m >= TP_C00;
+        const int per = c00 ? 4 : 7, layer = c00 ? (m - TP_C00) / 4 : m / 7, r = c00 ? (m - TP_C00) % 4 : m % 7;
+        const int c = 16 * r + blk;
+        const int k = c00 ? c >> 1 : c >> 2;
+        (void)per;
+        if (k < 27) {
+            const float* W = P + (c00 ? t.c00_w[layer] : (m < TP_PRUNE ? t.conv0_w[layer] : t.pr_w[layer - 9]));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (c00) w[kk] = W[(k * 8 + 4 * (c & 1) + kk) * 4 + i];
+                else w[kk] = W[(k * 8 + 4 * (c & 1) + kk) * 8 + 4 * ((c >> 1) & 1) + i];
+            }
+        }
+    } else if (m < TP_OCC) {            // c = 2 k + t -> (t ? W11 : W01)[k][kk][i]
+        const int layer = (m - TP_DUAL) / 4, r = (m - TP_DUAL) % 4;
+        const int c = 16 * r + blk, k = c >> 1;
+        if (k < 27) {
+            const float* W = P + ((c & 1) ? t.c11_w[layer] : t.c01_w[layer]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) w[kk] = W[(k * 4 + kk) * 4 + i];
+        }
+    } else {                             // c = 20 k + j, j -> (group g, output quad h, input quad q): W_g[k][4 q + kk][4 h + i], cin = g + 1
+        const int c = 16 * (m - TP_OCC) + blk, k = c / 20, j = c % 20;
+        if (k < 27) {
+            const int g = oj_g(j), h = oj_h(j), q = oj_q(j), cin = g + 1;
+            const float* W = P + t.occ_w[g];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (4 * q + kk < cin) w[kk] = W[(k * cin + 4 * q + kk) * 8 + 4 * h + i];
+        }
+    }
+    wimg[m * 64 + lane] = make_uint2(pack2(w[0], w[1]), pack2(w[2], w[3]));
+}
+
+// ---- the seven first convolutions of the outter blocks from ONE gather of the occupancy rows --------------------------------------
+// A[b] = relu(conv3(occ[:, :b]; a_b) + bias) for b = 1..7 (models/upsample.py:206-214, make_block :88-97): the seven convolutions read
+// the SAME rows, so forward and weight gradient gather them once instead of seven times (csrc/fused.hip: occ_conv7_k and
+// csrc/occ_wgrad.hip: occ_wgrad7_k do the same for the fp32 executor).  Per tap the (group g, output quad h, input quad q) blocks
+// that exist - input channels 4 q .. are only present when 4 q < g + 1: 2 blocks for the groups 0..3, 4 for the groups 4..6 = 20.
+struct BoArgs {
+    const bf16_t* occ;  bf16_t* out;  const float* P;  const uint2* wimg;
+    const int32_t* lo;  const uint32_t* mask;  int64_t ld, n;
+    int64_t b[7], g_out[7];
+};
+
+// forward: lane = output row, 540 weight blocks (27 taps x 20, images TP_OCC.. of tpack_k) in 68 registers, 14 accumulators; the arithmetic
+// of bconv_k<0> per group (same blocks, same tap order, fp32 accumulation from the bias) - bit-identical to seven separate launches
+__global__ __launch_bounds__(LINR_BLOCK) void bocc7_k(BoArgs a) {
+    constexpr int NG = (27 * 20 + 15) / 16;
+    const int lane = threadIdx.x & 63;
+    s16x4 wv[NG];
+    {
+        const uint2* wp = a.wimg + (int64_t)TP_OCC * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < NG; ++r) wv[r] = __builtin_bit_cast(s16x4, wp[r * 64]);
+    }
+    const int64_t row_raw = (int64_t)blockIdx.x * LINR_BLOCK + threadIdx.x;
+    const bool live = row_raw < a.n;
+    const int64_t row = live ? row_raw : a.n - 1;
+    const char* pad = reinterpret_cast<const char*>(a.occ - 8);
+    uint32_t off[27];
+    decode_offsets16(a.lo, a.mask, a.ld, row, off);
+    f32x4 acc[7][2];
+#pragma unroll
+    for (int g = 0; g < 7; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][h][j] = a.P[a.b[g] + 4 * h + j];
+    constexpr int PF = 4;
+    uint4 x[PF + 1];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(u)]);
+    sfor<27>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int k = LINR_TAP(kk);
+        if constexpr (kk + PF < 27) x[(kk + PF) % (PF + 1)] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(kk + PF)]);
+        const uint4 r = x[kk % (PF + 1)];
+        const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(r.x, r.y));
+        const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(r.z, r.w));
+        sfor<20>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int c0 = 20 * k + j, g = oj_g(j), h = oj_h(j);
+            if constexpr (oj_q(j) == 0) acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q0, acc[g][h], 4, c0 % 16, 0);
+            else acc[g][h] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wv[c0 / 16], q1, acc[g][h], 4, c0 % 16, 0);
+        });
+    });
+    if (!live) return;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = fmaxf(acc[g][0][j], 0.0f); o[4 + j] = fmaxf(acc[g][1][j], 0.0f); }
+        *reinterpret_cast<uint4*>(a.out + a.g_out[g] + row * 8) = pack_row(o);
+    }
+}
+
+// weight gradients gW_g[k][ci][co] = sum_rows occ[nbr(row, k)][ci] gA_g[row][co], gb_g = sum_rows gA_g[row]: the gathered occupancy rows
+// are the A operand, the rows' own gradients of the seven groups the B operand of v_mfma_f32_4x4x4_16b_bf16 with the ROWS as its K
+// dimension (transposed LDS reads, like bbwd_k).  The A operand does not depend on the group: ONE transposed read delivers 16 (tap,
+// input quad) pieces and CBSZ broadcasts one of them to all blocks, whose B operand - block = (group, output quad) - stays in place:
+//   input quad 0: CBSZ 4, 14 of 16 blocks = the 7 groups x 2 output quads;   input quad 1 (groups 4..6 only): CBSZ 3 - the two halves
+//   of 8 blocks broadcast separately - 6 + 6 blocks = two taps per instruction.
+// Wave w of a block owns the taps of steps 7 w .. 7 w + 6 (wave 3: six taps and, in its spare slot, an all-ones pseudo tap whose product
+// is the bias gradient) and walks over ALL tiles of the block with 11 accumulators: no fold across waves, every wave writes its own
+// part of the block's slab row.  11 matrix instructions and 3 transposed reads per four rows and wave.
+#define OW_SLOTS 15                     // 7 tap slots + the 7 groups' own rows + 1 spare (alignment of nothing; keeps 16-slot arithmetic obvious)
+struct OwArgs {
+    const bf16_t* occ;  const bf16_t* g;
+    const int32_t* lo;  const uint32_t* mask;  int64_t ld, n;
+    int tiles_per_block;
+    float* big;  int64_t block_stride;
+    int64_t g_g[7], w[7], b[7];
+};
+
+__global__ __launch_bounds__(BB_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
+    __shared__ uint4 smem[BB_WAVES * OW_SLOTS * BB_SLOT / 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntaps = wave == 3 ? 6 : 7;
+    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int blk = lane >> 2;                                                 // = 4 tg + tp as the RECEIVING block ... and as the supplying one:
+    const int sblk = 4 * tg + tp;                                              // the piece this lane's address supplies belongs to block 4 tg + tp
+    char* img = reinterpret_cast<char*>(smem) + wave * (OW_SLOTS * BB_SLOT);
+    char* imgW = img + lane * 16;
+    // A pieces: block sb -> (tap slot sb >> 1, input quad sb & 1)
+    const char* aR = img + (sblk >> 1) * BB_SLOT + tq * 16 + 8 * (sblk & 1);
+    // B pieces, input quad 0: block sb < 14 -> (group sb >> 1, output quad sb & 1); blocks 14, 15: a valid address, result unused
+    const int sb0 = sblk < 14 ? sblk : 13;
+    const char* b0R = img + (7 + (sb0 >> 1)) * BB_SLOT + tq * 16 + 8 * (sb0 & 1);
+    // input quad 1: block (sb & 7) < 6 -> (group 4 + ((sb & 7) >> 1), output quad sb & 1) in both halves
+    const int sb1 = (sblk & 7) < 6 ? (sblk & 7) : 5;
+    const char* b1R = img + (7 + 4 + (sb1 >> 1)) * BB_SLOT + tq * 16 + 8 * (sb1 & 1);
+    f32x4 d0[7], d1[4];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) d0[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d1[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int64_t n = a.n;
+    const int64_t T64 = (n + 63) >> 6;
+    const int64_t tb0 = (int64_t)blockIdx.x * a.tiles_per_block;
+    const int64_t tb1 = tb0 + a.tiles_per_block < T64 ? tb0 + a.tiles_per_block : T64;
+    const char* pad = reinterpret_cast<const char*>(a.occ - 8);
+    if (wave == 3) {                                                           // the pseudo tap: ones (bf16 1.0 = 0x3f80) in slot 6, written once
+        *reinterpret_cast<uint4*>(imgW + 6 * BB_SLOT) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    }
+    // One wave per SIMD and block: nothing hides a latency but the wave's own instruction stream, so the loads of tile t + 1 (index
+    // words, the wave's 7 gathers, the 7 groups' own rows) are issued before the matrix instructions of tile t.
+    uint4 x[7], own[7], xn[7], ownn[7];
+    auto load_tile = [&](int64_t tile, auto nxt) {
+        constexpr bool NXT = decltype(nxt)::value;
+        const int64_t row_raw = (tile << 6) + lane;
+        const bool live = row_raw < n;
+        const int64_t row = live ? row_raw : n - 1;
+        uint32_t off[27];
+        decode_offsets16(a.lo, a.mask, a.ld, row, off);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            // off[LINR_TAP(7 wave + t)]: the table is indexed with compile-time steps, the wave selects among the four constants
+            const uint32_t o = wave == 0 ? off[LINR_TAP(t)] : wave == 1 ? off[LINR_TAP(7 + t)] : wave == 2 ? off[LINR_TAP(14 + t)] : off[LINR_TAP(t < 6 ? 21 + t : 26)];
+            const uint4 v = *reinterpret_cast<const uint4*>(pad + o);
+            if constexpr (NXT) xn[t] = v; else x[t] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);                              // dead lanes contribute nothing
+            if (live) v = *reinterpret_cast<const uint4*>(a.g + a.g_g[g] + row * 8);
+            if constexpr (NXT) ownn[g] = v; else own[g] = v;
+        }
+    };
+    if (tb0 < tb1) load_tile(tb0, std::false_type{});
+    for (int64_t tile = tb0; tile < tb1; ++tile) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < ntaps) *reinterpret_cast<uint4*>(imgW + t * BB_SLOT) = x[t];
+#pragma unroll
+        for (int g = 0; g < 7; ++g) *reinterpret_cast<uint4*>(imgW + (7 + g) * BB_SLOT) = own[g];
+        if (tile + 1 < tb1) load_tile(tile + 1, std::true_type{});
+#pragma unroll 4
+        for (int rq = 0; rq < 16; ++rq) {
+            const s16x4 av = tr_read(aR + rq * 64);
+            const s16x4 b0 = tr_read(b0R + rq * 64);
+            const s16x4 b1 = tr_read(b1R + rq * 64);
+            sfor<7>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                d0[t] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, b0, d0[t], 4, 2 * t, 0);
+            });
+            sfor<4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;                          // taps t (blocks 0..7) and t + 4 (blocks 8..15)
+                d1[t] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, b1, d1[t], 3, 2 * t + 1, 0);
+            });
+        }
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { x[t] = xn[t]; own[t] = ownn[t]; }
+    }
+    // ---- every wave writes the slab entries of its own taps: D block b, lane j, register i --------------------------------------------
+    float* dst = a.big + (int64_t)blockIdx.x * a.block_stride;
+    const int j = lane & 3;
+    if (blk < 14) {
+        const int g = blk >> 1, oq = blk & 1, cin = g + 1;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            if (t < ntaps) {
+                const int kk = 7 * wave + t;
+                const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < cin) dst[a.w[g] + ((int64_t)k * cin + i) * 8 + 4 * oq + j] = d0[t][i];
+            } else if (wave == 3 && t == 6) {
+                dst[a.b[g] + 4 * oq + j] = d0[t][0];                          // the all-ones pseudo tap: every register holds the bias gradient
+            }
+        }
+    }
+    if ((blk & 7) < 6) {
+        const int bb = blk & 7, g = 4 + (bb >> 1), oq = bb & 1, cin = g + 1, half = blk >> 3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int slot = t + 4 * half;
+            if (slot < ntaps) {
+                const int kk = 7 * wave + slot;
+                const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 + i < cin) dst[a.w[g] + ((int64_t)k * cin + 4 + i) * 8 + 4 * oq + j] = d1[t][i];
+            }
+        }
+    }
 }
 
 // ---- backward of the occupancy heads (csrc/fused.hip: head_bwd_k with bf16 rows in and out) ---------------------------------------------
@@ -595,6 +888,7 @@ struct TArena {
     char* base;
     int64_t cur;                     // bytes
     float *HID, *gX0, *PR, *GSUM, *BIG;
+    uint2* WIMG;                     // [TP_IMAGES][64] weight-block images of the forward kernels (tpack_k)
     double* part;
     bf16_t *X0, *OCC, *A[8], *H[8], *I[8], *O[8], *C[8], *M[8];
     bf16_t *gC[8], *gO[8], *gXG, *gI[8], *G2[8], *gH[8], *gA[8];
@@ -623,6 +917,7 @@ static void make_tarena(TArena& a, int64_t rows, char* base, int64_t n_params, b
     a.gX0 = (float*)tbytes(a, rows * 8 * 4);
     a.PR = (float*)tbytes(a, rows * 8 * 4);
     a.part = (double*)tbytes(a, (int64_t)8 * linr_grid(rows, LINR_BLOCK) * 8);
+    a.WIMG = (uint2*)tbytes(a, (int64_t)TP_IMAGES * 64 * 8);
     a.GSUM = (float*)tbytes(a, n_params * 4);
     a.BIG = (float*)tbytes(a, (int64_t)LINR_WG_BLOCKS * n_params * 4);
     a.mats = reinterpret_cast<bf16_t*>(base + a.cur);
@@ -699,7 +994,7 @@ static int tcheck(const linr_frame* f, const float* params, void* arena, size_t 
 static BArgs tbase(const TCtx& c) {
     BArgs a = BArgs();
     a.lo = c.f->nbr_lo; a.mask = c.f->nbr_mask; a.ld = c.f->nbr_ld; a.n = c.R;
-    a.codes = nullptr; a.minv = 0.0f; a.range = 0.0f; a.pf = c.P;
+    a.codes = nullptr; a.minv = 0.0f; a.range = 0.0f; a.pf = c.P; a.wimg = c.A.WIMG;
     for (int g = 0; g < BMAXG; ++g) a.cin[g] = 8;
     return a;
 }
@@ -707,18 +1002,18 @@ static BArgs tbase(const TCtx& c) {
 template <int MODE>
 static int tlaunch(const TCtx& c, const BArgs& a, int groups) {
     LinrProf ps(c.s, TK_FWD, groups);
-    bconv_k<MODE, 1, true><<<dim3(linr_grid(c.R, LINR_BLOCK), groups), LINR_BLOCK, 0, c.s>>>(a);
+    bconv_k<MODE, 2, true><<<dim3(linr_grid(c.R, LINR_BLOCK), groups), LINR_BLOCK, 0, c.s>>>(a);
     return linr_launch_rc();
 }
 
 // conv3 cin->8 (+ res) (ReLU) over `groups` layers; ptrs[g] are the groups' matrices (offsets are taken against ptrs[0])
 static int tconv(const TCtx& c, const bf16_t* const* in, bf16_t* const* out, const bf16_t* const* res, int relu, int groups,
-                 const int64_t* w, const int64_t* b, const int* cin) {
+                 const int64_t* w, const int64_t* b, int layer0) {
     BArgs a = tbase(c);
     a.in = in[0]; a.out = out[0]; a.res = res ? res[0] : nullptr; a.relu = relu;
     for (int g = 0; g < groups; ++g) {
         a.g_in[g] = in[g] - in[0]; a.g_out[g] = out[g] - out[0]; a.g_res[g] = res ? res[g] - res[0] : 0;
-        a.w[g] = w[g]; a.b[g] = b[g]; a.cin[g] = cin ? cin[g] : 8;
+        a.w[g] = w[g]; a.b[g] = b[g]; a.cin[g] = 8; a.wi[g] = TP_CONV0 + 7 * (layer0 + g);       // (layers of tpack_k's first range)
     }
     return tlaunch<0>(c, a, groups);
 }
@@ -733,6 +1028,14 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
         LinrProf ps(c.s, TK_MISC, 1);
         if (c.OCC == a.OCC) occ_bf16_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(f->occ, c.R, a.OCC);
         zero_pads16_k<<<a.pads.n, 64, 0, c.s>>>(a.mats, a.pads);
+        TPack tp;
+        tp.conv0_w[0] = L.block_in.a_w; tp.conv0_w[1] = L.block_in.b_w;
+        for (int g = 0; g < 7; ++g) { tp.conv0_w[2 + g] = L.outter[g].b_w; tp.occ_w[g] = L.outter[g].a_w; }
+        for (int k = 0; k < 8; ++k) {
+            const IncP& q = (k == 0 ? L.block_in : L.outter[k - 1]).inc[0];
+            tp.pr_w[k] = L.pr_w[k]; tp.c00_w[k] = q.c00_w; tp.c01_w[k] = q.c01_w; tp.c11_w[k] = q.c11_w;
+        }
+        tpack_k<<<TP_IMAGES, 64, 0, c.s>>>(c.P, tp, a.WIMG);
         SceArgs sa;
         sa.n_scales = f->n_scales;
         for (int s = 0; s < f->n_scales; ++s) {
@@ -751,10 +1054,13 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
     {   // A[0] = relu(conv3(x_low)) (block_in) and A[b] = relu(conv3(occ[:, :b])) (outter block b)
         const bf16_t* in0[1] = {a.X0};
         bf16_t* out0[1] = {a.A[0]};
-        TRY(tconv(c, in0, out0, nullptr, 1, 1, &L.block_in.a_w, &L.block_in.a_b, nullptr));
-        const bf16_t* in[7]; bf16_t* out[7]; int64_t w[7], b[7]; int cin[7];
-        for (int g = 0; g < 7; ++g) { in[g] = c.OCC; out[g] = a.A[g + 1]; w[g] = L.outter[g].a_w; b[g] = L.outter[g].a_b; cin[g] = g + 1; }
-        TRY(tconv(c, in, out, nullptr, 1, 7, w, b, cin));
+        TRY(tconv(c, in0, out0, nullptr, 1, 1, &L.block_in.a_w, &L.block_in.a_b, 0));
+        BoArgs o;
+        o.occ = c.OCC; o.out = a.A[1]; o.P = c.P; o.wimg = a.WIMG; o.lo = f->nbr_lo; o.mask = f->nbr_mask; o.ld = f->nbr_ld; o.n = c.R;
+        for (int g = 0; g < 7; ++g) { o.b[g] = L.outter[g].a_b; o.g_out[g] = a.A[g + 1] - a.A[1]; }
+        LinrProf ps(c.s, TK_FWD, 7);
+        bocc7_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(o);
+        TRY(linr_launch_rc());
     }
     {   // the Inception layer of all eight blocks: H = [relu(conv0_0(A)) | relu(conv1_0(A))], then I, M
         BArgs h = tbase(c), i2 = tbase(c);
@@ -763,9 +1069,10 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
         for (int g = 0; g < 8; ++g) {
             const IncP& q = (g == 0 ? L.block_in : L.outter[g - 1]).inc[0];
             h.g_in[g] = a.A[g] - a.A[0]; h.g_out[g] = a.H[g] - a.H[0];
-            h.w[g] = q.c00_w; h.b[g] = q.c00_b; h.w2[g] = q.c10_w; h.b2[g] = q.c10_b;
+            h.w[g] = q.c00_w; h.b[g] = q.c00_b; h.w2[g] = q.c10_w; h.b2[g] = q.c10_b; h.wi[g] = TP_C00 + 4 * g;
             i2.g_in[g] = a.H[g] - a.H[0]; i2.g_out[g] = a.I[g] - a.I[0]; i2.g_res[g] = a.A[g] - a.A[0]; i2.g_m[g] = a.M[g] - a.M[0];
             i2.w[g] = q.c01_w; i2.b[g] = q.c01_b; i2.w2[g] = q.c11_w; i2.b2[g] = q.c11_b; i2.w3[g] = q.c12_w; i2.b3[g] = q.c12_b;
+            i2.wi[g] = TP_DUAL + 4 * g;
         }
         TRY(tlaunch<2>(c, h, 8));
         TRY(tlaunch<3>(c, i2, 8));
@@ -773,10 +1080,10 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
     {   // x_glob = O[0] = conv3(I[0]); prior_b = O[b] = conv3(I[b]) + x_glob
         const bf16_t* in0[1] = {a.I[0]};
         bf16_t* out0[1] = {a.O[0]};
-        TRY(tconv(c, in0, out0, nullptr, 0, 1, &L.block_in.b_w, &L.block_in.b_b, nullptr));
+        TRY(tconv(c, in0, out0, nullptr, 0, 1, &L.block_in.b_w, &L.block_in.b_b, 1));
         const bf16_t* in[7]; bf16_t* out[7]; const bf16_t* res[7]; int64_t w[7], b[7];
         for (int g = 0; g < 7; ++g) { in[g] = a.I[g + 1]; out[g] = a.O[g + 1]; res[g] = a.O[0]; w[g] = L.outter[g].b_w; b[g] = L.outter[g].b_b; }
-        TRY(tconv(c, in, out, res, 0, 7, w, b, nullptr));
+        TRY(tconv(c, in, out, res, 0, 7, w, b, 2));
     }
     {   // the 8 heads: C_k = prune conv(prior_k) (stored), p_k, bits partials
         BArgs h = tbase(c);
@@ -785,7 +1092,7 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
         h.p_out = a.PR; h.partial = a.part;
         for (int k = 0; k < 8; ++k) {
             h.g_in[k] = a.O[k] - a.O[0]; h.g_out[k] = a.C[k] - a.C[0];
-            h.w[k] = L.pr_w[k]; h.b[k] = L.pr_b[k];
+            h.w[k] = L.pr_w[k]; h.b[k] = L.pr_b[k]; h.wi[k] = TP_PRUNE + 7 * k;
             h.h_w1[k] = L.h0_w[k]; h.h_b1[k] = L.h0_b[k]; h.h_w2[k] = L.h2_w[k]; h.h_b2[k] = L.h2_b[k];
             h.t_col[k] = k; h.p_off[k] = (int64_t)k * c.R; h.part_off[k] = (int64_t)k * nblk;
         }
@@ -804,13 +1111,13 @@ static BbArgs bb_base(const TCtx& c) {
     return a;
 }
 
-template <int KIND, int EPI>
+template <int KIND, int EPI, bool NOBWD = false>
 static int bb_launch(TCtx& c, BbArgs& a, int groups, int kind_prof, int* rows) {
     int blocks = 1;
     tb_grid(c.R, c.nb, groups, a.tiles_per_wave, blocks);
     *rows = blocks;
     LinrProf ps(c.s, kind_prof, groups);
-    bbwd_k<KIND, EPI><<<dim3(blocks, groups), BB_WAVES * 64, 0, c.s>>>(a);
+    bbwd_k<KIND, EPI, NOBWD><<<dim3(blocks, groups), BB_WAVES * 64, 0, c.s>>>(a);
     return linr_launch_rc();
 }
 
@@ -890,14 +1197,19 @@ static int tbackward(TCtx& c, float gscale) {
         TRY((bb_launch<2, 0>(c, b, 8, TK_BWD_C00, &r2)));
         if (r2 != rows) return LINR_EINVAL;
     }
-    {   // A[b] = relu(conv3(occ[:, :b]; a)): kernel / bias gradients of the seven first convolutions (their input is data)
-        BbArgs b = bb_base(c);
-        b.g = a.gA[1]; b.xin = c.OCC; b.flags = TB_NO_BWD;
-        for (int g = 0; g < 7; ++g) {
-            b.g_g[g] = a.gA[g + 1] - a.gA[1]; b.g_x[g] = 0;
-            b.w[g] = L.outter[g].a_w; b.b[g] = L.outter[g].a_b; b.cin[g] = g + 1;
-        }
-        TRY((bb_launch<0, 0>(c, b, 7, TK_FIRST_WGRAD, &rows)));
+    {   // A[b] = relu(conv3(occ[:, :b]; a)): kernel / bias gradients of the seven first convolutions from ONE gather of the occupancy
+        OwArgs o;
+        o.occ = c.OCC; o.g = a.gA[1]; o.lo = c.f->nbr_lo; o.mask = c.f->nbr_mask; o.ld = c.f->nbr_ld; o.n = c.R;
+        o.big = a.BIG; o.block_stride = L.total;
+        for (int g = 0; g < 7; ++g) { o.g_g[g] = a.gA[g + 1] - a.gA[1]; o.w[g] = L.outter[g].a_w; o.b[g] = L.outter[g].a_b; }
+        const int64_t t64 = (c.R + 63) >> 6;
+        int64_t target = 2 * tb_cus();
+        if (target > c.nb) target = c.nb;
+        o.tiles_per_block = (int)((t64 + target - 1) / target);
+        rows = (int)((t64 + o.tiles_per_block - 1) / o.tiles_per_block);
+        LinrProf ps(c.s, TK_FIRST_WGRAD, 7);
+        bocc_wgrad7_k<<<rows, BB_WAVES * 64, 0, c.s>>>(o);
+        TRY(linr_launch_rc());
         for (int g = 0; g < 7; ++g) c.note_short(L.outter[g].a_w, L.outter[g].a_b + 8, rows);
     }
     {   // A[0] = relu(conv3(x_low; a)) of block_in: gx_low (fp32 for the scale context's backward) and its gradients
@@ -968,6 +1280,6 @@ extern "C" int linr_spconv_bwd_fused_bf16(const uint16_t* gout, const uint16_t* 
     int blocks = 1;
     tb_grid(n, nblocks, 1, a.tiles_per_wave, blocks);
     *rows_written = blocks;
-    bbwd_k<0, 0><<<dim3(blocks, 1), BB_WAVES * 64, 0, (hipStream_t)stream>>>(a);
+    bbwd_k<0, 0, false><<<dim3(blocks, 1), BB_WAVES * 64, 0, (hipStream_t)stream>>>(a);
     return linr_launch_rc();
 }

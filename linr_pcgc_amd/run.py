@@ -48,6 +48,9 @@ def parse(argv=None):
                     help="which epoch's model is coded / handed to the next GOPs: the one with the lowest mean loss (the reference: main.py:413-426) or the last")
     ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'],
                     help='arithmetic of the coding forward: f32, or bf16 features with the uint8 weight codes de-quantised in-kernel (BASELINE config[4]); travels in side_info.json')
+    ap.add_argument('--train-precision', '--train_precision', dest='train_precision', default=None, choices=['f32', 'bf16'],
+                    help='arithmetic of the overfit step: f32 (the headline), or bf16 feature / gradient rows with fp32 master weights and '
+                         'accumulation (BASELINE config[4] "bf16 SparseConv"; hidden_channel_conv 8, block_layers 1).  Default: follows --precision')
     ap.add_argument('--decode', action='store_true', help='decode every GOP again and check it is lossless')
     ap.add_argument('--mid-test', action='store_true',
                     help='main.py --mid_test: measure the model through Test_one_gop (model.codec) at epochs 0..9 and every --check-freq-th '
@@ -55,6 +58,17 @@ def parse(argv=None):
     ap.add_argument('--check-freq', '--check_freq', dest='check_freq', type=int, default=5, help='main.py --check_freq')
     ap.add_argument('--write-real-bitstream', action='store_true', help='main.py --write_real_bitstream: the mid-test also writes its bins at every 50th epoch')
     return ap.parse_args(argv)
+
+
+def train_precision(args):
+    """--train-precision, or what --precision says when it is not given (--precision bf16 = BASELINE config[4]: bf16 SparseConv for
+    the overfit AND the codec); the wide models (hidden_channel_conv 16 / 32) and deeper block_in variants train in fp32 only."""
+    tp = getattr(args, 'train_precision', None)
+    if tp is None:
+        tp = getattr(args, 'precision', 'f32')
+        if getattr(args, 'hidden_channel_conv', 8) != 8 or getattr(args, 'block_layers', 1) != 1:
+            tp = 'f32'
+    return tp
 
 
 def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=None, decode_frames=None):
@@ -133,6 +147,7 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         gop, stage_s = staged if staged is not None else stage(group)
         t0 = time.time()
         model = overfit.gen_model(gop.scale_num, device, seed=args.seed, block_layers=getattr(args, 'block_layers', 1), hidden=getattr(args, 'hidden_channel_conv', 8))
+        model.train_precision = train_precision(args)
         opt = make_opt(model)
         if ckpt is not None:
             overfit.warm_start(model, opt, ckpt)                 # main.py:241-248

@@ -186,7 +186,8 @@ def test_config4_owlii11_bf16_lossless():
 
 def test_config4_owlii11_gop64_sequence_bf16(tmp_path):
     """BASELINE config[4] at its own GOP size: 64 frames of the Owlii stand-in (11-bit, ~2.9 M points, ~1.25 M rows each: ~27 GB of
-    kernel maps and inputs resident in HBM) as ONE GOP through the sequence driver - one epoch of fp32 overfit, the bf16 /
+    kernel maps and inputs resident in HBM) as ONE GOP through the sequence driver - one epoch of overfit on the bf16 training
+    executor (--precision bf16 = bf16 SparseConv for the overfit and the codec; tests/test_gpu_bf16_train.py), the bf16 /
     uint8-weight codec to the reference's file layout, 3 frames decoded from the files alone (the precision travels in
     side_info.json): lossless."""
     import os

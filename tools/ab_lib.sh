@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of lab builds of the library on the default bench:  gpurun -- 'bash tools/ab_lib.sh tools/_lab/liblinr_fb_10.so ...'
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-b(){ LINR_SKIP_ROOFLINE=1 LINR_SKIP_BPP_SEEDS=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-sequence --steps 96 2>/tmp/ab_err.txt | python3 -c "
+b(){ LINR_SKIP_ROOFLINE=1 LINR_SKIP_BPP_SEEDS=1 LINR_SKIP_BF16_TRAIN=1 LINR_SKIP_WIDE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-sequence --steps 96 2>/tmp/ab_err.txt | python3 -c "
 import json,sys
 t=sys.stdin.read()
 try:
