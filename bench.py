@@ -400,8 +400,12 @@ def bf16_train_leg(gop, L, _lib, epochs):
     opt = FlatAdam(model)
     init = model.flat_parameters().detach().clone()
     bits = torch.zeros(1, dtype=torch.float64, device='cuda')
-    for i in range(400):                                    # clock ramp on the kernels that are about to be timed
-        train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)], out=bits)
+    t_ramp, i = time.time(), 0
+    while time.time() - t_ramp < 1.5:                       # clock ramp on the kernels that are about to be timed (the legs before this one are host-bound)
+        for _ in range(64):
+            train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)], out=bits)
+            i += 1
+        torch.cuda.synchronize()
     model.flat_parameters().copy_(init)
     opt.reset()
     L.linr_prof_mask(1 << 17)
@@ -464,6 +468,339 @@ def bf16_train_leg(gop, L, _lib, epochs):
 
 
 
+class Headline:
+    """The timed region: K steps of the per-GOP overfit (main.py:297-321) on this rank's GOP, then the rest of the complete overfit.
+    Holds everything the timed loop touches (created before the ramp): the loss accumulators, the per-step events, the device-side
+    best-epoch snapshot (the reference codes with the epoch of the lowest mean loss, main.py:413-426,440-451; tracked on the device
+    so that the loop never waits for the host)."""
+
+    def __init__(self, args, rank, L, _lib):
+        from linr_pcgc_amd import overfit, synthetic
+        from linr_pcgc_amd.model_core import FlatAdam, train_step
+        self.args, self.L, self._lib, self.train_step = args, L, _lib, train_step
+        # rank r owns GOP r of the sequence: frames [gop*r, gop*(r+1))  (GOPs are independent: no collective)
+        t_setup = time.time()
+        clouds = [synthetic.sequence_frame_device(args.config, rank * args.gop + t, 'cuda') for t in range(args.gop)]
+        self.gop = gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+        del clouds
+        self.model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+        self.init_sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        self.init_flat = self.model.flat_parameters().detach().clone()           # device copy: the reset before t0 is one D2D copy
+        self.setup_s = time.time() - t_setup
+        log('setup done: %d frames, frame0 %d points / %d rows, %d scales' % (len(gop), gop.point_nums[0], gop.frames[0].rows, gop.scale_num))
+        self.opt = FlatAdam(self.model)
+        self.total_steps = EPOCHS * len(gop)
+        self.prof_every = 1 if args.steps <= 32 else PROF_EVERY
+        L.linr_prof_mask(3)                                       # timed region: the dominant kernel and the forward conv only
+        _lib.check(L.linr_prof_enable(1), 'linr_prof_enable')     # creates the event pairs ...
+        L.linr_prof_enable(0)                                     # ... and stops; sampled steps switch it on (mode 2)
+        self.acc = torch.zeros(len(gop), dtype=torch.float64, device='cuda')
+        self.pns = torch.tensor([float(pn) for pn in gop.point_nums], dtype=torch.float64, device='cuda')
+        epoch_end = (self.acc / self.pns).sum()                   # loads the torch kernels the epoch end uses
+        del epoch_end
+        self.step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        self.epoch_loss = []
+        self.flat = self.model.flat_parameters()
+        self.best = {'loss': torch.full((), float('inf'), dtype=torch.float64, device='cuda'),
+                     'epoch': torch.full((), -1, dtype=torch.int64, device='cuda'), 'p': self.flat.detach().clone(),
+                     'm': self.opt.exp_avg.clone(), 'v': self.opt.exp_avg_sq.clone(), 'meta': []}
+
+    def best_reset(self):
+        self.best['loss'].fill_(float('inf'))
+        self.best['epoch'].fill_(-1)
+        self.best['meta'].clear()
+
+    def best_offer(self, l):
+        best, opt = self.best, self.opt
+        better = l < best['loss']
+        torch.where(better, self.flat.detach(), best['p'], out=best['p'])
+        torch.where(better, opt.exp_avg, best['m'], out=best['m'])
+        torch.where(better, opt.exp_avg_sq, best['v'], out=best['v'])
+        best['epoch'].copy_(torch.where(better, torch.full_like(best['epoch'], len(best['meta'])), best['epoch']))
+        best['loss'].copy_(torch.minimum(best['loss'], l))
+        best['meta'].append((opt.t, opt.t_scale.copy(), opt.lr, opt.sched_steps))
+
+    def body(self, i, sample):
+        """One iteration of the timed loop - warm-up and ramp run exactly this."""
+        gop = self.gop
+        j = i % len(gop)
+        if sample:
+            self.L.linr_prof_enable(2)
+        self.train_step(self.model, self.opt, gop.frames[j], gop.point_nums[j], out=self.acc[j:j + 1])      # bits of frame j into its own slot
+        if sample:
+            self.L.linr_prof_enable(0)
+        if j == len(gop) - 1:
+            l = (self.acc / self.pns).sum()                 # like overfit.overfit_gop: per-epoch loss, no per-step torch kernels
+            self.best_offer(l)                              # before the clamp, as the reference saves (main.py:413-437)
+            self.opt.clamp_lr(4e-4)
+            self.epoch_loss.append(l)
+            self.acc.zero_()
+
+    def run(self, barrier, dist):
+        """Ramp + W warm-up steps, reset in place, the K timed steps, then the rest of the complete overfit (second timed region)."""
+        args, L = self.args, self.L
+        # a fresh box starts at idle clocks (sclk level 1): ramp the device with ~1 s of the same steps before the W warm-up
+        # steps, otherwise the first few hundred timed steps run ~10 % slow (measured: 3.22 vs 2.92 ms/step)
+        t_ramp, i_ramp = time.time(), 0
+        while time.time() - t_ramp < args.ramp_s:
+            for _ in range(32):
+                self.body(i_ramp, i_ramp % self.prof_every == 0)
+                i_ramp += 1
+            torch.cuda.synchronize()
+        for i in range(args.warmup):
+            self.body(i, i % self.prof_every == 0)
+        # reset to the seeded initialisation IN PLACE (one D2D copy + three memsets on the stream; nothing is allocated and
+        # the host does not wait), drop the warm-up's samples
+        self.model.flat_parameters().copy_(self.init_flat)
+        self.opt.reset()
+        self.acc.zero_()
+        self.epoch_loss.clear()
+        self.best_reset()
+        barrier()
+        L.linr_prof_enable(1)                                     # clears the records (the events are reused, none is created)
+        L.linr_prof_enable(0)
+        log('warm-up done (%d ramp + %d warm-up steps)' % (i_ramp, args.warmup))
+        barrier()
+        t0 = time.time()
+        self.step_ev[0].record()
+        for i in range(args.steps):
+            self.body(i, i % self.prof_every == 0)
+            self.step_ev[i + 1].record()
+        barrier()
+        elapsed = time.time() - t0
+        per_step_ms = [self.step_ev[i].elapsed_time(self.step_ev[i + 1]) for i in range(args.steps)]
+        self.live = _read_prof(L, self._lib)
+        # carry the overfit on to its full length (second timed region) so that bits/point and value describe one training
+        rest = max(0, self.total_steps - args.steps)
+        barrier()
+        t1 = time.time()
+        for i in range(args.steps, args.steps + rest):
+            self.body(i, False)
+        # leave model and optimiser in the state of the best epoch (what the reference's model.pth holds) - inside the timed region
+        best, opt = self.best, self.opt
+        self.coded_epoch = int(best['epoch'])
+        if 0 <= self.coded_epoch < len(best['meta']) and steps_done_so_far(args.steps, rest, self.total_steps):
+            self.flat.detach().copy_(best['p'])
+            opt.exp_avg.copy_(best['m'])
+            opt.exp_avg_sq.copy_(best['v'])
+            opt.t, opt.t_scale, opt.lr, opt.sched_steps = (best['meta'][self.coded_epoch][0], best['meta'][self.coded_epoch][1].copy(),
+                                                           best['meta'][self.coded_epoch][2], best['meta'][self.coded_epoch][3])
+        barrier()
+        rest_s = time.time() - t1
+        if dist is not None:
+            t = torch.tensor([elapsed, rest_s], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, rest_s = float(t[0]), float(t[1])
+        self.elapsed, self.rest_s = elapsed, rest_s
+        self.ms_per_step = elapsed * 1e3 / args.steps
+        self.steps_done = args.steps + rest
+        self.full_overfit_s = (elapsed + rest_s) * (self.total_steps / float(self.steps_done))       # steps > total: scaled back to one overfit
+        self.losses = [float(x) / len(self.gop) for x in self.epoch_loss]
+        srt = sorted(per_step_ms)
+        self.step_stats = {'min': round(srt[0], 4), 'median': round(srt[len(srt) // 2], 4), 'max': round(srt[-1], 4),
+                           'first8': [round(x, 3) for x in per_step_ms[:8]], 'sum_over_wall': round(sum(per_step_ms) / (elapsed * 1e3), 4)}
+        log('timed %d steps: %.3f ms/step (events: min %.3f median %.3f max %.3f); full overfit %d steps %.3f s; epoch losses %s'
+            % (args.steps, self.ms_per_step, srt[0], srt[len(srt) // 2], srt[-1], self.steps_done, elapsed + rest_s,
+               ['%.4f' % x for x in self.losses]))
+
+    def kernel_table_leg(self):
+        """Per-kernel table: TABLE_STEPS more steps with every launch of a step bracketed by an event pair (outside every timed region;
+        parameters and optimiser state are saved and put back, so the codec leg codes the model of the complete overfit)."""
+        L, opt = self.L, self.opt
+        snap = (self.model.flat_parameters().detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t, opt.t_scale.copy(),
+                opt.lr, opt.sched_steps)
+        n_loss = len(self.epoch_loss)
+        L.linr_prof_mask(0xFFFFFFFF)
+        L.linr_prof_enable(1)
+        for i in range(TABLE_STEPS):
+            self.body(i, False)
+        L.linr_prof_enable(0)
+        torch.cuda.synchronize()
+        table_prof = _read_prof(L, self._lib)
+        L.linr_prof_mask(3)
+        self.model.flat_parameters().copy_(snap[0])
+        opt.exp_avg.copy_(snap[1])
+        opt.exp_avg_sq.copy_(snap[2])
+        opt.t, opt.t_scale, opt.lr, opt.sched_steps = snap[3], snap[4], snap[5], snap[6]
+        self.acc.zero_()
+        del self.epoch_loss[n_loss:]
+        torch.cuda.synchronize()
+        return table_prof
+
+
+def codec_leg(h, rank, dist, barrier):
+    """Outside the K timed steps: model compression + per-frame forward + D2H + AC + the bitstream files of encoder.py:13-18,81-118
+    (T_write of the metric).  Timed twice: the FIRST call of a process pays for the pinned staging ring (hipHostMalloc of ~54 MB), the
+    coder's thread pool and first-use kernels - one-time costs that a single 32-frame GOP would otherwise be charged with (3.0-3.7 vs
+    1.5 ms/frame); like the W warm-up steps of the overfit it is reported (`codec_first_call`) but `value` uses the second,
+    steady-state call - what every later GOP of a sequence costs."""
+    import shutil
+    import tempfile
+    from linr_pcgc_amd import codec, overfit
+    gop, model = h.gop, h.model
+    model_ori = overfit.gen_model(gop.scale_num, 'cuda')
+    out_dir = tempfile.mkdtemp(prefix='linr_bench_rank%d_' % rank)
+    barrier()
+    t0 = time.time()
+    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
+    codec.write_gop(enc, out_dir)
+    barrier()
+    codec_cold_s = time.time() - t0
+    shutil.rmtree(out_dir, ignore_errors=True)
+    barrier()
+    t0 = time.time()
+    enc = codec.encode_gop(model, model_ori, gop, 8)
+    codec.write_gop(enc, out_dir)
+    barrier()
+    codec_s = time.time() - t0
+    shutil.rmtree(out_dir, ignore_errors=True)
+    if dist is not None:
+        t = torch.tensor([codec_s], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        codec_s = float(t)
+    log('encode leg: %.3f s/frame, bpp %.4f' % (codec_s / len(gop), enc['bpp']['bpp_all']))
+    return enc, codec_s, codec_cold_s
+
+
+def decode_leg(h, enc):
+    """Decode check (outside the metric): frames 0..3 from the streams alone, 4 frames in flight (the first call also pays for the pinned
+    staging buffers, so the timing is taken on a second pass); then the decoder's two other operating points: one frame alone
+    (latency: 56 dependent stage forwards + range decoding of ~2.7 M symbols on one host thread) and 8 frames in flight
+    (throughput); the once-per-GOP part of decode_gop (model.bin -> parameters, coarsest coordinates) is reported on its own."""
+    from linr_pcgc_amd import codec, overfit
+    gop = h.gop
+    nd = min(4, len(gop))
+    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
+    lossless = True
+    for i in range(nd):
+        ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
+        lossless = lossless and bool(torch.equal(dec[i], ref))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
+    torch.cuda.synchronize()
+    decode_s = (time.time() - t0) / nd
+    log('decode frames 0..%d: %.3f s/frame, lossless=%s' % (nd - 1, decode_s, lossless))
+    decode_pts = {}
+    for w in (1, 8):
+        if w > len(gop):
+            continue
+        best = 1e9
+        for rep in range(3):          # best of three: a shared host has bursts that last longer than one repetition
+            shell = overfit.gen_model(gop.scale_num, 'cuda')
+            tm = {}
+            torch.cuda.synchronize()
+            t0 = time.time()
+            codec.decode_gop(shell, enc, 'cuda', frames=list(range(w)), workers=w, timing=tm)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            if (dt - tm['setup_s']) / w < best:
+                best, decode_pts['gop_setup_s'] = (dt - tm['setup_s']) / w, tm['setup_s']
+        decode_pts[w] = best
+    log('decode: %s' % {k: round(v, 4) for k, v in decode_pts.items()})
+    return lossless, decode_s, decode_pts, nd
+
+
+def wide_leg(h):
+    """--hidden_channel_conv 16 (main.py:520): the channel-blocked executor, a few training steps on frame 0.  Reported beside the
+    headline (which is the reference's default width 8), never instead of it."""
+    from linr_pcgc_amd import overfit
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    gop = h.gop
+    try:
+        mw = overfit.gen_model(gop.scale_num, 'cuda', seed=8807, hidden=16)
+        ow = FlatAdam(mw)
+        bw = torch.zeros(1, dtype=torch.float64, device='cuda')
+        for _ in range(3):          # the first step builds the executor's buffer pool
+            train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
+        torch.cuda.synchronize()
+        leg = {'hidden_channel_conv': 16, 'ms_per_step': round((time.time() - t0) * 1e3 / 10, 2), 'steps_timed': 10, 'parameters': int(mw.flat_parameters().numel()),
+               'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py) on csrc/wide.hip: a convolution, its backward-data, its weight gradient '
+                           '(one gather per input block for all gradient blocks), a pointwise layer, a head and the backward of all 8 heads '
+                           'are one launch each; the scale context runs on the 8-wide kernels; Python schedule'}
+        del mw, ow
+    except Exception as e:
+        leg = {'error': repr(e)}
+    log('hidden_channel_conv 16: %s' % leg)
+    return leg
+
+
+def bf16_codec_leg(h, enc, nd, barrier):
+    """bf16 / uint8-weight codec leg (BASELINE config[4]'s numerics on this workload): the SAME trained model coded with the bf16
+    executor (features bf16, weights as the uint8 codes of model.bin, de-quantised in-kernel).  Reported beside the fp32 headline,
+    never instead of it.  Returns (leg, lossless)."""
+    from linr_pcgc_amd import codec, overfit
+    gop, model = h.gop, h.model
+    try:
+        from linr_pcgc_amd.model_codec import Model_Estimate
+        barrier()
+        t0 = time.time()
+        enc_bf = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
+        barrier()
+        bf_codec_s = time.time() - t0
+        dec_bf = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc_bf, 'cuda', frames=list(range(nd)), workers=nd)
+        bf_lossless = all(bool(torch.equal(dec_bf[i], torch.as_tensor(gop.infos[i]['ori']).cuda() +
+                                           torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32))) for i in range(nd))
+        coded = Model_Estimate().compress_model(model, 8, True, overfit.gen_model(gop.scale_num, 'cuda'))['new_model']
+        fwd = {}
+        for prec in ('f32', 'bf16'):
+            fwd[prec] = _time_launches(lambda: coded.frame_probs(gop.frames[0], precision=prec), 20) * 1e3
+        rows0 = gop.frames[0].rows
+        # algorithmic bytes of one inference forward at 2-byte features: 48 conv3 x (2*(8+8) + 108) per row (SURVEY.md 8d form)
+        leg = {'dtype': 'bf16', 'weights': 'uint8 codes of quant_uniform2, de-quantised in-kernel',
+               'codec_s_per_frame': round(bf_codec_s / len(gop), 5), 'bits_per_point': round(float(enc_bf['bpp']['bpp_all']), 5),
+               'point_bpp': round(enc_bf['bpp']['point_bpp'], 6), 'point_bpp_fp32': round(enc['bpp']['point_bpp'], 6),
+               'lossless_decode_frames0to3': bf_lossless,
+               'forward_ms_per_frame': {k: round(v, 4) for k, v in fwd.items()},
+               'forward_alg_gbs': {'bf16': round(rows0 * 48 * (2 * 16 + 108) / (fwd['bf16'] * 1e-3) / 1e9, 1),
+                                   'f32': round(rows0 * 48 * (4 * 16 + 108) / (fwd['f32'] * 1e-3) / 1e9, 1)}}
+        log('bf16 leg: %s' % leg)
+        return leg, bf_lossless
+    except Exception as e:
+        log('bf16 leg failed: %r' % (e,))
+        return {'error': repr(e)}, True
+
+
+def bpp_seeds_leg(h, enc):
+    """bits/point of ONE run is only good to a few per cent: the 10-epoch overfit is run-to-run deterministic but chaotic in the
+    rounding.  Two more complete overfits from other initialisation seeds (untimed) show the spread."""
+    from linr_pcgc_amd import codec, overfit
+    from linr_pcgc_amd.model_core import FlatAdam
+    gop = h.gop
+    vals = [float(enc['bpp']['bpp_all'])]
+    seeds = [8807, 8808, 8809]
+    for sd_ in seeds[1:]:
+        m2 = overfit.gen_model(gop.scale_num, 'cuda', seed=sd_)
+        overfit.overfit_gop(m2, FlatAdam(m2), gop, EPOCHS)
+        vals.append(float(codec.encode_gop(m2, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)['bpp']['bpp_all']))
+        del m2
+    out = {'seeds': seeds, 'values': [round(v, 5) for v in vals], 'mean': round(sum(vals) / len(vals), 5),
+           'min': round(min(vals), 5), 'max': round(max(vals), 5),
+           'note': 'complete %d-epoch overfits of the same GOP from three initialisation seeds; `bits_per_point` is seed 8807' % EPOCHS}
+    log('bits/point over seeds: %s' % out)
+    return out
+
+
+def device_report(world, dist, local):
+    """Who ran: every rank's device (name, index, PCI bus id) and the collective backend - a SCALE record then shows N ranks on N
+    different devices.  The only collectives are a start-up barrier and the MAX / SUM of times and bit counts (no data path)."""
+    prop = torch.cuda.get_device_properties(local)
+    mine = {'rank': int(os.environ.get('RANK', 0)), 'local_rank': local, 'device_index': torch.cuda.current_device(), 'device_name': prop.name,
+            'pci_bus_id': getattr(prop, 'pci_bus_id', None), 'hbm_gib': round(prop.total_memory / 2.0 ** 30, 1)}
+    ranks = [mine]
+    if dist is not None:
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        ranks = box
+    return {'ranks': ranks, 'world_size': world,
+            'backend': ('%s (RCCL)' % dist.get_backend() if dist.get_backend() == 'nccl' else dist.get_backend()) if dist is not None else None,
+            'distinct_devices': len({(r['device_index'], r.get('pci_bus_id')) for r in ranks})}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -486,10 +823,9 @@ def main():
     if world > 1:
         from linr_pcgc_amd.run import init_dist
         dist = init_dist(local)
-    from linr_pcgc_amd import _lib, codec, overfit, synthetic
-    from linr_pcgc_amd.model_core import FlatAdam, train_step
-    import ctypes
+    from linr_pcgc_amd import _lib, synthetic
     L = _lib.lib()
+    devices = device_report(world, dist, local)
 
     def barrier():
         torch.cuda.synchronize()
@@ -506,247 +842,23 @@ def main():
                    'ms_per_step': round(seq['wall_s'] * 1e3 / (args.seq_frames * args.seq_epochs), 4),
                    'higher_is_better': False, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                    'config': {'workload': seq['workload'], 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
-                   'bits_per_point': seq['bits_per_point'], 'sequence': seq, 'roofline': None, 'cpu_baseline': None}
+                   'bits_per_point': seq['bits_per_point'], 'sequence': seq, 'roofline': None, 'cpu_baseline': None, 'devices': devices}
             print(json.dumps(out))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # rank r owns GOP r of the sequence: frames [gop*r, gop*(r+1))  (GOPs are independent: no collective)
-    t_setup = time.time()
-    clouds = [synthetic.sequence_frame_device(args.config, rank * args.gop + t, 'cuda') for t in range(args.gop)]
-    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
-    del clouds
-    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
-    init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    init_flat = model.flat_parameters().detach().clone()           # device copy: the reset before t0 is one D2D copy
-    setup_s = time.time() - t_setup
-    log('setup done: %d frames, frame0 %d points / %d rows, %d scales' % (len(gop), gop.point_nums[0], gop.frames[0].rows, gop.scale_num))
-
-    opt = FlatAdam(model)
-    total_steps = EPOCHS * len(gop)
-    # everything the timed loop touches exists before the ramp: the event pool of the live kernel timing, the float64
-    # accumulators and their (lazily loaded) torch kernels, the per-step events
-    prof_every = 1 if args.steps <= 32 else PROF_EVERY
-    L.linr_prof_mask(3)                                       # timed region: the dominant kernel and the forward conv only
-    _lib.check(L.linr_prof_enable(1), 'linr_prof_enable')     # creates the event pairs ...
-    L.linr_prof_enable(0)                                     # ... and stops; sampled steps switch it on (mode 2)
-    acc = torch.zeros(len(gop), dtype=torch.float64, device='cuda')
-    pns = torch.tensor([float(pn) for pn in gop.point_nums], dtype=torch.float64, device='cuda')
-    epoch_end = (acc / pns).sum()                             # loads the torch kernels the epoch end uses
-    del epoch_end
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    epoch_loss = []
-    # the reference keeps the checkpoint of the epoch with the lowest mean loss (main.py:413-426,440-451) and codes with it.
-    # Tracked on the device so that the timed loop never waits for the host: a conditional copy of the parameters and both
-    # Adam moments at the end of every epoch (3 x 54,712 floats), the host-side counters by epoch.
-    flat = model.flat_parameters()
-    best = {'loss': torch.full((), float('inf'), dtype=torch.float64, device='cuda'),
-            'epoch': torch.full((), -1, dtype=torch.int64, device='cuda'), 'p': flat.detach().clone(),
-            'm': opt.exp_avg.clone(), 'v': opt.exp_avg_sq.clone(), 'meta': []}
-
-    def best_reset():
-        best['loss'].fill_(float('inf'))
-        best['epoch'].fill_(-1)
-        best['meta'].clear()
-
-    def best_offer(l):
-        better = l < best['loss']
-        torch.where(better, flat.detach(), best['p'], out=best['p'])
-        torch.where(better, opt.exp_avg, best['m'], out=best['m'])
-        torch.where(better, opt.exp_avg_sq, best['v'], out=best['v'])
-        best['epoch'].copy_(torch.where(better, torch.full_like(best['epoch'], len(best['meta'])), best['epoch']))
-        best['loss'].copy_(torch.minimum(best['loss'], l))
-        best['meta'].append((opt.t, opt.t_scale.copy(), opt.lr, opt.sched_steps))
-
-    def body(i, sample):
-        """One iteration of the timed loop - warm-up and ramp run exactly this."""
-        j = i % len(gop)
-        if sample:
-            L.linr_prof_enable(2)
-        train_step(model, opt, gop.frames[j], gop.point_nums[j], out=acc[j:j + 1])      # bits of frame j into its own slot
-        if sample:
-            L.linr_prof_enable(0)
-        if j == len(gop) - 1:
-            l = (acc / pns).sum()                           # like overfit.overfit_gop: per-epoch loss, no per-step torch kernels
-            best_offer(l)                                   # before the clamp, as the reference saves (main.py:413-437)
-            opt.clamp_lr(4e-4)
-            epoch_loss.append(l)
-            acc.zero_()
-
-    # a fresh box starts at idle clocks (sclk level 1): ramp the device with ~1 s of the same steps before the W warm-up
-    # steps, otherwise the first few hundred timed steps run ~10 % slow (measured: 3.22 vs 2.92 ms/step)
-    t_ramp, i_ramp = time.time(), 0
-    while time.time() - t_ramp < args.ramp_s:
-        for _ in range(32):
-            body(i_ramp, i_ramp % prof_every == 0)
-            i_ramp += 1
-        torch.cuda.synchronize()
-    for i in range(args.warmup):
-        body(i, i % prof_every == 0)
-    # reset to the seeded initialisation IN PLACE (one D2D copy + three memsets on the stream; nothing is allocated and
-    # the host does not wait), drop the warm-up's samples
-    model.flat_parameters().copy_(init_flat)
-    opt.reset()
-    acc.zero_()
-    epoch_loss.clear()
-    best_reset()
-    barrier()
-    L.linr_prof_enable(1)                                     # clears the records (the events are reused, none is created)
-    L.linr_prof_enable(0)
-    log('warm-up done (%d ramp + %d warm-up steps)' % (i_ramp, args.warmup))
-    barrier()
-    t0 = time.time()
-    step_ev[0].record()
-    for i in range(args.steps):
-        body(i, i % prof_every == 0)
-        step_ev[i + 1].record()
-    barrier()
-    elapsed = time.time() - t0
-    per_step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
-    live = _read_prof(L, _lib)
-    # carry the overfit on to its full length (second timed region) so that bits/point and value describe one training
-    rest = max(0, total_steps - args.steps)
-    barrier()
-    t1 = time.time()
-    for i in range(args.steps, args.steps + rest):
-        body(i, False)
-    # leave model and optimiser in the state of the best epoch (what the reference's model.pth holds) - inside the timed region
-    coded_epoch = int(best['epoch'])
-    if 0 <= coded_epoch < len(best['meta']) and steps_done_so_far(args.steps, rest, total_steps):
-        flat.detach().copy_(best['p'])
-        opt.exp_avg.copy_(best['m'])
-        opt.exp_avg_sq.copy_(best['v'])
-        opt.t, opt.t_scale, opt.lr, opt.sched_steps = (best['meta'][coded_epoch][0], best['meta'][coded_epoch][1].copy(),
-                                                       best['meta'][coded_epoch][2], best['meta'][coded_epoch][3])
-    barrier()
-    rest_s = time.time() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed, rest_s], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, rest_s = float(t[0]), float(t[1])
-    ms_per_step = elapsed * 1e3 / args.steps
-    steps_done = args.steps + rest
-    full_overfit_s = (elapsed + rest_s) * (total_steps / float(steps_done))       # steps > total: scaled back to one overfit
-    losses = [float(x) / len(gop) for x in epoch_loss]
-    srt = sorted(per_step_ms)
-    step_stats = {'min': round(srt[0], 4), 'median': round(srt[len(srt) // 2], 4), 'max': round(srt[-1], 4),
-                  'first8': [round(x, 3) for x in per_step_ms[:8]], 'sum_over_wall': round(sum(per_step_ms) / (elapsed * 1e3), 4)}
-    log('timed %d steps: %.3f ms/step (events: min %.3f median %.3f max %.3f); full overfit %d steps %.3f s; epoch losses %s'
-        % (args.steps, ms_per_step, srt[0], srt[len(srt) // 2], srt[-1], steps_done, elapsed + rest_s, ['%.4f' % x for x in losses]))
-
-    # per-kernel table: TABLE_STEPS more steps with every launch of a step bracketed by an event pair (outside every timed region;
-    # parameters and optimiser state are saved and put back, so the codec leg below codes the model of the complete overfit)
-    table_prof = None
-    if rank == 0 and not os.environ.get('LINR_SKIP_ROOFLINE'):
-        snap = (model.flat_parameters().detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t, opt.t_scale.copy(),
-                opt.lr, opt.sched_steps)
-        n_loss = len(epoch_loss)
-        L.linr_prof_mask(0xFFFFFFFF)
-        L.linr_prof_enable(1)
-        for i in range(TABLE_STEPS):
-            body(i, False)
-        L.linr_prof_enable(0)
-        torch.cuda.synchronize()
-        table_prof = _read_prof(L, _lib)
-        L.linr_prof_mask(3)
-        model.flat_parameters().copy_(snap[0])
-        opt.exp_avg.copy_(snap[1])
-        opt.exp_avg_sq.copy_(snap[2])
-        opt.t, opt.t_scale, opt.lr, opt.sched_steps = snap[3], snap[4], snap[5], snap[6]
-        acc.zero_()
-        del epoch_loss[n_loss:]
-        torch.cuda.synchronize()
-
-    # codec leg (outside the K timed steps): model compression + per-frame forward + D2H + AC + the bitstream files of
-    # encoder.py:13-18,81-118 (T_write of the metric), then the lossless check
-    import shutil
-    import tempfile
-    model_ori = overfit.gen_model(gop.scale_num, 'cuda')
-    out_dir = tempfile.mkdtemp(prefix='linr_bench_rank%d_' % rank)
-    # The codec leg is timed twice.  The FIRST call of a process pays for the pinned staging ring (hipHostMalloc of ~54 MB),
-    # the coder's thread pool and first-use kernels - one-time costs that a single 32-frame GOP would otherwise be charged
-    # with (3.0-3.7 vs 1.5 ms/frame); like the W warm-up steps of the overfit it is reported (`codec_first_call`) but
-    # `value` uses the second, steady-state call - what every later GOP of a sequence costs.
-    barrier()
-    t0 = time.time()
-    enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)
-    codec.write_gop(enc, out_dir)
-    barrier()
-    codec_cold_s = time.time() - t0
-    shutil.rmtree(out_dir, ignore_errors=True)
-    barrier()
-    t0 = time.time()
-    enc = codec.encode_gop(model, model_ori, gop, 8)
-    codec.write_gop(enc, out_dir)
-    barrier()
-    codec_s = time.time() - t0
-    shutil.rmtree(out_dir, ignore_errors=True)
-    if dist is not None:
-        t = torch.tensor([codec_s], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        codec_s = float(t)
+    # ---- headline: K timed steps of the overfit, then the rest of the complete overfit -------------------------------------------------
+    h = Headline(args, rank, L, _lib)
+    h.run(barrier, dist)
+    gop = h.gop
+    table_prof = h.kernel_table_leg() if rank == 0 and not os.environ.get('LINR_SKIP_ROOFLINE') else None
+    # ---- codec, decoder, the legs reported beside the headline ------------------------------------------------------------------------
+    enc, codec_s, codec_cold_s = codec_leg(h, rank, dist, barrier)
     codec_s_per_frame = codec_s / len(gop)
-    log('encode leg: %.3f s/frame, bpp %.4f' % (codec_s_per_frame, enc['bpp']['bpp_all']))
-    # decode check (outside the metric): frames 0..3 from the streams alone, 4 frames in flight; the first call also pays
-    # for the pinned staging buffers, so the timing is taken on a second pass
-    nd = min(4, len(gop))
-    dec = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
-    lossless = True
-    for i in range(nd):
-        ref = torch.as_tensor(gop.infos[i]['ori']).cuda() + torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32)
-        lossless = lossless and bool(torch.equal(dec[i], ref))
-    torch.cuda.synchronize()
-    t0 = time.time()
-    codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc, 'cuda', frames=list(range(nd)), workers=nd)
-    torch.cuda.synchronize()
-    decode_s = (time.time() - t0) / nd
-    log('decode frames 0..%d: %.3f s/frame, lossless=%s' % (nd - 1, decode_s, lossless))
-    # the decoder's two other operating points: one frame alone (latency: 56 dependent stage forwards + range decoding of
-    # ~2.7 M symbols on one host thread) and 8 frames in flight (throughput); the once-per-GOP part of decode_gop (model.bin ->
-    # parameters, coarsest coordinates) is reported on its own
-    decode_pts = {}
-    for w in (1, 8):
-        if w > len(gop):
-            continue
-        best = 1e9
-        for rep in range(3):          # best of three: a shared host has bursts that last longer than one repetition
-            shell = overfit.gen_model(gop.scale_num, 'cuda')
-            tm = {}
-            torch.cuda.synchronize()
-            t0 = time.time()
-            codec.decode_gop(shell, enc, 'cuda', frames=list(range(w)), workers=w, timing=tm)
-            torch.cuda.synchronize()
-            dt = time.time() - t0
-            if (dt - tm['setup_s']) / w < best:
-                best, decode_pts['gop_setup_s'] = (dt - tm['setup_s']) / w, tm['setup_s']
-        decode_pts[w] = best
-    log('decode: %s' % {k: round(v, 4) for k, v in decode_pts.items()})
-
-    # --hidden_channel_conv 16 (main.py:520): the channel-blocked executor on the 8-wide kernels, a few training steps on frame 0.
-    # Reported beside the headline (which is the reference's default width 8), never instead of it.
-    wide_leg = None
-    if rank == 0 and not os.environ.get('LINR_SKIP_WIDE'):
-        try:
-            mw = overfit.gen_model(gop.scale_num, 'cuda', seed=8807, hidden=16)
-            ow = FlatAdam(mw)
-            bw = torch.zeros(1, dtype=torch.float64, device='cuda')
-            for _ in range(3):          # the first step builds the executor's buffer pool
-                train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
-            torch.cuda.synchronize()
-            t0 = time.time()
-            for _ in range(10):
-                train_step(mw, ow, gop.frames[0], gop.point_nums[0], out=bw)
-            torch.cuda.synchronize()
-            wide_leg = {'hidden_channel_conv': 16, 'ms_per_step': round((time.time() - t0) * 1e3 / 10, 2), 'steps_timed': 10, 'parameters': int(mw.flat_parameters().numel()),
-                        'executor': 'channel-blocked (linr_pcgc_amd/wide_net.py) on csrc/wide.hip: a convolution, its backward-data, its weight gradient '
-                                    '(one gather per input block for all gradient blocks), a pointwise layer, a head and the backward of all 8 heads '
-                                    'are one launch each; the scale context runs on the 8-wide kernels; Python schedule'}
-            del mw, ow
-        except Exception as e:
-            wide_leg = {'error': repr(e)}
-        log('hidden_channel_conv 16: %s' % wide_leg)
+    lossless, decode_s, decode_pts, nd = decode_leg(h, enc)
+    wide = wide_leg(h) if rank == 0 and not os.environ.get('LINR_SKIP_WIDE') else None
     bf16_train = None
     if rank == 0 and not os.environ.get('LINR_SKIP_BF16_TRAIN'):
         try:
@@ -754,63 +866,16 @@ def main():
         except Exception as e:
             bf16_train = {'error': repr(e)}
         log('bf16 training leg: %s' % bf16_train)
-    # bf16 / uint8-weight codec leg (BASELINE config[4]'s numerics on this workload): the SAME trained model coded with the
-    # bf16 executor (features bf16, weights as the uint8 codes of model.bin, de-quantised in-kernel).  Reported beside the fp32
-    # headline, never instead of it.
-    bf16_leg = None
-    try:
-        from linr_pcgc_amd.model_codec import Model_Estimate
-        barrier()
-        t0 = time.time()
-        enc_bf = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
-        barrier()
-        bf_codec_s = time.time() - t0
-        dec_bf = codec.decode_gop(overfit.gen_model(gop.scale_num, 'cuda'), enc_bf, 'cuda', frames=list(range(nd)), workers=nd)
-        bf_lossless = all(bool(torch.equal(dec_bf[i], torch.as_tensor(gop.infos[i]['ori']).cuda() +
-                                           torch.tensor(gop.coord_mins[i], device='cuda', dtype=torch.int32))) for i in range(nd))
-        coded = Model_Estimate().compress_model(model, 8, True, overfit.gen_model(gop.scale_num, 'cuda'))['new_model']
-        fwd = {}
-        for prec in ('f32', 'bf16'):
-            fwd[prec] = _time_launches(lambda: coded.frame_probs(gop.frames[0], precision=prec), 20) * 1e3
-        rows0 = gop.frames[0].rows
-        # algorithmic bytes of one inference forward at 2-byte features: 48 conv3 x (2*(8+8) + 108) per row (SURVEY.md 8d form)
-        bf16_leg = {'dtype': 'bf16', 'weights': 'uint8 codes of quant_uniform2, de-quantised in-kernel',
-                    'codec_s_per_frame': round(bf_codec_s / len(gop), 5), 'bits_per_point': round(float(enc_bf['bpp']['bpp_all']), 5),
-                    'point_bpp': round(enc_bf['bpp']['point_bpp'], 6), 'point_bpp_fp32': round(enc['bpp']['point_bpp'], 6),
-                    'lossless_decode_frames0to3': bf_lossless,
-                    'forward_ms_per_frame': {k: round(v, 4) for k, v in fwd.items()},
-                    'forward_alg_gbs': {'bf16': round(rows0 * 48 * (2 * 16 + 108) / (fwd['bf16'] * 1e-3) / 1e9, 1),
-                                        'f32': round(rows0 * 48 * (4 * 16 + 108) / (fwd['f32'] * 1e-3) / 1e9, 1)}}
-        lossless = lossless and bf_lossless
-        log('bf16 leg: %s' % bf16_leg)
-        del enc_bf, dec_bf, coded
-    except Exception as e:
-        bf16_leg = {'error': repr(e)}
-        log('bf16 leg failed: %r' % (e,))
+    bf16_leg, bf_lossless = bf16_codec_leg(h, enc, nd, barrier)
+    lossless = lossless and bf_lossless
+    bpp_seeds = bpp_seeds_leg(h, enc) if rank == 0 and not os.environ.get('LINR_SKIP_BPP_SEEDS') else None
 
-    # bits/point of ONE run is only good to a few per cent: the 10-epoch overfit is run-to-run deterministic but chaotic in the
-    # rounding.  Two more complete overfits from other initialisation seeds (untimed) show the spread.
-    bpp_seeds = None
-    if rank == 0 and not os.environ.get('LINR_SKIP_BPP_SEEDS'):
-        vals = [float(enc['bpp']['bpp_all'])]
-        seeds = [8807, 8808, 8809]
-        for sd_ in seeds[1:]:
-            m2 = overfit.gen_model(gop.scale_num, 'cuda', seed=sd_)
-            overfit.overfit_gop(m2, FlatAdam(m2), gop, EPOCHS)
-            vals.append(float(codec.encode_gop(m2, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8)['bpp']['bpp_all']))
-            del m2
-        bpp_seeds = {'seeds': seeds, 'values': [round(v, 5) for v in vals], 'mean': round(sum(vals) / len(vals), 5),
-                     'min': round(min(vals), 5), 'max': round(max(vals), 5),
-                     'note': 'complete %d-epoch overfits of the same GOP from three initialisation seeds; `bits_per_point` is seed 8807' % EPOCHS}
-        log('bits/point over seeds: %s' % bpp_seeds)
-
-    overfit_s_per_frame = full_overfit_s / len(gop)
+    overfit_s_per_frame = h.full_overfit_s / len(gop)
     value = (overfit_s_per_frame + codec_s_per_frame) / world
-
     out = None
     if rank == 0:
         out = {'metric': 'encode_sec_per_frame', 'value': round(value, 5), 'unit': 's/frame', 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(h.ms_per_step, 4),
                'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'BASELINE config[%s] stand-in: synthetic %s (%d-bit sphere shell r~%d, %s voxel thick, %d points and %d '
                                       'parent rows in frame 0, %d scales), 1 GOP of %d frames per GPU, first_epoch=%d, '
@@ -820,20 +885,21 @@ def main():
                                          '%g' % (2 * synthetic.CONFIGS[args.config]['thickness']), gop.point_nums[0], gop.frames[0].rows,
                                          gop.scale_num, len(gop), EPOCHS),
                           'frames_per_gpu': len(gop), 'epochs': EPOCHS, 'parallelism': 'gop-per-gpu x%d (no collective)' % world},
+               'devices': devices,
                'value_note': 'overfit (complete %d epochs) + the steady-state codec call, per frame; a process\'s FIRST codec call also '
                              'pays for pinned buffers and coder threads: value_cold below uses it' % EPOCHS,
                'value_cold': round((overfit_s_per_frame + codec_cold_s / len(gop)) / world, 5),
                'bits_per_point': round(enc['bpp']['bpp_all'], 5),
                'bits_per_point_seeds': bpp_seeds,
-               'bits_per_point_after_steps': steps_done,
-               'coded_epoch': coded_epoch, 'coded_epoch_policy': 'best mean loss of the overfit (main.py:413-426); epochs count from 0',
+               'bits_per_point_after_steps': h.steps_done,
+               'coded_epoch': h.coded_epoch, 'coded_epoch_policy': 'best mean loss of the overfit (main.py:413-426); epochs count from 0',
                'bpp_components': {k: round(v, 6) for k, v in enc['bpp'].items()},
                'lossless_decode_frames0to3': lossless,
-               'full_overfit': {'steps': steps_done, 'seconds': round(elapsed + rest_s, 4),
-                                'ms_per_step': round((elapsed + rest_s) * 1e3 / steps_done, 4),
+               'full_overfit': {'steps': h.steps_done, 'seconds': round(h.elapsed + h.rest_s, 4),
+                                'ms_per_step': round((h.elapsed + h.rest_s) * 1e3 / h.steps_done, 4),
                                 'note': 'value and bits_per_point both come from this complete %d-epoch overfit; ms_per_step is '
                                         'the mean of its first `steps` steps' % EPOCHS},
-               'per_step_ms_hip_events': step_stats,
+               'per_step_ms_hip_events': h.step_stats,
                'components_s_per_frame': {'overfit': round(overfit_s_per_frame, 5), 'codec_modelcomp_fwd_ac_write': round(codec_s_per_frame, 5),
                                           'codec_first_call': round(codec_cold_s / len(gop), 5),
                                           'decode_s_per_frame_4_in_flight': round(decode_s, 4),
@@ -842,25 +908,25 @@ def main():
                                           'decode_gop_setup_s': round(decode_pts.get('gop_setup_s', 0.0), 4)},
                'bf16_codec': bf16_leg,
                'bf16_train': bf16_train,
-               'hidden16': wide_leg,
-               'epoch_loss_bpp': [round(x, 4) for x in losses], 'setup_s': round(setup_s, 1),
+               'hidden16': wide,
+               'epoch_loss_bpp': [round(x, 4) for x in h.losses], 'setup_s': round(h.setup_s, 1),
                'reference_logged': {'train_s_per_frame_epoch': 0.55, 'codec_s_per_frame': 0.43,
                                     'source': 'loot/info.log, loot/gop_32_62/*/result.json (RTX 3090, real loot)'}}
-        out['roofline'] = None if os.environ.get('LINR_SKIP_ROOFLINE') else kernel_roofline(gop, live, table_prof, TABLE_STEPS, ms_per_step)
+        out['roofline'] = None if os.environ.get('LINR_SKIP_ROOFLINE') else kernel_roofline(gop, h.live, table_prof, TABLE_STEPS, h.ms_per_step)
         log('roofline: %s' % out['roofline'])
     parity_ok = True
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_threads())
             log('cpu baseline on %d threads ...' % host_threads())
-            out['cpu_baseline'], o_bits, o_grads = cpu_baseline(init_sd, gop.infos[0], gop.point_nums[0], args.cpu_sample_rows)
-            out['full_size_parity'] = full_size_parity(init_sd, gop.frames[0], gop.point_nums[0], o_bits, o_grads, gop.scale_num)
+            out['cpu_baseline'], o_bits, o_grads = cpu_baseline(h.init_sd, gop.infos[0], gop.point_nums[0], args.cpu_sample_rows)
+            out['full_size_parity'] = full_size_parity(h.init_sd, gop.frames[0], gop.point_nums[0], o_bits, o_grads, gop.scale_num)
             parity_ok = out['full_size_parity']['ok']
             log('full-size parity vs oracle: %s' % out['full_size_parity'])
         else:
             out['cpu_baseline'] = None
     # free the headline's GOP before the sequence leg stages its own frames
-    del gop, enc, dec
+    del gop, enc, h
     torch.cuda.empty_cache()
     seq = None
     if not args.no_sequence:

@@ -195,7 +195,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
             for (int j = 0; j < 4; ++j) acc[1][j] = b1[j];
         }
     }
-    constexpr int PF = 4;
+#ifndef BCONV_PF
+#define BCONV_PF 4
+#endif
+    constexpr int PF = BCONV_PF;
     uint4 x[PF + 1];
 #pragma unroll
     for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(u)]);
