@@ -55,7 +55,8 @@ struct LinrAdamRanges {
     int active[16];
     float step_size[16], bc2_sqrt[16];
 };
-// torch.optim.Adam's single-tensor update, the ONE definition every kernel that applies it uses (adam_k, step_tail_k): the operations
+// torch.optim.Adam's single-tensor update, the ONE definition every kernel that applies it uses (adam_k; the tail-fold experiments of
+// round 4 used it too): the operations
 // are pinned - separate multiplies and adds for the moments, one fused multiply-add for the step (what adam_k has compiled to since
 // round 1) - so that the fused and the stand-alone path update parameters bit-identically whatever the surrounding code looks like.
 __device__ __forceinline__ float linr_adam_update(float p, float grad, float& m, float& v, float step_size, float bc2_sqrt, float beta1,

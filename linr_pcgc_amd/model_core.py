@@ -556,7 +556,7 @@ def train_step(model, opt, frame, point_num, out=None):
     if model._wide is not None:          # hidden_channel_conv 16 / 32: the channel-blocked executor + the segment-wise Adam
         if model.train_precision != 'f32':
             raise _lib.LinrError('the bf16 training executor exists for hidden_channel_conv=8 only')
-        with torch.no_grad():
+        with torch.no_grad(), model._wide.lock:          # (the pooled buffers of the forward must survive until the backward has run)
             tape = model._wide.forward(frame, 0, 8, None, bits, keep=True, pool=True)
             model._ensure_grad_views()
             model._flat_grad.zero_()

@@ -116,10 +116,17 @@ class octree_level(nn.Module):
         super().__init__()
         self.offsets = torch.tensor([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], dtype=torch.int64)
 
-    def forward(self, leaf, qsc=None, coord_bits=20):
-        if leaf.is_cuda and leaf.dtype == torch.int32:        # GPU: parents (key sort + unique of leaf >> 1) and their child occupancy
-            from . import ops                                  # (sorted-key search) in ONE library call; leaf coordinates are >= 0
-            return ops.octree_level(leaf.contiguous(), coord_bits)
+    def forward(self, leaf, qsc=None, coord_bits=None):
+        """coord_bits: the caller vouches that every coordinate is in [0, 2^coord_bits) (prepare_frame does); None: checked here -
+        the library's keys hold 20 bits per axis and its kernels do not validate (negative or wider values would build garbage
+        keys silently), so anything outside takes the torch path below, which handles the full int range like the reference."""
+        if leaf.is_cuda and leaf.dtype == torch.int32 and leaf.numel() > 0:
+            if coord_bits is None:
+                lo, hi = torch.aminmax(leaf)
+                coord_bits = 20 if int(lo) >= 0 and int(hi) < (1 << 20) else 0
+            if 0 < coord_bits <= 20:      # GPU: parents (key sort + unique of leaf >> 1) and their child occupancy (sorted-key search)
+                from . import ops         # in ONE library call
+                return ops.octree_level(leaf.contiguous(), coord_bits)
         parent = unique_sorted(torch.div(leaf.to(torch.int64), 2, rounding_mode='floor'))
         off = self.offsets.to(leaf.device)
         # all 8 child lookups of every parent as ONE batched search over the sorted leaf keys

@@ -18,6 +18,7 @@ training step at widths 16 / 32 on the loot-like frame (profiles/r04_wide.txt; ~
 8-wide model (every BASELINE config, the reference's default and its shipped checkpoint) never comes here.
 """
 import os
+import threading
 
 import torch
 
@@ -47,7 +48,8 @@ class _Pool:
         self.i += 1
         if i < len(self.bufs):
             b = self.bufs[i]
-            if b.shape[0] == nb and b.shape[1] > n and b.device.type == dev.type and (dev.index is None or dev.index == b.device.index):
+            want = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == 'cuda' else None)
+            if b.shape[0] == nb and b.shape[1] > n and b.device.type == dev.type and want == b.device.index:
                 return [b[j, 1:n + 1] for j in range(nb)]
         b = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
         b[:, 0].zero_()
@@ -59,14 +61,25 @@ class _Pool:
 
 
 _FUSE_PW = os.environ.get('LINR_WIDE_FUSE_PW', '1') != '0'          # the pointwise layers of an Inception layer in the convolutions' epilogues
-_POOL = None          # the pool of the running forward / backward (WideNet.forward(pool=True)), else fresh buffers
-_DEFER = None         # the running backward's list of deferred weight-gradient reductions (one launch per 32 at its end), else None
+# Per-THREAD state of the running pass (two threads may train two wide models at once, each call sees only its own): `pool` = the
+# buffer pool of the running forward / backward (WideNet.forward(pool=True)), else fresh buffers; `defer` = the running backward's
+# list of deferred weight-gradient reductions (one launch per 32 at its end), else None.  One MODEL is used by one thread at a
+# time: WideNet.forward / backward hold the model's lock (its pool and the frame bound by _bind() are per-model state).
+_TLS = threading.local()
+
+
+def _pool():
+    return getattr(_TLS, 'pool', None)
+
+
+def _defer():
+    return getattr(_TLS, 'defer', None)
 
 
 def _blocks(n, nb, dev):
     """nb zero-padded [n, 8] matrices (views buf[1:] of [n + 1, 8] buffers whose row 0 is zero)."""
-    if _POOL is not None:
-        return _POOL.take(n, nb, dev if isinstance(dev, torch.device) else torch.device(dev))
+    if _pool() is not None:
+        return _pool().take(n, nb, dev if isinstance(dev, torch.device) else torch.device(dev))
     buf = torch.empty((nb, n + 1, B), dtype=torch.float32, device=dev)
     buf[:, 0].zero_()
     return [buf[i, 1:] for i in range(nb)]
@@ -108,7 +121,7 @@ class _Conv:
         # fixed-order reduction straight into the parameter gradients (views of the flat gradient)
         if wgrad:
             ops.spconv_wgrad_wide(xs[:self.nbi], gouts[:self.nbo], net.nbr_full, net.tile8t, n, self.ci, self.co,
-                                  gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1), defer=_DEFER)
+                                  gw=self.mod.kernel.grad, gb=self.mod.bias.grad.reshape(-1), defer=_defer())
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -147,14 +160,14 @@ class _Pointwise:
     def wgrad(self, xs, gouts):
         """Parameter gradients only (the backward-data pass rides in a convolution's epilogue)."""
         ops.linear_wgrad_wide(xs[:self.nbi], self.cin, gouts[:self.nbo], self.cout, self.w.grad, self.ws[0], self.ws[1],
-                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_DEFER)
+                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_defer())
 
     def bwd(self, xs, gouts, gins=None, act=None, need_input_grad=True):
         """Parameter gradients into .grad (one grouped launch + one reduction); the input gradient (masked by act > 0) accumulated
         into gins (list of [buffer, has_content]) or returned as fresh blocks."""
         n = gouts[0].shape[0]
         ops.linear_wgrad_wide(xs[:self.nbi], self.cin, gouts[:self.nbo], self.cout, self.w.grad, self.ws[0], self.ws[1],
-                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_DEFER)
+                              self.b.grad.reshape(-1), g_blocked=self.blocked_out, defer=_defer())
         if not need_input_grad:
             return None
         fresh = gins is None
@@ -241,13 +254,13 @@ class _Block:
             else:
                 g_m = q['c12'].bwd(t['m'], g_i[nh:], act=t['m'])
             # the weight gradients of conv0_1 and conv1_1 (same shape, independent) as ONE launch: alone each is one wave per SIMD
-            pair = fuse and _DEFER is not None and net.tile8t is not None and n > 0
+            pair = fuse and _defer() is not None and net.tile8t is not None and n > 0
             g_h1 = q['c11'].bwd(net, t['h1'], g_m, act=t['h1'], wgrad=not pair)
             g_h0 = q['c01'].bwd(net, t['h0'], g_i[:nh], act=t['h0'], wgrad=not pair)
             if pair:
                 c01, c11 = q['c01'].mod, q['c11'].mod
                 ops.spconv_wgrad_wide2(t['h0'], g_i[:nh], c01.kernel.grad, c01.bias.grad.reshape(-1), t['h1'], g_m, c11.kernel.grad,
-                                       c11.bias.grad.reshape(-1), net.tile8t, n, _DEFER)
+                                       c11.bias.grad.reshape(-1), net.tile8t, n, _defer())
             # the layer's input gradient: the residual's share g_i rides in conv0_0's backward-data epilogue (+ res), conv1_0's share
             # is added last - and with it, for the block's first layer of a one-layer block, the ReLU mask of a = relu(first conv)
             last_mask = tape['a'] if (nl == 1 and li == nl - 1) else None
@@ -292,6 +305,9 @@ class WideNet:
         self.model, self.C = model, hidden
         self._built = False
         self._pool = None
+        # one thread at a time per model: the pool and the frame bound by _bind() are per-model state (train_step holds it across forward,
+        # backward and the optimiser step)
+        self.lock = threading.RLock()
 
     def _build(self):
         up = self.model.upsampler
@@ -337,19 +353,19 @@ class WideNet:
         """Stages [k0, k1) teacher-forced on frame.occ (decoder: the columns decoded so far): probs [8, rows] rows k0..k1-1, bits
         (float64[1]) += their cost.  keep: record the activations for backward (k0 = 0, k1 = 8).  pool: the padded block buffers
         come from this executor's pool, i.e. they are valid until the NEXT pooled forward (train_step: forward, backward, done)."""
-        global _POOL
-        self._bind(frame)
-        if frame.rows == 0:
-            return None
-        if pool:
-            if self._pool is None:
-                self._pool = _Pool()
-            self._pool.reset()
-        _POOL = self._pool if pool else None
-        try:
-            return self._forward(frame, k0, k1, probs, bits, keep)
-        finally:
-            _POOL = None
+        with self.lock:
+            self._bind(frame)
+            if frame.rows == 0:
+                return None
+            if pool:
+                if self._pool is None:
+                    self._pool = _Pool()
+                self._pool.reset()
+            _TLS.pool = self._pool if pool else None
+            try:
+                return self._forward(frame, k0, k1, probs, bits, keep)
+            finally:
+                _TLS.pool = None
 
     def _forward(self, frame, k0, k1, probs, bits, keep):
         x0, sce_tape = self._scale_context(frame, keep)
@@ -376,14 +392,14 @@ class WideNet:
     def backward(self, frame, tape, gscale, pool=False):
         """d (gscale * bits) / d params into the parameters' .grad (model._ensure_grad_views(): views of the flat gradient).
         pool: continue in the pool of the forward that made `tape`."""
-        global _POOL, _DEFER
-        _POOL = self._pool if pool else None
-        _DEFER = []
-        try:
-            self._backward(frame, tape, gscale)
-            ops.wide_reduce_many(_DEFER)          # the ~64 slab reductions of the pass, 32 per launch
-        finally:
-            _POOL, _DEFER = None, None
+        with self.lock:
+            _TLS.pool = self._pool if pool else None
+            _TLS.defer = []
+            try:
+                self._backward(frame, tape, gscale)
+                ops.wide_reduce_many(_TLS.defer)          # the ~64 slab reductions of the pass, 32 per launch
+            finally:
+                _TLS.pool, _TLS.defer = None, None
 
     def _backward(self, frame, tape, gscale):
         self._bind(frame)

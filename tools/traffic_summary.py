@@ -1,5 +1,14 @@
 """Per-kernel HBM bytes per dispatch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB); writes traffic.json."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
+
+# once-per-frame staging kernels (kernel map, octree) that a profiled run also contains: not part of a training step
+STAGING = ('kmap_', 'su_', 'minmax_k', 'octree_', 'occ_bf16_k')
+
+
+def kernel_key(name):
+    """'void (anonymous namespace)::xtg_wgrad_k<2, 1>(Args...)' -> 'void xtg_wgrad_k<2, 1>': the anonymous-namespace marker holds the
+    first '(' of such a name, so cutting at it collapsed those kernels into the single key 'void ' (ADVICE r4)."""
+    return name.replace('(anonymous namespace)::', '').split('(')[0].strip()
 
 
 def load(d, counter):
@@ -7,7 +16,12 @@ def load(d, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:
-            agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+            key = kernel_key(r['Kernel_Name'])
+            bare = key[5:] if key.startswith('void ') else key
+            # the library's own kernels are all named *_k (torch's *_kernel and rocprim's match a plain "_k" too)
+            if not re.search(r'_k(<.*>)?$', bare) or bare.startswith(STAGING):
+                continue
+            agg[key].append(float(r['Counter_Value']))
     return agg
 
 
