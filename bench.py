@@ -123,16 +123,26 @@ def _read_prof(L, _lib):
     return out
 
 
-def load_traffic():
-    """profiles/traffic.json: HBM bytes of every kernel of a training step from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes over tools/traffic_probe.py (tools/traffic_pmc.sh; FETCH_SIZE doubled for gfx950)."""
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+def load_traffic(name='traffic.json'):
+    """profiles/traffic.json (fp32 executor) / traffic_bf16.json (bf16 training executor): HBM bytes of every kernel of a training step
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/traffic_probe.py (tools/traffic_pmc.sh; FETCH_SIZE doubled
+    for gfx950).  STORED numbers of the build named inside the file (`library`), not a measurement of this run: traffic_source() says so."""
+    tpath = os.path.join(ROOT, 'profiles', name)
     if not os.path.exists(tpath):
         return {}
     try:
         return json.load(open(tpath))
     except Exception:
         return {}
+
+
+def traffic_source(traffic, name='traffic.json'):
+    """One sentence for the bench line: where the stored counter bytes came from and which library build they describe."""
+    lib = traffic.get('library') or {}
+    here = os.path.join(ROOT, 'linr_pcgc_amd', 'liblinr_hip.so')
+    now = time.strftime('%Y-%m-%d %H:%M:%S', time.gmtime(os.path.getmtime(here))) if os.path.exists(here) else None
+    return ('stored counters of profiles/%s (collected %s on the library built %s, %s bytes; the library running now: built %s, %s bytes)'
+            % (name, traffic.get('collected_utc'), lib.get('built_utc'), lib.get('bytes'), now, os.path.getsize(here) if now else None))
 
 
 def counter_bytes_per_step(traffic, prefixes, mean_rows):
@@ -227,7 +237,7 @@ def kernel_roofline(gop, live, table_prof, table_steps, ms_per_step):
                 'kernel': 'conv_bwd_wgrad_k<0> not launched (LINR_FUSED_BWD=0?)'}
     if roof.get('traffic') is not None:
         roof['traffic_note'] = ('HBM bytes of the 8-group tail-convolution launch (conv_bwd_wgrad_k<0,3>); live launches average '
-                                '%.2f groups' % roof.get('passes_per_launch', 0.0))
+                                '%.2f groups; %s' % (roof.get('passes_per_launch', 0.0), traffic_source(traffic_all)))
     roof['conv'] = entry(1, KERNEL_CLASSES[1][1], 172, 2 * 27 * 8 * 8, 'voidcconv_mfma_k<8,8,false,8,0>')
     step_gbs = STEP_ALG_BYTES_PER_ROW * mean_rows / (ms_per_step * 1e-3) / 1e9
     roof['step'] = {'alg_bytes_per_row': STEP_ALG_BYTES_PER_ROW, 'rows': round(mean_rows, 1), 'ms_per_step': round(ms_per_step, 4),
@@ -238,7 +248,7 @@ def kernel_roofline(gop, live, table_prof, table_steps, ms_per_step):
         if counter_total > 0:
             roof['step'].update({'traffic': int(counter_total), 'traffic_over_algorithmic': round(counter_total / (STEP_ALG_BYTES_PER_ROW * mean_rows), 4),
                                  'frac_counter': round(counter_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                 'traffic_note': 'sum of the counter bytes of every kernel class of a step (profiles/traffic.json)'
+                                 'traffic_note': 'sum of the counter bytes of every kernel class of a step; ' + traffic_source(traffic_all)
                                                  + ('; no counters for: ' + ', '.join(counter_missing) if counter_missing else '')})
         roof['kernels_note'] = ('%d extra steps with EVERY launch bracketed by a HIP event pair, outside the timed region (state '
                                 'saved and restored); sum %.1f us = %.3f of the un-instrumented step'
@@ -437,11 +447,20 @@ def bf16_train_leg(gop, L, _lib, epochs):
         us_launch = tot.value * 1e3 / nl.value
         groups = npass.value / float(nl.value)
         achieved = groups * mean_rows * 2 * alg_row_pass / (us_launch * 1e-6) / 1e9
+        # counter bytes (profiles/traffic_bf16.json): the 8-group launches bbwd_k<0,0> (prune) / <0,3> (tail), scaled to this launch mix
+        tb = load_traffic('traffic_bf16.json')
+        tr_launch, tr_note = None, None
+        per_group = [v['bytes_per_dispatch'] / 8.0 * (mean_rows / float(tb['rows'])) for k, v in tb.get('kernels', {}).items()
+                     if k.replace(' ', '').startswith('voidbbwd_k<0,3') and tb.get('rows')]
+        if per_group:
+            tr_launch = int(groups * per_group[0])
+            tr_note = 'HBM bytes per 8-group launch of bbwd_k<0,3> / 8 x the mean groups per launch; ' + traffic_source(tb, 'traffic_bf16.json')
         out['roofline'] = {'kernel': 'bbwd_k<0>: fused backward-data + weight gradient of the convolutions 8->8 (17 of a step\'s 33 backward row passes, 3 launches)',
                            'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(achieved / 8000.0, 4),
                            'alg_bytes_per_row_pass': alg_row_pass, 'row_passes_per_fused_group': 2, 'mean_groups_per_launch': round(groups, 3),
                            'mean_launch_us': round(us_launch, 2), 'us_per_group_pass': round(tot.value * 1e3 / max(npass.value, 1), 2),
-                           'launches_sampled': int(nl.value), 'traffic': None,
+                           'launches_sampled': int(nl.value), 'traffic': tr_launch, 'traffic_note': tr_note,
+                           'frac_counter': None if tr_launch is None else round(tr_launch / (us_launch * 1e-6) / 1e9 / 8000.0, 4),
                            'step': {'alg_bytes_per_row': 20514, 'achieved': round(20514 * mean_rows / (ms * 1e-3) / 1e9, 1),
                                     'frac': round(20514 * mean_rows / (ms * 1e-3) / 1e9 / 8000.0, 4),
                                     'note': 'SURVEY 8(d) at 2-byte features: 3 passes x (1,654 B features + 5,184 B neighbour table) per row'}}

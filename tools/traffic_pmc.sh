@@ -14,4 +14,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --kernel-include-regex "_k" --pmc $c --output-format csv -d /tmp/tr_$c -- python3 $R/tools/traffic_probe.py 3 $PREC > /tmp/tr_$c.log 2>&1 || { tail -5 /tmp/tr_$c.log; exit 1; }
   echo "pass $c done"
 done
-python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic$SUF.json 3 "$(grep -h "^rows" /tmp/tr_FETCH_SIZE.log | tail -1)" | tee -a $OUT
+python3 $R/tools/traffic_summary.py /tmp/tr_FETCH_SIZE /tmp/tr_WRITE_SIZE $R/gpurun_out/traffic$SUF.json 3 "$(grep -h "^rows" /tmp/tr_FETCH_SIZE.log | tail -1)" $PREC | tee -a $OUT

@@ -37,5 +37,13 @@ for name in sorted(fetch):
     out['kernels'][name] = {'dispatches': len(f), 'dispatches_per_step': round(len(f) / steps, 3), 'bytes_per_step': int((fb + wb) * len(f) / steps), 'fetch_bytes_x2': int(fb), 'write_bytes': int(wb), 'bytes_per_dispatch': int(fb + wb)}
     print('%-60s n=%3d  2xFETCH %8.1f MB  WRITE %7.1f MB' % (name[:60], len(f), fb / 1e6, wb / 1e6))
 out['bytes_per_step_all_kernels'] = int(sum(k['bytes_per_step'] for k in out['kernels'].values()))
+# which build the counters describe: bench.py repeats this beside the stored bytes (roofline.traffic_note)
+import os, time
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'linr_pcgc_amd', 'liblinr_hip.so')
+if os.path.exists(lib):
+    out['library'] = {'file': 'linr_pcgc_amd/liblinr_hip.so', 'bytes': os.path.getsize(lib),
+                      'built_utc': time.strftime('%Y-%m-%d %H:%M:%S', time.gmtime(os.path.getmtime(lib)))}
+out['collected_utc'] = time.strftime('%Y-%m-%d %H:%M:%S', time.gmtime())
+out['precision'] = sys.argv[6] if len(sys.argv) > 6 else 'f32'
 print('all kernels: %.3f GB per training step' % (out['bytes_per_step_all_kernels'] / 1e9))
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
