@@ -418,21 +418,31 @@ def bf16_train_leg(gop, L, _lib, epochs):
         torch.cuda.synchronize()
     model.flat_parameters().copy_(init)
     opt.reset()
-    L.linr_prof_mask(1 << 17)
-    L.linr_prof_enable(1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     info = {}
     e0.record()
-    losses = overfit.overfit_gop(model, opt, gop, epochs, info=info)
+    losses = overfit.overfit_gop(model, opt, gop, epochs, info=info)          # the complete overfit, un-instrumented: ms_per_step, bits/point
     e1.record()
     torch.cuda.synchronize()
-    L.linr_prof_enable(0)
     steps = epochs * len(gop)
     ms = e0.elapsed_time(e1) / steps
+    # launch durations of the dominant kernel class, live (event pairs on the launch stream), from 64 more steps of a scratch copy of the
+    # trained state - outside the timed overfit, whose model is what gets coded below
+    snap = (model.flat_parameters().detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.t, opt.t_scale.copy(), opt.lr, opt.sched_steps)
+    L.linr_prof_mask(1 << 17)
+    L.linr_prof_enable(1)
+    for i in range(64):
+        train_step(model, opt, gop.frames[i % len(gop)], gop.point_nums[i % len(gop)], out=bits)
+    torch.cuda.synchronize()
+    L.linr_prof_enable(0)
     tot, nl, npass = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
     _lib.check(L.linr_prof_read(17, ctypes.byref(tot), ctypes.byref(nl), ctypes.byref(npass)), 'linr_prof_read')
     L.linr_prof_mask(3)
+    model.flat_parameters().copy_(snap[0])
+    opt.exp_avg.copy_(snap[1])
+    opt.exp_avg_sq.copy_(snap[2])
+    opt.t, opt.t_scale, opt.lr, opt.sched_steps = snap[3], snap[4], snap[5], snap[6]
     mean_rows = sum(f.rows for f in gop.frames) / float(len(gop))
     enc = codec.encode_gop(model, overfit.gen_model(gop.scale_num, 'cuda'), gop, 8, precision='bf16')
     nd = min(2, len(gop))
