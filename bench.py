@@ -493,6 +493,39 @@ def bf16_train_leg(gop, L, _lib, epochs):
     except Exception as e:
         out['config4_owlii11_frame'] = {'error': repr(e)}
     torch.cuda.empty_cache()
+    # ... and config[4] as BASELINE states it: ONE GOP of 64 such frames, bf16 SparseConv for the overfit, the uint8 weight pack + bf16
+    # features for the codec: encode sec/frame and bits/point of the whole GOP on this GPU (the config's 8 GPUs run 8 such GOPs)
+    if not os.environ.get('LINR_SKIP_CONFIG4'):
+        try:
+            t0 = time.time()
+            g64 = overfit.Gop(None, [synthetic.sequence_frame_device('owlii11', t, 'cuda') for t in range(64)], None, 64, 'cuda')
+            torch.cuda.synchronize()
+            stage_s = time.time() - t0
+            m64 = overfit.gen_model(g64.scale_num, 'cuda', seed=8807)
+            m64.train_precision = 'bf16'
+            o64 = FlatAdam(m64)
+            info64 = {}
+            torch.cuda.synchronize()
+            t0 = time.time()
+            l64 = overfit.overfit_gop(m64, o64, g64, epochs, info=info64)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            e64 = codec.encode_gop(m64, overfit.gen_model(g64.scale_num, 'cuda'), g64, 8, precision='bf16')
+            torch.cuda.synchronize()
+            t2 = time.time()
+            d64 = codec.decode_gop(overfit.gen_model(g64.scale_num, 'cuda'), e64, 'cuda', frames=[0])
+            ok64 = bool(torch.equal(d64[0], torch.as_tensor(g64.infos[0]['ori']).cuda() + torch.tensor(g64.coord_mins[0], device='cuda', dtype=torch.int32)))
+            out['config4_gop64'] = {'workload': 'BASELINE config[4] stand-in: synthetic owlii11 (11-bit sphere shell, %d points and %d rows in frame 0, %d scales), ONE GOP of 64 '
+                                                'frames, %d epochs of bf16 training, bf16 / uint8-weight codec' % (g64.point_nums[0], g64.frames[0].rows, g64.scale_num, epochs),
+                                    'encode_sec_per_frame': round((t2 - t0) / 64.0, 5), 'overfit_s': round(t1 - t0, 3), 'codec_s': round(t2 - t1, 3),
+                                    'ms_per_step': round((t1 - t0) * 1e3 / (epochs * 64), 4), 'staging_s': round(stage_s, 2),
+                                    'bits_per_point': round(float(e64['bpp']['bpp_all']), 5), 'epoch_loss_bpp': [round(x, 4) for x in l64],
+                                    'coded_epoch': info64.get('coded_epoch'), 'lossless_decode_frame0': ok64,
+                                    'note': 'encode = overfit + codec of the whole GOP on this one GPU, inputs resident; the first codec call of this GOP size (it sizes the pinned staging ring)'}
+            del g64, m64, o64, e64, d64
+        except Exception as e:
+            out['config4_gop64'] = {'error': repr(e)}
+    torch.cuda.empty_cache()
     return out
 
 

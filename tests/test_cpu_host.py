@@ -587,3 +587,16 @@ def test_reference_checkpoint_optimizer_state_loads(golden_dir):
     ref = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-4)
     ref.load_state_dict(back)                                    # and torch takes it back
     assert ref.param_groups[0]['lr'] == float(g['lr'])
+
+
+def test_run_train_precision_flag():
+    """run.py: --train-precision selects the overfit's arithmetic; without it the overfit follows --precision (BASELINE config[4]:
+    '--precision bf16' = bf16 SparseConv for the overfit and the codec), except where the bf16 training executor does not exist
+    (hidden_channel_conv 16 / 32, block_layers > 1)."""
+    from linr_pcgc_amd import run
+    assert run.train_precision(run.parse([])) == 'f32'
+    assert run.train_precision(run.parse(['--precision', 'bf16'])) == 'bf16'
+    assert run.train_precision(run.parse(['--precision', 'bf16', '--train-precision', 'f32'])) == 'f32'
+    assert run.train_precision(run.parse(['--train-precision', 'bf16'])) == 'bf16'
+    assert run.train_precision(run.parse(['--precision', 'bf16', '--block_layers', '2'])) == 'f32'
+    assert run.train_precision(run.parse(['--precision', 'bf16', '--hidden-channel-conv', '16'])) == 'f32'

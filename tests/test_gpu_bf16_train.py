@@ -355,3 +355,27 @@ def test_bf16_overfit_of_owlii11_reaches_the_fp32_rate():
     r = _overfit_pair('owlii11', 8, 10, (8807, 1, 2))
     m32, mbf = sum(r['f32']) / 3, sum(r['bf16']) / 3
     assert mbf <= 1.01 * m32, r
+
+
+def test_checkpoints_cross_the_two_training_executors(pkg, shell):
+    """Both executors train the same fp32 master parameters with the same optimiser state (main.py:241-248: GOPs >= 1 warm-start from
+    GOP 0's model AND optimiser): a GOP trained in bf16 hands over to one trained in fp32 and back, the loss keeps falling."""
+    from linr_pcgc_amd import overfit
+    from linr_pcgc_amd.model_core import FlatAdam, train_step
+    model = overfit.gen_model(5, 'cuda', seed=8807)
+    model.train_precision = 'bf16'
+    frame = model.make_frame(shell['scales'])
+    opt = FlatAdam(model)
+    first = [float(train_step(model, opt, frame, shell['point_num'])) for _ in range(8)]
+    ck = overfit.checkpoint(model, opt, 0, first[-1])
+    m2 = overfit.gen_model(5, 'cuda', seed=1)
+    o2 = FlatAdam(m2)
+    overfit.warm_start(m2, o2, ck)
+    assert o2.t == opt.t and torch.equal(m2.flat_parameters(), model.flat_parameters())
+    second = [float(train_step(m2, o2, m2.make_frame(shell['scales']), shell['point_num'])) for _ in range(8)]      # fp32 from here
+    m2.train_precision = 'bf16'
+    third = [float(train_step(m2, o2, m2.make_frame(shell['scales']), shell['point_num'])) for _ in range(8)]       # and back
+    assert second[0] < first[0] and second[-1] < first[-1] and third[-1] < second[-1], (first, second, third)
+    # the fp32 step right behind the hand-over sees (to bf16 rounding) the loss the bf16 executor would have seen next
+    nxt = float(train_step(model, opt, frame, shell['point_num']))
+    assert abs(second[0] - nxt) <= 5e-3 * nxt, (second[0], nxt)
