@@ -159,8 +159,8 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     const int64_t tb0 = (int64_t)blockIdx.x * (BB_WAVES * a.tiles_per_wave);
     const int64_t tb1 = (tb0 + BB_WAVES * a.tiles_per_wave < T64) ? tb0 + BB_WAVES * a.tiles_per_wave : T64;
     const char* pad = reinterpret_cast<const char*>(gbase - 8);
-    constexpr int PF = 5;
-    typedef typename std::conditional<KIND == 2, uint2, uint4>::type XR;
+    constexpr int PF = 14;                                                   // gathers in flight per wave: two waves per SIMD need them deep
+    typedef typename std::conditional<KIND == 2, uint2, uint4>::type XR;      // (5 / 8 / 11 / 14 / 17 / 20: 0.892 / 0.890 / 0.867 / 0.852 / 0.852 / 0.860 ms per step)
     // The row loop is software-pipelined ACROSS tiles (two to three waves share a SIMD, but every wave still walks through the same
     // phases): the index words, the own row and the epilogue's own-row operands of the wave's NEXT tile are requested at step 1 of the
     // current one; the 16 transposed reads of a chunk are issued behind its last tap and its 16 weight-gradient instructions are
@@ -192,20 +192,20 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     if (tile < tb1) {                                                        // wave-uniform
         uint32_t off[27], raw[10];
         Own ow, own_n;
-        {
+        XR x[PF + 1];                                                        // the ring of gathered rows; a tile's first PF gathers are issued
+        {                                                                    // before the PREVIOUS tile's epilogue (here: before the loop)
             const int64_t r = (tile << 6) + lane;
             idx_load(r < n ? r : n - 1, raw);
             idx_decode(raw, off);
             own_load(tile, ow);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
         }
         for (; tile < tb1; tile += BB_WAVES) {
             const int64_t row_raw = (tile << 6) + lane;
             const bool live = row_raw < n;
             const int64_t row = live ? row_raw : n - 1;                      // every lane stays in the matrix instructions (they ignore EXEC)
             const int64_t ntile = tile + BB_WAVES < tb1 ? tile + BB_WAVES : tile;          // the last tile "prefetches" itself
-            XR x[PF + 1];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
             *reinterpret_cast<uint4*>(ximgW) = ow.xr;
             s16x4 av[16], bv[16];
 #pragma unroll
@@ -284,6 +284,12 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
 #pragma unroll
             for (int rq = 0; rq < 16; ++rq)                                   // the last chunk of the tile
                 wacc[NCH - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[NCH - 1], 0, 0, 0);
+            // the next tile's offsets (its index words came in at step 1) and its first gathers, in flight during this tile's epilogue
+            idx_decode(raw, off);
+            if (tile + BB_WAVES < tb1) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const XR*>(pad + off[LINR_TAP(u)]);
+            }
             // ---- epilogue: the row's input gradient, rounded to bf16; everything derived from it uses the rounded value ---------------
             float o[8];
 #pragma unroll
@@ -350,7 +356,6 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
                     }
                 }
             }
-            idx_decode(raw, off);                                             // the next tile's offsets (its index words came in at step 1)
             ow = own_n;
         }
     }
