@@ -40,6 +40,14 @@
 enum { TK_BWD88 = 17, TK_BWD_DUAL = 18, TK_BWD_C00 = 19, TK_FWD = 20, TK_HEAD_BWD = 21, TK_FIRST_WGRAD = 22, TK_MISC = 23 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_16x16x32_bf16: D[m][n] += sum_k A[m][k] B[k][n]; lane l holds A[l & 15][8 (l >> 4) + j], B[8 (l >> 4) + j][l & 15] in element j
+// of its two 64-bit halves (lo = j 0..3, hi = j 4..7) and D[4 (l >> 4) + reg][l & 15]
+__device__ __forceinline__ f32x4 mfma16(s16x4 alo, s16x4 ahi, s16x4 blo, s16x4 bhi, f32x4 c) {
+    const s16x8 a = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7), b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 // transposed LDS read (ds_read_b64_tr_b16): per 16-lane group, lane 4 q + p supplies the address of an 8-byte piece (q, p); lane
 // 4 p + j of the group receives element j of the pieces (0, p) .. (3, p) - four rows of one 16-bit column
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
@@ -76,12 +84,17 @@ template <int KIND> struct BbT {
     static constexpr int NCH = (27 + CT - 1) / CT;              // chunks per tile: 7 / 4 / 4
     static constexpr int WAVE_BYTES = BB_SLOT * (1 + 2 * SL);   // own rows + two chunk buffers
     static constexpr int NW = KIND == 0 ? 108 : 54;             // backward-data weight blocks
+    // weight gradient: KIND 0 / 2 on v_mfma_f32_16x16x32_bf16 (M = the 8 own channels, padded to 16; N = two image slots x 8 columns; K = 32
+    // rows): two accumulators per chunk; KIND 1 (two 4 x 4 products per tap, a quarter of such a tile) on v_mfma_f32_4x4x4_16b_bf16: one
+    static constexpr bool BIG = KIND != 1;
+    static constexpr int NACC = BIG ? 2 * NCH : NCH;
 };
 
 template <int KIND, int EPI, bool NOBWD>
 __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     using T = BbT<KIND>;
-    constexpr int CT = T::CT, SL = T::SL, NCH = T::NCH, NG = (T::NW + 15) / 16;
+    constexpr int CT = T::CT, SL = T::SL, NCH = T::NCH, NG = (T::NW + 15) / 16, NACC = T::NACC;
+    constexpr bool BIG = T::BIG;
     __shared__ uint4 smem[BB_WAVES * T::WAVE_BYTES / 16];
     __shared__ float sbias[BB_WAVES][8];
     __shared__ float s12[BB_WAVES][20];
@@ -134,9 +147,14 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     // gathered rows: KIND 0: slot tg (tap 4 c + tg), channel quad tp >> 1; KIND 1: slot 2 tg + (tp >> 1), quad tp & 1 (the
     // convolution); KIND 2: slot tg holds the tap PAIR 2 tg, 2 tg + 1 as the two halves of a 16-byte row: half tp >> 1
     const char* bufR = img + BB_SLOT + (KIND == 1 ? (2 * tg + (tp >> 1)) * BB_SLOT + 8 * (tp & 1) : tg * BB_SLOT + 8 * (tp >> 1)) + tq * 16;
-    f32x4 wacc[NCH];
+    // 16x16x32 form (KIND 0 / 2): group tg of 16 lanes = rows 8 tg .. 8 tg + 7 of a 32-row K step (two transposed reads of four rows);
+    // A columns = own channels (tp & 1: quads 0 / 1; the lanes m >= 8 of the tile are padding), B columns = slot pair: piece tp of
+    // [slot 2 u: 8 columns | slot 2 u + 1: 8 columns]
+    const char* ximgR16 = img + (8 * tg + tq) * 16 + 8 * (tp & 1);
+    const char* bufR16 = img + BB_SLOT + (tp >> 1) * BB_SLOT + (8 * tg + tq) * 16 + 8 * (tp & 1);
+    f32x4 wacc[NACC];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) wacc[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < NACC; ++c) wacc[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
@@ -208,8 +226,13 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
             const int64_t ntile = tile + BB_WAVES < tb1 ? tile + BB_WAVES : tile;          // the last tile "prefetches" itself
             *reinterpret_cast<uint4*>(ximgW) = ow.xr;
             s16x4 av[16], bv[16];
+            if constexpr (BIG) {                                              // av[2 ks + h]: rows 32 ks + 8 tg + 4 h .. + 3 of the own channels
 #pragma unroll
-            for (int rq = 0; rq < 16; ++rq) av[rq] = tr_read(ximgR + rq * 64);
+                for (int j = 0; j < 4; ++j) av[j] = tr_read(ximgR16 + (32 * (j >> 1) + 4 * (j & 1)) * 16);
+            } else {
+#pragma unroll
+                for (int rq = 0; rq < 16; ++rq) av[rq] = tr_read(ximgR + rq * 64);
+            }
             f32x4 acc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
             sfor<27>([&](auto kc) {
                 constexpr int kk = decltype(kc)::value;                      // step; k = LINR_TAP(kk) the tap it handles
@@ -270,20 +293,41 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
                     }
                 }
                 if constexpr (ch >= 1) {                                      // this step's share of the previous chunk's weight gradient
-                    constexpr int r0 = (s * 16) / nst, r1 = ((s + 1) * 16) / nst;
-                    sfor<r1 - r0>([&](auto rc) {
-                        constexpr int rq = r0 + decltype(rc)::value;
-                        wacc[ch - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[ch - 1], 0, 0, 0);
-                    });
+                    if constexpr (BIG) {                                      // 4 instructions: (slot pair u, K step ks) = mi >> 1, mi & 1
+                        constexpr int m0 = (s * 4) / nst, m1 = ((s + 1) * 4) / nst;
+                        sfor<m1 - m0>([&](auto mc) {
+                            constexpr int mi = m0 + decltype(mc)::value, u = mi >> 1, ks = mi & 1;
+                            wacc[2 * (ch - 1) + u] = mfma16(av[2 * ks], av[2 * ks + 1], bv[4 * u + 2 * ks], bv[4 * u + 2 * ks + 1], wacc[2 * (ch - 1) + u]);
+                        });
+                    } else {
+                        constexpr int r0 = (s * 16) / nst, r1 = ((s + 1) * 16) / nst;
+                        sfor<r1 - r0>([&](auto rc) {
+                            constexpr int rq = r0 + decltype(rc)::value;
+                            wacc[ch - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[ch - 1], 0, 0, 0);
+                        });
+                    }
                 }
-                if constexpr (s == nst - 1) {                                 // the chunk is complete: its 16 transposed reads
+                if constexpr (s == nst - 1) {                                 // the chunk is complete: its transposed reads (8 / 16)
+                    if constexpr (BIG) {                                      // bv[4 u + 2 ks + h]
 #pragma unroll
-                    for (int rq = 0; rq < 16; ++rq) bv[rq] = tr_read(bufR + (ch & 1) * SL * BB_SLOT + rq * 64);
+                        for (int j = 0; j < 8; ++j)
+                            bv[j] = tr_read(bufR16 + ((ch & 1) * SL + 2 * (j >> 2)) * BB_SLOT + (32 * ((j >> 1) & 1) + 4 * (j & 1)) * 16);
+                    } else {
+#pragma unroll
+                        for (int rq = 0; rq < 16; ++rq) bv[rq] = tr_read(bufR + (ch & 1) * SL * BB_SLOT + rq * 64);
+                    }
                 }
             });
+            if constexpr (BIG) {                                              // the last chunk of the tile
 #pragma unroll
-            for (int rq = 0; rq < 16; ++rq)                                   // the last chunk of the tile
-                wacc[NCH - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[NCH - 1], 0, 0, 0);
+                for (int mi = 0; mi < 4; ++mi)
+                    wacc[2 * (NCH - 1) + (mi >> 1)] = mfma16(av[2 * (mi & 1)], av[2 * (mi & 1) + 1], bv[4 * (mi >> 1) + 2 * (mi & 1)],
+                                                             bv[4 * (mi >> 1) + 2 * (mi & 1) + 1], wacc[2 * (NCH - 1) + (mi >> 1)]);
+            } else {
+#pragma unroll
+                for (int rq = 0; rq < 16; ++rq)
+                    wacc[NCH - 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av[rq], bv[rq], wacc[NCH - 1], 0, 0, 0);
+            }
             // the next tile's offsets (its index words came in at step 1) and its first gathers, in flight during this tile's epilogue
             idx_decode(raw, off);
             if (tile + BB_WAVES < tb1) {
@@ -361,11 +405,15 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     }
     __syncthreads();
     // ---- fold: the four waves' partial sums of every element in wave order, one slab row per block ------------------------------------
-    float* sacc = reinterpret_cast<float*>(smem);                            // [wave][NCH * 4][64]
+    // [wave][NACC * 4][LW lanes]: the 16x16x32 tiles keep their useful rows m < 8 in the lanes 0..31 (the other half is padding)
+    constexpr int LW = BIG ? 32 : 64;
+    float* sacc = reinterpret_cast<float*>(smem);
+    if (lane < LW) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NACC; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sacc[((wave * NCH + c) * 4 + i) * 64 + lane] = wacc[c][i];
+            for (int i = 0; i < 4; ++i) sacc[((wave * NACC + c) * 4 + i) * LW + lane] = wacc[c][i];
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float t = bsum[j];
@@ -391,28 +439,28 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     for (int e = tid; e < nsteps * per_tap; e += BB_WAVES * 64) {
         const int kk = e / per_tap, r = e % per_tap;                         // step kk handled tap k (common.h: LINR_TAP)
         const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
-        const int c = kk / CT, s = kk % CT;
-        int L, i;
+        int c = kk / CT, L, i;
+        const int s = kk % CT;
         int64_t dofs;
         bool valid = true;
-        if constexpr (KIND == 0) {          // r = ci * 8 + co: group s, block (ci / 4) | (co / 4) << 1, lane co % 4, register ci % 4
+        if constexpr (KIND == 0) {          // r = ci * 8 + co: accumulator 2 c + s / 2, tile row ci, tile column 8 (s % 2) + co
             const int ci = r >> 3, co = r & 7;
-            L = 16 * s + 4 * ((ci >> 2) | ((co >> 2) << 1)) + (co & 3); i = ci & 3;
+            c = 2 * c + (s >> 1); L = 16 * (ci >> 2) + 8 * (s & 1) + co; i = ci & 3;
             valid = ci < cinv;
             dofs = a.w[gi] + ((int64_t)k * cinv + ci) * 8 + co;
         } else if constexpr (KIND == 1) {   // r = conv * 16 + ci * 4 + co: group s / 2, block conv | (s % 2) << 1, lane co, register ci
             const int cv = r >> 4, ci = (r >> 2) & 3, co = r & 3;
             L = 16 * (s >> 1) + 4 * (cv | ((s & 1) << 1)) + co; i = ci;
             dofs = (cv ? a.w1[gi] : a.w[gi]) + (int64_t)k * 16 + (r & 15);
-        } else {                            // r = ci * 4 + co: group s / 2, block (ci / 4) | (s % 2) << 1, lane co, register ci % 4
-            const int ci = r >> 2, co = r & 3;
-            L = 16 * (s >> 1) + 4 * ((ci >> 2) | ((s & 1) << 1)) + co; i = ci & 3;
+        } else {                            // r = ci * 4 + co: slot s / 2 -> accumulator 2 c + slot / 2, column 8 (slot % 2) + 4 (s % 2) + co
+            const int ci = r >> 2, co = r & 3, slot = s >> 1;
+            c = 2 * c + (slot >> 1); L = 16 * (ci >> 2) + 8 * (slot & 1) + 4 * (s & 1) + co; i = ci & 3;
             dofs = kk < 27 ? a.w[gi] + (int64_t)k * 32 + r : a.wp[gi] + r;  // conv1_0.kernel [8][4]
         }
         if (!valid) continue;
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < BB_WAVES; ++w) t += sacc[((w * NCH + c) * 4 + i) * 64 + L];
+        for (int w = 0; w < BB_WAVES; ++w) t += sacc[((w * NACC + c) * 4 + i) * LW + L];
         dst[dofs] = t;
     }
     if (tid < 8) {
