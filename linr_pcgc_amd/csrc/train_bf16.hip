@@ -622,16 +622,15 @@ __global__ __launch_bounds__(LINR_BLOCK) void bocc7_k(BoArgs a) {
     }
 }
 
-// weight gradients gW_g[k][ci][co] = sum_rows occ[nbr(row, k)][ci] gA_g[row][co], gb_g = sum_rows gA_g[row]: the gathered occupancy rows
-// are the A operand, the rows' own gradients of the seven groups the B operand of v_mfma_f32_4x4x4_16b_bf16 with the ROWS as its K
-// dimension (transposed LDS reads, like bbwd_k).  The A operand does not depend on the group: ONE transposed read delivers 16 (tap,
-// input quad) pieces and CBSZ broadcasts one of them to all blocks, whose B operand - block = (group, output quad) - stays in place:
-//   input quad 0: CBSZ 4, 14 of 16 blocks = the 7 groups x 2 output quads;   input quad 1 (groups 4..6 only): CBSZ 3 - the two halves
-//   of 8 blocks broadcast separately - 6 + 6 blocks = two taps per instruction.
-// Wave w of a block owns the taps of steps 7 w .. 7 w + 6 (wave 3: six taps and, in its spare slot, an all-ones pseudo tap whose product
-// is the bias gradient) and walks over ALL tiles of the block with 11 accumulators: no fold across waves, every wave writes its own
-// part of the block's slab row.  11 matrix instructions and 3 transposed reads per four rows and wave.
-#define OW_SLOTS 15                     // 7 tap slots + the 7 groups' own rows + 1 spare (alignment of nothing; keeps 16-slot arithmetic obvious)
+// weight gradients gW_g[k][ci][co] = sum_rows occ[nbr(row, k)][ci] gA_g[row][co], gb_g = sum_rows gA_g[row]: v_mfma_f32_16x16x32_bf16 with the
+// ROWS as its K dimension (32 per instruction; transposed LDS reads, like bbwd_k): M = 2 taps x 8 input channels of the gathered
+// occupancy rows, N = 2 groups x 8 output channels of the rows' own gradients - every lane of every tile useful (but for the
+// triangle ci <= group).  Wave w of a block owns the taps of steps 7 w .. 7 w + 6 as four tap pairs (wave 3: six taps and, in its
+// seventh slot, an all-ones pseudo tap whose product is the bias gradient) and walks over ALL tiles of the block with 4 x 4
+// accumulators (tap pair x group pair): no fold across waves, every wave writes its own part of the block's slab row.  32 matrix
+// instructions and 32 transposed reads per 64-row tile and wave (the 4x4x4 form: 176 and 48).
+#define OW_SLOTS 16                     // 7 tap slots + the 7 groups' own rows + 2 never written (the pair partner of group 6: its columns are unused)
+#define OW_WAVES 8                      // two waves per tap set (alternating tiles): two waves per SIMD, one block per CU (139 KB of LDS)
 struct OwArgs {
     const bf16_t* occ;  const bf16_t* g;
     const int32_t* lo;  const uint32_t* mask;  int64_t ld, n;
@@ -640,29 +639,23 @@ struct OwArgs {
     int64_t g_g[7], w[7], b[7];
 };
 
-__global__ __launch_bounds__(BB_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
-    __shared__ uint4 smem[BB_WAVES * OW_SLOTS * BB_SLOT / 16];
+__global__ __launch_bounds__(OW_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
+    extern __shared__ uint4 smem[];                                            // OW_WAVES * OW_SLOTS * BB_SLOT bytes
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3, half = wave8 >> 2;                             // tap set; which tiles of the block (even / odd)
     const int ntaps = wave == 3 ? 6 : 7;
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int blk = lane >> 2;                                                 // = 4 tg + tp as the RECEIVING block ... and as the supplying one:
-    const int sblk = 4 * tg + tp;                                              // the piece this lane's address supplies belongs to block 4 tg + tp
-    char* img = reinterpret_cast<char*>(smem) + wave * (OW_SLOTS * BB_SLOT);
+    char* img = reinterpret_cast<char*>(smem) + wave8 * (OW_SLOTS * BB_SLOT);
     char* imgW = img + lane * 16;
-    // A pieces: block sb -> (tap slot sb >> 1, input quad sb & 1)
-    const char* aR = img + (sblk >> 1) * BB_SLOT + tq * 16 + 8 * (sblk & 1);
-    // B pieces, input quad 0: block sb < 14 -> (group sb >> 1, output quad sb & 1); blocks 14, 15: a valid address, result unused
-    const int sb0 = sblk < 14 ? sblk : 13;
-    const char* b0R = img + (7 + (sb0 >> 1)) * BB_SLOT + tq * 16 + 8 * (sb0 & 1);
-    // input quad 1: block (sb & 7) < 6 -> (group 4 + ((sb & 7) >> 1), output quad sb & 1) in both halves
-    const int sb1 = (sblk & 7) < 6 ? (sblk & 7) : 5;
-    const char* b1R = img + (7 + 4 + (sb1 >> 1)) * BB_SLOT + tq * 16 + 8 * (sb1 & 1);
-    f32x4 d0[7], d1[4];
+    // both operands: piece tp of [slot 2 j: 8 columns | slot 2 j + 1: 8 columns], rows 8 tg + tq (+ 32 ks + 4 h) - A: tap slots 0.., B: own rows 7..
+    const char* aR = img + (tp >> 1) * BB_SLOT + (8 * tg + tq) * 16 + 8 * (tp & 1);
+    const char* bR = aR + 7 * BB_SLOT;
+    f32x4 d[4][4];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) d0[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) d1[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4; ++j) d[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int64_t n = a.n;
     const int64_t T64 = (n + 63) >> 6;
     const int64_t tb0 = (int64_t)blockIdx.x * a.tiles_per_block;
@@ -671,8 +664,8 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
     if (wave == 3) {                                                           // the pseudo tap: ones (bf16 1.0 = 0x3f80) in slot 6, written once
         *reinterpret_cast<uint4*>(imgW + 6 * BB_SLOT) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     }
-    // One wave per SIMD and block: nothing hides a latency but the wave's own instruction stream, so the loads of tile t + 1 (index
-    // words, the wave's 7 gathers, the 7 groups' own rows) are issued before the matrix instructions of tile t.
+    // Two waves per SIMD: the loads of the wave's next tile (index words, its 7 gathers, the 7 groups' own rows) are still issued before
+    // the matrix instructions of the current one.
     uint4 x[7], own[7], xn[7], ownn[7];
     auto load_tile = [&](int64_t tile, auto nxt) {
         constexpr bool NXT = decltype(nxt)::value;
@@ -691,67 +684,77 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
 #pragma unroll
         for (int g = 0; g < 7; ++g) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);                              // dead lanes contribute nothing
-            if (live) v = *reinterpret_cast<const uint4*>(a.g + a.g_g[g] + row * 8);
+            if (live) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.g + a.g_g[g]) + ((uint32_t)row << 4));
             if constexpr (NXT) ownn[g] = v; else own[g] = v;
         }
     };
-    if (tb0 < tb1) load_tile(tb0, std::false_type{});
-    for (int64_t tile = tb0; tile < tb1; ++tile) {
+    if (tb0 + half < tb1) load_tile(tb0 + half, std::false_type{});
+    for (int64_t tile = tb0 + half; tile < tb1; tile += 2) {
 #pragma unroll
         for (int t = 0; t < 7; ++t)
             if (t < ntaps) *reinterpret_cast<uint4*>(imgW + t * BB_SLOT) = x[t];
 #pragma unroll
         for (int g = 0; g < 7; ++g) *reinterpret_cast<uint4*>(imgW + (7 + g) * BB_SLOT) = own[g];
-        if (tile + 1 < tb1) load_tile(tile + 1, std::true_type{});
-#pragma unroll 4
-        for (int rq = 0; rq < 16; ++rq) {
-            const s16x4 av = tr_read(aR + rq * 64);
-            const s16x4 b0 = tr_read(b0R + rq * 64);
-            const s16x4 b1 = tr_read(b1R + rq * 64);
-            sfor<7>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                d0[t] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, b0, d0[t], 4, 2 * t, 0);
-            });
-            sfor<4>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;                          // taps t (blocks 0..7) and t + 4 (blocks 8..15)
-                d1[t] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(av, b1, d1[t], 3, 2 * t + 1, 0);
-            });
+        if (tile + 2 < tb1) load_tile(tile + 2, std::true_type{});
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x4 av[4][2], bv[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    av[j][h] = tr_read(aR + 2 * j * BB_SLOT + (32 * ks + 4 * h) * 16);
+                    bv[j][h] = tr_read(bR + 2 * j * BB_SLOT + (32 * ks + 4 * h) * 16);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = mfma16(av[i][0], av[i][1], bv[j][0], bv[j][1], d[i][j]);
         }
 #pragma unroll
         for (int t = 0; t < 7; ++t) { x[t] = xn[t]; own[t] = ownn[t]; }
     }
-    // ---- every wave writes the slab entries of its own taps: D block b, lane j, register i --------------------------------------------
+    // ---- the two waves of a tap set: even tiles + odd tiles, through the second wave's own image (16 x 4 x 64 floats = 16 KB) ----------------
+    __syncthreads();
+    float* fold = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (wave + 4) * (OW_SLOTS * BB_SLOT));
+    if (half == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fold[((i * 4 + j) * 4 + r) * 64 + lane] = d[i][j][r];
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[i][j][r] += fold[((i * 4 + j) * 4 + r) * 64 + lane];
+    // ---- every tap set writes its own slab entries: tile (tap pair i, group pair j), row m = 4 (lane >> 4) + reg, column lane & 15 ------------
     float* dst = a.big + (int64_t)blockIdx.x * a.block_stride;
-    const int j = lane & 3;
-    if (blk < 14) {
-        const int g = blk >> 1, oq = blk & 1, cin = g + 1;
+    const int nn = lane & 15, g_lo = nn >> 3, co = nn & 7;
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            if (t < ntaps) {
-                const int kk = 7 * wave + t;
-                const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < cin) dst[a.w[g] + ((int64_t)k * cin + i) * 8 + 4 * oq + j] = d0[t][i];
-            } else if (wave == 3 && t == 6) {
-                dst[a.b[g] + 4 * oq + j] = d0[t][0];                          // the all-ones pseudo tap: every register holds the bias gradient
+        for (int j = 0; j < 4; ++j) {
+            const int g = 2 * j + g_lo;
+            if (g > 6) continue;
+            const int cin = g + 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * (lane >> 4) + r, slot = 2 * i + (m >> 3), ci = m & 7;
+                if (slot < ntaps) {
+                    const int kk = 7 * wave + slot;
+                    const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
+                    if (ci < cin) dst[a.w[g] + ((int64_t)k * cin + ci) * 8 + co] = d[i][j][r];
+                } else if (wave == 3 && slot == 6 && ci == 0) {
+                    dst[a.b[g] + co] = d[i][j][r];                            // the all-ones pseudo tap: every row holds the bias gradient
+                }
             }
         }
-    }
-    if ((blk & 7) < 6) {
-        const int bb = blk & 7, g = 4 + (bb >> 1), oq = bb & 1, cin = g + 1, half = blk >> 3;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int slot = t + 4 * half;
-            if (slot < ntaps) {
-                const int kk = 7 * wave + slot;
-                const int k = kk / 9 + 3 * ((kk / 3) % 3) + 9 * (kk % 3);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (4 + i < cin) dst[a.w[g] + ((int64_t)k * cin + 4 + i) * 8 + 4 * oq + j] = d1[t][i];
-            }
-        }
-    }
 }
 
 // ---- backward of the occupancy heads (csrc/fused.hip: head_bwd_k with bf16 rows in and out) ---------------------------------------------
@@ -1256,12 +1259,15 @@ static int tbackward(TCtx& c, float gscale) {
         o.big = a.BIG; o.block_stride = L.total;
         for (int g = 0; g < 7; ++g) { o.g_g[g] = a.gA[g + 1] - a.gA[1]; o.w[g] = L.outter[g].a_w; o.b[g] = L.outter[g].a_b; }
         const int64_t t64 = (c.R + 63) >> 6;
-        int64_t target = 2 * tb_cus();
+        int64_t target = tb_cus();                            // one 8-wave block per CU (two waves per SIMD)
         if (target > c.nb) target = c.nb;
         o.tiles_per_block = (int)((t64 + target - 1) / target);
         rows = (int)((t64 + o.tiles_per_block - 1) / o.tiles_per_block);
         LinrProf ps(c.s, TK_FIRST_WGRAD, 7);
-        bocc_wgrad7_k<<<rows, BB_WAVES * 64, 0, c.s>>>(o);
+        static const bool big_lds = hipFuncSetAttribute((const void*)bocc_wgrad7_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        OW_WAVES * OW_SLOTS * BB_SLOT) == hipSuccess;
+        if (!big_lds) return LINR_EINVAL;
+        bocc_wgrad7_k<<<rows, OW_WAVES * 64, OW_WAVES * OW_SLOTS * BB_SLOT, c.s>>>(o);
         TRY(linr_launch_rc());
         for (int g = 0; g < 7; ++g) c.note_short(L.outter[g].a_w, L.outter[g].a_b + 8, rows);
     }
