@@ -470,6 +470,9 @@ def bf16_train_leg(gop, L, _lib, epochs):
                            'alg_bytes_per_row_pass': alg_row_pass, 'row_passes_per_fused_group': 2, 'mean_groups_per_launch': round(groups, 3),
                            'mean_launch_us': round(us_launch, 2), 'us_per_group_pass': round(tot.value * 1e3 / max(npass.value, 1), 2),
                            'launches_sampled': int(nl.value), 'traffic': tr_launch, 'traffic_note': tr_note,
+                           'frac_note': 'algorithmic bytes of SURVEY 8(d): each of the two row passes a fused launch replaces is priced with a 108-byte '
+                                        'neighbour table, which the kernel streams as 40 bytes and once - frac can exceed 1; frac_counter prices the bytes '
+                                        'the memory system moved',
                            'frac_counter': None if tr_launch is None else round(tr_launch / (us_launch * 1e-6) / 1e9 / 8000.0, 4),
                            'step': {'alg_bytes_per_row': 20514, 'achieved': round(20514 * mean_rows / (ms * 1e-3) / 1e9, 1),
                                     'frac': round(20514 * mean_rows / (ms * 1e-3) / 1e9 / 8000.0, 4),
