@@ -90,7 +90,7 @@ template <int KIND> struct BbT {
     static constexpr int NACC = BIG ? 2 * NCH : NCH;
 };
 
-template <int KIND, int EPI, bool NOBWD>
+template <int KIND, int EPI>
 __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     using T = BbT<KIND>;
     constexpr int CT = T::CT, SL = T::SL, NCH = T::NCH, NG = (T::NW + 15) / 16, NACC = T::NACC;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
     //   KIND 1: c = 2 k + t       -> (t ? W11 : W01)[k][i][kk]
     //   KIND 2: c = 2 k + h       -> W00[k][4 h + i][kk]
     s16x4 wv[NG];
-    if constexpr (!NOBWD) {
+    {
         const int blk = lane >> 2, i = lane & 3;
         float raw[NG][4];
         bool ok[NG];
@@ -134,9 +134,6 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
             for (int kk = 0; kk < 4; ++kk) v[kk] = ok[r] ? (short)f2bf(raw[r][kk]) : (short)0;
             wv[r] = v;
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < NG; ++r) wv[r] = (s16x4){0, 0, 0, 0};
     }
     // ---- the lane's roles in the transposed reads: group tg = lane >> 4, piece row tq = (lane >> 2) & 3, piece column tp = lane & 3 ---
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -246,7 +243,7 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
                     own_load(ntile, own_n);
                 }
                 const XR xk = x[kk % (PF + 1)];
-                if constexpr (!NOBWD) {
+                {
                     if constexpr (KIND == 0) {
                         const s16x4 q0 = __builtin_bit_cast(s16x4, make_uint2(xk.x, xk.y));
                         const s16x4 q1 = __builtin_bit_cast(s16x4, make_uint2(xk.z, xk.w));
@@ -366,7 +363,7 @@ __global__ __launch_bounds__(BB_WAVES * 64, 2) void bbwd_k(BbArgs a) {
                 }
             }
             const uint4 po = pack_row(o);                                     // the ONE rounding of the row (v_cvt_pk_bf16_f32)
-            if constexpr (!NOBWD) {
+            {
                 if (live) {
                     const uint32_t rb16 = (uint32_t)row << 4;
                     if (EPI == 3 || (a.flags & TB_OUT_F32)) unpack_row(po, o);   // what follows uses the STORED values
@@ -1167,13 +1164,13 @@ static BbArgs bb_base(const TCtx& c) {
     return a;
 }
 
-template <int KIND, int EPI, bool NOBWD = false>
+template <int KIND, int EPI>
 static int bb_launch(TCtx& c, BbArgs& a, int groups, int kind_prof, int* rows) {
     int blocks = 1;
     tb_grid(c.R, c.nb, groups, a.tiles_per_wave, blocks);
     *rows = blocks;
     LinrProf ps(c.s, kind_prof, groups);
-    bbwd_k<KIND, EPI, NOBWD><<<dim3(blocks, groups), BB_WAVES * 64, 0, c.s>>>(a);
+    bbwd_k<KIND, EPI><<<dim3(blocks, groups), BB_WAVES * 64, 0, c.s>>>(a);
     return linr_launch_rc();
 }
 
@@ -1339,6 +1336,6 @@ extern "C" int linr_spconv_bwd_fused_bf16(const uint16_t* gout, const uint16_t* 
     int blocks = 1;
     tb_grid(n, nblocks, 1, a.tiles_per_wave, blocks);
     *rows_written = blocks;
-    bbwd_k<0, 0, false><<<dim3(blocks, 1), BB_WAVES * 64, 0, (hipStream_t)stream>>>(a);
+    bbwd_k<0, 0><<<dim3(blocks, 1), BB_WAVES * 64, 0, (hipStream_t)stream>>>(a);
     return linr_launch_rc();
 }

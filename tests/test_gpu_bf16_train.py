@@ -387,3 +387,38 @@ def test_checkpoints_cross_the_two_training_executors(pkg, shell):
     # the fp32 step right behind the hand-over sees (to bf16 rounding) the loss the bf16 executor would have seen next
     nxt = float(train_step(model, opt, frame, shell['point_num']))
     assert abs(second[0] - nxt) <= 5e-3 * nxt, (second[0], nxt)
+
+
+def test_bf16_step_keeps_the_per_scale_adam_semantics(pkg, shell):
+    """The context MLP of a scale no frame has contained yet is left alone (torch.optim.Adam skips .grad None; torch 1.13.1,
+    enviroment.yaml:30), afterwards it is updated on every step, zero gradient or not (main.py:320): the bf16 step shares the fp32
+    step's reduction and Adam.  Frames: 4 scales, 4 scales, 5 scales, 4 scales - the coarsest scale's MLP starts at step 3; the fused
+    bf16 step against its own unfused entries (forward, backward, FlatAdam.step) bit for bit."""
+    from linr_pcgc_amd import engine
+    from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model, train_step
+    model, sd = _model_and_oracle(pkg, 5)
+    model.train_precision = 'bf16'
+    full = shell['scales']
+    frames = [model.make_frame(full[:-1]), model.make_frame(full[:-1]), model.make_frame(full), model.make_frame(full[:-1])]
+    opt = FlatAdam(model)
+    model2 = LINR_PCGC_Model({'scale_num': 5, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8, 'instage': 1}).cuda()
+    model2.load_state_dict(sd)
+    opt2 = FlatAdam(model2)
+    frames2 = [model2.make_frame(full[:-1]), model2.make_frame(full[:-1]), model2.make_frame(full), model2.make_frame(full[:-1])]
+    w4 = lambda m: dict(m.named_parameters())['scale_mlp.4.0.weight'].detach().clone()
+    w4_init = w4(model)
+    for it in range(6):
+        j = it % 4
+        bits_fused = train_step(model, opt, frames[j], shell['point_num'])
+        bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+        engine.net_forward_train_bf16(frames2[j], model2.flat_parameters(), None, bits)
+        assert float(bits_fused) == float(bits), 'bits of the fused bf16 step differ from linr_net_forward_train_bf16 at step %d' % it
+        opt2.zero_grad()
+        engine.net_backward_bf16(frames2[j], model2.flat_parameters(), opt2.grad, 1.0 / shell['point_num'])
+        opt2.step(frames2[j])
+        if it < 2:
+            assert torch.equal(w4(model), w4_init), 'scale 4 has had no gradient yet: its MLP must be untouched'
+    assert not torch.equal(w4(model), w4_init)
+    assert opt.t == 6 and opt.t_scale.tolist() == [6, 6, 6, 6, 4] and opt2.t_scale.tolist() == [6, 6, 6, 6, 4]
+    assert torch.equal(model.flat_parameters(), model2.flat_parameters()), 'fused bf16 train_step and forward + backward + FlatAdam.step differ'
+    assert torch.equal(opt.exp_avg, opt2.exp_avg) and torch.equal(opt.exp_avg_sq, opt2.exp_avg_sq)
