@@ -21,13 +21,17 @@
 //              broadcast (CBSZ = 4): 64 rows x 4 cout x 4 cin per instruction, a quarter of the fp32 path's matrix instructions
 //   backward   bbwd_k<KIND>: backward-data AND weight gradient of a convolution from ONE gather of the output gradient (the
 //              re-indexing of csrc/fused_bwd.hip: gW[k] = sum_i in[i]^T g[nbr(i, 26 - k)]).  Backward-data is the forward kernel
-//              at the mirrored taps.  For the weight gradient the ROWS are the K dimension of v_mfma_f32_4x4x4_16b_bf16 (four rows
-//              per instruction, 16 independent 4 x 4 blocks = (tap, input quad, output quad) combos, no padding, no broadcast):
-//              the gathered rows are parked in a wave-private LDS image [tap slot][row][16 B] as they arrive (one ds_write_b128
-//              per tap) and read back TRANSPOSED by ds_read_b64_tr_b16 - lane (block, j) receives channel j of four consecutive
-//              rows - as are the rows' own inputs.  220 matrix instructions per 64-row tile for a convolution 8->8 (fp32: 880),
-//              ~170 registers and 10 KB of LDS per wave: two to three waves per SIMD hide the gather latency that the fp32 kernel,
-//              at one wave per SIMD, has to software-pipeline around.
+//              at the mirrored taps.  For the weight gradient the ROWS are the K dimension of the matrix instruction: the gathered
+//              rows are parked in a wave-private LDS image [tap slot][row][16 B] as they arrive (one ds_write_b128 per tap) and read
+//              back TRANSPOSED by ds_read_b64_tr_b16 - a lane receives one channel of four consecutive rows - as are the rows' own
+//              inputs.  Convolutions 8->8 (KIND 0, and KIND 2 with the second convolution 8->4 of the same input) use
+//              v_mfma_f32_16x16x32_bf16: M = the 8 own channels (padded to 16), N = two tap slots x 8 columns, K = 32 rows - 28
+//              weight-gradient instructions per 64-row tile beside the 108 (4x4x4) of backward-data; the 4->4 pair of KIND 1 stays on
+//              v_mfma_f32_4x4x4_16b_bf16 (16 independent 4 x 4 blocks, four rows per instruction).  ~250 registers and 10 KB of LDS
+//              per wave, two waves per SIMD, 14 gathers in flight per wave and the next tile's first gathers issued before the
+//              epilogue of the current one.
+//   first conv bocc7_k / bocc_wgrad7_k: the seven 1->8 / 8->8 convolutions that read the occupancy codes share one gather.
+//   per step   tpack_k rounds every 3x3x3 kernel once into the operand images the kernels above load (wimg).
 #include "bf16_common.h"
 #include "sce.h"
 #include "net_shared.h"
