@@ -541,6 +541,14 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
     }
 }
 
+#include "fused_bwd_split.h"
+
+// LINR_FUSED_SPLIT=0 selects the single-stream kernels (conv_bwd_wgrad_k), anything else the wave-specialised ones
+static bool fb_split() {
+    const char* e = getenv("LINR_FUSED_SPLIT");
+    return !(e && e[0] == '0');
+}
+
 // Grid of the fused kernels.  One block per CU is resident (registers, LDS) and a block's prologue (weights, index decode,
 // first gathers) and epilogue (fold, slab row) run with idle matrix cores, so the launch is sized as ONE round of
 // long-lived blocks: about CUs / groups blocks per group (never more than the slab's nb rows), m tiles per wave.
@@ -589,7 +597,10 @@ int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     const dim3 grid(blocks, ngroups);
-    if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
+    if (fb_split()) {
+        if (pw) conv_bwd_wgrad_split_k<0, 3><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
+        else conv_bwd_wgrad_split_k<0, 0><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
+    } else if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
     else conv_bwd_wgrad_k<0, 0><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
     return linr_launch_rc();
 }
@@ -608,7 +619,8 @@ int linr_dual44_bwd_wgrad_launch(const float* gI, const float* gM, const float* 
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
-    conv_bwd_wgrad_k<1, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
+    if (fb_split()) conv_bwd_wgrad_split_k<1, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
+    else conv_bwd_wgrad_k<1, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
     return linr_launch_rc();
 }
 
@@ -627,7 +639,8 @@ int linr_conv84_bwd_wgrad_launch(const float* gH, const float* A, const float* g
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     PwArgs pw = {w10, nullptr, nullptr, nullptr};
-    conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
+    if (fb_split()) conv_bwd_wgrad_split_k<2, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
+    else conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
     return linr_launch_rc();
 }
 

@@ -398,3 +398,89 @@ def test_inception_backward_fused_pairs(env, nblocks, flags):
     _rel_own_max(tot[1736:1740], wo['b11'].grad, 'gb11')
     _rel_own_max(tot[1740:1772].view(8, 4), wo['w10'].grad, 'gW10 (conv1_0 rides in the conv0_0 launch)')
     _rel_own_max(tot[1772:1776], wo['b10'].grad, 'gb10')
+
+
+class _single_stream:
+    """LINR_FUSED_SPLIT=0 for the launches inside: conv_bwd_wgrad_k instead of the wave-specialised conv_bwd_wgrad_split_k."""
+    def __enter__(self):
+        self.old = os.environ.get('LINR_FUSED_SPLIT')
+        os.environ['LINR_FUSED_SPLIT'] = '0'
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            del os.environ['LINR_FUSED_SPLIT']
+        else:
+            os.environ['LINR_FUSED_SPLIT'] = self.old
+
+
+@pytest.mark.parametrize('nblocks', [256, 5, 1])
+def test_wave_specialised_fused_backward_is_bit_identical(env, nblocks):
+    """conv_bwd_wgrad_split_k (producer / consumer wave pairs, csrc/fused_bwd_split.h) against conv_bwd_wgrad_k (one stream) on the
+    same inputs: every input gradient and every slab partial bit-identical, for the conv 8->8 and for both conv pairs of an Inception
+    layer (nblocks 5 / 1: waves without a tile only run the barriers; many tiles per wave)."""
+    from linr_pcgc_amd import ops
+    L, dev, n = env['L'], env['dev'], env['n']
+    gen = torch.Generator().manual_seed(5 + nblocks)
+    x_h = torch.relu(torch.randn(n, 8, generator=gen))
+    go_h = torch.randn(n, 8, generator=gen)
+    w = (torch.randn(27, 8, 8, generator=gen) * 0.2).to(dev).contiguous()
+    _, go = _padded(go_h, dev)
+    x = x_h.to(dev).contiguous()
+    gin, slab = ops.spconv_bwd_fused(go, x, env['lo'], env['mask'], n, w, nblocks=nblocks, reduce=False)
+    with _single_stream():
+        gin1, slab1 = ops.spconv_bwd_fused(go, x, env['lo'], env['mask'], n, w, nblocks=nblocks, reduce=False)
+    assert torch.equal(gin, gin1) and torch.equal(slab, slab1)
+    w_h, w_d = _inc_params(gen, dev)
+    q = _inc_struct(env, w_d)
+    _, xp = _padded(x_h, dev)
+    _, H = _padded(torch.relu(torch.randn(n, 8, generator=gen)), dev)
+    _, gI = _padded(torch.randn(n, 8, generator=gen), dev)
+    _, gM = _padded(torch.randn(n, 4, generator=gen), dev)
+    old = torch.randn(n, 8, generator=gen).to(dev)
+    outs = []
+    for single in (False, True):
+        _, gH = _empty_padded(n, 8, dev)
+        _, gX = _empty_padded(n, 8, dev)
+        gX[:] = old
+        sl = torch.full((nblocks, 1776), float('nan'), device=dev)
+
+        def run():
+            env['lib'].check(L.linr_inception_bwd_fused(gI.data_ptr(), gM.data_ptr(), xp.data_ptr(), H.data_ptr(), env['lo'].data_ptr(),
+                                                        env['mask'].data_ptr(), env['ld'], n, ctypes.byref(q), gH.data_ptr(), gX.data_ptr(),
+                                                        6, sl.data_ptr(), nblocks, _stream()), 'linr_inception_bwd_fused')
+        if single:
+            with _single_stream():
+                run()
+        else:
+            run()
+        torch.cuda.synchronize()
+        outs.append((gH.clone(), gX.clone(), sl.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_wave_specialised_backward_in_the_executor(pkg, shell):
+    """The training step's gradients (grouped launches, the tail convolution's gM / conv1_2 epilogue) with the wave-specialised fused
+    backward kernels and with the single-stream ones: bit-identical, for --block_layers 1 and 2."""
+    from linr_pcgc_amd import engine
+    from gpu_common import _model_and_oracle
+    for block_layers in (1, 2):
+        model, _ = _model_and_oracle(pkg, 5, block_layers=block_layers)
+        frame = model.make_frame(shell['scales'])
+        flat = model.flat_parameters()
+        res = []
+        for single in (False, True):
+            bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+            grads = torch.zeros_like(flat)
+
+            def run():
+                engine.net_forward(frame, flat, 0, 8, None, bits)
+                engine.net_backward(frame, flat, grads, 1.0 / shell['point_num'])
+                torch.cuda.synchronize()
+            if single:
+                with _single_stream():
+                    run()
+            else:
+                run()
+            res.append(grads)
+        assert float(res[0].abs().max()) > 0 and torch.equal(res[0], res[1])
