@@ -25,6 +25,10 @@
 // SIMD, one 256-thread block per CU, 130 KB of LDS; the block is persistent over `tiles_per_wave` tiles per wave, folds its 16
 // (wave, quarter) partial sums in fixed order and writes ONE slab row - the reduction contract of every weight-gradient
 // kernel (common.h: LinrWgradDst).  The same skeleton serves the two other convolution pairs of an Inception layer (KIND below).
+//
+// conv_bwd_wgrad_single_k below is this schedule in ONE instruction stream per SIMD; the launchers use its wave-specialised form
+// conv_bwd_wgrad_k (csrc/fused_bwd_split.h: producer / consumer wave pairs, bit-identical results, 8 % faster) and keep the
+// single-stream kernel selectable (LINR_FUSED_SPLIT=0) as the reference the parity test compares against.
 #include "common.h"
 #include "conv_common.h"
 #include <stdlib.h>
@@ -71,7 +75,7 @@ template <int KIND> struct FbT {
 
 // EPI 3 (KIND 0 only): also gM = (gin[4:8] @ W12^T) * (M > 0)  (PwArgs as in cconv_mfma_k)
 template <int KIND, int EPI>
-__global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, const int32_t* __restrict__ lo,
+__global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_single_k(FbArgs a, const int32_t* __restrict__ lo,
                                                                     const uint32_t* __restrict__ mask, int64_t ld, int64_t n,
                                                                     PwArgs pw, LinrWgradDst d, FbDst2 d2, Grp gp) {
     using T = FbT<KIND>;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(FB_WAVES * 64, 1) void conv_bwd_wgrad_k(FbArgs a, c
 
 #include "fused_bwd_split.h"
 
-// LINR_FUSED_SPLIT=0 selects the single-stream kernels (conv_bwd_wgrad_k), anything else the wave-specialised ones
+// LINR_FUSED_SPLIT=0 selects the single-stream kernels (conv_bwd_wgrad_single_k), anything else the wave-specialised ones
 static bool fb_split() {
     const char* e = getenv("LINR_FUSED_SPLIT");
     return !(e && e[0] == '0');
@@ -598,10 +602,10 @@ int linr_conv88_bwd_wgrad_launch(const float* g, const float* xin, const int32_t
     if (rows_written) *rows_written = blocks;
     const dim3 grid(blocks, ngroups);
     if (fb_split()) {
-        if (pw) conv_bwd_wgrad_split_k<0, 3><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
-        else conv_bwd_wgrad_split_k<0, 0><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
-    } else if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
-    else conv_bwd_wgrad_k<0, 0><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
+        if (pw) conv_bwd_wgrad_k<0, 3><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
+        else conv_bwd_wgrad_k<0, 0><<<grid, FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
+    } else if (pw) conv_bwd_wgrad_single_k<0, 3><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, *pw, d, FbDst2{w12_off, b12_off}, g0);
+    else conv_bwd_wgrad_single_k<0, 0><<<grid, FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{0, 0}, g0);
     return linr_launch_rc();
 }
 
@@ -619,8 +623,8 @@ int linr_dual44_bwd_wgrad_launch(const float* gI, const float* gM, const float* 
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     LinrWgradDst d = {big, block_stride, w_off0, b_off0, 4};
-    if (fb_split()) conv_bwd_wgrad_split_k<1, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
-    else conv_bwd_wgrad_k<1, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
+    if (fb_split()) conv_bwd_wgrad_k<1, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
+    else conv_bwd_wgrad_single_k<1, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, PwArgs(), d, FbDst2{w_off1, b_off1}, g0);
     return linr_launch_rc();
 }
 
@@ -639,8 +643,8 @@ int linr_conv84_bwd_wgrad_launch(const float* gH, const float* A, const float* g
     fb_grid(n, nb, ngroups, a.tiles_per_wave, blocks);
     if (rows_written) *rows_written = blocks;
     PwArgs pw = {w10, nullptr, nullptr, nullptr};
-    if (fb_split()) conv_bwd_wgrad_split_k<2, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
-    else conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
+    if (fb_split()) conv_bwd_wgrad_k<2, 0><<<dim3(blocks, ngroups), FS_THREADS, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
+    else conv_bwd_wgrad_single_k<2, 0><<<dim3(blocks, ngroups), FB_WAVES * 64, 0, s>>>(a, lo, mask, ld, n, pw, d, FbDst2{w10_off, b10_off}, g0);
     return linr_launch_rc();
 }
 

@@ -1,18 +1,23 @@
-// Wave-specialised form of conv_bwd_wgrad_k (csrc/fused_bwd.hip includes this file): the same arithmetic in the same order - every
-// input gradient and every slab partial bit-identical - issued from TWO instruction streams per SIMD instead of one.
+// Wave-specialised form of conv_bwd_wgrad_single_k (csrc/fused_bwd.hip includes this file) and the kernel the launchers use: the same
+// arithmetic in the same order - every input gradient and every slab partial bit-identical (tests/test_gpu_fused_ops.py) - issued from
+// TWO instruction streams per SIMD instead of one.
 //
-// conv_bwd_wgrad_k keeps ~400 registers alive, so one wave per SIMD is resident and its single in-order stream has to issue the 880
-// matrix instructions of a tile AND the ~1250 other instructions (index decode, gathers, LDS traffic, waits) that feed them: the
-// matrix pipe idles whenever more than one non-matrix instruction stands between two MFMAs (measured: 53 % busy).  Here a block is
-// FOUR PAIRS of waves; the waves w and w + 4 of a pair share a SIMD and a tile:
+// conv_bwd_wgrad_single_k keeps ~400 registers alive, so one wave per SIMD is resident and its single in-order stream has to issue the
+// 880 matrix instructions of a tile AND the ~1250 other instructions (index decode, gathers, LDS traffic, waits) that feed them: a late
+// gather stalls the matrix pipe and a busy matrix pipe delays the next gather (matrix pipe 53 % busy).  Here a block is FOUR PAIRS of
+// waves; the waves w and w + 4 of a pair share a SIMD and a tile:
 //   producer (wave w)      index decode, the gather ring, backward-data MFMAs, the LDS image of the gathered rows, the epilogue
-//                          of the input gradient (and the 1x1 convolutions riding on it)                        ~250 registers
-//   consumer (wave w + 4)  transposed reads of the image, the weight-gradient MFMAs against the rows' own inputs ~230 registers
-// Both fit the 256 registers of two waves per SIMD, and the SIMD's arbiter issues the producer's vector / memory instructions under
-// the consumer's MFMAs.  The image stays double-buffered by chunk (8 taps; KIND 2: 16): while the producer gathers chunk c of a tile,
-// the consumer multiplies chunk c - 1 - the schedule of conv_bwd_wgrad_k, made explicit by ONE block barrier per chunk (s_barrier;
+//                          of the input gradient (and the 1x1 convolutions riding on it)                      200-230 registers
+//   consumer (wave w + 4)  transposed reads of the image, the weight-gradient MFMAs against the rows' own inputs
+// Both fit the 256 registers of two waves per SIMD, and the SIMD's arbiter issues one wave's vector / memory instructions under the
+// other's MFMAs.  The image stays double-buffered by chunk (8 taps; KIND 2: 16): while the producer gathers chunk c of a tile, the
+// consumer multiplies chunk c - 1 - the schedule of conv_bwd_wgrad_single_k, made explicit by ONE block barrier per chunk (s_barrier;
 // the producer waits for its LDS writes only, the gathers in flight stay in flight).  Every wave of the block runs the same number
 // of chunk phases (waves without a tile only execute the barriers).
+// Measured (profiles/r05_split_lab.txt): 8-group launch of the conv 8->8 202 -> 185 us, step 1.62 -> 1.58 ms; the gathers + decode
+// alone take 117 us and the 880 fp32 MFMAs have a floor of 121 us, so the two streams overlap them better but not perfectly.  Giving
+// ALL matrix instructions to one wave (a pure data mover beside it) was tried and is slower (236 us): one stream cannot keep the pipe
+// busy across its LDS reads.
 #define FS_THREADS (2 * FB_WAVES * 64)
 #ifndef FS_LAB
 #define FS_LAB 0                         // kernel-floor experiments (tools/split_lab.sh): 1 no gathers, 2 no weight-gradient MFMAs, 4 no
@@ -22,7 +27,7 @@ __device__ __forceinline__ void fs_barrier_producer() { if constexpr (!(FS_LAB &
 __device__ __forceinline__ void fs_barrier_consumer() { if constexpr (!(FS_LAB & 32)) asm volatile("s_barrier" ::: "memory"); }
 
 template <int KIND, int EPI>
-__global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_split_k(FbArgs a, const int32_t* __restrict__ lo,
+__global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_k(FbArgs a, const int32_t* __restrict__ lo,
                                                                        const uint32_t* __restrict__ mask, int64_t ld, int64_t n,
                                                                        PwArgs pw, LinrWgradDst d, FbDst2 d2, Grp gp) {
     using T = FbT<KIND>;
@@ -30,7 +35,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_split_k(FbArgs a
     __shared__ float4 smem[FB_WAVES * FB_WAVE_BYTES / 16];
     __shared__ float sbias[FB_WAVES][8];
     __shared__ float s12[FB_WAVES][20];
-    {   // group offsets: as in conv_bwd_wgrad_k
+    {   // group offsets: as in conv_bwd_wgrad_single_k
         const int gi = blockIdx.y;
         a.g += gp.in[gi]; a.xin += gp.res[gi]; a.W += gp.w[gi]; a.out += gp.out[gi];
         if constexpr (KIND == 1) { a.g1 += gp.e5[gi]; a.W1 += gp.e6[gi]; d2.w_off1 += gp.e0[gi]; d2.b_off1 += gp.e1[gi]; }
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_split_k(FbArgs a
         __builtin_amdgcn_s_setprio(FS_PRIO_P);
 #endif
         constexpr int WI = KIND == 0 ? 8 : 4;
-        float wv[4][WI];                        // backward-data weights as A-operand images (conv_bwd_wgrad_k)
+        float wv[4][WI];                        // backward-data weights as A-operand images (conv_bwd_wgrad_single_k)
         {
             const int blk = lane >> 2, j = lane & 3;
             const int kl = blk >> 1, co = 4 * (blk & 1) + j;
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_split_k(FbArgs a
 #ifdef FS_PRIO_C
         __builtin_amdgcn_s_setprio(FS_PRIO_C);
 #endif
-        // weight-gradient roles of the lane: as in conv_bwd_wgrad_k
+        // weight-gradient roles of the lane: as in conv_bwd_wgrad_single_k
         const int Q = lane >> 4;
         const int wq = KIND == 0 ? (lane & 1) : KIND == 1 ? ((lane >> 3) & 1) : 0;
         const int wslot = KIND == 0 ? ((lane & 15) >> 1) : KIND == 1 ? (lane & 7) : (lane & 15);

@@ -401,7 +401,7 @@ def test_inception_backward_fused_pairs(env, nblocks, flags):
 
 
 class _single_stream:
-    """LINR_FUSED_SPLIT=0 for the launches inside: conv_bwd_wgrad_k instead of the wave-specialised conv_bwd_wgrad_split_k."""
+    """LINR_FUSED_SPLIT=0 for the launches inside: conv_bwd_wgrad_single_k (one stream) instead of the wave-specialised conv_bwd_wgrad_k."""
     def __enter__(self):
         self.old = os.environ.get('LINR_FUSED_SPLIT')
         os.environ['LINR_FUSED_SPLIT'] = '0'
@@ -415,7 +415,7 @@ class _single_stream:
 
 @pytest.mark.parametrize('nblocks', [256, 5, 1])
 def test_wave_specialised_fused_backward_is_bit_identical(env, nblocks):
-    """conv_bwd_wgrad_split_k (producer / consumer wave pairs, csrc/fused_bwd_split.h) against conv_bwd_wgrad_k (one stream) on the
+    """conv_bwd_wgrad_k (producer / consumer wave pairs, csrc/fused_bwd_split.h) against conv_bwd_wgrad_single_k (one stream) on the
     same inputs: every input gradient and every slab partial bit-identical, for the conv 8->8 and for both conv pairs of an Inception
     layer (nblocks 5 / 1: waves without a tile only run the barriers; many tiles per wave)."""
     from linr_pcgc_amd import ops
