@@ -126,6 +126,38 @@ def test_config4_owlii11_size_properties(pkg):
     _frame_properties(gop, overfit.gen_model(gop.scale_num, 'cuda', seed=8807), steps=2)
 
 
+def test_config4_size_wave_specialised_backward_is_bit_identical(pkg):
+    """At BASELINE config[4]'s frame size (~1.24 M rows, 8 scales): the training step's gradients with the wave-specialised fused backward
+    kernels (conv_bwd_wgrad_k: producer / consumer wave pairs) and with the single-stream ones (LINR_FUSED_SPLIT=0) - bit-identical, and
+    run-to-run reproducible."""
+    import os
+    from linr_pcgc_amd import engine, overfit, synthetic
+    gop = overfit.Gop(None, [synthetic.sequence_frame_device('owlii11', 0, 'cuda')], None, 64, 'cuda')
+    model = overfit.gen_model(gop.scale_num, 'cuda', seed=8807)
+    frame, flat = gop.frames[0], model.flat_parameters()
+    assert frame.rows > 1200000
+
+    def grads_now():
+        bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+        g = torch.zeros_like(flat)
+        engine.net_forward(frame, flat, 0, 8, None, bits)
+        engine.net_backward(frame, flat, g, 1.0 / gop.point_nums[0])
+        torch.cuda.synchronize()
+        return g
+    a, b = grads_now(), grads_now()
+    old = os.environ.get('LINR_FUSED_SPLIT')
+    os.environ['LINR_FUSED_SPLIT'] = '0'
+    try:
+        c = grads_now()
+    finally:
+        if old is None:
+            del os.environ['LINR_FUSED_SPLIT']
+        else:
+            os.environ['LINR_FUSED_SPLIT'] = old
+    assert float(a.abs().max()) > 0 and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def _smallest_relu_input(sd, sc):
     """Smallest |x| any ReLU of the network sees on this scale, from the oracle in float64.  Below ~3e-7 (inputs are O(1)) the sign of x - and with
     it a whole term of the gradient - is decided by fp32 rounding order, so no two fp32 implementations need agree there."""
