@@ -89,7 +89,10 @@ __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_k(FbArgs a, cons
         for (int j = 0; j < 8; ++j) bsum[j] = 0.0f;
         const char* pad = reinterpret_cast<const char*>(a.g - 8);
         const char* pad1 = KIND == 1 ? reinterpret_cast<const char*>(a.g1 - 4) : nullptr;
-        constexpr int PF = 8, RING = 9;
+#ifndef FS_PF
+#define FS_PF 8
+#endif
+        constexpr int PF = FS_PF, RING = FS_PF + 1;
         static_assert(27 % RING == 0 && PF + 1 == RING, "ring slots must not depend on the tile");
         const char* lob = reinterpret_cast<const char*>(lo);
         const uint32_t ld4 = (uint32_t)ld << 2;

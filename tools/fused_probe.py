@@ -25,3 +25,20 @@ def t(fn):
 print('rows', R)
 print('fused bwd+wgrad  %.1f us' % t(lambda: ops.spconv_bwd_fused(go[1:], x, lo, mask, R, w, nblocks=nb, reduce=False)))
 print('bwd-data alone   %.1f us' % t(lambda: ops.spconv_cmap(go[1:], lo, mask, R, w, None, bwd=True)))
+# both conv pairs of an Inception layer's backward (conv_bwd_wgrad_k<1> then <2>): time them apart with rocprofv3 --kernel-trace --stats
+import ctypes
+from linr_pcgc_amd import _lib
+L = _lib.lib()
+gen = torch.Generator().manual_seed(1)
+shapes = {'w00': (27, 8, 4), 'b00': (4,), 'w01': (27, 4, 4), 'b01': (4,), 'w10': (8, 4), 'b10': (4,), 'w11': (27, 4, 4), 'b11': (4,), 'w12': (4, 4), 'b12': (4,)}
+wd = {k: (torch.randn(*s, generator=gen) * 0.2).to(dev).contiguous() for k, s in shapes.items()}
+q = _lib.LinrInceptionParams(**{k: v.data_ptr() for k, v in wd.items()})
+def padded(c):
+    t = torch.zeros((R + 1, c), device=dev); t[1:].normal_(); return t
+gI, gM, xp, H, gH, gX = padded(8), padded(4), padded(8), padded(8), padded(8), padded(8)
+slab = torch.zeros((nb, 1776), device=dev)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def inc():
+    _lib.check(L.linr_inception_bwd_fused(gI[1:].data_ptr(), gM[1:].data_ptr(), xp[1:].data_ptr(), H[1:].data_ptr(), lo.data_ptr(), mask.data_ptr(),
+                                          lo.stride(0), R, ctypes.byref(q), gH[1:].data_ptr(), gX[1:].data_ptr(), 2, slab.data_ptr(), nb, st), 'inc')
+print('inception bwd (two 4->4 convs, then conv0_0 8->4 + conv1_0)  %.1f us' % t(inc))
