@@ -94,6 +94,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_k(FbArgs a, cons
 #endif
         constexpr int PF = FS_PF, RING = FS_PF + 1;
         static_assert(27 % RING == 0 && PF + 1 == RING, "ring slots must not depend on the tile");
+        static_assert(27 - PF > 10, "the next tile's offsets are decoded at step 10 and first used at step 27 - PF");
         const char* lob = reinterpret_cast<const char*>(lo);
         const uint32_t ld4 = (uint32_t)ld << 2;
         auto idx_load = [&](int64_t row, int32_t (&raw)[10]) {
