@@ -123,7 +123,8 @@ __attribute__((visibility("hidden")))
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
-                         hipStream_t s, const Grp* gp = nullptr, int ngroups = 1, int nblocks = LINR_WG_BLOCKS);
+                         hipStream_t s, const Grp* gp = nullptr, int ngroups = 1, int nblocks = LINR_WG_BLOCKS,
+                         int* rows_written = nullptr);
 __attribute__((visibility("hidden")))
 int linr_slab_reduce_launch(const float* big, int nblocks, int64_t total, float* gsum, hipStream_t s);
 __attribute__((visibility("hidden")))

@@ -6,6 +6,7 @@
 // becomes 13.5 MB, i.e. one XCD's share (1.7 MB) stays L2-resident across the ~140 conv passes of a training step.
 #include "common.h"
 #include "conv_common.h"
+#include "head_bwd.h"
 #include <stdlib.h>
 #define WG_WAVES 4          // waves per block of the MFMA weight-gradient kernels (same-box A/B: 2 -> 2.765, 4 -> 2.574, 8 -> 2.596 ms/step)
 
@@ -1089,192 +1090,62 @@ int linr_conv3_wgrad_dual44(const float* H, const float* g0, int g0_ld, const fl
 }
 
 // ---- fused backward of the occupancy head ------------------------------------------------------------------------------
-// Per row: recompute the hidden layer from C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]).  The per-row MLP runs on
-// the matrix cores like the convolutions (v_mfma_f32_4x4x1, weights as broadcast A blocks held in 8 VGPRs; K = 1 keeps
-// the forward head's fmaf chains: bias first, inputs ascending).  The weight gradients
-//   gW1[24][8] = sum_r gh[r] (x) c[r],  gb1 = sum_r gh[r]
-// are X^T G products with the row reduction as the K dimension of v_mfma_f32_16x16x4_f32: each wave transposes its
-// 64 rows of X = gh (24 cols) and G = [c | 1] (9 cols) through a wave-private LDS tile into fragment layout;
-//   gw2[24] = sum_r gz[r] h[r],  gb2 = sum_r gz[r]
-// accumulate per lane and are reduced once per block (fixed shuffle tree, waves in order).
-// Persistent blocks (LINR_WG_BLOCKS) keep all accumulators in registers and emit one partial per parameter.
-#define HB_LDW 33          // 24 + 9 columns, odd stride (49 would spread the fragment reads over all banks but costs a workgroup per CU: 86.6 vs 77 us)
+// csrc/head_bwd.h holds the arithmetic (shared with the bf16 training executor); here: fp32 rows in and out, grouped launches.
 struct HeadBwdArgs {
     const float* c;  const float* p;  const float* target; int target_ld;
     const float* w1; const float* b1; const float* w2;
     float gscale;                     // d loss / d nats
     float* gc;                        // [n][8]
     float* big; int64_t block_stride; int64_t off_w1, off_b1, off_w2, off_b2;
+    int active;
 };
 
-__global__ __launch_bounds__(LINR_BLOCK, 4) void head_bwd_k(HeadBwdArgs A, int64_t n, Grp gp = Grp()) {
-    {   // group offsets: in = c, e0 = p, e1 = target, w = w1, b = b1, e2 = w2, out = gc, e3..e6 = slab offsets of w1, b1, w2, b2
-        const int gi = blockIdx.y;
-        A.c += gp.in[gi]; A.p += gp.e0[gi]; A.target += gp.e1[gi]; A.w1 += gp.w[gi]; A.b1 += gp.b[gi]; A.w2 += gp.e2[gi];
-        A.gc += gp.out[gi];
-        A.off_w1 += gp.e3[gi]; A.off_b1 += gp.e4[gi]; A.off_w2 += gp.e5[gi]; A.off_b2 += gp.e6[gi];
-    }
-    __shared__ float sT[(LINR_BLOCK / 64) * 64 * HB_LDW];
-    __shared__ float sfold[64 * 9];
-    __shared__ float sw2[(LINR_BLOCK / 64) * 25];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mm = lane & 15, rr = lane >> 4;
-    // A-operand images of the weights: block (lane >> 2) of register v is "combo" 16 v + block
-    //   wA: combo = 6 i + hq -> W1[4 hq + j][i] (i < 8), combos 48..53 -> b1[4 (combo - 48) + j]
-    //   wB: combo = 2 jj + q -> W1[jj][4 q + j]  (jj < 24)
-    //   wC: block hq < 6     -> w2[4 hq + j]
-    float wA[4], wB[3], wC;
-    {
-        const int blk = lane >> 2, j = lane & 3;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int cb = 16 * v + blk;
-            wA[v] = cb < 48 ? A.w1[(4 * (cb % 6) + j) * 8 + cb / 6] : (cb < 54 ? A.b1[4 * (cb - 48) + j] : 0.0f);
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int cb = 16 * v + blk;
-            wB[v] = A.w1[(cb / 2) * 8 + 4 * (cb % 2) + j];
-        }
-        wC = blk < 6 ? A.w2[4 * blk + j] : 0.0f;
-    }
-    float* T = sT + wave * 64 * HB_LDW;
-    f32x4 acc[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) acc[a] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float gw2[24];
-#pragma unroll
-    for (int j = 0; j < 24; ++j) gw2[j] = 0.0f;
-    float gz_sum = 0.0f;
-    const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t row = t * LINR_BLOCK + threadIdx.x;
-        const bool live = row < n;
-        float c[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c[i] = 0.0f;
-        float gz = 0.0f;
-        if (live) {
-            const float4 c0 = *reinterpret_cast<const float4*>(A.c + row * 8);
-            const float4 c1 = *reinterpret_cast<const float4*>(A.c + row * 8 + 4);
-            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
-            const float pp = A.p[row], tt = A.target[row * A.target_ld];
-            const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
-            gz = gp * ((1.0f - pp) * pp);
-        }
-        // hpre = b1 + W1 c  (6 output quads; bias through x = 1, then inputs ascending)
-        f32x4 hp[6];
-        static_for<6>([&](auto hc) {
-            constexpr int hq = decltype(hc)::value;
-            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);   // combo 48 + hq
-        });
-        static_for<8>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            static_for<6>([&](auto hc) {
-                constexpr int hq = decltype(hc)::value;
-                constexpr int cb = 6 * i + hq;
-                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
-            });
-        });
-        // gh = [hpre > 0] gz w2 ;  gw2 += gz relu(hpre)
-        float gh[24];
-        static_for<6>([&](auto hc) {
-            constexpr int hq = decltype(hc)::value;
-            const f32x4 g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wC, gz, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float hv = hp[hq][j];
-                gh[4 * hq + j] = (live && hv > 0.0f) ? g4[j] : 0.0f;
-                gw2[4 * hq + j] = fmaf(gz, fmaxf(hv, 0.0f), gw2[4 * hq + j]);
-            }
-        });
-        // gC = W1^T gh  (2 output quads, hidden units ascending)
-        f32x4 gcq[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
-        static_for<24>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            static_for<2>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                constexpr int cb = 2 * jj + q;
-                gcq[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wB[cb / 16], gh[jj], gcq[q], 4, cb % 16, 0);
-            });
-        });
-        if (live) {
-            *reinterpret_cast<float4*>(A.gc + row * 8) = make_float4(gcq[0][0], gcq[0][1], gcq[0][2], gcq[0][3]);
-            *reinterpret_cast<float4*>(A.gc + row * 8 + 4) = make_float4(gcq[1][0], gcq[1][1], gcq[1][2], gcq[1][3]);
-        }
-        gz_sum += gz;
-        float* Tr = T + lane * HB_LDW;
-#pragma unroll
-        for (int j = 0; j < 24; ++j) Tr[j] = gh[j];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Tr[24 + i] = c[i];
-        Tr[32] = live ? 1.0f : 0.0f;
-        // X^T G over this wave's 64 rows (wave-private tile: in-order LDS, no block barrier needed)
-#pragma unroll 4
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const float* Tq = T + (4 * s4 + rr) * HB_LDW;
-            const float b = (mm < 9) ? Tq[24 + mm] : 0.0f;
-            const float a0 = Tq[mm];
-            const float a1 = (mm < 8) ? Tq[16 + mm] : 0.0f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
-        }
-    }
-    // fold the 4 waves in wave order, then one partial per destination element
-    float* mine = sfold + lane * 9;
-    for (int w = 0; w < LINR_BLOCK / 64; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mine[a * 4 + j] = (w == 0) ? acc[a][j] : mine[a * 4 + j] + acc[a][j];
-        }
-        __syncthreads();
-    }
-    // gw2, gb2: fixed-order wave reduction, then waves in order
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
-#pragma unroll
-    for (int j = 0; j < 24; ++j) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) gw2[j] += __shfl_xor(gw2[j], d, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 24; ++j) sw2[wave * 25 + j] = gw2[j];
-        sw2[wave * 25 + 24] = gz_sum;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float* dst = A.big + (int64_t)blockIdx.x * A.block_stride;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = 16 * a + rr * 4 + j;      // C/D map: row = (lane>>4)*4 + reg, col = lane&15
-                const float v = mine[a * 4 + j];
-                if (m < 24) {
-                    if (mm < 8) dst[A.off_w1 + m * 8 + mm] = v;
-                    else if (mm == 8) dst[A.off_b1 + m] = v;
-                }
-            }
-        if (lane < 25) {
-            const float v = ((sw2[lane] + sw2[25 + lane]) + sw2[50 + lane]) + sw2[75 + lane];
-            if (lane < 24) dst[A.off_w2 + lane] = v;
-            else dst[A.off_b2] = v;
-        }
-    }
+__global__ __launch_bounds__(HB_WAVES * 64, 2) void head_bwd_k(HeadBwdArgs A, int64_t n, Grp gp = Grp()) {
+    __shared__ float lds[HB_LDS_FLOATS];
+    // group offsets: in = c, e0 = p, e1 = target, w = w1, b = b1, e2 = w2, out = gc, e3..e6 = slab offsets of w1, b1, w2, b2
+    const int gi = blockIdx.y;
+    const float* C = A.c + gp.in[gi];
+    float* GC = A.gc + gp.out[gi];
+    HbParams h;
+    h.p = A.p + gp.e0[gi]; h.target = A.target + gp.e1[gi]; h.target_ld = A.target_ld;
+    h.w1 = A.w1 + gp.w[gi]; h.b1 = A.b1 + gp.b[gi]; h.w2 = A.w2 + gp.e2[gi];
+    h.gscale = A.gscale; h.n = n;
+    h.dst = A.big + (int64_t)blockIdx.x * A.block_stride;
+    h.off_w1 = A.off_w1 + gp.e3[gi]; h.off_b1 = A.off_b1 + gp.e4[gi]; h.off_w2 = A.off_w2 + gp.e5[gi]; h.off_b2 = A.off_b2 + gp.e6[gi];
+    h.active = A.active;
+    head_bwd_body<HbRaw32>(h,
+        [&](int64_t row) { return HbRaw32{*reinterpret_cast<const f32x4*>(C + row * 8), *reinterpret_cast<const f32x4*>(C + row * 8 + 4)}; },
+        [](const HbRaw32& r, float (&c)[8]) {
+            c[0] = r.a[0]; c[1] = r.a[1]; c[2] = r.a[2]; c[3] = r.a[3]; c[4] = r.b[0]; c[5] = r.b[1]; c[6] = r.b[2]; c[7] = r.b[3];
+        },
+        [&](int64_t row, const float (&g)[8]) {
+            *reinterpret_cast<float4*>(GC + row * 8) = make_float4(g[0], g[1], g[2], g[3]);
+            *reinterpret_cast<float4*>(GC + row * 8 + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }, lds);
 }
 
+static int hb_cus() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    return v;
+}
+
+// rows_written == nullptr: slab rows 0 .. nblocks - 1 are all written (rows beyond the active blocks get zeros); otherwise only the
+// active blocks' rows are written and *rows_written tells the caller how many (its reduction must stop there)
 int linr_head_bwd_launch(const float* c, const float* p, const float* target, int target_ld, const float* w1,
                          const float* b1, const float* w2, float gscale, float* gc, int64_t n, float* big,
                          int64_t block_stride, int64_t off_w1, int64_t off_b1, int64_t off_w2, int64_t off_b2,
-                         hipStream_t s, const Grp* gp, int ngroups, int nblocks) {
+                         hipStream_t s, const Grp* gp, int ngroups, int nblocks, int* rows_written) {
+    if (rows_written) *rows_written = 0;
     if (n == 0) return 0;
     const Grp g0 = gp ? *gp : Grp();
-    HeadBwdArgs A = {c, p, target, target_ld, w1, b1, w2, gscale, gc, big, block_stride, off_w1, off_b1, off_w2, off_b2};
-    head_bwd_k<<<dim3(nblocks, ngroups), LINR_BLOCK, 0, s>>>(A, n, g0);
+    const int active = hb_blocks(n, ngroups, hb_cus(), nblocks);
+    HeadBwdArgs A = {c, p, target, target_ld, w1, b1, w2, gscale, gc, big, block_stride, off_w1, off_b1, off_w2, off_b2, active};
+    head_bwd_k<<<dim3(rows_written ? active : nblocks, ngroups), HB_WAVES * 64, 0, s>>>(A, n, g0);
+    if (rows_written) *rows_written = active;
     return linr_launch_rc();
 }
 

@@ -24,7 +24,18 @@
 #endif                                   // backward-data MFMAs, 8 no LDS traffic, 32 no phase barriers
 
 __device__ __forceinline__ void fs_barrier_producer() { if constexpr (!(FS_LAB & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void fs_barrier_consumer() { if constexpr (!(FS_LAB & 32)) asm volatile("s_barrier" ::: "memory"); }
+// The consumer's reads of image buffer (pc & 1) must have RETURNED before the producer overwrites that buffer in the next phase.  Every
+// such read feeds an MFMA of this phase, and the compiler's lgkmcnt wait sits in front of that MFMA - but MFMAs are not memory
+// operations, so the asm's "memory" clobber alone would not stop a scheduler from sinking one (and its wait) below the barrier.  The
+// scheduling barrier in FRONT of the asm makes the order structural: nothing moves across it (no change in the emitted code).
+__device__ __forceinline__ void fs_barrier_consumer() {
+    if constexpr (!(FS_LAB & 32)) {
+#ifndef FS_NO_CONSUMER_SB                 // (lab knob: the code as it shipped in round 5, for the same-box A/B of profiles/r06_*)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        asm volatile("s_barrier" ::: "memory");
+    }
+}
 
 template <int KIND, int EPI>
 __global__ __launch_bounds__(FS_THREADS, 1) void conv_bwd_wgrad_k(FbArgs a, const int32_t* __restrict__ lo,

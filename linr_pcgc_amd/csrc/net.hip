@@ -1029,8 +1029,10 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
             for (int k = 0; k < 8; ++k) gp.e1[k] = k;
             goffs_i(gp.e3, o_w1, 8); goffs_i(gp.e4, o_b1, 8); goffs_i(gp.e5, o_w2, 8); goffs_i(gp.e6, o_b2, 8);
             ProfScope ps(c.s, PK_HEAD_BWD, 8);
+            int hrows = 0;
             TRY(linr_head_bwd_launch(a.C[0], a.P[0], a.OCC, 8, h_w1[0], h_b1[0], h_w2[0], gz_scale, a.gC[0], c.R, a.BIG, L.total,
-                                     o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8, c.nb));
+                                     o_w1[0], o_b1[0], o_w2[0], o_b2[0], c.s, &gp, 8, c.nb, &hrows));
+            c.note_short(L.h0_w[0], L.h2_b[7] + 1, hrows);          // the heads' parameters are one contiguous range
         }
         if (fused_bwd(c)) {   // C = conv3(prior_k; prune_k): gO[k] = bwd(gC[k]) and the weight gradients from one gather of gC
             Grp gp = Grp();

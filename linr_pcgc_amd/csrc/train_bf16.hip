@@ -33,6 +33,7 @@
 //   first conv bocc7_k / bocc_wgrad7_k: the seven 1->8 / 8->8 convolutions that read the occupancy codes share one gather.
 //   per step   tpack_k rounds every 3x3x3 kernel once into the operand images the kernels above load (wimg).
 #include "bf16_common.h"
+#include "head_bwd.h"
 #include "sce.h"
 #include "net_shared.h"
 #include <stdlib.h>
@@ -758,168 +759,33 @@ __global__ __launch_bounds__(OW_WAVES * 64, 2) void bocc_wgrad7_k(OwArgs a) {
         }
 }
 
-// ---- backward of the occupancy heads (csrc/fused.hip: head_bwd_k with bf16 rows in and out) ---------------------------------------------
-// Per row: recompute the hidden layer from the STORED C_k, gz from (p, t), gC = W1^T (gz * w2 * [hpre > 0]) -> bf16; the weight
-// gradients gW1 = sum_r gh[r] (x) c[r], gb1, gw2, gb2 in fp32 (v_mfma_f32_4x4x1 for the per-row MLP, v_mfma_f32_16x16x4_f32 for
-// X^T G through a wave-private LDS tile) - the MLP is fp32 arithmetic in this executor, only its input and output rows are bf16.
-#define THB_LDW 33
+// ---- backward of the occupancy heads (csrc/head_bwd.h, shared with the fp32 executor's head_bwd_k) -----------------------------------
+// bf16 rows in (the STORED C_k) and out (gC); the MLP, its weight gradients and gz are fp32 arithmetic in this executor as well.
 struct THeadArgs {
     const bf16_t* c;  const float* p;  const float* target;  int target_ld;
     const float* P;  float gscale;  bf16_t* gc;  int64_t n;
     float* big;  int64_t block_stride;
     int64_t g_c[8], g_p[8], g_t[8], g_gc[8];
     int64_t w1[8], b1[8], w2[8], b2[8];
+    int active;
 };
 
-__global__ __launch_bounds__(LINR_BLOCK, 4) void thead_bwd_k(THeadArgs A) {
+__global__ __launch_bounds__(HB_WAVES * 64, 2) void thead_bwd_k(THeadArgs A) {
+    __shared__ float lds[HB_LDS_FLOATS];
     const int gi = blockIdx.y;
     const bf16_t* Cm = A.c + A.g_c[gi];
-    const float* Pp = A.p + A.g_p[gi];
-    const float* Tg = A.target + A.g_t[gi];
     bf16_t* GC = A.gc + A.g_gc[gi];
-    const float* W1 = A.P + A.w1[gi];
-    const float* B1 = A.P + A.b1[gi];
-    const float* W2 = A.P + A.w2[gi];
-    const int64_t n = A.n;
-    __shared__ float sT[(LINR_BLOCK / 64) * 64 * THB_LDW];
-    __shared__ float sfold[64 * 9];
-    __shared__ float sw2[(LINR_BLOCK / 64) * 25];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mm = lane & 15, rr = lane >> 4;
-    float wA[4], wB[3], wC;
-    {
-        const int blk = lane >> 2, j = lane & 3;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int cb = 16 * v + blk;
-            wA[v] = cb < 48 ? W1[(4 * (cb % 6) + j) * 8 + cb / 6] : (cb < 54 ? B1[4 * (cb - 48) + j] : 0.0f);
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const int cb = 16 * v + blk;
-            wB[v] = W1[(cb / 2) * 8 + 4 * (cb % 2) + j];
-        }
-        wC = blk < 6 ? W2[4 * blk + j] : 0.0f;
-    }
-    float* T = sT + wave * 64 * THB_LDW;
-    f32x4 acc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) acc[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float gw2[24];
-#pragma unroll
-    for (int j = 0; j < 24; ++j) gw2[j] = 0.0f;
-    float gz_sum = 0.0f;
-    const int64_t tiles = (n + LINR_BLOCK - 1) / LINR_BLOCK;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t row = t * LINR_BLOCK + threadIdx.x;
-        const bool live = row < n;
-        float c[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c[i] = 0.0f;
-        float gz = 0.0f;
-        if (live) {
-            unpack_row(*reinterpret_cast<const uint4*>(Cm + row * 8), c);
-            const float pp = Pp[row], tt = Tg[row * A.target_ld];
-            const float gp = A.gscale * (pp - tt) / fmaxf((1.0f - pp) * pp, 1e-12f);
-            gz = gp * ((1.0f - pp) * pp);
-        }
-        f32x4 hp[6];
-        sfor<6>([&](auto hc) {
-            constexpr int hq = decltype(hc)::value;
-            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
-        });
-        sfor<8>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            sfor<6>([&](auto hc) {
-                constexpr int hq = decltype(hc)::value;
-                constexpr int cb = 6 * i + hq;
-                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
-            });
-        });
-        float gh[24];
-        sfor<6>([&](auto hc) {
-            constexpr int hq = decltype(hc)::value;
-            const f32x4 g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wC, gz, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float hv = hp[hq][j];
-                gh[4 * hq + j] = (live && hv > 0.0f) ? g4[j] : 0.0f;
-                gw2[4 * hq + j] = fmaf(gz, fmaxf(hv, 0.0f), gw2[4 * hq + j]);
-            }
-        });
-        f32x4 gcq[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
-        sfor<24>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            sfor<2>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                constexpr int cb = 2 * jj + q;
-                gcq[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(wB[cb / 16], gh[jj], gcq[q], 4, cb % 16, 0);
-            });
-        });
-        if (live) {
-            const float o[8] = {gcq[0][0], gcq[0][1], gcq[0][2], gcq[0][3], gcq[1][0], gcq[1][1], gcq[1][2], gcq[1][3]};
-            *reinterpret_cast<uint4*>(GC + row * 8) = pack_row(o);
-        }
-        gz_sum += gz;
-        float* Tr = T + lane * THB_LDW;
-#pragma unroll
-        for (int j = 0; j < 24; ++j) Tr[j] = gh[j];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Tr[24 + i] = c[i];
-        Tr[32] = live ? 1.0f : 0.0f;
-#pragma unroll 4
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const float* Tq = T + (4 * s4 + rr) * THB_LDW;
-            const float b = (mm < 9) ? Tq[24 + mm] : 0.0f;
-            const float a0 = Tq[mm];
-            const float a1 = (mm < 8) ? Tq[16 + mm] : 0.0f;
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
-        }
-    }
-    float* mine = sfold + lane * 9;
-    for (int w = 0; w < LINR_BLOCK / 64; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mine[q * 4 + j] = (w == 0) ? acc[q][j] : mine[q * 4 + j] + acc[q][j];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) gz_sum += __shfl_xor(gz_sum, d, 64);
-#pragma unroll
-    for (int j = 0; j < 24; ++j) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) gw2[j] += __shfl_xor(gw2[j], d, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 24; ++j) sw2[wave * 25 + j] = gw2[j];
-        sw2[wave * 25 + 24] = gz_sum;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float* dst = A.big + (int64_t)blockIdx.x * A.block_stride;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = 16 * q + rr * 4 + j;
-                const float v = mine[q * 4 + j];
-                if (m < 24) {
-                    if (mm < 8) dst[A.w1[gi] + m * 8 + mm] = v;
-                    else if (mm == 8) dst[A.b1[gi] + m] = v;
-                }
-            }
-        if (lane < 25) {
-            const float v = ((sw2[lane] + sw2[25 + lane]) + sw2[50 + lane]) + sw2[75 + lane];
-            if (lane < 24) dst[A.w2[gi] + lane] = v;
-            else dst[A.b2[gi]] = v;
-        }
-    }
+    HbParams h;
+    h.p = A.p + A.g_p[gi]; h.target = A.target + A.g_t[gi]; h.target_ld = A.target_ld;
+    h.w1 = A.P + A.w1[gi]; h.b1 = A.P + A.b1[gi]; h.w2 = A.P + A.w2[gi];
+    h.gscale = A.gscale; h.n = A.n;
+    h.dst = A.big + (int64_t)blockIdx.x * A.block_stride;
+    h.off_w1 = A.w1[gi]; h.off_b1 = A.b1[gi]; h.off_w2 = A.w2[gi]; h.off_b2 = A.b2[gi];
+    h.active = A.active;
+    head_bwd_body<u32x4>(h,
+        [&](int64_t row) { return *reinterpret_cast<const u32x4*>(Cm + row * 8); },
+        [](const u32x4& r, float (&c)[8]) { unpack_row(make_uint4(r[0], r[1], r[2], r[3]), c); },
+        [&](int64_t row, const float (&g)[8]) { *reinterpret_cast<uint4*>(GC + row * 8) = pack_row(g); }, lds);
 }
 
 // x_glob's gradient: the fan-in of the eight priors (models/upsample.py:206-214 under autograd), summed in fp32 in the order of the
@@ -1001,12 +867,12 @@ extern "C" int linr_occ_to_bf16(const float* occ, int64_t rows, uint16_t* out_pa
     if (rows < 0) return LINR_EINVAL;
     if (!out_padded) return LINR_EINVAL;
     if ((((uintptr_t)out_padded) & 15u) || (occ && !linr_aligned16(occ))) return LINR_EALIGN;
+    if (rows > 0 && !occ) return LINR_EINVAL;                  // every argument check in front of the first launch
     hipStream_t s = (hipStream_t)stream;
     BPads pl;
     pl.n = 1; pl.off[0] = 0; pl.w[0] = 8;
     zero_pads16_k<<<1, 64, 0, s>>>(out_padded, pl);
     if (rows > 0) {
-        if (!occ) return LINR_EINVAL;
         occ_bf16_k<<<linr_grid(rows, LINR_BLOCK), LINR_BLOCK, 0, s>>>(occ, rows, out_padded + 8);
     }
     return linr_launch_rc();
@@ -1192,9 +1058,11 @@ static int tbackward(TCtx& c, float gscale) {
             h.g_c[k] = a.C[k] - a.C[0]; h.g_p[k] = (int64_t)k * c.R; h.g_t[k] = k; h.g_gc[k] = a.gC[k] - a.gC[0];
             h.w1[k] = L.h0_w[k]; h.b1[k] = L.h0_b[k]; h.w2[k] = L.h2_w[k]; h.b2[k] = L.h2_b[k];
         }
+        h.active = hb_blocks(c.R, 8, tb_cus(), c.nb);
         LinrProf ps(c.s, TK_HEAD_BWD, 8);
-        thead_bwd_k<<<dim3(c.nb, 8), LINR_BLOCK, 0, c.s>>>(h);
+        thead_bwd_k<<<dim3(h.active, 8), HB_WAVES * 64, 0, c.s>>>(h);
         TRY(linr_launch_rc());
+        c.note_short(L.h0_w[0], L.h2_b[7] + 1, h.active);          // the heads' parameters are one contiguous range
     }
     int rows = 0;
     {   // C_k = conv3(prior_k; prune_k): gO[k] = bwd(gC[k]) and the kernel / bias gradients, one gather of gC
@@ -1212,6 +1080,7 @@ static int tbackward(TCtx& c, float gscale) {
         for (int k = 0; k < 8; ++k) src.p[k] = a.gO[k];
         LinrProf ps(c.s, TK_MISC, 1);
         tsum8_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(src, c.R, a.gXG);
+        TRY(linr_launch_rc());
     }
     {   // O = conv3(I; b): gI = bwd(gO), gM, G2 = [gI[:, 0:4] | gM], the kernel / bias gradients and conv1_2's
         BbArgs b = bb_base(c);

@@ -115,9 +115,14 @@ class Frame:
         base = (a.data_ptr() + 63) & ~63
         return base, a.numel() - (base - a.data_ptr())
 
+    def invalidate_occ(self):
+        """To be called by whoever rewrites frame.occ in place (the decode paths): drops the cached bf16 copy, so that a later bf16
+        forward / training step converts the NEW occupancy instead of mixing old inputs with new targets."""
+        self._occ_bf16 = None
+
     def occ_bf16(self):
         """The frame's occupancy as bf16 [1 + rows][8] with the zero row in front, converted once (linr_occ_to_bf16): it does not
-        change over the epochs of an overfit.  Returns the address of the ZERO row."""
+        change over the epochs of an overfit (writers of frame.occ call invalidate_occ()).  Returns the address of the ZERO row."""
         if getattr(self, '_occ_bf16', None) is None:
             t = torch.empty((self.rows + 1, 8), dtype=torch.int16, device=self.device)
             check(_lib.lib().linr_occ_to_bf16(self.occ.data_ptr(), self.rows, t.data_ptr(), _stream()), 'linr_occ_to_bf16')
@@ -168,6 +173,7 @@ def net_decode_stages(frame, flat_params, streams_per_scale, probs, p_pinned, s_
         base = (arena.data_ptr() + 63) & ~63
         nbytes = arena.numel() - (base - arena.data_ptr())
         codes, lo, hi = qcodes.data_ptr(), float(qrange[0]), float(qrange[1])
+    frame.invalidate_occ()                         # the call rewrites frame.occ column by column
     check(_lib.lib().linr_net_decode_stages(frame.cref(), None if flat_params is None else flat_params.data_ptr(), codes, lo, hi,
                                             base, nbytes, ptrs, lens, probs.data_ptr(), p_pinned.data_ptr(), s_pinned.data_ptr(),
                                             s_dev.data_ptr(), _stream()), 'linr_net_decode_stages')

@@ -49,16 +49,39 @@ def ideal_speedup(groups, world):
     return total / float(len(groups[0]) + phase_b)
 
 
-def wait_for_file(path, timeout_s=24 * 3600.0, poll_s=0.02, alive=None):
+def wait_for_file(path, timeout_s=24 * 3600.0, poll_s=0.02, alive=None, writer_pid_file=None, grace_s=2.0):
     """Host-side poll for the GOP-0 checkpoint.  `alive`: optional callable returning False when rank 0 is known to have
-    failed (its error marker exists) - the wait then raises instead of hanging."""
+    failed (its error marker exists) - the wait then raises instead of hanging.  `writer_pid_file`: rank 0's rank0_pid file
+    (mark_alive): a rank 0 killed by a signal during GOP 0 (GPU-fault abort, out-of-memory kill) leaves no error marker, so
+    when the process it names is gone - and the checkpoint still absent after `grace_s` (the atomic rename may just have
+    happened) - the wait raises instead of polling for the whole timeout."""
     t0 = time.time()
+    gone_at = None
     while not os.path.exists(path):
         if alive is not None and not alive():
             raise RuntimeError('rank 0 failed before writing %s' % path)
-        if time.time() - t0 > timeout_s:
+        now = time.time()
+        if writer_pid_file is not None:
+            pid = _read_pid(writer_pid_file)
+            if pid is None or _pid_alive(pid):
+                gone_at = None                           # not started yet (no pid file) or still working
+            else:
+                if gone_at is None:
+                    gone_at = now
+                if now - gone_at > grace_s and not os.path.exists(path):
+                    raise RuntimeError('rank 0 (process %d) is gone without writing %s or a failure marker: killed by a signal?'
+                                       % (pid, path))
+        if now - t0 > timeout_s:
             raise TimeoutError('checkpoint %s did not appear' % path)
         time.sleep(poll_s)
+
+
+def _read_pid(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return None
 
 
 def _claim(claim_dir, g, rank):
@@ -161,7 +184,7 @@ def run_sequence(groups, work_dir, first_fn, other_fn, rank=0, world=1, dist=Non
             first_claim = next((g for g in order if _claim(claim_dir, g, rank)), None)
         if first_claim is not None and prepare_fn is not None and first_claim not in prepared:
             prepared[first_claim] = prepare_fn(groups[first_claim])
-        wait_for_file(ck_path, alive=lambda: not os.path.exists(err_path))
+        wait_for_file(ck_path, alive=lambda: not os.path.exists(err_path), writer_pid_file=os.path.join(work_dir, 'rank0_pid'))
     ckpt = None
 
     def load():
@@ -216,10 +239,8 @@ def wait_all_done(work_dir, world, poll_s=0.05, timeout_s=12 * 3600.0, grace_s=2
             return
         now = time.time()
         for r in missing:
-            try:
-                with open(os.path.join(work_dir, 'rank%d_pid' % r)) as f:
-                    pid = int(f.read().strip())
-            except (OSError, ValueError):
+            pid = _read_pid(os.path.join(work_dir, 'rank%d_pid' % r))
+            if pid is None:
                 continue                                 # not started yet (or an external launcher without pid files)
             if _pid_alive(pid):
                 gone_since.pop(r, None)

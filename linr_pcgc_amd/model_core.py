@@ -351,6 +351,7 @@ class LINR_PCGC_Model(nn.Module):
         stage: one D2H of the probabilities into pinned memory, linr_ac_decode_binary per scale straight on those
         buffers, one H2D of the decoded byte column (no torch CPU ops: they fan out over every host core)."""
         frame.occ.zero_()
+        frame.invalidate_occ()
         rows = frame.rows
         probs = torch.empty((8, rows), dtype=torch.float32, device=frame.device)
         s_dev = torch.empty(max(rows, 1), dtype=torch.uint8, device=frame.device)

@@ -74,6 +74,9 @@ def sequence_params(config, t):
 
 def sequence_frame_device(config, t, device='cuda'):
     """sequence_frame(config, t) enumerated on `device` (identical points, int32 tensor)."""
+    cfg = CONFIGS[config] if isinstance(config, str) else config
+    if cfg.get('figure'):
+        return rough_figure_device(cfg['bitdepth'], t, device)
     b, r, c, th = sequence_params(config, t)
     return sphere_shell_device(b, r, c, th, device)
 
@@ -82,8 +85,128 @@ def sequence_frame(config, t):
     """Frame t of the synthetic sequence: centre += (floor(3 sin(2 pi t/30)), 0, floor(2 cos(2 pi t/45))),
     radius += floor(4 sin(2 pi t/20)) - integer, seed-free motion."""
     cfg = CONFIGS[config] if isinstance(config, str) else config
+    if cfg.get('figure'):
+        return rough_figure(cfg['bitdepth'], t)
     size = 1 << cfg['bitdepth']
     cx = size // 2 + int(math.floor(3 * math.sin(2 * math.pi * t / 30)))
     cz = size // 2 + int(math.floor(2 * math.cos(2 * math.pi * t / 45)))
     r = cfg['radius'] + int(math.floor(4 * math.sin(2 * math.pi * t / 20)))
     return sphere_shell(cfg['bitdepth'], r, (cx, size // 2, cz), cfg['thickness'])
+
+
+# ---- a non-spherical stress workload: 'loot10_rough' ------------------------------------------------------------------------------
+# Every stand-in above is a sphere shell - the smoothest surface there is - while the reference's data are scanned human figures
+# (datautils/custom_dataset.py:259-355 on 8iVFB PLYs, loot/info.log:3-26).  The rough figure is a union of generalised cylinders along
+# y - torso, head, two legs, two thin slanted arms and a thin sheet - each given by per-y TABLES of its elliptical cross-section
+# (centre cx, cz and semi-axes ax, az in 1/8 voxel), inflated by a low-frequency displacement of +-8 voxels
+#   d(x, y, z) = (SX[x] * SY[y] * SZ[z]) >> 12   (tables in [-64, 64], periods 97 / 131 / 113 voxels),
+# voxelised as the boundary of the solid (an inside voxel with a 6-neighbour outside).  The tables are built on the host in float64
+# and rounded to integers; everything per voxel is int64 arithmetic, so the numpy and the GPU enumeration give identical points.
+# Motion is integer and seed-free like the sphere sequences: the figure translates, the arms swing, the wrinkles drift.
+# Never a default, never the headline: bench.py's `rough` leg and tests/test_gpu_configs.py use it beside the spheres.
+def _figure_tables(bitdepth, t):
+    size = 1 << bitdepth
+    s = size / 1024.0
+    y = np.arange(size, dtype=np.float64)
+    tx = int(math.floor(3 * math.sin(2 * math.pi * t / 30)))
+    tz = int(math.floor(2 * math.cos(2 * math.pi * t / 45)))
+    swing = math.sin(2 * math.pi * t / 25)
+
+    def ellipsoid(cx, cy, cz, rx, ry, rz):
+        u = (y - cy * s) / (ry * s)
+        prof = np.sqrt(np.clip(1.0 - u * u, 0.0, None))
+        return np.full(size, cx * s), np.full(size, cz * s), rx * s * prof, rz * s * prof
+
+    def limb(x0, y0, z0, x1, y1, z1, r0, r1, flat=1.0):
+        """tapered, slanted cylinder from (x0, y0, z0) to (x1, y1, z1) (y0 > y1) with rounded ends; flat < 1 squeezes it in z"""
+        u = np.clip((y0 * s - y) / ((y0 - y1) * s), 0.0, 1.0)
+        cx, cz = (x0 + (x1 - x0) * u) * s, (z0 + (z1 - z0) * u) * s
+        r = (r0 + (r1 - r0) * u) * s
+        cap_hi = np.clip((y - y0 * s) / (r0 * s), 0.0, 1.0)
+        cap_lo = np.clip((y1 * s - y) / (r1 * s), 0.0, 1.0)
+        prof = np.sqrt(np.clip(1.0 - cap_hi ** 2, 0.0, None)) * np.sqrt(np.clip(1.0 - cap_lo ** 2, 0.0, None))
+        return cx, cz, r * prof, r * prof * flat
+
+    parts = [ellipsoid(512, 560, 512, 118, 200, 78),                                  # torso
+             ellipsoid(512, 836, 522, 64, 80, 68),                                    # head
+             limb(468, 420, 510, 446, 70, 524, 52, 30),                               # legs
+             limb(556, 420, 510, 584, 70, 496, 52, 30),
+             limb(404, 700, 512, 318 - 10 * swing, 410, 548 + 40 * swing, 26, 15),    # thin, slanted, swinging arms
+             limb(620, 700, 512, 712 + 10 * swing, 430, 476 - 40 * swing, 26, 15),
+             limb(512, 760, 584, 512, 330, 640 + 12 * swing, 150, 120, flat=0.03)]    # a thin sheet behind the torso
+    tabs = []
+    for cx, cz, ax, az in parts:
+        ax8, az8 = np.rint(8 * ax).astype(np.int64), np.rint(8 * az).astype(np.int64)
+        ax8[az8 <= 0] = 0
+        tabs.append((np.rint(cx).astype(np.int64) + tx, np.rint(cz).astype(np.int64) + tz, ax8, az8))
+    i = np.arange(size, dtype=np.float64)
+    sx = np.rint(64 * np.sin(2 * math.pi * (i + 2 * t) / (97 * s))).astype(np.int64)
+    sy = np.rint(64 * np.sin(2 * math.pi * i / (131 * s) + 0.7)).astype(np.int64)
+    sz = np.rint(64 * np.cos(2 * math.pi * (i - t) / (113 * s))).astype(np.int64)
+    live = np.zeros(size, dtype=bool)
+    xlo, xhi, zlo, zhi = size, 0, size, 0
+    for cx, cz, ax8, az8 in tabs:
+        on = ax8 > 0
+        live |= on
+        if on.any():
+            xlo = min(xlo, int((cx[on] - (ax8[on] + 71) // 8 - 2).min()))
+            xhi = max(xhi, int((cx[on] + (ax8[on] + 71) // 8 + 3).max()))
+            zlo = min(zlo, int((cz[on] - (az8[on] + 71) // 8 - 2).min()))
+            zhi = max(zhi, int((cz[on] + (az8[on] + 71) // 8 + 3).max()))
+    ys = np.nonzero(live)[0]
+    box = (max(xlo, 1), min(xhi, size - 1), max(int(ys.min()) - 1, 1), min(int(ys.max()) + 2, size - 1), max(zlo, 1), min(zhi, size - 1))
+    return tabs, (sx, sy, sz), box
+
+
+def _figure_points(bitdepth, t, xp, to_dev, slab):
+    """Shared enumeration: xp = numpy or torch; to_dev moves a host int64 array to where xp computes."""
+    tabs, (sx, sy, sz), (x0, x1, y0, y1, z0, z1) = _figure_tables(bitdepth, t)
+    ya, za = slice(y0 - 1, y1 + 1), slice(z0 - 1, z1 + 1)                       # one voxel of halo: the box never touches the cube's faces
+    sy_d, sz_d = to_dev(sy[ya])[None, :, None], to_dev(sz[za])[None, None, :]
+    zc = to_dev(np.arange(z0 - 1, z1 + 1, dtype=np.int64))[None, None, :]
+    part_d = [(to_dev(cx[ya])[None, :, None], to_dev(cz[ya])[None, :, None],
+               to_dev(ax8[ya])[None, :, None], to_dev(az8[ya])[None, :, None]) for cx, cz, ax8, az8 in tabs]
+
+    def inside(xa, xb):
+        xc = to_dev(np.arange(xa, xb, dtype=np.int64))[:, None, None]
+        d = (to_dev(sx[xa:xb])[:, None, None] * sy_d * sz_d) >> 12             # 1/8 voxel, [-64, 64]
+        acc = None
+        for cx, cz, ax8, az8 in part_d:
+            AX, AZ = ax8 + d, az8 + d
+            DX, DZ = 8 * (xc - cx), 8 * (zc - cz)
+            m = (ax8 > 0) & (AX > 0) & (AZ > 0) & ((DX * AZ) ** 2 + (DZ * AX) ** 2 < (AX * AZ) ** 2)
+            acc = m if acc is None else (acc | m)
+        return acc
+
+    chunks = []
+    for xa in range(x0, x1, slab):
+        xb = min(xa + slab, x1)
+        v = inside(xa - 1, xb + 1)                                              # [xb - xa + 2, ny + 2, nz + 2]
+        c = v[1:-1, 1:-1, 1:-1]
+        full = v[:-2, 1:-1, 1:-1] & v[2:, 1:-1, 1:-1] & v[1:-1, :-2, 1:-1] & v[1:-1, 2:, 1:-1] & v[1:-1, 1:-1, :-2] & v[1:-1, 1:-1, 2:]
+        idx = (c & ~full).nonzero()                                             # row-major = x, then y, then z: the x-major order
+        if xp is np:
+            if len(idx[0]):
+                chunks.append(np.stack([idx[0] + xa, idx[1] + y0, idx[2] + z0], axis=1).astype(np.int32))
+        elif idx.shape[0]:
+            import torch
+            off = torch.tensor([xa, y0, z0], dtype=torch.int64, device=idx.device)
+            chunks.append((idx + off).to(torch.int32))
+    return chunks
+
+
+def rough_figure(bitdepth=10, t=0, slab=16):
+    """Frame t of the rough figure at `bitdepth` (numpy; ~10 s at 10 bit - tests use 7 or 8 bit)."""
+    chunks = _figure_points(bitdepth, t, np, lambda a: a, slab)
+    return np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 3), np.int32)
+
+
+def rough_figure_device(bitdepth=10, t=0, device='cuda', slab=16):
+    """rough_figure(bitdepth, t) enumerated on `device` (identical points, int32 tensor, x-major sorted)."""
+    import torch
+    chunks = _figure_points(bitdepth, t, torch, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device), slab)
+    return torch.cat(chunks, dim=0) if chunks else torch.zeros((0, 3), dtype=torch.int32, device=device)
+
+
+CONFIGS['loot10_rough'] = {'bitdepth': 10, 'figure': True}      # ~0.8 M points; the stress workload beside loot10
+CONFIGS['rough8'] = {'bitdepth': 8, 'figure': True}             # its small sibling for the oracle-parity tests

@@ -246,6 +246,46 @@ def test_wait_all_done_notices_a_rank_killed_by_a_signal(tmp_path):
     assert gp.wait_all_done.__defaults__[1] is not None           # the default wait is bounded
 
 
+def _doomed_rank0(work, started):
+    """Rank 0 of a two-rank job (no torch.distributed: a fresh directory) that is killed by a signal in the middle of GOP 0."""
+    import time
+
+    def first(group):
+        started.set()
+        time.sleep(60)
+        return {'result': 0}
+
+    gp.run_sequence(gp.split_gops(8, 4), work, first, lambda g, ck: 1, rank=0, world=2)
+
+
+def test_phase_a_wait_notices_rank0_killed_by_a_signal(tmp_path):
+    """rank 0 SIGKILLed during GOP 0 (the longest single phase) writes neither the checkpoint nor rank0_failed; ranks
+    >= 1, polling for the checkpoint, probe the process named in rank0_pid and raise instead of waiting out the 24 h timeout."""
+    import signal
+    import time
+    work = str(tmp_path / 'work')
+    ctx = mp.get_context('spawn')
+    started = ctx.Event()
+    p = ctx.Process(target=_doomed_rank0, args=(work, started))
+    p.start()
+    assert started.wait(60)
+    ck = os.path.join(work, gp.gop_name([0, 1, 2, 3]), 'model.pth')
+    pidf = os.path.join(work, 'rank0_pid')
+    assert os.path.exists(pidf)
+    with pytest.raises(TimeoutError):                              # alive and training: only the bound ends the wait
+        gp.wait_for_file(ck, timeout_s=0.3, writer_pid_file=pidf, grace_s=0.1)
+    os.kill(p.pid, signal.SIGKILL)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='rank 0 .* is gone'):
+        gp.run_sequence(gp.split_gops(8, 4), work, None, lambda g, ck: 1, rank=1, world=2)       # the real phase-A wait of rank 1
+    assert time.time() - t0 < 20
+    p.join()
+    # a checkpoint that appeared while rank 0 exited normally is NOT an error: the file wins over the liveness probe
+    os.makedirs(os.path.dirname(ck), exist_ok=True)
+    open(ck, 'w').close()
+    gp.wait_for_file(ck, timeout_s=1, writer_pid_file=pidf, grace_s=0.0)
+
+
 def test_done_marker_is_the_callers_when_asked(tmp_path):
     """run.py writes rank<N>_done itself, after its device synchronisation: run_sequence(done_marker=False) leaves only the pid file."""
     work = str(tmp_path / 'work')

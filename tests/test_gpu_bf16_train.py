@@ -111,6 +111,50 @@ def test_conv88_backward_fused_bf16_op(env, which, nblocks):
     assert torch.equal(slab[:r], slab2[:r]) and torch.equal(gin[1:], gin2[1:])
 
 
+def test_weight_gradients_of_the_16x16x32_path_are_exact_sums_up_to_fp32_summation_order(env):
+    """the kernel / bias gradients of the fused bf16 backward moved to v_mfma_f32_16x16x32_bf16 in round 5 (K = 32
+    rows per instruction: another fp32 summation order than the 4x4x4 form before it).  On bf16-representable inputs every product
+    in[i][ci] * gout[j][co] is EXACT in fp32, so the only error a correct kernel can make is the rounding of its fp32 partial sums:
+    anchored in float64, |error| <= 1e-5 of the tensor's own largest entry on a 39 k-row kernel map (sphere8's finest scale: ~150
+    tiles per wave chain, 256 slab rows) - a kernel that dropped, duplicated or mis-paired rows would be off by 1e-3 or more."""
+    from linr_pcgc_amd import ops, synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    dev, L = env['dev'], env['L']
+    fr = prepare_frame(synthetic.sphere_shell(8, 100), None, 64, device=dev)
+    coord = fr['all_input_info'][0]['coord']
+    n = int(coord.shape[0])
+    nbr = ops.kmap_build(coord)
+    lo, mask = ops.kmap_compress(nbr)
+    gen = torch.Generator().manual_seed(616)
+    x_h = obf.rb(torch.randn(n, 8, generator=gen))
+    go_h = obf.rb(torch.randn(n, 8, generator=gen) * (torch.rand(n, 1, generator=gen) < 0.7))      # some all-zero gradient rows
+    w = (torch.randn(27, 8, 8, generator=gen) * 0.2).to(dev).contiguous()
+    go = torch.zeros((n + 1, 8), dtype=torch.int16, device=dev)
+    go[1:] = _bf16_bits(go_h).to(dev)
+    x = torch.zeros((n + 1, 8), dtype=torch.int16, device=dev)
+    x[1:] = _bf16_bits(x_h).to(dev)
+    gin = torch.zeros((n + 1, 8), dtype=torch.int16, device=dev)
+    for nblocks in (256, 32):
+        slab = torch.full((nblocks, 1736), float('nan'), device=dev)
+        rows = ctypes.c_int32(0)
+        env['lib'].check(L.linr_spconv_bwd_fused_bf16(go[1:].data_ptr(), x[1:].data_ptr(), lo.data_ptr(), mask.data_ptr(), nbr.shape[1], n,
+                                                      w.data_ptr(), gin[1:].data_ptr(), slab.data_ptr(), nblocks, ctypes.byref(rows), _stream()),
+                         'linr_spconv_bwd_fused_bf16')
+        torch.cuda.synchronize()
+        tot = slab[:rows.value].double().sum(dim=0)
+        xd, gd = x_h.to(dev).double(), go_h.to(dev).double()
+        ref_w = torch.zeros(27, 8, 8, dtype=torch.float64, device=dev)
+        for k in range(27):                              # out[j] = sum_k in[nbr(j, k)] W[k]  =>  gW[k] = sum_j in[nbr(j, k)]^T gout[j]
+            idx = nbr[k, :n].long()
+            ok = idx >= 0
+            ref_w[k] = xd[idx[ok]].t() @ gd[ok]
+        ref_b = gd.sum(dim=0)
+        for got, ref, what in ((tot[:1728].view(27, 8, 8), ref_w, 'kernel gradient'), (tot[1728:], ref_b, 'bias gradient')):
+            gmax = float(ref.abs().max())
+            err = float((got - ref).abs().max())
+            assert err <= 1e-5 * gmax, '%s with %d slab rows: err %.3e, own max %.3e (ratio %.2e)' % (what, nblocks, err, gmax, err / gmax)
+
+
 def _moved_model(pkg, shell, steps):
     """a model `steps` fp32 Adam steps away from its initialisation (GPU) and its state dict (CPU)"""
     from linr_pcgc_amd.model_core import FlatAdam, train_step
@@ -340,29 +384,61 @@ def _overfit_pair(config, gop_frames, epochs, seeds):
     return out
 
 
-def _assert_same_rate(r):
-    """SURVEY.md section 8c's bf16 tolerance: bits/point within +1 % of fp32.  One overfit is deterministic but chaotic in the rounding
-    (three seeds of ONE executor spread by +-3-6 %), so the comparison is between the MEANS over the seeds, and the bound carries the
-    seeds' own noise: mean_bf16 <= 1.01 * mean_f32 + 2 standard errors of the difference of the two means."""
+def _assert_same_rate(r, what):
+    """What the FULL-RECIPE tests assert: the reference's recipe (lr 0.01, 10 epochs, best-epoch checkpoint,
+    8-bit weight codec) is chaotic in the rounding - one executor's seeds spread by +-3-6 % and an occasional run lands 12-25 % high
+    when the 8-bit weight quantiser meets an outlier weight (profiles/r06_bf16_overfit_seeds.txt: 8 seeds of each executor) - so no
+    3-seed statistic can carry SURVEY section 8c's +1 %.  That bound is asserted where it can be, per epoch and per seed, by
+    test_bf16_tracks_fp32_outside_the_chaotic_regime below.  Here: a SANITY CAP - the MEDIAN bits/point over the seeds (robust
+    against one outlier run of either executor) of bf16 training within +5 % of fp32 training; the measured ratios are printed."""
+    med = lambda v: sorted(v)[len(v) // 2]
     n = len(r['f32'])
     m32, mbf = sum(r['f32']) / n, sum(r['bf16']) / n
-    var = lambda v, m: sum((x - m) ** 2 for x in v) / (n - 1)
-    se = ((var(r['f32'], m32) + var(r['bf16'], mbf)) / n) ** 0.5
-    assert mbf <= 1.01 * m32 + 2.0 * se, (r, m32, mbf, se)
-    assert mbf <= 1.05 * m32, (r, m32, mbf)                                  # and never far off, whatever the spread
+    print('%s: bits/point fp32 %s  bf16 %s  ratio of means %.4f  ratio of medians %.4f'
+          % (what, ['%.4f' % x for x in r['f32']], ['%.4f' % x for x in r['bf16']], mbf / m32, med(r['bf16']) / med(r['f32'])))
+    assert med(r['bf16']) <= 1.05 * med(r['f32']), (r, med(r['f32']), med(r['bf16']))
 
 
 def test_bf16_overfit_of_loot10_reaches_the_fp32_rate():
-    """BASELINE config[1]'s GOP (32 frames of the loot stand-in, 10 epochs) trained with the bf16 executor: mean bits/point over
-    three initialisation seeds against the fp32 executor's (_assert_same_rate), every run lossless through the bf16 / uint8-weight
-    codec."""
-    _assert_same_rate(_overfit_pair('loot10', 32, 10, (8807, 1, 2)))
+    """BASELINE config[1]'s GOP (32 frames of the loot stand-in, 10 epochs, the reference's recipe) trained with the bf16 executor over
+    five initialisation seeds against the fp32 executor's: _assert_same_rate's +5 % cap on the medians (NOT the +1 % of SURVEY 8c:
+    see there), every run lossless through the bf16 / uint8-weight codec."""
+    _assert_same_rate(_overfit_pair('loot10', 32, 10, (8807, 1, 2, 3, 4)), 'loot10 GOP 32')
 
 
 def test_bf16_overfit_of_owlii11_reaches_the_fp32_rate():
     """BASELINE config[4]'s geometry (Owlii stand-in: 11-bit, ~2.9 M points, 8 scales, ~1.24 M rows per frame), a 16-frame GOP, 10
-    epochs: the same criterion (the 64-frame GOP of the config: profiles/r05_bf16_overfit_owlii11.txt, bench.py's config4_gop64)."""
-    _assert_same_rate(_overfit_pair('owlii11', 16, 10, (8807, 1, 2)))
+    epochs, three seeds: the same +5 % cap on the medians (the 64-frame GOP of the config: bench.py's config4_gop64, lossless in both
+    precisions from one seed)."""
+    _assert_same_rate(_overfit_pair('owlii11', 16, 10, (8807, 1, 2)), 'owlii11 GOP 16')
+
+
+@pytest.mark.parametrize('config,gop_frames', [('loot10', 32), ('owlii11', 16)])
+def test_bf16_tracks_fp32_outside_the_chaotic_regime(config, gop_frames):
+    """VERDICT r5 item 1(i) - the test that carries SURVEY section 8c's bf16 tolerance (+-1 %).  Same initialisations (seeds 8807, 1, 2),
+    CONSTANT learning rate 1e-3 (a tenth of the recipe's: small steps keep the two trajectories together, so a biased kernel shows
+    and rounding chaos does not), 3 epochs over the GOP, both executors: EVERY epoch's mean loss (bits per point of the training
+    forward, main.py:305-321) of EVERY seed within +-1 % of the fp32 executor's - no averaging over seeds, no standard-error term."""
+    from linr_pcgc_amd import overfit, synthetic
+    from linr_pcgc_amd.model_core import FlatAdam
+    clouds = [synthetic.sequence_frame_device(config, t, 'cuda') for t in range(gop_frames)]
+    gop = overfit.Gop(None, clouds, None, 64, 'cuda')
+    worst = 0.0
+    for seed in (8807, 1, 2):
+        losses = {}
+        for prec in ('f32', 'bf16'):
+            model = overfit.gen_model(gop.scale_num, 'cuda', seed=seed)
+            model.train_precision = prec
+            opt = FlatAdam(model, lr=1e-3, gamma=1.0)
+            losses[prec] = overfit.overfit_gop(model, opt, gop, 3, min_lr=0.0, keep='last')
+        ratios = [b / f for b, f in zip(losses['bf16'], losses['f32'])]
+        print('%s seed %d: fp32 %s  bf16 %s  ratios %s' % (config, seed, ['%.4f' % x for x in losses['f32']],
+                                                           ['%.4f' % x for x in losses['bf16']], ['%.4f' % x for x in ratios]))
+        assert losses['f32'][-1] < losses['f32'][0] and losses['bf16'][-1] < losses['bf16'][0], 'both executors must be learning'
+        for e, q in enumerate(ratios):
+            worst = max(worst, abs(q - 1.0))
+            assert abs(q - 1.0) <= 0.01, 'seed %d epoch %d: bf16 / fp32 = %.4f (%s)' % (seed, e, q, losses)
+    print('%s: worst |bf16 / fp32 - 1| over 3 seeds x 3 epochs = %.4f' % (config, worst))
 
 
 def test_checkpoints_cross_the_two_training_executors(pkg, shell):
