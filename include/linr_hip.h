@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LINR_ABI_VERSION 10
+#define LINR_ABI_VERSION 11
 #define LINR_API __attribute__((visibility("default")))
 
 #define LINR_EINVAL   (-1)   /* bad argument (null pointer, negative size, unsupported channel count) */
@@ -95,6 +95,21 @@ LINR_API int linr_coords_minmax(const int32_t* coords, int64_t n, int32_t* out, 
  * ws: linr_sort_unique_workspace_bytes(m) bytes, 256-byte aligned. */
 LINR_API int linr_octree_level(const int32_t* child, int64_t m, int32_t coord_bits, int32_t* parent, float* occ, int64_t* count, void* ws,
                                size_t ws_bytes, void* stream);
+/* ALL octree levels of a frame as one call, without a sort (csrc/octree.hip; the loop of datautils/custom_dataset.py:289-344 over
+ * octree_level.forward, models/module_utils.py:86-110): the parents of a sorted unique child list are the set bits of a bitmap over
+ * their compact x-major keys, read in word order.  child: int32 [m,3] sorted x-major and unique, coordinates in [0, 2^coord_bits),
+ * 2 <= coord_bits <= 11 (12-bit clouds and deeper: linr_octree_level per level); m_dev: NULL, or a DEVICE int64 holding the live row
+ * count (<= m: the count linr_coords_sort_unique left on the device - no host read between the two calls).  Level l = 0 ..
+ * linr_octree_levels_count(coord_bits, max_levels) - 1 has child coordinates of coord_bits - l bits; its parents (int32 rows) and their
+ * child occupancy (float32 [.,8], column 4 dx + 2 dy + dz) are written BACK TO BACK into parents / occ, level after level, each
+ * buffer with room for linr_octree_levels_rows(m, coord_bits, max_levels) rows; counts: DEVICE int64 [levels] = rows of every level
+ * (the caller reads them once, behind the call, and slices).  Bit-identical to linr_octree_level applied level by level.
+ * ws: linr_octree_levels_workspace_bytes(m, coord_bits, max_levels) bytes, 256-byte aligned. */
+LINR_API int32_t linr_octree_levels_count(int32_t coord_bits, int32_t max_levels);
+LINR_API int64_t linr_octree_levels_rows(int64_t m, int32_t coord_bits, int32_t max_levels);
+LINR_API size_t linr_octree_levels_workspace_bytes(int64_t m, int32_t coord_bits, int32_t max_levels);
+LINR_API int linr_octree_levels(const int32_t* child, int64_t m, const int64_t* m_dev, int32_t coord_bits, int32_t max_levels,
+                                int32_t* parents, float* occ, int64_t* counts, void* ws, size_t ws_bytes, void* stream);
 /* sets *bad (device int32, pre-zeroed by the caller) to non-zero if coords are not sorted/unique/in range */
 LINR_API int linr_kmap_validate(const int32_t* coords, int64_t n, int32_t* bad, void* stream);
 

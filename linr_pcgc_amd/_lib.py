@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('LINR_HIP_LIB') or os.path.join(_HERE, 'liblinr_hip.so
 
 LINR_RELU, LINR_ACCUM, LINR_RELU_MASK, LINR_NO_BIAS, LINR_PAD_ROW = 1, 2, 4, 8, 16
 LINR_FRAME_OCC_PADDED = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_i32, c_i64, c_u32, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
@@ -69,6 +69,10 @@ _PROTOS = {
     'linr_coords_sort_unique': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'linr_coords_minmax': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'linr_octree_level': (ctypes.c_int, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
+    'linr_octree_levels_count': (c_i32, [c_i32, c_i32]),
+    'linr_octree_levels_rows': (c_i64, [c_i64, c_i32, c_i32]),
+    'linr_octree_levels_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i32, c_i32]),
+    'linr_octree_levels': (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_size_t, c_ptr]),
     'linr_kmap_offset_feat': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'linr_kmap_compress': (ctypes.c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'linr_spconv_fwd': (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i32,

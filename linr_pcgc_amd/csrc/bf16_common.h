@@ -243,14 +243,35 @@ __global__ __launch_bounds__(LINR_BLOCK) void bconv_k(BArgs a) {
         // (every store of this kernel comes BEHIND the MLP: with a store to memory the compiler cannot tell apart from the parameters
         // in front of them, the 265 uniform weight loads below become per-lane vector loads - 54 extra 64-lane loads per tile, the cost
         // of two convolution passes - instead of scalar loads)
+        // hidden layer on the matrix cores (round 6; before: 192 v_fma per lane with scalar weights, as long as the convolution itself):
+        // v_mfma_f32_4x4x1 with the weight 4-vector broadcast (CBSZ = 4), K = 1 - every instruction IS one fmaf per output, in the
+        // order of the loop it replaces (bias first, inputs ascending), so the probabilities keep their bits (stream format unchanged).
+        //   wA: combo = 6 i + hq -> W1[4 hq + j][i] (i < 8), combos 48..53 -> b1[4 (combo - 48) + j]   (the fp32 executor's head images)
+        float wA[4];
+        {
+            const int blk = lane >> 2, j4 = lane & 3;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int cb = 16 * v + blk;
+                wA[v] = cb < 48 ? w1[(4 * (cb % 6) + j4) * 8 + cb / 6] : (cb < 54 ? b1[4 * (cb - 48) + j4] : 0.0f);
+            }
+        }
+        f32x4 hp[6];
+        sfor<6>([&](auto hc) {
+            constexpr int hq = decltype(hc)::value;
+            hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, hq, 0);       // combo 48 + hq
+        });
+        sfor<8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            sfor<6>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                constexpr int cb = 6 * i + hq;
+                hp[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], c[i], hp[hq], 4, cb % 16, 0);
+            });
+        });
         float z = a.pf[a.h_b2[gi]];
 #pragma unroll
-        for (int j = 0; j < 24; ++j) {
-            float hj = b1[j];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) hj = fmaf(c[i], w1[j * 8 + i], hj);
-            z = fmaf(fmaxf(hj, 0.0f), w2[j], z);
-        }
+        for (int j = 0; j < 24; ++j) z = fmaf(fmaxf(hp[j >> 2][j & 3], 0.0f), w2[j], z);
         const float p = 1.0f / (1.0f + expf(-z));
         float t = 0.0f;
         if (a.partial != nullptr && live) t = a.target[a.t_col[gi] + row * a.target_ld];

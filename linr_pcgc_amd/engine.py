@@ -53,18 +53,32 @@ class Frame:
         self.n_scales = len(scales)
         R = self.rows
         self.nbr_ld = (R + 63) // 64 * 64          # padded leading dimension: 16-byte aligned index rows
-        self.nbr = torch.full((27, self.nbr_ld), -1, dtype=torch.int32, device=device)     # padding columns: no neighbour
+        # Buffers are allocated uninitialised and only what the kernels below do not write is filled (the padding columns of the maps,
+        # the zero row in front of the occupancy): a 337 k-row frame's neighbour table alone is 36 MB.
+        self.nbr = torch.empty((27, self.nbr_ld), dtype=torch.int32, device=device)
+        if self.nbr_ld > R:
+            self.nbr[:, R:] = -1                                                           # padding columns: no neighbour
         self.offset_feat = torch.empty((R, 7), dtype=torch.float32, device=device)
         # occupancy with a zero row in front: the executor gathers it in place (LINR_FRAME_OCC_PADDED)
-        self._occ_buf = torch.zeros((R + 1, 8), dtype=torch.float32, device=device)
+        self._occ_buf = torch.empty((R + 1, 8), dtype=torch.float32, device=device)
+        self._occ_buf[0].zero_()
         self.occ = self._occ_buf[1:]
+        bad = torch.zeros(1, dtype=torch.int32, device=device) if validate else None       # ONE flag for all scales, read once below
+        have_occ = [('occ' in s and s['occ'] is not None) or ('occ_lst' in s and s['occ_lst'] is not None) for s in scales]
+        if not all(have_occ):
+            self.occ.zero_()                                                               # decoder: the occupancy is filled stage by stage
+        need_feat = []
+        L = _lib.lib()
         for i, s in enumerate(scales):
             r0, r1 = int(self.row_off[i]), int(self.row_off[i + 1])
+            if r1 == r0:
+                continue
             coord = torch.as_tensor(s['coord']).to(device=device, dtype=torch.int32).contiguous()
-            ops.kmap_build_into(coord, self.nbr, r0, validate)
+            if validate:
+                check(L.linr_kmap_validate(coord.data_ptr(), r1 - r0, bad.data_ptr(), _stream()), 'linr_kmap_validate')
+            ops.kmap_build_into(coord, self.nbr, r0, False)
             if s.get('offset_tensor') is None:       # decoder fast path: the 7-neighbour occupancy is part of the kernel map
-                check(_lib.lib().linr_kmap_offset_feat(self.nbr.data_ptr(), self.nbr_ld, r0, r1 - r0,
-                                                       self.offset_feat[r0:r1].data_ptr(), _stream()), 'linr_kmap_offset_feat')
+                need_feat.append((r0, r1))
             else:
                 self.offset_feat[r0:r1] = torch.as_tensor(s['offset_tensor']).to(device=device, dtype=torch.float32)
             if 'occ' in s and s['occ'] is not None:
@@ -72,9 +86,22 @@ class Frame:
             elif 'occ_lst' in s and s['occ_lst'] is not None:
                 self.occ[r0:r1] = torch.cat([torch.as_tensor(o).reshape(-1, 1) for o in s['occ_lst']], dim=1).to(
                     device=device, dtype=torch.float32)
+        # the kernel map holds GLOBAL row ids, so adjacent row ranges share one launch (all scales of a staged frame: one)
+        merged = []
+        for r0, r1 in need_feat:
+            if merged and merged[-1][1] == r0:
+                merged[-1][1] = r1
+            else:
+                merged.append([r0, r1])
+        for r0, r1 in merged:
+            check(L.linr_kmap_offset_feat(self.nbr.data_ptr(), self.nbr_ld, r0, r1 - r0, self.offset_feat[r0:r1].data_ptr(), _stream()),
+                  'linr_kmap_offset_feat')
         # compressed kernel map (9 column bases + 27-bit mask per row) used by the network executor
-        self.nbr_lo = torch.zeros((9, self.nbr_ld), dtype=torch.int32, device=device)
-        self.nbr_mask = torch.zeros((self.nbr_ld,), dtype=torch.int32, device=device)      # padding columns: empty masks
+        self.nbr_lo = torch.empty((9, self.nbr_ld), dtype=torch.int32, device=device)
+        self.nbr_mask = torch.empty((self.nbr_ld,), dtype=torch.int32, device=device)
+        if self.nbr_ld > R:
+            self.nbr_lo[:, R:] = 0
+            self.nbr_mask[R:] = 0                                                          # padding columns: empty masks
         check(_lib.lib().linr_kmap_compress(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr_lo.data_ptr(),
                                             self.nbr_mask.data_ptr(), self.nbr_ld, _stream()), 'linr_kmap_compress')
         # the kernel map tiled by 8 rows in the gather-lane order of the stand-alone weight-gradient kernels (128 B per row)
@@ -82,6 +109,9 @@ class Frame:
         self.nbr8t = torch.empty(max(4, (nb8t + 3) // 4), dtype=torch.int32, device=device)
         check(_lib.lib().linr_kmap_tile8t(self.nbr.data_ptr(), self.nbr_ld, R, self.nbr8t.data_ptr(), self.nbr8t.numel() * 4,
                                           _stream()), 'linr_kmap_tile8t')
+        if validate and int(bad.item()) != 0:                                              # the frame's one host read
+            raise ValueError('coord must be unique, non-negative (< 2^20) and sorted by the x-major ravel key '
+                             '(models/module_utils.py:246-256)')
         self.arena = None
         if with_arena:
             self.alloc_arena()

@@ -5,6 +5,8 @@ BinaryArithmeticCoding feeds the C++ range coder of csrc/ac.cpp (streams follow 
 The octree helpers restate octree_level / QuickSearchCoord (models/module_utils.py:86-318) with 64-bit ravel keys and
 torch.searchsorted; they are device-agnostic torch code and run once per frame ("next" row N1 of SURVEY.md §8f).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -218,7 +220,32 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
     ori = cur.get_coord()
     info = []
     limit = 100000 if scale_num is None else scale_num
-    for s in range(limit):
+    s0 = 0
+    if dev.type == 'cuda' and not pts.dtype.is_floating_point and 2 <= bits <= 11 and not os.environ.get('LINR_OCTREE_PER_LEVEL'):
+        # every level in one library call and one host read (csrc/octree.hip: no sort, counts chained on the device); the per-level
+        # loop below only continues where this leaves off (it does not: the stop criterion is met inside unless scale_num asks for
+        # levels whose coordinates have no bits left)
+        from . import ops
+        lv = ops.octree_levels(ori, bits, min(limit, 64))
+        if lv is not None:
+            par_all, occ_all, counts = lv
+            off, child = 0, ori
+            for s0, n in enumerate(counts):
+                parent, occ = par_all[off:off + n], occ_all[off:off + n]
+                off += n
+                bits = max(1, bits - 1)
+                low = qscTensor(parent, presorted=True, coord_bits=bits)
+                if with_offsets:
+                    low.set_offset_tensor()
+                info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),
+                             'ground_truth': child, 'scale_idx': s0, 'occ': occ, 'occ_lst': [occ[:, i:i + 1] for i in range(8)]})
+                child = parent
+                if n < min_point_num or s0 == limit - 1:
+                    return {'all_input_info': info, 'point_num': int(ori.shape[0]), 'ori': ori,
+                            'coord_data_min': cmin.to('cpu', torch.int32).tolist(), 'scale_num': len(info)}
+            cur = low
+            s0 = len(counts)
+    for s in range(s0, limit):
         cur.set_oct_level()
         parent, occ = cur.get_oct_level()
         bits = max(1, bits - 1)

@@ -440,6 +440,30 @@ def octree_level(child, coord_bits=20):
     return parent[:n].clone(), occ[:n].clone()          # exact-size copies: the m-row buffers go back to the allocator
 
 
+def octree_levels(child, coord_bits, max_levels, count_dev=None):
+    """All octree levels below a sorted unique child list in ONE library call (linr_octree_levels: bitmap of the parents' compact keys,
+    no sort, counts chained on the device) and ONE host read.  child: int32 [m,3] on the GPU, coordinates in [0, 2^coord_bits),
+    coord_bits <= 11; count_dev: None or the device int64 live row count (<= m).  Returns (parents int32 [total,3], occ float32
+    [total,8], counts list): level l's rows are parents[sum(counts[:l]) : sum(counts[:l + 1])] - exact-size buffers shared by the
+    levels - or None when the library has no such levels (coord_bits out of range)."""
+    _dev(child, torch.int32, 'child')
+    L = _lib.lib()
+    m = child.shape[0]
+    nlev = L.linr_octree_levels_count(int(coord_bits), int(max_levels))
+    if nlev < 1 or m == 0:
+        return None
+    cap = L.linr_octree_levels_rows(m, int(coord_bits), int(max_levels))
+    parents = torch.empty((cap, 3), dtype=torch.int32, device=child.device)
+    occ = torch.empty((cap, 8), dtype=torch.float32, device=child.device)
+    counts = torch.empty(nlev, dtype=torch.int64, device=child.device)
+    ws, base, nbytes = _aligned_ws(L.linr_octree_levels_workspace_bytes(m, int(coord_bits), int(max_levels)), child.device)
+    check(L.linr_octree_levels(child.data_ptr(), m, None if count_dev is None else count_dev.data_ptr(), int(coord_bits), int(max_levels),
+                               parents.data_ptr(), occ.data_ptr(), counts.data_ptr(), base, nbytes, _stream()), 'linr_octree_levels')
+    ch = counts.tolist()                                  # the one host read
+    total = int(sum(ch))
+    return parents[:total].clone(), occ[:total].clone(), ch
+
+
 def octree_occupancy(child, parent):
     """occ float32 [N,8] of the parents (sorted unique floor(child/2)) of a sorted unique child list (int32 [M,3])."""
     _dev(child, torch.int32, 'child')

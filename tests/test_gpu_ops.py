@@ -329,3 +329,71 @@ def test_octree_levels_through_the_library_match_the_oracle(pkg):
     for a, b in zip(fr['all_input_info'], ref['scales']):
         assert np.array_equal(a['coord'].cpu().numpy(), b['coord'])
         assert np.array_equal(a['occ'].cpu().numpy(), b['occ'])
+
+
+def _frames_equal(a, b):
+    assert a['point_num'] == b['point_num'] and a['scale_num'] == b['scale_num'] and a['coord_data_min'] == b['coord_data_min']
+    assert torch.equal(a['ori'], b['ori'])
+    for x, y in zip(a['all_input_info'], b['all_input_info']):
+        assert x['scale_idx'] == y['scale_idx']
+        assert torch.equal(x['coord'], y['coord']) and torch.equal(x['occ'], y['occ']) and torch.equal(x['ground_truth'], y['ground_truth'])
+
+
+@pytest.mark.parametrize('case', ['sphere7', 'rough8', 'random6', 'tiny', 'scale_num_2', 'deep'])
+def test_all_levels_in_one_call_equal_the_per_level_entry(pkg, case, monkeypatch):
+    """linr_octree_levels (csrc/octree.hip: every level of a frame in one call - parents as the set bits of a key bitmap, no sort, counts
+    chained on the device, one host read) against linr_octree_level applied level by level (LINR_OCTREE_PER_LEVEL=1) and against the
+    numpy oracle: coordinates, child occupancy, counts, the stop criterion (min_point_num, a given scale_num, levels that run out of
+    coordinate bits) - bit-exact."""
+    from linr_pcgc_amd import synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    rng = np.random.default_rng(11)
+    scale_num, minp = None, 64
+    if case == 'sphere7':
+        pts = synthetic.sphere_shell(7, 50.0) + np.array([3, -9, 40], dtype=np.int32)
+    elif case == 'rough8':
+        pts = synthetic.rough_figure(8, 3)
+    elif case == 'random6':
+        pts = rng.integers(0, 64, size=(30000, 3)).astype(np.int32)           # dense random cloud with duplicates, unsorted
+    elif case == 'tiny':
+        pts = np.array([[5, 5, 5], [5, 5, 6], [9, 1, 0]], dtype=np.int32)
+        minp = 1
+    elif case == 'scale_num_2':
+        pts = synthetic.sphere_shell(7, 50.0)
+        scale_num = 2
+    else:                                                                      # 'deep': more levels asked for than coordinate bits
+        pts = synthetic.sphere_shell(5, 9.0)
+        scale_num, minp = 9, 0
+    dev_pts = torch.as_tensor(pts).cuda()
+    fast = prepare_frame(dev_pts, scale_num, minp, device='cuda', with_offsets=False)
+    monkeypatch.setenv('LINR_OCTREE_PER_LEVEL', '1')
+    slow = prepare_frame(dev_pts, scale_num, minp, device='cuda', with_offsets=False)
+    monkeypatch.delenv('LINR_OCTREE_PER_LEVEL')
+    _frames_equal(fast, slow)
+    ref = ooct.prepare_frame(pts, scale_num, minp)
+    assert fast['scale_num'] == ref['scale_num'] and fast['point_num'] == ref['point_num']
+    for a, b in zip(fast['all_input_info'], ref['scales']):
+        assert np.array_equal(a['coord'].cpu().numpy(), b['coord']) and np.array_equal(a['occ'].cpu().numpy(), b['occ'])
+
+
+def test_all_levels_in_one_call_at_config4_size(pkg, monkeypatch):
+    """... and at BASELINE config[4]'s frame size (11-bit, ~2.9 M points: the 128 MB bitmap of the finest parent level)."""
+    from linr_pcgc_amd import synthetic
+    from linr_pcgc_amd.module_utils import prepare_frame
+    pts = synthetic.sequence_frame_device('owlii11', 2, 'cuda')
+    fast = prepare_frame(pts, None, 64, device='cuda', with_offsets=False)
+    monkeypatch.setenv('LINR_OCTREE_PER_LEVEL', '1')
+    slow = prepare_frame(pts, None, 64, device='cuda', with_offsets=False)
+    _frames_equal(fast, slow)
+    assert fast['scale_num'] == 8 and fast['point_num'] > 2800000
+
+
+def test_sphere_generator_on_the_gpu_equals_the_numpy_one(pkg):
+    """synthetic.sphere_shell_device (candidate windows around the two roots per (x, y) column) gives sphere_shell's voxel list, row for
+    row, also at the equator, for thick shells, tiny radii and off-centre spheres."""
+    from linr_pcgc_amd import synthetic
+    for b, r, c, th in [(6, 20, None, 0.5), (7, 40, (60, 64, 70), 1.0), (8, 100, None, 0.5), (8, 100, (130, 128, 120), 1.0), (7, 5, None, 0.5),
+                        (8, 3, None, 2.5), (8, 90, None, 3.0), (7, 2, None, 0.5)]:
+        cc = [(1 << b) // 2] * 3 if c is None else c
+        assert np.array_equal(synthetic.sphere_shell(b, r, cc, th), synthetic.sphere_shell_device(b, r, cc, th, 'cuda').cpu().numpy()), (b, r, c, th)
+    assert synthetic.sequence_frame_device('loot10', 0, 'cuda').shape[0] == 784314

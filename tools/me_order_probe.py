@@ -14,8 +14,8 @@ from linr_pcgc_amd import overfit, synthetic          # noqa: E402
 
 g = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'loot_model_kat.npz'), allow_pickle=True)
 flat = torch.from_numpy(g['flat'].astype(np.float32))
-for cfg in ('loot10', 'andrew10'):
-    pts = synthetic.sequence_frame(cfg, 0)
+for cfg in (sys.argv[1:] or ['loot10', 'andrew10']):          # e.g. `me_order_probe.py loot10_rough`: the non-spherical figure
+    pts = synthetic.sequence_frame_device(cfg, 0, 'cuda')
     gop = overfit.Gop(None, [pts], 7, 64, 'cuda')
     model = overfit.gen_model(7, 'cuda', seed=8807)
     _, b0 = model.frame_probs(gop.frames[0])
