@@ -34,10 +34,7 @@ struct HbRaw32 { f32x4 a, b; };          // a row of c as loaded: fp32 (two 16-b
 
 #define HB_WAVES 4
 #ifndef HB_LAB
-#define HB_LAB 0                         // lab builds (tools/head_lab.sh): 1 no hpre MFMAs, 2 no gC MFMAs, 4 no transposes, 8 no X^T G, 16 no mask / per-lane sums
-#endif
-#ifndef HB_DEPTH
-#define HB_DEPTH 1                       // tiles per iteration = tiles of arithmetic a load has to arrive (see head_bwd_body)
+#define HB_LAB 0                         // lab builds (tools/head_lab.sh): 1 no hpre MFMAs, 2 no gC MFMAs, 4 no transposes, 8 no X^T G, 16 no mask / per-lane sums, 32 next tile's loads not pinned, 64 gC stored one tile late
 #endif
 #ifndef HB_GC_CHAINS
 #define HB_GC_CHAINS 2                   // independent accumulation chains per output quad of gC
@@ -106,25 +103,23 @@ __device__ __forceinline__ void head_bwd_body(const HbParams& A, LoadC loadc, Un
     const int64_t tiles = (A.n + 63) >> 6;
     const int64_t stride = (int64_t)A.active * HB_WAVES;
     int64_t t = (int64_t)blockIdx.x * HB_WAVES + wave;
-    // A wave works on HB_DEPTH tiles per iteration and loads the inputs of the NEXT iteration's tiles at the top of the current one
-    // (plain copies at the bottom: cur = next).  Depth does not pay here - 94.9 / 96.0 / 101.7 us at 1 / 2 / 3 tiles in the one-group
-    // probe, and 83.5 us remain with EVERY matrix instruction removed (tools/head_lab.sh, profiles/r06_head_bwd_lab.txt): what is
-    // left of this kernel is its row traffic (c in, gC out, p, the strided target column), not its arithmetic.  Rows beyond n (the
-    // last tile's tail, the prefetch behind a wave's last tile) read row n - 1 instead: finite data whose gz is forced to 0.
+    // The inputs of a wave's NEXT tile are loaded into the very registers the current tile has just been unpacked from, at the top of the
+    // iteration, and a scheduling barrier keeps them there: left alone, hipcc sinks those loads behind two thirds of the tile's
+    // arithmetic (register pressure) and the next iteration waits for them at its first instruction.  Worth 2-3 % (fp32 60.8 -> 59.0 us,
+    // bf16 58.1 -> 56.7, same box): load latency is NOT what holds this kernel - two waves per SIMD (208-224 registers) run ~1 us of
+    // dependent 4x4x1 chains and mask arithmetic per tile beside a row stream at 2.1 (bf16) / 3.5 (fp32) TB/s.  Rows beyond n (the last tile's tail, the prefetch behind a wave's last tile) read row n - 1 instead: finite data
+    // whose gz is forced to 0.
     const int64_t last = A.n - 1;
-    Raw cb[HB_DEPTH], nb[HB_DEPTH];
-    float pb[HB_DEPTH], tb[HB_DEPTH], pn[HB_DEPTH], tn[HB_DEPTH];
-#pragma unroll
-    for (int k = 0; k < HB_DEPTH; ++k) {
-        const int64_t row = (t + k * stride) * 64 + lane;
+    Raw cb;
+    float pb, tb;
+    {
+        const int64_t row = t * 64 + lane;
         const int64_t rc = row < last ? row : last;
-        cb[k] = loadc(rc); pb[k] = A.p[rc]; tb[k] = A.target[rc * A.target_ld];
+        cb = loadc(rc); pb = A.p[rc]; tb = A.target[rc * A.target_ld];
     }
-    auto tile = [&](const int64_t tk, const Raw& craw, const float pp, const float tt) {
+    auto tile = [&](const int64_t tk, const float (&c)[8], const float pp, const float tt, float (&o)[8]) {
         const int64_t row = tk * 64 + lane;
         const bool live = row < A.n;
-        float c[8];
-        unpack(craw, c);
         // torch: grad = (p - t) / max((1 - p) p, 1e-12) [BCELoss] * (1 - p) p [sigmoid]: the quotient and the product cancel unless clamped
         const float q = (1.0f - pp) * pp;
         const float gz = (live ? A.gscale : 0.0f) * (pp - tt) * (q < 1e-12f ? q * 1e12f : 1.0f);          // (branch-free)
@@ -199,9 +194,10 @@ __device__ __forceinline__ void head_bwd_body(const HbParams& A, LoadC loadc, Un
             gcq[0] = (f32x4){u[0], u[1], u[2], u[3]};
             gcq[1] = (f32x4){u[4], u[5], u[6], u[7]};
         }
-        if (live) {
-            const float o[8] = {gcq[0][0], gcq[0][1], gcq[0][2], gcq[0][3], gcq[1][0], gcq[1][1], gcq[1][2], gcq[1][3]};
-            storeg(row, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = gcq[i >> 2][i & 3];
+        if constexpr ((HB_LAB & 64) == 0) {
+            if (live) storeg(row, o);
         }
         f32x4 Tu[6];
         if constexpr ((HB_LAB & 4) == 0) {
@@ -235,20 +231,28 @@ __device__ __forceinline__ void head_bwd_body(const HbParams& A, LoadC loadc, Un
             for (int jq = 0; jq < 6; ++jq) { acc[jq][0] += Tu[jq]; acc[jq][1] += Tc[jq & 1]; }
         }
     };
-    for (; t < tiles; t += HB_DEPTH * stride) {
-#pragma unroll
-        for (int k = 0; k < HB_DEPTH; ++k) {
-            const int64_t row = (t + (HB_DEPTH + k) * stride) * 64 + lane;
+    // (lab, HB_LAB & 64: the gC rows of a tile stored at the top of the NEXT iteration, behind that iteration's loads, so that no wait
+    // for a tile's inputs includes a younger store - measured slower: fp32 65.2 against 59.0 us, bf16 57.3 against 56.7)
+    float og[8];
+    int64_t orow = A.n;                  // the row og belongs to (>= n: nothing pending)
+    for (; t < tiles; t += stride) {
+        float c[8];
+        unpack(cb, c);
+        const float pp = pb, tt = tb;
+        {
+            const int64_t row = (t + stride) * 64 + lane;
             const int64_t rc = row < last ? row : last;
-            nb[k] = loadc(rc); pn[k] = A.p[rc]; tn[k] = A.target[rc * A.target_ld];
+            cb = loadc(rc); pb = A.p[rc]; tb = A.target[rc * A.target_ld];
         }
-        hb_for<HB_DEPTH>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const int64_t tk = t + k * stride;
-            if (k == 0 || tk < tiles) tile(tk, cb[k], pb[k], tb[k]);           // wave-uniform
-        });
-#pragma unroll
-        for (int k = 0; k < HB_DEPTH; ++k) { cb[k] = nb[k]; pb[k] = pn[k]; tb[k] = tn[k]; }
+        if constexpr ((HB_LAB & 64) != 0) {
+            if (orow < A.n) storeg(orow, og);
+        }
+        if constexpr ((HB_LAB & 32) == 0) __builtin_amdgcn_sched_barrier(0);
+        tile(t, c, pp, tt, og);
+        orow = t * 64 + lane;
+    }
+    if constexpr ((HB_LAB & 64) != 0) {
+        if (orow < A.n) storeg(orow, og);
     }
     // ---- fold: blocks of lanes and waves in a fixed order --------------------------------------------------------------------------
     float* mine = lds + wave * 49 * HB_LSTR;

@@ -596,7 +596,10 @@ __global__ __launch_bounds__(LINR_BLOCK) void bocc7_k(BoArgs a) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[g][h][j] = a.P[a.b[g] + 4 * h + j];
-    constexpr int PF = 4;
+#ifndef BOCC_PF
+#define BOCC_PF 4
+#endif
+    constexpr int PF = BOCC_PF;
     uint4 x[PF + 1];
 #pragma unroll
     for (int u = 0; u < PF; ++u) x[u] = *reinterpret_cast<const uint4*>(pad + off[LINR_TAP(u)]);
