@@ -30,7 +30,9 @@
 //              v_mfma_f32_4x4x4_16b_bf16 (16 independent 4 x 4 blocks, four rows per instruction).  ~250 registers and 10 KB of LDS
 //              per wave, two waves per SIMD, 14 gathers in flight per wave and the next tile's first gathers issued before the
 //              epilogue of the current one.
-//   first conv bocc7_k / bocc_wgrad7_k: the seven 1->8 / 8->8 convolutions that read the occupancy codes share one gather.
+//   first conv bocc7m_k / bocc_wgrad7_k: the seven 1->8 .. 7->8 convolutions that read the occupancy codes share one gather; the forward is
+//              ONE matrix product on v_mfma_f32_16x16x32_bf16 (columns = (group, cout) as M, rows as N, the gathered 16-byte rows ARE the B
+//              operands; 22 us against 31 for the 4x4x4 form bocc7_k, kept behind LINR_BOCC7_MFMA16=0).
 //   per step   tpack_k rounds every 3x3x3 kernel once into the operand images the kernels above load (wimg).
 #include "bf16_common.h"
 #include "head_bwd.h"
@@ -509,16 +511,21 @@ static void tb_grid(int64_t n, int nb, int ngroups, int& tiles_per_wave, int& bl
 //   [119, 151)  conv0_0 of block 0-7 x 4                                                                (MODE 2)
 //   [151, 183)  [conv0_1 | conv1_1] of block 0-7 x 4                                                    (MODE 3)
 //   [183, 217)  the shared first convolution of the 7 outter blocks x 34                                (bocc7_k)
+//   [217, 273)  the same kernels as the A operands of v_mfma_f32_16x16x32_bf16: 28 images of 64 x 16 bytes (bocc7m_k)
 #define TP_CONV0 0
 #define TP_PRUNE 63
 #define TP_C00 119
 #define TP_DUAL 151
 #define TP_OCC 183
-#define TP_IMAGES 217
+#define TP_OCCM 217                     // [217, 273)  the same seven convolutions as ONE matrix: 28 operand images of 16 bytes per lane (bocc7m_k)
+#define TP_IMAGES 273
 struct TPack { int64_t conv0_w[9], pr_w[8], c00_w[8], c01_w[8], c11_w[8], occ_w[7]; };
 __host__ __device__ constexpr int oj_g(int j) { return j < 8 ? j >> 1 : 4 + ((j - 8) >> 2); }
 __host__ __device__ constexpr int oj_h(int j) { return j < 8 ? j & 1 : ((j - 8) >> 1) & 1; }
 __host__ __device__ constexpr int oj_q(int j) { return j < 8 ? 0 : (j - 8) & 1; }
+// bocc7m_k: slot s (0..26) of the matrix product's K dimension -> tap; column-major over the map's nine (x, y) columns, so that the
+// four slots of a K step are neighbours in memory (the three z taps of a column are consecutive rows)
+__host__ __device__ constexpr int bm_tap(int s) { return s / 3 + 9 * (s % 3); }
 
 __global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack t, uint2* __restrict__ wimg) {
     const int m = blockIdx.x, lane = threadIdx.x;
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) w[kk] = W[(k * 4 + kk) * 4 + i];
         }
-    } else {                             // c = 20 k + j, j -> (group g, output quad h, input quad q): W_g[k][4 q + kk][4 h + i], cin = g + 1
+    } else if (m < TP_OCCM) {           // c = 20 k + j, j -> (group g, output quad h, input quad q): W_g[k][4 q + kk][4 h + i], cin = g + 1
         const int c = 16 * (m - TP_OCC) + blk, k = c / 20, j = c % 20;
         if (k < 27) {
             const int g = oj_g(j), h = oj_h(j), q = oj_q(j), cin = g + 1;
@@ -557,6 +564,18 @@ __global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack
             for (int kk = 0; kk < 4; ++kk)
                 if (4 * q + kk < cin) w[kk] = W[(k * cin + 4 * q + kk) * 8 + 4 * h + i];
         }
+    } else {                             // bocc7m_k: image im = 4 ks + mt, half = input channels 4 half ..: lane (col = lane & 15, kb = lane >> 4)
+        const int im = (m - TP_OCCM) >> 1, half = (m - TP_OCCM) & 1;
+        const int ks = im >> 2, mt = im & 3, col = 16 * mt + (lane & 15), g = col >> 3, co = col & 7, slot = 4 * ks + (lane >> 4);
+        if (slot < 27 && g < 7) {
+            const int k = bm_tap(slot), cin = g + 1;
+            const float* W = P + t.occ_w[g];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (4 * half + kk < cin) w[kk] = W[(k * cin + 4 * half + kk) * 8 + co];
+        }
+        wimg[(int64_t)TP_OCCM * 64 + (im * 64 + lane) * 2 + half] = make_uint2(pack2(w[0], w[1]), pack2(w[2], w[3]));
+        return;
     }
     wimg[m * 64 + lane] = make_uint2(pack2(w[0], w[1]), pack2(w[2], w[3]));
 }
@@ -624,6 +643,121 @@ __global__ __launch_bounds__(LINR_BLOCK) void bocc7_k(BoArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[j] = fmaxf(acc[g][0][j], 0.0f); o[4 + j] = fmaxf(acc[g][1][j], 0.0f); }
         *reinterpret_cast<uint4*>(a.out + a.g_out[g] + row * 8) = pack_row(o);
+    }
+}
+
+// The same seven convolutions as ONE matrix product on v_mfma_f32_16x16x32_bf16 (round 6; bocc7_k stays behind LINR_BOCC7_MFMA16=0):
+//   out^T [56 columns = (group, cout), padded to 64] x [64 rows] = W^T [64 x 224] . gathered^T [224 = 28 slots x 8 channels x 64 rows]
+// with the COLUMNS as M and the rows as N: the A operand of lane (m = lane & 15, kb = lane >> 4) are the eight input channels of slot
+// 4 ks + kb for column 16 mt + m (tpack_k's images TP_OCCM.., 16 bytes per lane, kept in LDS for the whole block), the B operand of lane
+// (n = lane & 15, kb) IS the gathered 16-byte occupancy row of neighbour slot 4 ks + kb of row 16 nt + n - no transposition anywhere - and
+// a lane's four accumulator registers are four consecutive output channels of one row: 8-byte stores.  112 matrix instructions of 16
+// cycles per 64-row tile instead of 540 of 8.  The byte offsets are decoded lane = row as everywhere (decode_offsets16) and handed to the
+// (row, slot) lanes through a wave-private LDS image [row][kb][ks] (row stride 36 words: conflict-free 16-byte accesses both ways).
+// Accumulation order differs from bocc7_k's (32 products per instruction): results agree to fp32 summation order, not bit for bit.
+#define BM_XSTR 36
+__global__ __launch_bounds__(256, 2) void bocc7m_k(BoArgs a, int tile_quads) {
+    __shared__ uint4 wl[28 * 64];
+    __shared__ uint32_t xo[4][64 * BM_XSTR];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, kb = lane >> 4;
+    {
+        const uint4* wsrc = reinterpret_cast<const uint4*>(a.wimg + (int64_t)TP_OCCM * 64);
+        uint4 t[7];                                               // (all seven loads in flight: a rolled loop waits for each)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) t[i] = wsrc[i * 256 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) wl[i * 256 + threadIdx.x] = t[i];
+    }
+    // a lane's columns: 16 mt + 4 kb + r -> group 2 mt + (kb >> 1), output channels 4 (kb & 1) + r
+    float bias[4][4];
+    int64_t gout[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const bool hi = (kb >> 1) != 0;
+        const bool real = !(mt == 3 && hi);                     // group 7 does not exist
+        const int64_t bo = real ? (hi ? a.b[(2 * mt + 1) % 7] : a.b[2 * mt]) : 0;
+        gout[mt] = hi ? a.g_out[(2 * mt + 1) % 7] : a.g_out[2 * mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[mt][r] = real ? a.P[bo + 4 * (kb & 1) + r] : 0.0f;
+    }
+    __syncthreads();
+    uint32_t* xw = xo[wave];
+    const char* pad = reinterpret_cast<const char*>(a.occ - 8);
+    // the map words of a wave's NEXT tile are loaded behind the gathers of the current one (the decode is a dependent load chain:
+    // words -> offsets -> LDS -> gathers); all 28 gathers of a tile are in flight before its first matrix instruction
+    uint32_t raw[10];
+    auto words = [&](int64_t tq) {
+        const int64_t row_raw = (tq * 4 + wave) * 64 + lane;
+        const int64_t row = row_raw < a.n ? row_raw : a.n - 1;
+        load_words16(a.lo, a.mask, a.ld, row, raw);
+    };
+    if ((int64_t)blockIdx.x < tile_quads) words(blockIdx.x);
+    for (int64_t tq = blockIdx.x; tq < tile_quads; tq += gridDim.x) {
+        const int64_t row0 = (tq * 4 + wave) * 64;
+        {
+            uint32_t off[27];
+            decode_words16(raw, off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t v[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) v[ks] = (ks < 7 && 4 * ks + q < 27) ? off[bm_tap((4 * ks + q) % 27)] : 0u;
+                *reinterpret_cast<uint4*>(xw + lane * BM_XSTR + q * 8) = make_uint4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint4*>(xw + lane * BM_XSTR + q * 8 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+            }
+        }
+        uint4 x[7][4];
+        {
+            uint32_t go[4][8];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const uint4 lo4 = *reinterpret_cast<const uint4*>(xw + (16 * nt + n16) * BM_XSTR + kb * 8);
+                const uint4 hi4 = *reinterpret_cast<const uint4*>(xw + (16 * nt + n16) * BM_XSTR + kb * 8 + 4);
+                go[nt][0] = lo4.x; go[nt][1] = lo4.y; go[nt][2] = lo4.z; go[nt][3] = lo4.w;
+                go[nt][4] = hi4.x; go[nt][5] = hi4.y; go[nt][6] = hi4.z; go[nt][7] = hi4.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {                          // K step major (pinned): the first matrix instructions wait for the oldest gathers
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) x[ks][nt] = *reinterpret_cast<const uint4*>(pad + go[nt][ks]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        words(tq + gridDim.x);                                    // (unconditional - rows are clamped - so that the waits below count exactly)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){bias[mt][0], bias[mt][1], bias[mt][2], bias[mt][3]};
+        sfor<7>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            uint4 w[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) w[mt] = wl[(ks * 4 + mt) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[mt]),
+                                                                          __builtin_bit_cast(bf16x8, x[ks][nt]), acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                    // K steps in order: each waits for its own four gathers only
+        });
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int64_t row = row0 + 16 * nt + n16;
+            if (row >= a.n) continue;                             // (also the waves of the last quad that have no tile)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt == 3 && (kb >> 1)) continue;               // group 7
+                const f32x4 v = acc[mt][nt];
+                *reinterpret_cast<uint2*>(a.out + gout[mt] + row * 8 + 4 * (kb & 1)) =
+                    make_uint2(pack2(fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)), pack2(fmaxf(v[2], 0.0f), fmaxf(v[3], 0.0f)));
+            }
+        }
     }
 }
 
@@ -985,7 +1119,15 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
         o.occ = c.OCC; o.out = a.A[1]; o.P = c.P; o.wimg = a.WIMG; o.lo = f->nbr_lo; o.mask = f->nbr_mask; o.ld = f->nbr_ld; o.n = c.R;
         for (int g = 0; g < 7; ++g) { o.b[g] = L.outter[g].a_b; o.g_out[g] = a.A[g + 1] - a.A[1]; }
         LinrProf ps(c.s, TK_FWD, 7);
-        bocc7_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(o);
+        const char* e16 = getenv("LINR_BOCC7_MFMA16");       // 0: bocc7_k (v_mfma_f32_4x4x4_16b_bf16); read per call: tests compare the two
+        const int mfma16 = e16 ? atoi(e16) : 1;
+        if (mfma16) {
+            const int64_t tq = (linr_grid(c.R, 64) + 3) / 4;
+            const int64_t blocks = tq < 2 * (int64_t)tb_cus() ? tq : 2 * (int64_t)tb_cus();
+            bocc7m_k<<<(int)blocks, 256, 0, c.s>>>(o, (int)tq);
+        } else {
+            bocc7_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(o);
+        }
         TRY(linr_launch_rc());
     }
     {   // the Inception layer of all eight blocks: H = [relu(conv0_0(A)) | relu(conv1_0(A))], then I, M

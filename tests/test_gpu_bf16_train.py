@@ -197,6 +197,28 @@ def test_bf16_train_forward_matches_the_emulating_oracle(pkg, shell, steps):
     assert abs(float(bits) - ref32_bits) <= 1e-2 * ref32_bits, (float(bits), ref32_bits)
 
 
+def test_first_convolutions_as_one_matrix_product_match_the_4x4x4_kernel(pkg, shell, monkeypatch):
+    """bocc7m_k (v_mfma_f32_16x16x32_bf16: the seven first convolutions of the outter blocks as ONE matrix product, models/upsample.py:
+    206-214) against bocc7_k (4x4x4 blocks, lane = row): the inputs are 0 / 1 and the kernels bf16, so every product is exact and the two
+    differ by fp32 summation order only - a handful of activations round to the neighbouring bf16 value, which moves logits by a
+    few 1e-3 at most and the frame's bits by < 1e-5."""
+    from linr_pcgc_amd import engine
+    model, sd, frame = _moved_model(pkg, shell, 10)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('LINR_BOCC7_MFMA16', mode)
+        probs = torch.empty((8, frame.rows), dtype=torch.float32, device='cuda')
+        bits = torch.zeros(1, dtype=torch.float64, device='cuda')
+        engine.net_forward_train_bf16(frame, model.flat_parameters(), probs, bits)
+        out[mode] = (probs, float(bits))
+    monkeypatch.delenv('LINR_BOCC7_MFMA16')
+    d = (_logits(out['0'][0].cpu()) - _logits(out['1'][0].cpu())).abs()
+    assert float(d.max()) <= 1e-2, float(d.max())
+    assert float((d > 1e-4).double().mean()) <= 0.05, float((d > 1e-4).double().mean())
+    assert abs(out['0'][1] - out['1'][1]) <= 1e-4 * out['0'][1], (out['0'][1], out['1'][1])
+    assert bool(torch.equal(out['0'][0][0], out['1'][0][0])), 'stage 0 does not read the occupancy convolutions'
+
+
 @pytest.mark.parametrize('steps', [0, 10])
 def test_bf16_train_gradients_match_the_emulating_oracle(pkg, shell, steps):
     """every one of the 189 gradient tensors within 2e-2 of its own largest entry of the emulating oracle's autograd gradient,
