@@ -231,3 +231,12 @@ def scratch(nbytes, device):
     if os.environ.get('LINR_DEBUG_POISON'):
         t.fill_(0xFF)
     return t
+
+
+def current_stream_handle():
+    """The raw handle of PyTorch's current HIP stream on the current device.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (~9 us per call; a frame's staging makes twenty such calls): the two C entry points below are what it ends in."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:                                         # (a torch build without them)
+        return torch.cuda.current_stream().cuda_stream

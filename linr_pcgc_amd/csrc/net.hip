@@ -36,7 +36,7 @@ struct Arena {
     int pad_w[200];
     int npad;
     // forward (saved for backward)
-    float *HID, *X0, *OCC;
+    float *X0, *OCC;
     float *A[8], *H[8], *M[8], *I[8], *O[8];
     float *Hx[MAX_BL - 1], *Mx[MAX_BL - 1], *Ix[MAX_BL - 1];        // Inception layers 1.. of block_in (block_layers > 1)
     float *gIx[MAX_BL - 1], *gMx[MAX_BL - 1], *gHx[MAX_BL - 1];
@@ -65,7 +65,7 @@ static size_t slab_need(int64_t rows) {
 
 static void make_arena(Arena& a, int64_t rows, float* base, int64_t n_params, int block_layers = 1) {
     a.rows = rows; a.base = base; a.cur = 0; a.npad = 0;
-    a.HID = arena_mat(a, 16); a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
+    a.X0 = arena_mat(a, 8); a.OCC = arena_mat(a, 8);
     for (int b = 0; b < 8; ++b) {
         a.A[b] = arena_mat(a, 8); a.H[b] = arena_mat(a, 8); a.M[b] = arena_mat(a, 4);
         a.I[b] = arena_mat(a, 8); a.O[b] = arena_mat(a, 8);
@@ -143,6 +143,9 @@ __global__ __launch_bounds__(LINR_BLOCK) void sce_bwd_k(const float* __restrict_
 // the fragment layout.  Neither ghid nor the MLP input is written to memory (round 2/3: a 64 B/row matrix each, read back by two
 // pointwise weight-gradient launches).  One slab row per workgroup and scale, the four waves folded in order.
 #define SB_LD 57
+#ifndef SB_LAB
+#define SB_LAB 0            // lab builds (tools/lab_build.sh net <tag> -DSB_LAB=mask): 1 no X^T G loop, 2 no LDS tile writes, 4 no gh / h arithmetic, 8 one tile per wave only
+#endif
 #define SB_WAVES 4          // (8 waves per workgroup = one workgroup per CU: 63.6 instead of 50.3 us per step for the two scale-context kernels)
 __global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __restrict__ P, const float* __restrict__ off, SceArgs a,
                                                             const float* __restrict__ gx0, const float* __restrict__ hid,
@@ -164,54 +167,115 @@ __global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __re
     const int64_t b0 = (int64_t)sb * per;
     const int64_t b1 = (b0 + per < n) ? b0 + per : n;
     float* T = sT + wave * 64 * SB_LD;
-    // W2 in VECTOR registers: 128 uniform values are more than the scalar file holds beside the rest (the compiler spilled them
-    // into register lanes: 742 v_readlane per tile, 40 us per launch) - the empty asm pins each into a VGPR
-    // ... and through VECTOR loads (the address made lane-dependent in form only): as scalar loads pinned one by one they were 128
-    // s_load / s_waitcnt round trips in front of every workgroup's first tile; 32 dwordx4 loads are in flight together
-    float w2v[128];
+    // gh = g W2 on v_mfma_f32_4x4x1 with the weight 4-vector broadcast (CBSZ = 4), K = 1 - each instruction is one fmaf per output, output
+    // gradients ascending from 0 like the loop it replaces (same bits): the 128 weights are TWO registers per lane (combo 4 i + oq ->
+    // W2[i][4 oq + j], block (lane >> 2) of register v is combo 16 v + block) where rounds 2-5 pinned them into 128 vector registers
+    // per lane (one workgroup per CU; now two, LDS-bound).  Worth ~1 us of the kernel's 21-22 (profiles/r06_sce_lab.txt).
+    float wG[2];
     {
-        const float* w2p = W2 + __builtin_amdgcn_mbcnt_lo(0u, 0u);          // + 0, but a per-lane value to the compiler
-        if ((reinterpret_cast<uintptr_t>(w2p) & 15u) == 0) {
+        const int blk = lane >> 2, j4 = lane & 3;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const float4 t = *reinterpret_cast<const float4*>(w2p + 4 * j);
-                w2v[4 * j] = t.x; w2v[4 * j + 1] = t.y; w2v[4 * j + 2] = t.z; w2v[4 * j + 3] = t.w;
-            }
-        } else {
+        for (int v = 0; v < 2; ++v) {
+            const int cb = 16 * v + blk;
+            wG[v] = W2[(cb >> 2) * 16 + 4 * (cb & 3) + j4];
+        }
+    }
+    // sce_fwd_k's weight image of the first layer (csrc/sce.h: combo 4 i + hq -> W1[4 hq + j][i], 60 + hq -> b1[4 hq + j])
+    float wA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (hid == nullptr) {
+        const float* W1 = P + a.w1[s];
+        const float* b1p = P + a.b1[s];
+        const int blk = lane >> 2, j4 = lane & 3;
 #pragma unroll
-            for (int j = 0; j < 128; ++j) w2v[j] = w2p[j];
+        for (int v = 0; v < 4; ++v) {
+            const int cb = 16 * v + blk;
+            wA[v] = cb < 60 ? W1[(4 * (cb & 3) + j4) * 15 + (cb >> 2)] : b1p[4 * (cb - 60) + j4];
         }
     }
     f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f}, acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
     float bs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bs[j] = 0.0f;
+    // The inputs of a wave's NEXT tile are loaded while the current one is worked on (pinned by a scheduling barrier; rows behind the
+    // range read its last row, masked by `live`).  The kernel's time is mostly fixed cost per workgroup - one tile per wave instead of
+    // 3.75 still takes 17 of the 22 us (607 workgroups of 63 KB LDS on 512 slots: two rounds of prologue, tile, fold) - see
+    // profiles/r06_sce_lab.txt.
+    float4 ng0, ng1;
+    float noff[7];
+    auto fetch = [&](int64_t c0) {
+        const int64_t row = c0 + lane;
+        const int64_t r = r0 + (row < b1 ? row : b1 - 1);
+        ng0 = *reinterpret_cast<const float4*>(gx0 + r * 8); ng1 = *reinterpret_cast<const float4*>(gx0 + r * 8 + 4);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) noff[i] = off[r * 7 + i];
+    };
+    if (b0 + 64 * wave < b1) fetch(b0 + 64 * wave);
     for (int64_t c0 = b0 + 64 * wave; c0 < b1; c0 += 64 * SB_WAVES) {
         const int64_t row = c0 + lane;
         const bool live = row < b1;
         const int64_t r = r0 + (live ? row : b1 - 1);
-        const float4 g0 = *reinterpret_cast<const float4*>(gx0 + r * 8), g1 = *reinterpret_cast<const float4*>(gx0 + r * 8 + 4);
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        float h[16];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 t = *reinterpret_cast<const float4*>(hid + r * 16 + 4 * v);
-            h[4 * v] = t.x; h[4 * v + 1] = t.y; h[4 * v + 2] = t.z; h[4 * v + 3] = t.w;
-        }
+        const float g[8] = {ng0.x, ng0.y, ng0.z, ng0.w, ng1.x, ng1.y, ng1.z, ng1.w};
         float x[16];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = emb[i];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) x[8 + i] = off[r * 7 + i];
+        for (int i = 0; i < 7; ++i) x[8 + i] = noff[i];
         x[15] = 1.0f;                                          // the bias gradient's pseudo input
+        fetch(c0 + 64 * SB_WAVES);
+        __builtin_amdgcn_sched_barrier(0);
+        float h[16];
+        if constexpr ((SB_LAB & 4) != 0) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) h[o] = x[o];
+        } else
+        if (hid != nullptr) {                                  // (uniform) the op-level entry hands the forward's hidden layer in
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t = *reinterpret_cast<const float4*>(hid + r * 16 + 4 * v);
+                h[4 * v] = t.x; h[4 * v + 1] = t.y; h[4 * v + 2] = t.z; h[4 * v + 3] = t.w;
+            }
+        } else {
+            // the executors do not keep the hidden layer (64 bytes per row written by the forward and read back here): it is recomputed
+            // with sce_fwd_k's own instruction sequence - same bits - from inputs this kernel loads anyway
+            f32x4 hq4[4];
+            static_for<4>([&](auto hc) {
+                constexpr int hq = decltype(hc)::value;
+                hq4[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[3], 1.0f, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, 12 + hq, 0);
+            });
+            static_for<15>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<4>([&](auto hc) {
+                    constexpr int hq = decltype(hc)::value;
+                    constexpr int cb = 4 * i + hq;
+                    hq4[hq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[cb / 16], x[i], hq4[hq], 4, cb % 16, 0);
+                });
+            });
+#pragma unroll
+            for (int o = 0; o < 16; ++o) h[o] = fmaxf(hq4[o >> 2][o & 3], 0.0f);
+        }
         float gh[16];
+        if constexpr ((SB_LAB & 4) != 0) {
 #pragma unroll
-        for (int o = 0; o < 16; ++o) gh[o] = 0.0f;
+            for (int o = 0; o < 16; ++o) gh[o] = g[o & 7];
+        } else {
+            f32x4 ghq[4];
+            static_for<4>([&](auto oc) {
+                constexpr int oq = decltype(oc)::value;
+                ghq[oq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wG[0], g[0], (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 4, oq, 0);
+            });
+            static_for<7>([&](auto ic) {
+                constexpr int i = decltype(ic)::value + 1;
+                static_for<4>([&](auto oc) {
+                    constexpr int oq = decltype(oc)::value;
+                    constexpr int cb = 4 * i + oq;
+                    ghq[oq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wG[cb / 16], g[i], ghq[oq], 4, cb % 16, 0);
+                });
+            });
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int o = 0; o < 16; ++o) gh[o] = fmaf(g[i], w2v[i * 16 + o], gh[o]);
+            for (int o = 0; o < 16; ++o) gh[o] = ghq[o >> 2][o & 3];
+        }
         float* Tr = T + lane * SB_LD;
+        if constexpr ((SB_LAB & 2) == 0) {
 #pragma unroll
         for (int o = 0; o < 16; ++o) Tr[o] = (live && h[o] > 0.0f) ? gh[o] : 0.0f;
 #pragma unroll
@@ -220,11 +284,19 @@ __global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __re
         for (int j = 0; j < 8; ++j) Tr[32 + j] = live ? g[j] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) Tr[40 + i] = live ? h[i] : 0.0f;
+        } else {
+            float t = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) t += gh[o] + h[o] + x[o];
+            bs[0] += t;
+        }
         if (live) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) bs[j] += g[j];
         }
-        // wave-private tile: LDS operations of a wave execute in order, no barrier
+        // wave-private tile: LDS operations of a wave execute in order, no barrier.  (Round 6 lab, profiles/r06_sce_lab.txt: the tile
+        // transposed so that an operand is four 16-byte reads instead of sixteen 4-byte ones - same time, other summation order: not kept.)
+        if constexpr ((SB_LAB & 1) == 0)
 #pragma unroll 4
         for (int s4 = 0; s4 < 16; ++s4) {
             const float* Tq = T + (4 * s4 + rr) * SB_LD;
@@ -233,6 +305,7 @@ __global__ __launch_bounds__(SB_WAVES * 64) void sce_bwd_all_k(const float* __re
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1v, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2v, acc2, 0, 0, 0);
         }
+        if constexpr ((SB_LAB & 8) != 0) break;
     }
     // fold the 4 waves in wave order, then one partial per destination element (C/D map: row = (lane >> 4) * 4 + reg, col = lane & 15)
     float* mine = sfold + lane * 9;
@@ -837,7 +910,7 @@ extern "C" int linr_net_forward(const linr_frame* f, const float* params, float*
             ProfScope ps(c.s, PK_SCE, 1);
             const SceArgs sa = sce_args(c);
             sce_fwd_k<float><<<sa.blk_off[sa.n_scales] + (a.npad + LINR_BLOCK / 32 - 1) / (LINR_BLOCK / 32), LINR_BLOCK, 0, c.s>>>(
-                P, f->offset_feat, sa, c.R, nullptr, a.HID, a.X0, a.base, pl);
+                P, f->offset_feat, sa, c.R, nullptr, nullptr, a.X0, a.base, pl);      // (no hidden layer kept: sce_bwd_all_k recomputes it)
         }
         if (all_grouped && join_block_in(c)) {
             // block_in's first conv only: its Inception layer runs as group 0 of the outter blocks' launches (forward_batched)
@@ -1203,7 +1276,7 @@ static int backward_batched(Ctx& c, float gz_scale, bool join) {
 }
 
 // The tail of every backward pass (fp32 executor: backward_core below; bf16 training executor: csrc/train_bf16.hip): the scale
-// context's backward from gx0 [rows][8] fp32 and the hid [rows][16] its forward kept (ghid and all four parameter gradients of every
+// context's backward from gx0 [rows][8] fp32 and the hid [rows][16] of its forward (NULL: recomputed) (ghid and all four parameter gradients of every
 // scale's context MLP in one launch), the fixed-order reduction of the [nb][total] slab `big` into gsum - `sh` lists the parameter
 // ranges whose producers wrote fewer than nb slab rows - and the scale-embedding gradients derived from the reduced sums.
 int linr_bwd_tail_launch(const linr_frame* f, const Layout& L, const float* P, const float* gx0, const float* hid, float* big,
@@ -1306,7 +1379,7 @@ static int backward_core(Ctx& c, float gscale) {
     }
     std::vector<LinrShortRange> sh(c.shortr.size());
     for (size_t i = 0; i < sh.size(); ++i) sh[i] = {c.shortr[i].b, c.shortr[i].e, c.shortr[i].rows};
-    return linr_bwd_tail_launch(f, c.L, P, a.gX0, a.HID, a.BIG, a.GSUM, c.nb, sh.data(), (int)sh.size(), c.s);
+    return linr_bwd_tail_launch(f, c.L, P, a.gX0, nullptr, a.BIG, a.GSUM, c.nb, sh.data(), (int)sh.size(), c.s);
 }
 
 extern "C" int linr_net_backward(const linr_frame* f, const float* params, float* arena, size_t arena_bytes, float gscale,

@@ -947,7 +947,7 @@ struct TArena {
     int64_t rows;
     char* base;
     int64_t cur;                     // bytes
-    float *HID, *gX0, *PR, *GSUM, *BIG;
+    float *gX0, *PR, *GSUM, *BIG;
     uint2* WIMG;                     // [TP_IMAGES][64] weight-block images of the forward kernels (tpack_k)
     double* part;
     bf16_t *X0, *OCC, *A[8], *H[8], *I[8], *O[8], *C[8], *M[8];
@@ -973,7 +973,6 @@ static bf16_t* tmat(TArena& a, int w = 8) {          // [1 + rows][w] with the z
 
 static void make_tarena(TArena& a, int64_t rows, char* base, int64_t n_params, bool own_occ) {
     a.rows = rows; a.base = base; a.cur = 0; a.pads.n = 0; a.n_params = n_params;
-    a.HID = (float*)tbytes(a, rows * 16 * 4);
     a.gX0 = (float*)tbytes(a, rows * 8 * 4);
     a.PR = (float*)tbytes(a, rows * 8 * 4);
     a.part = (double*)tbytes(a, (int64_t)8 * linr_grid(rows, LINR_BLOCK) * 8);
@@ -1109,7 +1108,7 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
             sa.blk_off[s + 1] = sa.blk_off[s] + (int)linr_grid(sa.row_off[s + 1] - sa.row_off[s], LINR_BLOCK);
         PadList none;
         none.n = 0;
-        sce_fwd_k<bf16_t><<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, c.s>>>(c.P, f->offset_feat, sa, c.R, nullptr, a.HID, a.X0, nullptr, none);
+        sce_fwd_k<bf16_t><<<sa.blk_off[sa.n_scales], LINR_BLOCK, 0, c.s>>>(c.P, f->offset_feat, sa, c.R, nullptr, nullptr, a.X0, nullptr, none);
     }
     {   // A[0] = relu(conv3(x_low)) (block_in) and A[b] = relu(conv3(occ[:, :b])) (outter block b)
         const bf16_t* in0[1] = {a.X0};
@@ -1293,7 +1292,7 @@ static int tbackward(TCtx& c, float gscale) {
         TRY((bb_launch<0, 0>(c, b, 1, TK_BWD88, &rows)));
         c.note_short(L.block_in.a_w, L.block_in.a_b + 8, rows);
     }
-    return linr_bwd_tail_launch(c.f, L, c.P, a.gX0, a.HID, a.BIG, a.GSUM, c.nb, c.shortr.data(), (int)c.shortr.size(), c.s);
+    return linr_bwd_tail_launch(c.f, L, c.P, a.gX0, nullptr, a.BIG, a.GSUM, c.nb, c.shortr.data(), (int)c.shortr.size(), c.s);
 }
 
 // ---- C-ABI ----------------------------------------------------------------------------------------------------------------------------

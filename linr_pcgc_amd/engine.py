@@ -167,7 +167,7 @@ class Frame:
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def net_forward(frame, flat_params, stage_begin=0, stage_end=8, probs=None, bits=None, arena=None):

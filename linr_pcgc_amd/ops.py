@@ -11,7 +11,7 @@ from ._lib import LINR_ACCUM, LINR_NO_BIAS, LINR_PAD_ROW, LINR_RELU, LINR_RELU_M
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 def _dev(t, dtype, name):

@@ -29,7 +29,7 @@ B = 8
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.current_stream_handle()
 
 
 class _Pool:

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/ab_classes.sh "<class name filter regex>" tools/_lab/liblinr_x.so ...'
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 filt=$1; shift
-b(){ python3 tools/head_probe.py 2>&1 | grep 'head bwd' | sed 's/(gc.*//'; python3 tools/bf16_train_speed.py --classes 2>/dev/null | python3 -c "
+b(){ python3 tools/bf16_train_speed.py --classes 2>/dev/null | python3 -c "
 import json,sys,re
 t=sys.stdin.read(); d=json.loads(t[t.index('{'):])
 for k in ('f32','bf16'):
