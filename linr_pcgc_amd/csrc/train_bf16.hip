@@ -527,8 +527,14 @@ __host__ __device__ constexpr int oj_q(int j) { return j < 8 ? 0 : (j - 8) & 1; 
 // four slots of a K step are neighbours in memory (the three z taps of a column are consecutive rows)
 __host__ __device__ constexpr int bm_tap(int s) { return s / 3 + 9 * (s % 3); }
 
-__global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack t, uint2* __restrict__ wimg) {
+// (blocks behind the images clear the pad rows of the arena's matrices - zero_pads16_k's work: one launch less per step)
+__global__ __launch_bounds__(64) void tpack_k(const float* __restrict__ P, TPack t, uint2* __restrict__ wimg, bf16_t* __restrict__ pad_base, BPads pl) {
     const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= TP_IMAGES) {
+        const int b = m - TP_IMAGES;
+        if (b < pl.n && lane < pl.w[b]) pad_base[pl.off[b] + lane] = 0;
+        return;
+    }
     const int blk = lane >> 2, i = lane & 3;
     float w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (m < TP_DUAL) {
@@ -1086,7 +1092,6 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
     {
         LinrProf ps(c.s, TK_MISC, 1);
         if (c.OCC == a.OCC) occ_bf16_k<<<linr_grid(c.R, LINR_BLOCK), LINR_BLOCK, 0, c.s>>>(f->occ, c.R, a.OCC);
-        zero_pads16_k<<<a.pads.n, 64, 0, c.s>>>(a.mats, a.pads);
         TPack tp;
         tp.conv0_w[0] = L.block_in.a_w; tp.conv0_w[1] = L.block_in.b_w;
         for (int g = 0; g < 7; ++g) { tp.conv0_w[2 + g] = L.outter[g].b_w; tp.occ_w[g] = L.outter[g].a_w; }
@@ -1094,7 +1099,7 @@ static int tforward(TCtx& c, float* probs, double* bits_acc) {
             const IncP& q = (k == 0 ? L.block_in : L.outter[k - 1]).inc[0];
             tp.pr_w[k] = L.pr_w[k]; tp.c00_w[k] = q.c00_w; tp.c01_w[k] = q.c01_w; tp.c11_w[k] = q.c11_w;
         }
-        tpack_k<<<TP_IMAGES, 64, 0, c.s>>>(c.P, tp, a.WIMG);
+        tpack_k<<<TP_IMAGES + a.pads.n, 64, 0, c.s>>>(c.P, tp, a.WIMG, a.mats, a.pads);
         SceArgs sa;
         sa.n_scales = f->n_scales;
         for (int s = 0; s < f->n_scales; ++s) {

@@ -5,9 +5,9 @@
 //   C  compiler-scheduled loop, absent taps read the zero row (what the kernels do)
 //   U  inline-asm loads, 9 taps in flight, absent taps read the zero row (the asm form's own baseline)
 //   M  the same with   s_and_b64 exec, exec, (v >= 0)  around the tap's loads   (absent lanes issue no address)
-// Kernel map: argv[1] = file of int32 [27][ld] (the real map of a frame: tools/gather_exec_probe.sh dumps loot10's), rows = argv[2];
+// Kernel map: argv[1] = file of int32 [27][ld] (the real map of a frame: tools/lab/gather_exec_probe.sh dumps loot10's), rows = argv[2];
 // without arguments a synthetic x-major surface with random half-present taps.
-// build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_exec_probe tools/gather_exec_probe.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_exec_probe tools/lab/gather_exec_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

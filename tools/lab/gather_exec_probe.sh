@@ -1,9 +1,9 @@
 #!/bin/bash
-# EXEC-masked neighbour gathers against the zero-row read, on the REAL kernel map of a loot10 frame (tools/gather_exec_probe.hip).
-# Run on the GPU box from the repo root:  bash tools/gather_exec_probe.sh > gpurun_out/gather_exec.txt
+# EXEC-masked neighbour gathers against the zero-row read, on the REAL kernel map of a loot10 frame (tools/lab/gather_exec_probe.hip).
+# Run on the GPU box from the repo root:  bash tools/lab/gather_exec_probe.sh > gpurun_out/gather_exec.txt
 set -e
 mkdir -p tools/_lab gpurun_out
-hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_exec_probe tools/gather_exec_probe.hip
+hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_exec_probe tools/lab/gather_exec_probe.hip
 python3 - <<'PY'
 import torch
 from linr_pcgc_amd import overfit, synthetic

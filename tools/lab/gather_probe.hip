@@ -4,7 +4,7 @@
 //      instructions per tap and 64-row tile (the data then sits as (row, half) pairs and needs a lane swap before the MFMAs)
 //   C  lane = (tap of 4, row of 8, half): the transposing weight-gradient kernel's layout
 // Synthetic kernel map with the locality of an x-major sorted surface: tap (dx,dy,dz) -> row + 700 dx + 27 dy + dz.
-// build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_probe tools/gather_probe.hip ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/gather_probe tools/lab/gather_probe.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

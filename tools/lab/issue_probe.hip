@@ -1,7 +1,7 @@
 // Probe (not part of the product): does ONE wave per SIMD overlap its own v_mfma_f32_4x4x1 with its own VALU / LDS instructions, or
 // only with another wave's?  Per loop iteration NM MFMAs + NV plain v_fma + NL ds_read_b128, all independent.  Occupancy is forced
 // through the dynamic LDS size: 100 KB -> one 256-thread block per CU (one wave per SIMD), 60 KB -> two (two waves per SIMD).
-// Build: hipcc --offload-arch=gfx950 -O3 -w -o tools/_lab/issue_probe tools/issue_probe.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -w -o tools/_lab/issue_probe tools/lab/issue_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,6 +1,6 @@
 // Probe (not part of the product): SPECIALISED waves on one SIMD - wave A issues only v_mfma_f32_4x4x1, wave B only VALU (or only
 // ds_read_b128): do they overlap?  512-thread workgroups, one per CU (100 KB LDS): waves 0..3 = A, 4..7 = B, pairs share a SIMD.
-// Build: hipcc --offload-arch=gfx950 -O3 -w -o tools/_lab/issue_probe2 tools/issue_probe2.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -w -o tools/_lab/issue_probe2 tools/lab/issue_probe2.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the block-local convolution probe beside the lane = row baseline:  gpurun -- 'bash tools/lconv_pmc.sh'
+# SQ counters of the block-local convolution probe beside the lane = row baseline:  gpurun -- 'bash tools/lab/lconv_pmc.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/lconv_pmc.txt

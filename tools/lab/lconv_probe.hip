@@ -1,7 +1,7 @@
 // Probe: 3x3x3 convolution 8->8 on Morton blocks staged in LDS, 64-row tiles sorted by their 27-bit neighbour mask inside the
 // block, absent taps skipped per tile (wave-uniform), against the lane = x-major row / 27 gathers through the L1 form of today's
 // cconv_mfma_k.  Host builds the geometry (loot10 stand-in: 10-bit sphere r = 250, all octree scales in one row space), the
-// neighbour table and the block plan.  build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/lconv_probe tools/lconv_probe.hip
+// neighbour table and the block plan.  build: hipcc --offload-arch=gfx950 -O3 -o tools/_lab/lconv_probe tools/lab/lconv_probe.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>

@@ -1,5 +1,5 @@
 // Timing probe (not part of the product): how fast is the conv's pure FMA stream (27 x 64 FMAs per lane, weights in
-// SGPRs) with no memory traffic at all?   hipcc --offload-arch=gfx950 -O3 tools/valu_probe.hip -o /tmp/valu_probe
+// SGPRs) with no memory traffic at all?   hipcc --offload-arch=gfx950 -O3 tools/lab/valu_probe.hip -o /tmp/valu_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
