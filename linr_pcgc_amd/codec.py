@@ -68,6 +68,8 @@ def encode_gop(model, model_ori, gop, bitdepth=8, n_threads=None, precision='f32
         side_info['precision'] = precision
     side_info['arith_version'] = ARITH_VERSION
     side_info.update(model_shape(model))
+    # informational (the decoder does not need it): which training executor produced the coded model
+    side_info['train_precision'] = getattr(model, 'train_precision', 'f32')
     # Pipeline: the GPU forward + D2H of frame i+1 runs while host workers range-code earlier frames (the coder's C call
     # releases the GIL).  A frame has 8 x scales independent streams, but the 8 streams of its finest scale carry 73 % of the
     # symbols, so one frame keeps only ~8 threads busy: TWO frames are coded concurrently, each on half of the threads
