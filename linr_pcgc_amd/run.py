@@ -157,15 +157,14 @@ def run_sequence_job(args, rank=0, world=1, dist=None, stage_all=False, files=No
         gop_dir = os.path.join(args.out, 'output', gop_parallel.gop_name(group))
         os.makedirs(gop_dir, exist_ok=True)
         log = open(os.path.join(args.out, 'info.log' if rank == 0 else 'info_rank%d.log' % rank), 'a')
-        log.write('=' * 40 + '\nprocess_file: %d %d\ntrain_precision: %s\n' % (group[0], group[-1], model.train_precision))
+        log.write('=' * 40 + '\nprocess_file: %d %d\n' % (group[0], group[-1]))
         clock = {'mark': time.time(), 'train': 0.0}
 
         def on_epoch(epoch, loss_mean):
             # main.py:327-338,428-430: the epoch's record in info.log and in <gop>/result.json (train_time: cumulative seconds of the
             # frame loops of this GOP; train_time_avg: per frame).  overfit_gop has just read the loss, so the GPU is idle here.
             clock['train'] += time.time() - clock['mark']
-            entry = {'epoch': epoch, 'loss': loss_mean, 'train_time': clock['train'], 'train_time_avg': clock['train'] / len(group),
-                     'train_precision': model.train_precision}
+            entry = {'epoch': epoch, 'loss': loss_mean, 'train_time': clock['train'], 'train_time_avg': clock['train'] / len(group)}
             log.write('epoch: %d\nloss: %r\ntrain_time: %r\ntrain_time_avg: %r\n' % (epoch, loss_mean, entry['train_time'], entry['train_time_avg']))
             if getattr(args, 'mid_test', False) and (epoch < 10 or epoch % args.check_freq == 0):
                 # main.py:341-411: with --mid_test the checkpoint is written at every tested epoch (epochs 0..9 and every
