@@ -331,6 +331,32 @@ def test_synthetic_configs():
     assert (np.diff(key) > 0).all()
 
 
+def test_rough_figure_generator_is_a_deterministic_non_spherical_surface():
+    """synthetic.rough_figure (the non-spherical stress workload beside the sphere stand-ins; the reference's data are
+    human figures, datautils/custom_dataset.py:259-355): deterministic, x-major sorted and unique like every stand-in, in range, a
+    figure and not a ball (anisotropic extent, radii spread widely about the centroid where a sphere shell's do not), integer motion
+    from frame to frame, and a kernel map whose taps-per-row lie in the range of a surface (between a curve's 3 and a solid's 27)."""
+    from linr_pcgc_amd import synthetic
+    from oracle import octree
+    a, a2, b = synthetic.rough_figure(7, 0), synthetic.rough_figure(7, 0), synthetic.rough_figure(7, 1)
+    assert a.dtype == np.int32 and a.shape == (16412, 3) and np.array_equal(a, a2)
+    assert a.min() >= 0 and a.max() < 128
+    key = a[:, 0].astype(np.int64) << 40 | a[:, 1].astype(np.int64) << 20 | a[:, 2]
+    assert (np.diff(key) > 0).all()
+    ext = (a.max(0) - a.min(0)).astype(float)
+    assert ext.max() >= 2.5 * ext.min()                                      # taller than deep
+    c = a.astype(float)
+    r = np.linalg.norm(c - c.mean(0), axis=1)
+    assert r.std() / r.mean() > 0.3                                          # a 1-voxel sphere shell: < 0.01
+    s = synthetic.sphere_shell(7, 50).astype(float)
+    rs = np.linalg.norm(s - s.mean(0), axis=1)
+    assert rs.std() / rs.mean() < 0.01
+    assert b.shape != a.shape or not np.array_equal(a, b)                    # the figure moves
+    assert abs(len(b) - len(a)) < 0.02 * len(a)
+    taps = (octree.neighbour_table(a.astype(np.int64)) >= 0).sum(1).mean()
+    assert 9.0 < taps < 18.0, taps
+
+
 def test_flat_adam_state_dict_roundtrip():
     from linr_pcgc_amd.model_core import FlatAdam, LINR_PCGC_Model
     m = LINR_PCGC_Model({'scale_num': 6, 'in_channel': 7, 'hidden_channel_conv': 8, 'block_layers': 1, 'outstage': 8,
