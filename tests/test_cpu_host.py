@@ -1,5 +1,6 @@
 """CPU: host logic, the C-ABI library's exports, the C++ range coder against the oracle, golden-vector checks of the
 product's own octree prep and bitstream container.  No GPU compute is called here."""
+import json
 import os
 import re
 
@@ -355,6 +356,27 @@ def test_rough_figure_generator_is_a_deterministic_non_spherical_surface():
     assert abs(len(b) - len(a)) < 0.02 * len(a)
     taps = (octree.neighbour_table(a.astype(np.int64)) >= 0).sum(1).mean()
     assert 9.0 < taps < 18.0, taps
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """The line bench.py printed for the driver's command at the end of the round (profiles/r06_final_bench_driver_cmd.json): every key
+    of the bench contract, BASELINE.json's metric and unit, the roofline and cpu_baseline objects with their fields, a lossless run."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r0*_final_bench_driver_cmd.json')))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 's/frame' and d['higher_is_better'] is False and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['n_gpus'] == 1 and 'workload' in d['config'] and 'model' not in d['config']
+    r, c = d['roofline'], d['cpu_baseline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['traffic'] is None or r['traffic'] > 0
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
+    assert d['lossless_decode_frames0to3'] is True and d['sequence']['lossless'] is True
+    assert 0 < d['value'] < 1 and abs(d['value'] - (d['components_s_per_frame']['overfit'] + d['components_s_per_frame']['codec_modelcomp_fwd_ac_write'])) < 2e-5
 
 
 def test_flat_adam_state_dict_roundtrip():
