@@ -216,7 +216,9 @@ class LINR_PCGC_Model(nn.Module):
         s = {'coord': coord, 'offset_tensor': d.get('offset_tensor'), 'scale_idx': d['scale_idx']}
         if not need_occ:
             return self.make_frame([s])
-        occ_lst, off = d['occ_lst'], d.get('offset_tensor')
+        occ_lst, off = d.get('occ_lst'), d.get('offset_tensor')
+        if occ_lst is None:                                  # the GOP drivers' lean dicts carry the matrix only (module_utils.prepare_frame)
+            occ_lst = list(d['occ'].split(1, dim=1))
         occ0 = occ_lst[0]
         # identity AND shape of every input: slices of the cached tensors share their data pointers
         key = (coord.data_ptr(), tuple(coord.shape), int(d['scale_idx']), None if off is None else (off.data_ptr(), tuple(off.shape)),

@@ -185,8 +185,11 @@ class qscTensor:
 
 def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_offsets=True):
     """MyDataset.handle_data (datautils/custom_dataset.py:259-355) for an in-memory point list [P,3].
-    with_offsets=False leaves 'offset_tensor' None: engine.Frame then reads the 7-neighbour occupancy off the kernel map
-    it builds anyway (linr_kmap_offset_feat) and overfit.Gop stores those rows back into the dicts."""
+    with_offsets=False (the GOP drivers' lean form) leaves 'offset_tensor' None: engine.Frame then reads the 7-neighbour occupancy off
+    the kernel map it builds anyway (linr_kmap_offset_feat) and overfit.Gop stores those rows back into the dicts; it also leaves
+    'occ_lst' (the eight [N,1] column views of 'occ' that the reference's model.forward takes) None - the executor takes 'occ' as one
+    matrix, LINR_PCGC_Model makes the views itself when it is handed such a dict, and 56 view objects per frame were 6 % of a frame's
+    staging time."""
     dev = torch.device(device)
     if torch.is_tensor(points):                    # device-resident input (synthetic.sequence_frame_device): no host round trip
         pts = points[:, :3].to(device=dev)
@@ -238,7 +241,7 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
                 if with_offsets:
                     low.set_offset_tensor()
                 info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),
-                             'ground_truth': child, 'scale_idx': s0, 'occ': occ, 'occ_lst': [occ[:, i:i + 1] for i in range(8)]})
+                             'ground_truth': child, 'scale_idx': s0, 'occ': occ, 'occ_lst': list(occ.split(1, dim=1)) if with_offsets else None})
                 child = parent
                 if n < min_point_num or s0 == limit - 1:
                     return {'all_input_info': info, 'point_num': int(ori.shape[0]), 'ori': ori,
@@ -254,7 +257,7 @@ def prepare_frame(points, scale_num=None, min_point_num=64, device='cpu', with_o
             low.set_offset_tensor()
         info.append({'xyzqsc_t': low, 'coord': low.get_coord(), 'offset_tensor': low.get_offset_tensor(),
                      'ground_truth': cur.get_coord(), 'scale_idx': s, 'occ': occ,
-                     'occ_lst': [occ[:, i:i + 1] for i in range(8)]})
+                     'occ_lst': list(occ.split(1, dim=1)) if with_offsets else None})
         if parent.shape[0] < min_point_num or s == limit - 1:
             break
         cur = low
